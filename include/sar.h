@@ -1,0 +1,228 @@
+/*
+ * sar.h — C ABI of the MI355X-native strange-attractor iterate/accumulate path.
+ *
+ * This is the drop-in boundary for ONE hot path of Icelk/strange-attractor-renderer:
+ *   iterate the polynomial-Sprott map -> scatter-accumulate count / depth / colour index
+ *   -> merge partial buffers -> tone-map (colorize).
+ *
+ * The reference has no FFI: its boundary is the Rust crate surface
+ *   Config / View / Colors / RenderKind          (reference src/lib.rs:228-492)
+ *   Runtime::{new, reset, merge}                 (src/lib.rs:631-739)
+ *   render(&Config, &mut Runtime)                (src/lib.rs:747-838)
+ *   colorize(&Config, &Runtime) -> FinalImage    (src/lib.rs:841-904)
+ *   ParallelRenderer::{new, shutdown}            (src/lib.rs:908-1031)
+ *   render_parallel(&mut ParallelRenderer, Config, jobs_per_thread) (src/lib.rs:1051-1082)
+ * Each entry point below names the reference item it replaces. A Rust `extern "C"` block a
+ * maintainer would add to bind these is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns an int status (SAR_OK == 0); nothing unwinds across this boundary
+ *     (the reference panics instead: src/lib.rs:709-710, 990, 1024);
+ *   - plain pointers and sizes only; no C++/torch types;
+ *   - a sar_runtime is bound to one HIP device + one HIP stream and is NOT thread-safe
+ *     (same contract as `&mut Runtime`);
+ *   - pointers named *_host are host memory, *_dev are device memory on the runtime's device;
+ *   - image buffers are row-major, index = y*width + x (image::ImageBuffer Luma layout,
+ *     src/lib.rs:808).
+ */
+#ifndef SAR_H
+#define SAR_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAR_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------ */
+enum {
+    SAR_OK = 0,
+    SAR_ERR_INVALID = 1,      /* NULL pointer / bad enum / empty palette (ref: Palette::new panics, :413-418) */
+    SAR_ERR_DIM_MISMATCH = 2, /* merge of runtimes with different sizes (ref: assert_eq!, :709-710) */
+    SAR_ERR_NO_DEVICE = 3,    /* no HIP device / HIP runtime unavailable */
+    SAR_ERR_HIP = 4,          /* a HIP call failed; see sar_last_error() */
+    SAR_ERR_OOM = 5,
+    SAR_ERR_RANGE = 6         /* a size exceeds what one launch chunk can order (see sar_render_jobs) */
+};
+
+/* ---- closed enums (Rust generics / closures cannot cross a C ABI) ------------------------- */
+enum { SAR_RENDER_GAS = 0, SAR_RENDER_DEPTH = 1 };            /* RenderKind, src/lib.rs:233-239 */
+enum { SAR_ATTRACTOR_SPROTT2 = 0 };                           /* PolynomialSprott2Degree, :575-580 */
+enum { SAR_CT_POISSON_SATURNE = 0, SAR_CT_ADJUSTED_VELOCITY = 1 }; /* color_transforms, :498-559 */
+
+#define SAR_PALETTE_MAX 15   /* user entries; the duplicated last entry (:416-418) is added internally */
+
+/*
+ * POD mirror of Config<A,T> + View + Colors (src/lib.rs:253-308, 389-492), plus the two things
+ * the reference hides: `seed` (it seeds SmallRng from OS entropy, :656) and `jobs_total`
+ * (it derives T*J from the thread pool, :1058-1062).
+ */
+typedef struct sar_config {
+    uint64_t iterations;          /* Config::iterations (:267) */
+    uint32_t width;               /* :269 */
+    uint32_t height;              /* :271 */
+    int32_t  render_kind;         /* SAR_RENDER_*  (:273) */
+    int32_t  transparent;         /* bool (:275) */
+    double   angle;               /* radians (:277) */
+    int32_t  silent;              /* bool (:280); this library never prints */
+    int32_t  attractor_kind;      /* SAR_ATTRACTOR_* */
+    double   coeff_x[10];         /* PolynomialSprott2Degree::x (:577) */
+    double   coeff_y[10];         /* :578 */
+    double   coeff_z[10];         /* :579 */
+    uint32_t palette_len;         /* number of entries in palette_rgb, 1..SAR_PALETTE_MAX */
+    uint32_t _pad0;
+    double   palette_rgb[SAR_PALETTE_MAX][3]; /* Palette list (:409), linear r,g,b */
+    double   brightness_offset;   /* BrighnessConstants::offset (:394) */
+    double   brightness_factor;   /* BrighnessConstants::factor (:395) */
+    double   center_camera[3];    /* View::center_camera (:257) */
+    double   rotation_axis[3];    /* EulerAxisRotation::axis (:172) — NOT normalised (release build, :181-183) */
+    double   rotation_angle;      /* EulerAxisRotation::rotation (:174) */
+    double   scale;               /* View::scale (:260) */
+    int32_t  color_transform;     /* SAR_CT_* */
+    int32_t  _pad1;
+    double   ct_offset;           /* AdjustedVelocity::offset (:508) */
+    double   ct_factor;           /* AdjustedVelocity::factor (:509) */
+    uint64_t seed;                /* seed of the runtime's start-point stream (see sar_start_points) */
+    uint32_t jobs_total;          /* number of independent trajectories ("jobs", :1062) sar_render_jobs runs */
+    uint32_t _pad2;
+} sar_config;
+
+typedef struct sar_runtime sar_runtime;     /* opaque; Runtime, src/lib.rs:631-646 */
+typedef struct sar_renderer sar_renderer;   /* opaque; ParallelRenderer, src/lib.rs:908-915 */
+
+/* Per-call device timings (HIP events on the runtime's stream), filled when timing is enabled. */
+typedef struct sar_timing {
+    float    iterate_ms;    /* sum over launch chunks of the iterate/accumulate kernel */
+    float    resolve_ms;    /* depth-winner payload resolve + max reduction */
+    float    colorize_ms;   /* last colorize */
+    float    merge_ms;      /* last merge */
+    uint32_t iterate_launches;
+    uint32_t _pad;
+    uint64_t iterations_counted; /* jobs * iterations-per-job executed by the last render call */
+} sar_timing;
+
+/* ---- misc ---------------------------------------------------------------------------------- */
+int         sar_abi_version(void);
+const char* sar_status_string(int status);
+const char* sar_last_error(void);           /* thread-local, human readable */
+int         sar_device_count(int* out_count);
+
+/* ---- Config presets (data only) -------------------------------------------------------------- */
+/* Config::new defaults (:289-307) + poisson_saturne() values (:310-352). */
+int sar_config_poisson_saturne(sar_config* out);
+/* Config::new defaults + solar_sail() values (:354-387) (library scale 1.7; the CLI overrides to 1). */
+int sar_config_solar_sail(sar_config* out);
+/* Checks enums, palette_len, non-zero dimensions. */
+int sar_config_validate(const sar_config* cfg);
+
+/* ---- host-side setup math (no device needed) -------------------------------------------------- */
+/* EulerAxisRotation::to_rotation_matrix, release semantics (:176-196). m is row-major 3x3. */
+int sar_rotation_matrix(const sar_config* cfg, double m_out[9]);
+/*
+ * The start-point stream the reference leaves to OS entropy (:656, :748): SplitMix64(seed) seeds
+ * xoshiro256++; every f64 is (next_u64 >> 11) * 2^-53; job k takes draws 3k..3k+2 as x,y,z, each
+ * multiplied by 0.1 (`rng.random::<Vec3>() * 0.1`). Writes n_jobs*3 doubles for jobs
+ * [first_job, first_job+n_jobs).
+ */
+int sar_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double* xyz_out_host);
+
+/* ---- Runtime (src/lib.rs:631-739) -------------------------------------------------------------- */
+/* Runtime::new (:660-665): allocates count/steps/zbuf for cfg->width x cfg->height on `device`,
+ * resets them, seeds the start-point stream with cfg->seed. */
+int sar_runtime_new(const sar_config* cfg, int device, sar_runtime** out);
+int sar_runtime_free(sar_runtime* rt);
+/* Runtime::reset (:682-699): count<-0, steps<-0.0, zbuf<--1.0, max<-0. The RNG stream is NOT reseeded. */
+int sar_runtime_reset(sar_runtime* rt);
+/* Runtime::set_width_height (:667-675): reallocates + resets only when the size changes. */
+int sar_runtime_set_width_height(sar_runtime* rt, uint32_t width, uint32_t height);
+/* Reseed the start-point stream (the reference has no equivalent; needed for reproducibility). */
+int sar_runtime_seed(sar_runtime* rt, uint64_t seed);
+/* Runtime::merge (:708-738): dst.count += src.count (wrapping); dst.max = max(dst.max, merged counts);
+ * where src.zbuf > dst.zbuf (strict; dst wins ties) take src's steps and zbuf. Same device required. */
+int sar_runtime_merge(sar_runtime* dst, const sar_runtime* src);
+int sar_runtime_synchronize(sar_runtime* rt);
+int sar_runtime_dims(const sar_runtime* rt, uint32_t* width, uint32_t* height);
+/* Use an existing hipStream_t (passed as void*) instead of the runtime's own stream. */
+int sar_runtime_set_stream(sar_runtime* rt, void* hip_stream);
+int sar_runtime_get_stream(const sar_runtime* rt, void** hip_stream_out);
+
+/* ---- render (src/lib.rs:747-838) ------------------------------------------------------------------ */
+/* Exactly `render`: ONE trajectory of cfg->iterations counted iterations after a start point drawn
+ * from the runtime's stream and 1000 uncounted warm-up iterations. Accumulates into rt (no reset). */
+int sar_render(const sar_config* cfg, sar_runtime* rt);
+/*
+ * The data-parallel form: equivalent to calling `render` cfg->jobs_total times on this un-reset
+ * runtime (what one reference worker does, :956-988) with iterations = cfg->iterations / jobs_total
+ * (floor; the job split of :1056-1058). Results are defined as the SEQUENTIAL result in job order
+ * (job-major, iteration-minor ties). starts_xyz_host: jobs_total*3 doubles (pre-warm-up start points,
+ * already scaled) or NULL to draw them from the runtime's stream.
+ */
+int sar_render_jobs(const sar_config* cfg, sar_runtime* rt, const double* starts_xyz_host);
+/* Shard form: run only jobs [first_job, first_job+n_jobs) of the split above, each with
+ * iters_per_job counted iterations. starts_xyz_host holds n_jobs*3 doubles for THIS slice (required). */
+int sar_render_job_range(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
+                         uint64_t iters_per_job, const double* starts_xyz_host);
+
+/* ---- colorize (src/lib.rs:841-904) ---------------------------------------------------------------- */
+/* Writes width*height*4 uint16 (RGBA16, FinalImage layout :625) to host memory. */
+int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host);
+/* Same, leaving the image in device memory (width*height*8 bytes); stream-ordered, no host sync. */
+int sar_colorize_device(const sar_config* cfg, sar_runtime* rt, void* rgba_out_dev);
+
+/* ---- read-back accessors (the reference keeps these fields private, :633-643) ---------------------- */
+int sar_runtime_count(sar_runtime* rt, uint32_t* out_host);   /* width*height */
+int sar_runtime_steps(sar_runtime* rt, double* out_host);     /* width*height */
+int sar_runtime_zbuf(sar_runtime* rt, float* out_host);       /* width*height */
+int sar_runtime_max(sar_runtime* rt, uint32_t* out_max);
+/* Upload a full state (used to move a partial render between processes / devices). */
+int sar_runtime_load(sar_runtime* rt, const uint32_t* count_host, const double* steps_host,
+                     const float* zbuf_host, uint32_t max);
+
+/* ---- multi-GPU exchange (Runtime::merge folded in rank order, over device buffers) ------------------
+ * One process per GPU; the collective itself (RCCL via torch.distributed, or anything else) is the
+ * caller's. All buffers are device pointers on the runtime's device, npix = width*height.
+ *   1. export:  key_out[p]  = sortable int64 of (zbuf[p], lowest-rank-wins)     -> all-reduce MAX
+ *   2. select:  sum_out[0..npix)       = count[p] as int32 (wrapping == u32 add)
+ *               sum_out[npix..3*npix)  = the two int32 halves of steps[p] if this rank holds the
+ *                                        winning key, else 0                     -> reduce SUM (int32)
+ *   3. import:  count/zbuf/steps/max of rt replaced by the reduced buffers.
+ */
+int sar_runtime_exchange_export(sar_runtime* rt, uint32_t rank, void* key_i64_out_dev);
+int sar_runtime_exchange_select(sar_runtime* rt, uint32_t rank, const void* key_i64_reduced_dev,
+                                void* sum_i32_out_dev /* 3*npix int32 */);
+int sar_runtime_exchange_import(sar_runtime* rt, const void* key_i64_reduced_dev,
+                                const void* sum_i32_reduced_dev);
+
+/* ---- ParallelRenderer / render_parallel (src/lib.rs:908-1082) -------------------------------------- */
+/* ParallelRenderer::new (:919-1004). `units` plays the role of num_threads (:920-922): the number of
+ * execution units the job split divides by; 0 selects the device default (one lane per SIMD lane of
+ * the chip: CUs*4*64). The renderer owns one runtime on `device`, seeded with `seed`. */
+int sar_renderer_new(int device, uint32_t units, uint64_t seed, sar_renderer** out);
+int sar_renderer_num_units(const sar_renderer* r, uint32_t* out_units);
+/* ParallelRenderer::shutdown (:1020-1025). */
+int sar_renderer_shutdown(sar_renderer* r);
+/* render_parallel (:1051-1082): iterations/units/jobs_per_unit per job (:1058), units*jobs_per_unit
+ * jobs (:1062), reset, render, colorize. rgba_out_host: width*height*4 uint16. */
+int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_per_unit,
+                        uint16_t* rgba_out_host);
+/* The renderer's runtime (borrowed), e.g. to read the count buffer after render_parallel. */
+int sar_renderer_runtime(sar_renderer* r, sar_runtime** out_borrowed);
+
+/* ---- measurement ----------------------------------------------------------------------------------- */
+int sar_runtime_enable_timing(sar_runtime* rt, int enabled);
+int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
+/* Tuning knobs (0 keeps the default): lanes per workgroup of the iterate kernel and checkpoint
+ * stride (iterations between trajectory checkpoints used by the payload resolve).
+ * variant: bits 0-3 scratch-bin layout (0 default, 1 one copy + agent-scope atomics, 2 one copy per
+ * XCD + L2-local atomics); bits 4-7 measurement-only kernels (0 full path, 1 count only, 2 arithmetic
+ * only — results are NOT the render); bits 8-31 test hook: cap on jobs per launch chunk. */
+int sar_runtime_set_tuning(sar_runtime* rt, uint32_t block_threads, uint32_t checkpoint_stride,
+                           uint32_t variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAR_H */

@@ -1,0 +1,84 @@
+/*
+ * sar_oracle.h — CPU oracle for the iterate/accumulate path. TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (strange_attractor_renderer_amd/) never links, imports or calls it.
+ *
+ * It is a plain-C restatement of the reference's arithmetic (Icelk/strange-attractor-renderer,
+ * src/lib.rs), op for op, to be built with -ffp-contract=off (Rust/LLVM never contracts a*b+c).
+ *
+ * PARITY STATUS: the reference is Rust and cannot be built here (no cargo/rustc, no lockfile, no
+ * vendored crates), and its own test-suite holds no vectors for this path (the only `cargo test`
+ * item is a doc-test that constructs a Config, src/lib.rs:9-15). Bit-level parity is therefore
+ * UNPINNED; the oracle is pinned (a) statistically against the one artefact the reference ships,
+ * media/poisson-saturne.png (tests/golden/ref_png_stats.json, tests/test_oracle_reference_png.py)
+ * and (b) by known-answer vectors produced independently and frozen under
+ * tests/golden/.
+ */
+#ifndef SAR_ORACLE_H
+#define SAR_ORACLE_H
+
+#include <stdint.h>
+#include "../include/sar.h" /* sar_config POD only */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Runtime, src/lib.rs:631-646 (rng kept outside: start points are explicit here). */
+typedef struct sar_oracle_runtime {
+    uint32_t width, height;
+    uint32_t max;
+    uint32_t _pad;
+    uint32_t* count; /* width*height */
+    double*   steps;
+    float*    zbuf;
+} sar_oracle_runtime;
+
+/* PolynomialSprott2Degree::next_point, src/lib.rs:583-621 */
+void sar_oracle_next_point(const sar_config* cfg, const double p[3], double out[3]);
+/* EulerAxisRotation::to_rotation_matrix (release: axis not normalised), src/lib.rs:176-196 */
+void sar_oracle_rotation_matrix(const sar_config* cfg, double m[9]);
+/* color transforms, src/lib.rs:507-516 and 520-558 */
+double sar_oracle_color_transform(const sar_config* cfg, const double delta[3], const double ss[3]);
+
+/* Runtime::new / reset / merge, src/lib.rs:660-665, 682-699, 708-738 */
+sar_oracle_runtime* sar_oracle_runtime_new(uint32_t width, uint32_t height);
+void sar_oracle_runtime_free(sar_oracle_runtime* rt);
+void sar_oracle_runtime_reset(sar_oracle_runtime* rt);
+int  sar_oracle_runtime_merge(sar_oracle_runtime* dst, const sar_oracle_runtime* src);
+
+/* render, src/lib.rs:747-838, with the start point (pre-warm-up, already scaled by 0.1) explicit. */
+void sar_oracle_render(const sar_config* cfg, sar_oracle_runtime* rt, const double p0[3],
+                       uint64_t iterations);
+/* `jobs` sequential render calls on one un-reset runtime (one worker's loop, src/lib.rs:956-988). */
+void sar_oracle_render_jobs(const sar_config* cfg, sar_oracle_runtime* rt, const double* starts_xyz,
+                            uint32_t jobs, uint64_t iters_per_job);
+/* Iterates only (no accumulation): writes the point after `n` applications of next_point. */
+void sar_oracle_iterate(const sar_config* cfg, const double p0[3], uint64_t n, double out[3]);
+
+/* Palette::interpolate, src/lib.rs:442-472 */
+void sar_oracle_palette(const sar_config* cfg, double value, double rgb[3]);
+/* colorize, src/lib.rs:841-904; rgba: width*height*4 uint16 */
+void sar_oracle_colorize(const sar_config* cfg, const sar_oracle_runtime* rt, uint16_t* rgba);
+
+/* Start-point stream (defined by this project, see include/sar.h sar_start_points). */
+void sar_oracle_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double* xyz);
+
+/* FNV-1a 64 over raw bytes (fixture hashing). */
+uint64_t sar_oracle_fnv1a64(const void* data, uint64_t nbytes);
+
+/*
+ * CPU baseline shaped like render_parallel (src/lib.rs:1051-1082, pool :919-1004): `threads`
+ * workers with private runtimes, a shared atomic job counter of threads*jobs_per_thread jobs of
+ * iterations/threads/jobs_per_thread iterations each, then SERIAL merge and SERIAL colorize.
+ * Returns wall seconds; counted iterations in *iters_done. rgba may be NULL.
+ */
+double sar_oracle_render_parallel(const sar_config* cfg, uint32_t threads, uint32_t jobs_per_thread,
+                                  uint64_t seed, uint16_t* rgba, uint64_t* iters_done,
+                                  sar_oracle_runtime* out_merged /* nullable, pre-allocated */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,12 @@
+"""MI355X-native iterate/accumulate path of Icelk/strange-attractor-renderer.
+
+`libsar_hip.so` (HIP, gfx950) is the product; this package is the thin host-side mirror of the
+reference crate's Config / Runtime / render / colorize / ParallelRenderer / render_parallel surface
+over the C ABI declared in include/sar.h. No CPU fallback exists by design.
+"""
+from .api import (Config, ParallelRenderer, Runtime, SarError, Timing, colorize, colorize_device,  # noqa: F401
+                  device_count, render, render_job_range, render_jobs, render_parallel, start_points)
+from ._abi import (SAR_CT_ADJUSTED_VELOCITY, SAR_CT_POISSON_SATURNE, SAR_RENDER_DEPTH,  # noqa: F401
+                   SAR_RENDER_GAS, load_library)
+
+RenderKind = type("RenderKind", (), {"Gas": SAR_RENDER_GAS, "Depth": SAR_RENDER_DEPTH})

@@ -1,0 +1,151 @@
+"""ctypes mirror of include/sar.h (the C ABI of the HIP library).
+
+Plumbing only: struct layouts, prototypes and the loader for ``libsar_hip.so``. The library is the
+product; there is NO CPU fallback — loading fails loudly when the shared object is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+SAR_OK = 0
+SAR_ERR_INVALID = 1
+SAR_ERR_DIM_MISMATCH = 2
+SAR_ERR_NO_DEVICE = 3
+SAR_ERR_HIP = 4
+SAR_ERR_OOM = 5
+SAR_ERR_RANGE = 6
+
+SAR_RENDER_GAS = 0
+SAR_RENDER_DEPTH = 1
+SAR_ATTRACTOR_SPROTT2 = 0
+SAR_CT_POISSON_SATURNE = 0
+SAR_CT_ADJUSTED_VELOCITY = 1
+SAR_PALETTE_MAX = 15
+
+
+class SarConfig(C.Structure):
+    """``struct sar_config`` — POD mirror of the reference's Config/View/Colors (src/lib.rs:253-308)."""
+
+    _fields_ = [
+        ("iterations", C.c_uint64),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("render_kind", C.c_int32),
+        ("transparent", C.c_int32),
+        ("angle", C.c_double),
+        ("silent", C.c_int32),
+        ("attractor_kind", C.c_int32),
+        ("coeff_x", C.c_double * 10),
+        ("coeff_y", C.c_double * 10),
+        ("coeff_z", C.c_double * 10),
+        ("palette_len", C.c_uint32),
+        ("_pad0", C.c_uint32),
+        ("palette_rgb", (C.c_double * 3) * SAR_PALETTE_MAX),
+        ("brightness_offset", C.c_double),
+        ("brightness_factor", C.c_double),
+        ("center_camera", C.c_double * 3),
+        ("rotation_axis", C.c_double * 3),
+        ("rotation_angle", C.c_double),
+        ("scale", C.c_double),
+        ("color_transform", C.c_int32),
+        ("_pad1", C.c_int32),
+        ("ct_offset", C.c_double),
+        ("ct_factor", C.c_double),
+        ("seed", C.c_uint64),
+        ("jobs_total", C.c_uint32),
+        ("_pad2", C.c_uint32),
+    ]
+
+
+class SarTiming(C.Structure):
+    _fields_ = [
+        ("iterate_ms", C.c_float),
+        ("resolve_ms", C.c_float),
+        ("colorize_ms", C.c_float),
+        ("merge_ms", C.c_float),
+        ("iterate_launches", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("iterations_counted", C.c_uint64),
+    ]
+
+
+_P = C.POINTER
+_cfg_p = _P(SarConfig)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/sar.h declares
+PROTOTYPES = {
+    "sar_abi_version": (C.c_int, []),
+    "sar_status_string": (C.c_char_p, [C.c_int]),
+    "sar_last_error": (C.c_char_p, []),
+    "sar_device_count": (C.c_int, [_P(C.c_int)]),
+    "sar_config_poisson_saturne": (C.c_int, [_cfg_p]),
+    "sar_config_solar_sail": (C.c_int, [_cfg_p]),
+    "sar_config_validate": (C.c_int, [_cfg_p]),
+    "sar_rotation_matrix": (C.c_int, [_cfg_p, _P(C.c_double)]),
+    "sar_start_points": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, _P(C.c_double)]),
+    "sar_runtime_new": (C.c_int, [_cfg_p, C.c_int, _P(_vp)]),
+    "sar_runtime_free": (C.c_int, [_vp]),
+    "sar_runtime_reset": (C.c_int, [_vp]),
+    "sar_runtime_set_width_height": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "sar_runtime_seed": (C.c_int, [_vp, C.c_uint64]),
+    "sar_runtime_merge": (C.c_int, [_vp, _vp]),
+    "sar_runtime_synchronize": (C.c_int, [_vp]),
+    "sar_runtime_dims": (C.c_int, [_vp, _P(C.c_uint32), _P(C.c_uint32)]),
+    "sar_runtime_set_stream": (C.c_int, [_vp, _vp]),
+    "sar_runtime_get_stream": (C.c_int, [_vp, _P(_vp)]),
+    "sar_render": (C.c_int, [_cfg_p, _vp]),
+    "sar_render_jobs": (C.c_int, [_cfg_p, _vp, _P(C.c_double)]),
+    "sar_render_job_range": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _P(C.c_double)]),
+    "sar_colorize": (C.c_int, [_cfg_p, _vp, _P(C.c_uint16)]),
+    "sar_colorize_device": (C.c_int, [_cfg_p, _vp, _vp]),
+    "sar_runtime_count": (C.c_int, [_vp, _P(C.c_uint32)]),
+    "sar_runtime_steps": (C.c_int, [_vp, _P(C.c_double)]),
+    "sar_runtime_zbuf": (C.c_int, [_vp, _P(C.c_float)]),
+    "sar_runtime_max": (C.c_int, [_vp, _P(C.c_uint32)]),
+    "sar_runtime_load": (C.c_int, [_vp, _P(C.c_uint32), _P(C.c_double), _P(C.c_float), C.c_uint32]),
+    "sar_runtime_exchange_export": (C.c_int, [_vp, C.c_uint32, _vp]),
+    "sar_runtime_exchange_select": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
+    "sar_runtime_exchange_import": (C.c_int, [_vp, _vp, _vp]),
+    "sar_renderer_new": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, _P(_vp)]),
+    "sar_renderer_num_units": (C.c_int, [_vp, _P(C.c_uint32)]),
+    "sar_renderer_shutdown": (C.c_int, [_vp]),
+    "sar_render_parallel": (C.c_int, [_vp, _cfg_p, C.c_uint32, _P(C.c_uint16)]),
+    "sar_renderer_runtime": (C.c_int, [_vp, _P(_vp)]),
+    "sar_runtime_enable_timing": (C.c_int, [_vp, C.c_int]),
+    "sar_runtime_last_timing": (C.c_int, [_vp, _P(SarTiming)]),
+    "sar_runtime_set_tuning": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+}
+
+LIB_NAME = "libsar_hip.so"
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, LIB_NAME)
+
+_lib = None
+
+
+class SarLibraryMissing(RuntimeError):
+    pass
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """dlopen the in-tree HIP library and attach prototypes. Raises if it is missing — by design
+    there is no fallback path."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise SarLibraryMissing(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib

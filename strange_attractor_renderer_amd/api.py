@@ -1,0 +1,332 @@
+"""Host-side mirror of the reference crate's surface for the iterate/accumulate path, over the C ABI.
+
+Names and argument meaning follow the reference (src/lib.rs):
+
+    Config.poisson_saturne() / Config.solar_sail()      config presets           (:310, :355)
+    Runtime(config)  .reset()  .merge(other)            Runtime                  (:631-739)
+    render(config, runtime)                             one trajectory           (:747-838)
+    colorize(config, runtime) -> HxWx4 uint16           FinalImage               (:841-904)
+    ParallelRenderer(...) / .shutdown()                 thread pool -> GPU lanes (:908-1031)
+    render_parallel(renderer, config, jobs_per_thread)  job split + merge        (:1051-1082)
+
+plus what the reference hides: a seed, the job count, explicit start points and read-back accessors.
+Everything here is plumbing (ctypes + numpy); all arithmetic runs in libsar_hip.so on the GPU.
+There is no CPU fallback: without the library or without a HIP device these calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _abi
+from ._abi import (SAR_CT_ADJUSTED_VELOCITY, SAR_CT_POISSON_SATURNE, SAR_RENDER_DEPTH,  # noqa: F401
+                   SAR_RENDER_GAS, SarConfig, SarTiming)
+
+
+class SarError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        lib = _abi.load_library()
+        msg = lib.sar_last_error().decode(errors="replace")
+        name = lib.sar_status_string(status).decode()
+        super().__init__(f"{where}: {name} ({status}) {msg}")
+        self.status = status
+
+
+def _check(status: int, where: str):
+    if status != _abi.SAR_OK:
+        raise SarError(status, where)
+
+
+def _lib():
+    return _abi.load_library()
+
+
+class Config:
+    """``Config<PolynomialSprott2Degree, _>`` as a thin wrapper around ``struct sar_config``.
+
+    Field names are the reference's; nested View/Colors fields are flattened
+    (``scale``, ``center_camera``, ``brightness_offset`` ...)."""
+
+    def __init__(self, c: SarConfig | None = None):
+        self.c = c if c is not None else SarConfig()
+
+    @classmethod
+    def poisson_saturne(cls, **overrides) -> "Config":
+        cfg = cls()
+        _check(_lib().sar_config_poisson_saturne(C.byref(cfg.c)), "sar_config_poisson_saturne")
+        return cfg.replace(**overrides)
+
+    @classmethod
+    def solar_sail(cls, **overrides) -> "Config":
+        cfg = cls()
+        _check(_lib().sar_config_solar_sail(C.byref(cfg.c)), "sar_config_solar_sail")
+        return cfg.replace(**overrides)
+
+    def copy(self) -> "Config":
+        out = SarConfig()
+        C.memmove(C.byref(out), C.byref(self.c), C.sizeof(SarConfig))
+        return Config(out)
+
+    def replace(self, **kw) -> "Config":
+        """``Config { iterations: ..., ..preset }`` update syntax (src/lib.rs:9-15)."""
+        out = self.copy()
+        for k, v in kw.items():
+            if k == "render":
+                k = "render_kind"
+            if not hasattr(out.c, k):
+                raise AttributeError(f"sar_config has no field {k!r}")
+            cur = getattr(out.c, k)
+            if isinstance(cur, C.Array):
+                arr = np.asarray(v, dtype=np.float64)
+                if k == "palette_rgb":
+                    out.c.palette_len = arr.shape[0]
+                    for i in range(arr.shape[0]):
+                        for ch in range(3):
+                            out.c.palette_rgb[i][ch] = float(arr[i, ch])
+                else:
+                    for i in range(len(cur)):
+                        cur[i] = float(arr[i])
+            else:
+                setattr(out.c, k, v)
+        return out
+
+    def validate(self):
+        _check(_lib().sar_config_validate(C.byref(self.c)), "sar_config_validate")
+
+    def __getattr__(self, name):
+        c = object.__getattribute__(self, "c")
+        if hasattr(c, name):
+            v = getattr(c, name)
+            return np.ctypeslib.as_array(v).copy() if isinstance(v, C.Array) else v
+        raise AttributeError(name)
+
+    def rotation_matrix(self) -> np.ndarray:
+        m = np.empty(9, dtype=np.float64)
+        _check(_lib().sar_rotation_matrix(C.byref(self.c), m.ctypes.data_as(C.POINTER(C.c_double))),
+               "sar_rotation_matrix")
+        return m.reshape(3, 3)
+
+
+def start_points(seed: int, first_job: int, n_jobs: int) -> np.ndarray:
+    """The start-point stream the reference leaves to OS entropy: (n_jobs, 3) f64, already * 0.1."""
+    out = np.empty((n_jobs, 3), dtype=np.float64)
+    _check(_lib().sar_start_points(seed, first_job, n_jobs, out.ctypes.data_as(C.POINTER(C.c_double))),
+           "sar_start_points")
+    return out
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    st = _lib().sar_device_count(C.byref(n))
+    return int(n.value) if st == _abi.SAR_OK else 0
+
+
+@dataclass
+class Timing:
+    iterate_ms: float
+    resolve_ms: float
+    colorize_ms: float
+    merge_ms: float
+    iterate_launches: int
+    iterations_counted: int
+
+
+class Runtime:
+    """``Runtime`` (src/lib.rs:631-646) living on one GPU."""
+
+    def __init__(self, config: Config, device: int = 0, _borrowed=None):
+        self._own = _borrowed is None
+        if _borrowed is not None:
+            self._h = _borrowed
+        else:
+            h = C.c_void_p()
+            _check(_lib().sar_runtime_new(C.byref(config.c), device, C.byref(h)), "sar_runtime_new")
+            self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) and self._own:
+            _lib().sar_runtime_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def dims(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        _check(_lib().sar_runtime_dims(self._h, C.byref(w), C.byref(h)), "sar_runtime_dims")
+        return int(w.value), int(h.value)
+
+    def reset(self):
+        _check(_lib().sar_runtime_reset(self._h), "sar_runtime_reset")
+
+    def set_width_height(self, width: int, height: int):
+        _check(_lib().sar_runtime_set_width_height(self._h, width, height), "sar_runtime_set_width_height")
+
+    def seed(self, seed: int):
+        _check(_lib().sar_runtime_seed(self._h, seed), "sar_runtime_seed")
+
+    def merge(self, other: "Runtime"):
+        _check(_lib().sar_runtime_merge(self._h, other._h), "sar_runtime_merge")
+
+    def synchronize(self):
+        _check(_lib().sar_runtime_synchronize(self._h), "sar_runtime_synchronize")
+
+    # ---- read-back ------------------------------------------------------------------------------
+    def count(self) -> np.ndarray:
+        w, h = self.dims()
+        out = np.empty((h, w), dtype=np.uint32)
+        _check(_lib().sar_runtime_count(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32))), "sar_runtime_count")
+        return out
+
+    def steps(self) -> np.ndarray:
+        w, h = self.dims()
+        out = np.empty((h, w), dtype=np.float64)
+        _check(_lib().sar_runtime_steps(self._h, out.ctypes.data_as(C.POINTER(C.c_double))), "sar_runtime_steps")
+        return out
+
+    def zbuf(self) -> np.ndarray:
+        w, h = self.dims()
+        out = np.empty((h, w), dtype=np.float32)
+        _check(_lib().sar_runtime_zbuf(self._h, out.ctypes.data_as(C.POINTER(C.c_float))), "sar_runtime_zbuf")
+        return out
+
+    def max(self) -> int:
+        m = C.c_uint32()
+        _check(_lib().sar_runtime_max(self._h, C.byref(m)), "sar_runtime_max")
+        return int(m.value)
+
+    def load(self, count: np.ndarray, steps: np.ndarray, zbuf: np.ndarray, max_: int):
+        count = np.ascontiguousarray(count, dtype=np.uint32)
+        steps = np.ascontiguousarray(steps, dtype=np.float64)
+        zbuf = np.ascontiguousarray(zbuf, dtype=np.float32)
+        _check(_lib().sar_runtime_load(self._h, count.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       steps.ctypes.data_as(C.POINTER(C.c_double)),
+                                       zbuf.ctypes.data_as(C.POINTER(C.c_float)), int(max_)), "sar_runtime_load")
+
+    # ---- measurement / tuning -----------------------------------------------------------------------
+    def enable_timing(self, on: bool = True):
+        _check(_lib().sar_runtime_enable_timing(self._h, 1 if on else 0), "sar_runtime_enable_timing")
+
+    def last_timing(self) -> Timing:
+        t = SarTiming()
+        _check(_lib().sar_runtime_last_timing(self._h, C.byref(t)), "sar_runtime_last_timing")
+        return Timing(t.iterate_ms, t.resolve_ms, t.colorize_ms, t.merge_ms, t.iterate_launches,
+                      t.iterations_counted)
+
+    def set_tuning(self, block_threads: int = 0, checkpoint_stride: int = 0, variant: int = 0):
+        _check(_lib().sar_runtime_set_tuning(self._h, block_threads, checkpoint_stride, variant),
+               "sar_runtime_set_tuning")
+
+    def stream(self) -> int:
+        s = C.c_void_p()
+        _check(_lib().sar_runtime_get_stream(self._h, C.byref(s)), "sar_runtime_get_stream")
+        return int(s.value or 0)
+
+    def set_stream(self, stream_ptr: int):
+        _check(_lib().sar_runtime_set_stream(self._h, C.c_void_p(stream_ptr)), "sar_runtime_set_stream")
+
+    # ---- multi-GPU exchange over caller-provided device buffers ------------------------------------
+    def exchange_export(self, rank: int, key_i64_dev_ptr: int):
+        _check(_lib().sar_runtime_exchange_export(self._h, rank, C.c_void_p(key_i64_dev_ptr)),
+               "sar_runtime_exchange_export")
+
+    def exchange_select(self, rank: int, key_reduced_dev_ptr: int, sum_i32_dev_ptr: int):
+        _check(_lib().sar_runtime_exchange_select(self._h, rank, C.c_void_p(key_reduced_dev_ptr),
+                                                  C.c_void_p(sum_i32_dev_ptr)), "sar_runtime_exchange_select")
+
+    def exchange_import(self, key_reduced_dev_ptr: int, sum_reduced_dev_ptr: int):
+        _check(_lib().sar_runtime_exchange_import(self._h, C.c_void_p(key_reduced_dev_ptr),
+                                                  C.c_void_p(sum_reduced_dev_ptr)), "sar_runtime_exchange_import")
+
+
+def _starts_ptr(starts, n_jobs: int):
+    if starts is None:
+        return None, None
+    s = np.ascontiguousarray(starts, dtype=np.float64)
+    if s.shape != (n_jobs, 3):
+        raise ValueError(f"starts must have shape ({n_jobs}, 3), got {s.shape}")
+    return s, s.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def render(config: Config, runtime: Runtime):
+    """``render(&config, &mut runtime)``: ONE trajectory of config.iterations (src/lib.rs:747)."""
+    _check(_lib().sar_render(C.byref(config.c), runtime.handle), "sar_render")
+
+
+def render_jobs(config: Config, runtime: Runtime, starts=None):
+    """config.jobs_total trajectories of config.iterations // jobs_total each, with the sequential
+    (job-major) semantics of calling ``render`` that many times on one un-reset runtime."""
+    keep, ptr = _starts_ptr(starts, config.c.jobs_total)
+    _check(_lib().sar_render_jobs(C.byref(config.c), runtime.handle, ptr), "sar_render_jobs")
+    del keep
+
+
+def render_job_range(config: Config, runtime: Runtime, iters_per_job: int, starts):
+    """A shard: the given jobs (explicit start points) with iters_per_job iterations each."""
+    s = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 3)
+    _check(_lib().sar_render_job_range(C.byref(config.c), runtime.handle, s.shape[0], iters_per_job,
+                                       s.ctypes.data_as(C.POINTER(C.c_double))), "sar_render_job_range")
+
+
+def colorize(config: Config, runtime: Runtime) -> np.ndarray:
+    """``colorize(&config, &runtime) -> FinalImage`` as an (H, W, 4) uint16 array (src/lib.rs:841)."""
+    out = np.empty((config.c.height, config.c.width, 4), dtype=np.uint16)
+    _check(_lib().sar_colorize(C.byref(config.c), runtime.handle, out.ctypes.data_as(C.POINTER(C.c_uint16))),
+           "sar_colorize")
+    return out
+
+
+def colorize_device(config: Config, runtime: Runtime, rgba_dev_ptr: int):
+    """colorize into a caller-provided device buffer (H*W*8 bytes); stream-ordered, no host sync."""
+    _check(_lib().sar_colorize_device(C.byref(config.c), runtime.handle, C.c_void_p(rgba_dev_ptr)),
+           "sar_colorize_device")
+
+
+class ParallelRenderer:
+    """``ParallelRenderer`` (src/lib.rs:908): `units` stands in for the thread count the job split
+    divides by (0 = one trajectory per SIMD lane of the device)."""
+
+    def __init__(self, device: int = 0, units: int = 0, seed: int = 0):
+        h = C.c_void_p()
+        _check(_lib().sar_renderer_new(device, units, seed, C.byref(h)), "sar_renderer_new")
+        self._h = h
+        self.device = device
+
+    def num_threads(self) -> int:
+        n = C.c_uint32()
+        _check(_lib().sar_renderer_num_units(self._h, C.byref(n)), "sar_renderer_num_units")
+        return int(n.value)
+
+    def runtime(self) -> Runtime:
+        h = C.c_void_p()
+        _check(_lib().sar_renderer_runtime(self._h, C.byref(h)), "sar_renderer_runtime")
+        return Runtime(None, self.device, _borrowed=h)
+
+    def shutdown(self):
+        if getattr(self, "_h", None):
+            _lib().sar_renderer_shutdown(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.shutdown()
+        except Exception:
+            pass
+
+
+def render_parallel(renderer: ParallelRenderer, config: Config, jobs_per_thread: int) -> np.ndarray:
+    """``render_parallel(&mut renderer, config, jobs_per_thread) -> FinalImage`` (src/lib.rs:1051)."""
+    out = np.empty((config.c.height, config.c.width, 4), dtype=np.uint16)
+    _check(_lib().sar_render_parallel(renderer._h, C.byref(config.c), jobs_per_thread,
+                                      out.ctypes.data_as(C.POINTER(C.c_uint16))), "sar_render_parallel")
+    return out

@@ -1,0 +1,91 @@
+"""Builds libsar_hip.so (the HIP library behind include/sar.h) in-tree with hipcc for gfx950.
+
+    python -m strange_attractor_renderer_amd.build [--force]
+
+The build also audits the device code: the iterate kernel must not contain a fused multiply-add
+(v_fma_f64 / v_fmac_f64) — a single contraction changes the chaotic trajectories and breaks parity
+with the reference (which Rust/LLVM never contracts).
+"""
+from __future__ import annotations
+
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+OUT = os.path.join(PKG, "libsar_hip.so")
+BUILD_DIR = os.path.join(os.path.dirname(PKG), "build", "sar_hip")
+SOURCES = ["sar_host.cpp", "sar_runtime.cpp", "sar_kernels.hip"]
+HEADERS = ["sar_internal.hpp", "sar_launch.hpp", os.path.join("..", "..", "include", "sar.h")]
+ARCH = "gfx950"
+
+FLAGS = [
+    f"--offload-arch={ARCH}", "-O3", "-std=c++17",
+    "-ffp-contract=off",          # mandatory for bit parity (host AND device)
+    "-fno-fast-math",
+    "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-unused-value",
+]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def audit_no_fma(asm_path: str) -> dict:
+    """Counts fused fp64 ops per kernel in the device assembly; k_iterate must have none."""
+    text = open(asm_path).read()
+    counts = {}
+    # kernels are delimited by "<name>:" labels ... ".end_amdhsa_kernel"/"s_endpgm"
+    # each function body runs from its "<name>:" label to the matching ".Lfunc_end<N>:" label
+    for m in re.finditer(r"^(_ZN3sar\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", text, flags=re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        counts[name] = len(re.findall(r"\bv_(fma|fmac|mad)_f64\b", body))
+    bad = {k: v for k, v in counts.items() if "k_iterate" in k and v}
+    if bad:
+        raise RuntimeError(f"fused fp64 ops found in the iterate kernel: {bad}")
+    if not any("k_iterate" in k for k in counts):
+        raise RuntimeError("audit could not find k_iterate in the device assembly")
+    return counts
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return OUT
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+    for s in SOURCES:
+        obj = os.path.join(BUILD_DIR, s + ".o")
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, s), "-o", obj]
+        if s.endswith(".hip"):
+            cmd += ["-save-temps=obj"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=BUILD_DIR)
+        objs.append(obj)
+    asm = os.path.join(BUILD_DIR, f"sar_kernels-hip-amdgcn-amd-amdhsa-{ARCH}.s")
+    counts = audit_no_fma(asm)
+    if verbose:
+        print("fused-fp64 audit:", {k[:60]: v for k, v in counts.items()})
+    tmp = OUT + ".tmp"
+    subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", tmp], check=True)
+    os.replace(tmp, OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,195 @@
+// sar_host.cpp — host-only part of the C ABI: Config presets, validation, setup math, the
+// start-point stream and status strings. No device code here; see sar_runtime.hip for the path.
+//
+// Built with -ffp-contract=off: sar_rotation_matrix must produce the same doubles as the reference's
+// EulerAxisRotation::to_rotation_matrix (src/lib.rs:176-196), which Rust/LLVM never contracts.
+#include "sar_internal.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace sar {
+
+thread_local char g_last_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+}
+
+// Config::new defaults, src/lib.rs:289-307; Colors::default :480-492; BrighnessConstants::default :397-404
+static void config_defaults(sar_config* c) {
+    std::memset(c, 0, sizeof(*c));
+    c->iterations = 10000000ull;
+    c->width = 1920;
+    c->height = 1080;
+    c->render_kind = SAR_RENDER_GAS;
+    c->transparent = 1;
+    c->angle = 0.0;
+    c->silent = 1;
+    c->attractor_kind = SAR_ATTRACTOR_SPROTT2;
+    static const double pal[6][3] = {
+        {1.0, 1.0, 0.5}, {0.5, 1.0, 0.5}, {1.0, 0.5, 0.5},
+        {0.5, 1.0, 1.0}, {0.5, 0.5, 1.0}, {1.0, 0.5, 1.0},
+    };
+    c->palette_len = 6;
+    for (int k = 0; k < 6; ++k)
+        for (int ch = 0; ch < 3; ++ch) c->palette_rgb[k][ch] = pal[k][ch];
+    c->brightness_offset = -0.15;
+    c->brightness_factor = 5. / 3.;
+    c->seed = 0;
+    c->jobs_total = 1;
+}
+
+// xoshiro256++ seeded through SplitMix64 (definition in include/sar.h, sar_start_points)
+void Rng::seed(uint64_t seed) {
+    uint64_t sm = seed;
+    for (int k = 0; k < 4; ++k) {
+        sm += 0x9e3779b97f4a7c15ull;
+        uint64_t z = sm;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        s[k] = z ^ (z >> 31);
+    }
+}
+
+uint64_t Rng::next_u64() {
+    auto rotl = [](uint64_t v, int k) { return (v << k) | (v >> (64 - k)); };
+    const uint64_t r = rotl(s[0] + s[3], 23) + s[0];
+    const uint64_t t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl(s[3], 45);
+    return r;
+}
+
+// `rng.random::<Vec3>() * 0.1` (src/lib.rs:748, :161-166): x, y, z drawn in that order
+void Rng::start_point(double out[3]) {
+    for (int k = 0; k < 3; ++k) {
+        const double u = static_cast<double>(next_u64() >> 11) * 0x1.0p-53;
+        out[k] = u * 0.1;
+    }
+}
+
+void rotation_matrix(const sar_config& cfg, double m[9]) {
+    const double x = cfg.rotation_axis[0], y = cfg.rotation_axis[1], z = cfg.rotation_axis[2];
+    const double c = std::cos(cfg.rotation_angle);
+    const double c1 = 1. - c;
+    const double s = std::sin(cfg.rotation_angle);
+    m[0] = c + x * x * c1;     m[1] = x * y * c1 - z * s; m[2] = x * z * c1 + y * s;
+    m[3] = y * x * c1 + z * s; m[4] = c + y * y * c1;     m[5] = y * z * c1 - x * s;
+    m[6] = z * x * c1 - y * s; m[7] = z * y * c1 + x * s; m[8] = c + z * z * c1;
+}
+
+int validate(const sar_config* cfg) {
+    if (!cfg) { set_error("config is NULL"); return SAR_ERR_INVALID; }
+    if (cfg->width == 0 || cfg->height == 0) { set_error("zero image dimension"); return SAR_ERR_INVALID; }
+    if (static_cast<uint64_t>(cfg->width) * cfg->height > 0x7fffffffull) {
+        set_error("width*height exceeds 2^31-1 pixels"); return SAR_ERR_RANGE;
+    }
+    if (cfg->render_kind != SAR_RENDER_GAS && cfg->render_kind != SAR_RENDER_DEPTH) {
+        set_error("unknown render_kind %d", cfg->render_kind); return SAR_ERR_INVALID;
+    }
+    if (cfg->attractor_kind != SAR_ATTRACTOR_SPROTT2) {
+        set_error("unknown attractor_kind %d", cfg->attractor_kind); return SAR_ERR_INVALID;
+    }
+    if (cfg->color_transform != SAR_CT_POISSON_SATURNE && cfg->color_transform != SAR_CT_ADJUSTED_VELOCITY) {
+        set_error("unknown color_transform %d", cfg->color_transform); return SAR_ERR_INVALID;
+    }
+    if (cfg->palette_len == 0 || cfg->palette_len > SAR_PALETTE_MAX) { // Palette::new panics on empty, :413-418
+        set_error("palette_len %u outside 1..%d", cfg->palette_len, SAR_PALETTE_MAX); return SAR_ERR_INVALID;
+    }
+    return SAR_OK;
+}
+
+}  // namespace sar
+
+extern "C" {
+
+int sar_abi_version(void) { return SAR_ABI_VERSION; }
+
+const char* sar_status_string(int status) {
+    switch (status) {
+        case SAR_OK: return "ok";
+        case SAR_ERR_INVALID: return "invalid argument";
+        case SAR_ERR_DIM_MISMATCH: return "runtime dimensions differ";
+        case SAR_ERR_NO_DEVICE: return "no HIP device";
+        case SAR_ERR_HIP: return "HIP call failed";
+        case SAR_ERR_OOM: return "out of memory";
+        case SAR_ERR_RANGE: return "size out of range";
+        default: return "unknown status";
+    }
+}
+
+const char* sar_last_error(void) { return sar::g_last_error; }
+
+int sar_config_poisson_saturne(sar_config* out) {
+    if (!out) return SAR_ERR_INVALID;
+    sar::config_defaults(out);
+    // values: src/lib.rs:311-350
+    static const double x[10] = {0.021, 1.182, -1.183, 0.128, -1.12, -0.641, -1.152, -0.834, -0.97, 0.722};
+    static const double y[10] = {0.243038, -0.825, -1.2, -0.835443, -0.835443, -0.364557, 0.458, 0.622785,
+                                 -0.394937, -1.032911};
+    static const double z[10] = {-0.455696, 0.673, 0.915, -0.258228, -0.495, -0.264, -0.432, -0.416, -0.877, -0.3};
+    for (int k = 0; k < 10; ++k) { out->coeff_x[k] = x[k]; out->coeff_y[k] = y[k]; out->coeff_z[k] = z[k]; }
+    out->center_camera[0] = -0.005;
+    out->center_camera[1] = 0.262;
+    out->center_camera[2] = -0.366 + 0.12;
+    out->rotation_axis[0] = 0.304289493528802;
+    out->rotation_axis[1] = 0.760492682863655;
+    out->rotation_axis[2] = 0.573636455813981;
+    out->rotation_angle = 1.78268191887446;
+    out->scale = 1.;
+    out->color_transform = SAR_CT_POISSON_SATURNE;
+    return SAR_OK;
+}
+
+int sar_config_solar_sail(sar_config* out) {
+    if (!out) return SAR_ERR_INVALID;
+    sar::config_defaults(out);
+    // values: src/lib.rs:356-385
+    static const double x[10] = {0.744304, -0.546835, 0.121519, -0.653165, 0.399, 0.379, 0.44, 1.014, -0.805063, 0.377};
+    static const double y[10] = {-0.683, 0.531646, -0.04557, -1.2, -0.546835, 0.091139, 0.744304, -0.273418,
+                                 -0.349367, -0.531646};
+    static const double z[10] = {0.712, 0.744304, -0.577215, 0.966, 0.04557, 1.063291, 0.01519, -0.425316, 0.212658,
+                                 -0.01519};
+    for (int k = 0; k < 10; ++k) { out->coeff_x[k] = x[k]; out->coeff_y[k] = y[k]; out->coeff_z[k] = z[k]; }
+    out->center_camera[0] = 0.28;
+    out->center_camera[1] = -0.12;
+    out->center_camera[2] = 0.22;
+    out->rotation_axis[0] = 0.02466;
+    out->rotation_axis[1] = 0.4618;
+    out->rotation_axis[2] = -0.54789;
+    out->rotation_angle = 2.2195;
+    out->scale = 1.7;
+    out->color_transform = SAR_CT_ADJUSTED_VELOCITY;
+    out->ct_factor = -0.2;
+    out->ct_offset = 0.8;
+    return SAR_OK;
+}
+
+int sar_config_validate(const sar_config* cfg) { return sar::validate(cfg); }
+
+int sar_rotation_matrix(const sar_config* cfg, double m_out[9]) {
+    if (!cfg || !m_out) return SAR_ERR_INVALID;
+    sar::rotation_matrix(*cfg, m_out);
+    return SAR_OK;
+}
+
+int sar_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double* xyz_out_host) {
+    if (!xyz_out_host && n_jobs) return SAR_ERR_INVALID;
+    sar::Rng rng;
+    rng.seed(seed);
+    double tmp[3];
+    for (uint64_t k = 0; k < first_job; ++k) rng.start_point(tmp);
+    for (uint32_t k = 0; k < n_jobs; ++k) rng.start_point(xyz_out_host + 3 * static_cast<size_t>(k));
+    return SAR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// sar_internal.hpp — declarations shared by the host and device halves of libsar_hip.so.
+#pragma once
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/sar.h"
+
+namespace sar {
+
+extern thread_local char g_last_error[512];
+void set_error(const char* fmt, ...);
+
+// Start-point stream (include/sar.h: sar_start_points).
+struct Rng {
+    uint64_t s[4];
+    void seed(uint64_t seed);
+    uint64_t next_u64();
+    void start_point(double out[3]);
+};
+
+void rotation_matrix(const sar_config& cfg, double m[9]);
+int validate(const sar_config* cfg);
+
+// ---- device-side argument blocks (passed by value as kernel arguments -> SGPRs) -------------------
+
+// Everything the per-iteration arithmetic needs; hoisted exactly like render's setup
+// (reference src/lib.rs:755-764).
+struct MapParams {
+    double cx[10], cy[10], cz[10];  // PolynomialSprott2Degree coefficients (c0 canonicalised: 0. + 1.*c0)
+    double m[9];                    // rotation matrix, row-major
+    double sin_v, cos_v;            // config.angle
+    double ccx, ccy, ccz;           // center_camera
+    double width, height;           // as f64
+    double half_height;             // height / 2.
+    double width_scaled;            // width * scale
+    double scale_adjusted_mid;      // 0.5 / scale
+};
+
+struct ColorTransformParams {
+    int32_t kind;
+    int32_t _pad;
+    double offset, factor;  // AdjustedVelocity
+    double ccx, ccy;        // center_camera.x / .y used by poisson_saturne's part()
+};
+
+struct IterArgs {
+    MapParams p;
+    uint64_t iters;            // counted iterations per job (<= 0xFFFFFFFE)
+    uint32_t n_jobs;           // jobs in this launch chunk; n_jobs*iters <= 0xFFFFFFFE
+    uint32_t width;            // image width (index = j*width + i)
+    uint32_t npix;             // width*height (stride between scratch copies)
+    uint32_t ckpt_stride;      // iterations between trajectory checkpoints
+    const double* starts;      // [3][n_jobs] SoA, pre-warm-up start points
+    uint32_t* scratch_count;   // [copies][npix]
+    unsigned long long* scratch_key;  // [copies][npix]
+    double* ckpt;              // [n_ckpt][3][n_jobs]
+};
+
+struct FoldArgs {
+    MapParams p;
+    ColorTransformParams ct;
+    uint64_t iters;
+    uint32_t n_jobs;
+    uint32_t npix;
+    uint32_t ckpt_stride;
+    uint32_t copies;
+    uint32_t* count;                 // persistent [npix]
+    unsigned long long* key;         // persistent [npix]: hi = sortable(zbuf), lo = 0xFFFFFFFF
+    double* steps;                   // persistent [npix]
+    uint32_t* scratch_count;         // [copies][npix], zeroed again by the fold
+    unsigned long long* scratch_key; // [copies][npix]
+    const double* ckpt;
+    uint32_t* scalars;               // [0] max, [1] wrap flag
+};
+
+struct PaletteParams {
+    uint32_t len;  // user entries; entry len == entry len-1 (Palette::new, src/lib.rs:416-418)
+    uint32_t _pad;
+    double rgb[SAR_PALETTE_MAX + 1][3];
+};
+
+enum ScalarSlot : uint32_t {
+    SC_MAX = 0,        // Runtime::max
+    SC_WRAP = 1,       // a count wrapped u32 (running max would have hit u32::MAX)
+    SC_ZMAX = 2,       // depth colorize: sortable(max z)
+    SC_ZMIN = 3,       // depth colorize: sortable(min z)
+    SC_COUNT = 8
+};
+
+// sortable u32 image of an f32 (monotone for all non-NaN values)
+static inline uint32_t f32_sortable_host(float f) {
+    uint32_t b;
+    __builtin_memcpy(&b, &f, 4);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+constexpr uint32_t kLnLutEntries = 1u << 20;  // ln(k+1), k < 2^20, host libm (exact parity with the oracle)
+constexpr uint64_t kMaxChunkOrdinals = 0xFFFFFFFEull;
+
+}  // namespace sar

@@ -1,0 +1,583 @@
+// sar_kernels.hip — gfx950 (MI355X) kernels of the iterate/accumulate path.
+//
+// Bit-exactness contract: every floating-point operation below is the reference's operation, in the
+// reference's order, with separate multiply and add (the file is compiled with -ffp-contract=off and
+// the build checks that k_iterate contains no v_fma_f64). The chaotic map amplifies a 1-ulp
+// deviation exponentially, so "close" does not exist here: either the op sequence is identical or
+// the images differ.
+//
+// Kernels
+//   k_iterate<XCD_LOCAL>  one trajectory ("job") per lane, fp64 state in registers; per counted
+//                         in-bounds iteration one no-return u32 atomic add (count) and one no-return
+//                         u64 atomic max (depth key = sortable(z as f32) << 32 | ~ordinal) into
+//                         scratch bins; trajectory checkpoints every `ckpt_stride` iterations.
+//                         No instruction in the loop waits on memory.
+//   k_fold_resolve        folds the scratch bins into the persistent Runtime buffers (count add,
+//                         running max, depth test with "earlier visit wins ties"), re-zeroes the
+//                         scratch, compacts the pixels whose depth winner changed (LDS) and recomputes
+//                         their colour-transform payload from the nearest checkpoint (the visit
+//                         ordinal in the key names job and iteration).
+//   k_merge, k_colorize_gas, k_zrange, k_colorize_depth, exchange pack/unpack, accessors.
+#include <hip/hip_runtime.h>
+
+#include "sar_internal.hpp"
+
+#pragma STDC FP_CONTRACT OFF
+#pragma clang fp contract(off)
+
+namespace sar {
+
+// ---------------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f32_sortable(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float sortable_f32(uint32_t s) {
+    const uint32_t b = (s & 0x80000000u) ? (s & 0x7fffffffu) : ~s;
+    return __uint_as_float(b);
+}
+
+// Forces a wave-uniform value into a VGPR (opaque to the optimiser, no instruction emitted).
+__device__ __forceinline__ double vgpr_pin(double v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// PolynomialSprott2Degree::next_point (reference src/lib.rs:583-621).
+// sum = ((((c0 + x*c1) + x²*c2) + xy*c3) + ... + z²*c9), strictly left to right, no FMA.
+// (`0. + 1.*c0` is exactly c0 once the host has canonicalised a -0.0 coefficient to +0.0.)
+__device__ __forceinline__ void next_point(const MapParams& p, double& x, double& y, double& z) {
+    const double xx = x * x;
+    const double xy = x * y;
+    const double xz = x * z;
+    const double yy = y * y;
+    const double yz = y * z;
+    const double zz = z * z;
+    double sx = p.cx[0], sy = p.cy[0], sz = p.cz[0];
+    sx = sx + x * p.cx[1];  sy = sy + x * p.cy[1];  sz = sz + x * p.cz[1];
+    sx = sx + xx * p.cx[2]; sy = sy + xx * p.cy[2]; sz = sz + xx * p.cz[2];
+    sx = sx + xy * p.cx[3]; sy = sy + xy * p.cy[3]; sz = sz + xy * p.cz[3];
+    sx = sx + xz * p.cx[4]; sy = sy + xz * p.cy[4]; sz = sz + xz * p.cz[4];
+    sx = sx + y * p.cx[5];  sy = sy + y * p.cy[5];  sz = sz + y * p.cz[5];
+    sx = sx + yy * p.cx[6]; sy = sy + yy * p.cy[6]; sz = sz + yy * p.cz[6];
+    sx = sx + yz * p.cx[7]; sy = sy + yz * p.cy[7]; sz = sz + yz * p.cz[7];
+    sx = sx + z * p.cx[8];  sy = sy + z * p.cy[8];  sz = sz + z * p.cz[8];
+    sx = sx + zz * p.cx[9]; sy = sy + zz * p.cy[9]; sz = sz + zz * p.cz[9];
+    x = sx; y = sy; z = sz;
+}
+
+// Matrix3x3::mul_right (src/lib.rs:205-216): (m0*x + m1*y) + m2*z per row.
+__device__ __forceinline__ void screen_space(const MapParams& p, double x, double y, double z,
+                                             double& sx, double& sy, double& sz) {
+    sx = p.m[0] * x + p.m[1] * y + p.m[2] * z;
+    sy = p.m[3] * x + p.m[4] * y + p.m[5] * z;
+    sz = p.m[6] * x + p.m[7] * y + p.m[8] * z;
+}
+
+// color transforms (src/lib.rs:507-516, 520-558); only evaluated for depth winners.
+__device__ __forceinline__ double color_transform(const ColorTransformParams& ct, double dx, double dy,
+                                                  double dz, double sx, double sy, double sz) {
+    const double mag = sqrt(dx * dx + dy * dy + dz * dz);  // Vec3::magnitude, :129-131
+    if (ct.kind == SAR_CT_ADJUSTED_VELOCITY) {
+        return (mag + ct.offset) * ct.factor;  // :514
+    }
+    const double COS = 0.7009092642998509;  // literal at :530
+    const double SIN = 0.7132504491541816;  // literal at :536
+    const double x2 = (sx + ct.ccx) * COS + (sz + ct.ccy) * SIN;  // :538-539
+    double part = 1.;
+    if (x2 < -0.0839 || 10.55 * x2 + sy < 0.46 - 1.0941 || 1.0426 * x2 + sy < 0.179 - 0.1576 ||
+        0.5139 * x2 - sy > -0.04 - 0.04092) {
+        part = 0.;
+    }
+    const double color = (part + mag) / 2.;  // :556
+    return (color - 0.1) / 0.9;              // :557
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_iterate — the hot loop (render, src/lib.rs:747-838)
+// ---------------------------------------------------------------------------------------------------
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void bin_count(uint32_t* addr, uint32_t v) {
+    if (XCD_LOCAL) {
+        // this scratch copy is only ever touched by CUs of ONE XCD (copy index = hardware XCC id),
+        // so the XCD's own L2 is a sufficient coherence point: workgroup scope keeps the atomic in L2.
+        __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void bin_key(unsigned long long* addr, unsigned long long v) {
+    if (XCD_LOCAL) {
+        __hip_atomic_fetch_max(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        __hip_atomic_fetch_max(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__device__ __forceinline__ uint32_t xcc_id() {
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): id 20, offset 0, size 4 -> simm16 = (3<<11)|(0<<6)|20
+    return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+}
+
+template <bool XCD_LOCAL, int MODE>
+__global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= a.n_jobs) return;
+    // 30 coefficients + 9 matrix entries + 10 projection constants are 98 SGPRs as kernel arguments —
+    // more than the scalar file holds next to pointers and exec masks, and the compiler then spills
+    // SGPRs to VGPR lanes inside the loop (v_readlane per use). The coefficients stay scalar operands;
+    // the matrix and the projection constants are pinned into (plentiful) VGPRs instead.
+    MapParams p = a.p;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p.m[k] = vgpr_pin(p.m[k]);
+    p.sin_v = vgpr_pin(p.sin_v);
+    p.cos_v = vgpr_pin(p.cos_v);
+    p.ccx = vgpr_pin(p.ccx);
+    p.ccy = vgpr_pin(p.ccy);
+    p.ccz = vgpr_pin(p.ccz);
+    p.width = vgpr_pin(p.width);
+    p.height = vgpr_pin(p.height);
+    p.half_height = vgpr_pin(p.half_height);
+    p.width_scaled = vgpr_pin(p.width_scaled);
+    p.scale_adjusted_mid = vgpr_pin(p.scale_adjusted_mid);
+
+    double x = a.starts[job];
+    double y = a.starts[a.n_jobs + job];
+    double z = a.starts[2u * a.n_jobs + job];
+
+    // "skip first 1000 to get good values in the attractor" (:750-752)
+    for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);
+
+    uint32_t* const count = a.scratch_count + (XCD_LOCAL ? (size_t)xcc_id() * a.npix : 0);
+    unsigned long long* const key = a.scratch_key + (XCD_LOCAL ? (size_t)xcc_id() * a.npix : 0);
+
+    const uint32_t n = (uint32_t)a.iters;
+    // visit ordinal = job*n + t (job-major, iteration-minor == the sequential order of the reference);
+    // the key's low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie.
+    const uint32_t lo_base = 0xFFFFFFFFu - job * n;
+    const uint32_t C = a.ckpt_stride;
+    const size_t cs = a.n_jobs;  // checkpoint component stride
+
+    uint32_t t = 0;
+    double* ck = a.ckpt + job;
+    while (t < n) {
+        // checkpoint: the state BEFORE iteration t (coalesced 512-B rows per wave)
+        ck[0] = x;
+        ck[cs] = y;
+        ck[2 * cs] = z;
+        ck += 3 * cs;
+        const uint32_t tend = (n - t > C) ? t + C : n;
+        for (; t < tend; ++t) {
+            next_point(p, x, y, z);  // :770
+            if (x != x) {
+                // Absorbing state: a NaN x makes every coordinate NaN from the next iteration on, and
+                // already makes all of screen space NaN now, so this and every remaining iteration
+                // passes the bounds test (:789, all comparisons false), casts to pixel (0,0)
+                // (:800-802) and never wins the depth test. Add them in one go instead of hammering
+                // one address n-t times.
+                if (MODE != 0) bin_count<XCD_LOCAL>(count, n - t);
+                return;
+            }
+            double sx, sy, sz;
+            screen_space(p, x, y, z, sx, sy, sz);  // :773
+            const double ax = sx + p.ccx;          // center_camera.x with screen_space.x
+            const double az = sz + p.ccy;          // center_camera.y with screen_space.z (:776-779)
+            const double x2 = ax * p.cos_v + az * p.sin_v;
+            const double z2 = ax * p.sin_v - az * p.cos_v;
+            const double fi = (p.scale_adjusted_mid - x2) * p.width_scaled;  // :783
+            const double fj = p.half_height - (sy + p.ccz) * p.width_scaled; // :786
+            if (fi >= p.width || fj >= p.height || fi < 0. || fj < 0.) continue;  // :789-795
+            const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;  // Rust `as u32`: NaN -> 0
+            const uint32_t j = (fj == fj) ? (uint32_t)fj : 0u;
+            const uint32_t idx = j * a.width + i;
+            if (MODE != 0) bin_count<XCD_LOCAL>(count + idx, 1u);  // :807-812
+            if (MODE == 2) {
+                float zf = (float)z2;  // `z2 as f32`
+                // strict `>` against an initial -1.0 (:693, :821): z <= -1 and NaN can never win
+                if (zf > -1.0f) {
+                    zf = zf + 0.0f;  // -0.0 -> +0.0 so the integer order agrees with the float order
+                    const unsigned long long k =
+                        ((unsigned long long)f32_sortable(zf) << 32) | (unsigned long long)(lo_base - t);
+                    bin_key<XCD_LOCAL>(key + idx, k);
+                }
+            }
+        }
+    }
+    if (MODE == 0) {  // measurement-only variant: keep the arithmetic alive
+        if (x + y + z == 12345.678) a.scratch_count[0] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// block-level reductions (result valid in thread 0)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_max_u32(uint32_t v, uint32_t* s_tmp /* [4] */) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_down(v, off);
+        v = o > v ? o : v;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) s_tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) v = s_tmp[w] > v ? s_tmp[w] : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t block_min_u32(uint32_t v, uint32_t* s_tmp /* [4] */) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_down(v, off);
+        v = o < v ? o : v;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) s_tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) v = s_tmp[w] < v ? s_tmp[w] : v;
+    }
+    return v;
+}
+// raise scalars[slot] to at least m (one lane); skips the atomic when the slot is already there
+__device__ __forceinline__ void raise_scalar(uint32_t* slot, uint32_t m) {
+    if (m > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_fold_resolve — scratch bins -> persistent Runtime buffers, then the payload of new depth winners
+// ---------------------------------------------------------------------------------------------------
+// Each block owns FOLD_PIX contiguous pixels: it folds the scratch copies into count / key (count add
+// with the running max, depth test where the value already held wins ties), re-zeroes the scratch,
+// compacts the pixels whose depth winner changed into LDS and then recomputes their colour-transform
+// payload (the rare branch of render, :821-834) from the nearest trajectory checkpoint — the visit
+// ordinal in the key names the job and the iteration. No global atomics except one max per block.
+constexpr uint32_t FOLD_PIX = 2048;
+
+__global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) {
+    __shared__ unsigned long long s_key[FOLD_PIX];
+    __shared__ uint32_t s_pix[FOLD_PIX];
+    __shared__ uint32_t s_n, s_wrap;
+    __shared__ uint32_t s_tmp[4];
+    if (threadIdx.x == 0) { s_n = 0; s_wrap = 0; }
+    __syncthreads();
+
+    uint32_t local_max = 0;
+    const uint32_t base = blockIdx.x * FOLD_PIX;
+    for (uint32_t k = threadIdx.x; k < FOLD_PIX; k += blockDim.x) {
+        const uint32_t px = base + k;
+        if (px >= a.npix) break;
+        unsigned long long add = 0, kbest = 0;
+        for (uint32_t c = 0; c < a.copies; ++c) {
+            const size_t o = (size_t)c * a.npix + px;
+            const uint32_t sc = a.scratch_count[o];
+            const unsigned long long sk = a.scratch_key[o];
+            if (sc) { add += sc; a.scratch_count[o] = 0; }
+            if (sk) { kbest = sk > kbest ? sk : kbest; a.scratch_key[o] = 0; }
+        }
+        if (add) {
+            // count += hits, wrapping like the release build (:811); if the u32 wraps, the reference's
+            // running max (:813-815) has seen u32::MAX on the way.
+            const unsigned long long total = (unsigned long long)a.count[px] + add;
+            if (total >> 32) s_wrap = 1;
+            const uint32_t c32 = (uint32_t)total;
+            a.count[px] = c32;
+            local_max = c32 > local_max ? c32 : local_max;
+        }
+        // depth test (:821): strictly greater than what the runtime already holds (an earlier render
+        // call or launch chunk wins ties; within the chunk the lowest ordinal already won the atomic max)
+        if (kbest && (uint32_t)(kbest >> 32) > (uint32_t)(a.key[px] >> 32)) {
+            const uint32_t pos = atomicAdd(&s_n, 1u);
+            s_key[pos] = kbest;
+            s_pix[pos] = px;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t total = s_n;
+    const uint32_t n = (uint32_t)a.iters;
+    const size_t cs = a.n_jobs;
+    for (uint32_t w = threadIdx.x; w < total; w += blockDim.x) {
+        const unsigned long long wk = s_key[w];
+        const uint32_t ord = 0xFFFFFFFFu - (uint32_t)wk;
+        const uint32_t job = ord / n;
+        const uint32_t t = ord - job * n;
+        const uint32_t k = t / a.ckpt_stride;
+        const uint32_t r = t - k * a.ckpt_stride;
+        const double* ck = a.ckpt + (size_t)k * 3 * cs + job;
+        double x = ck[0], y = ck[cs], z = ck[2 * cs];
+        for (uint32_t s = 0; s < r; ++s) next_point(a.p, x, y, z);
+        const double px = x, py = y, pz = z;  // previous_point (:766 / :836)
+        next_point(a.p, x, y, z);             // current_point (:770)
+        double sx, sy, sz;
+        screen_space(a.p, x, y, z, sx, sy, sz);
+        a.steps[s_pix[w]] = color_transform(a.ct, x - px, y - py, z - pz, sx, sy, sz);  // :822-830
+        a.key[s_pix[w]] = wk | 0xFFFFFFFFull;                                            // :832
+    }
+
+    const uint32_t m = block_max_u32(local_max, s_tmp);
+    if (threadIdx.x == 0) {
+        if (m) raise_scalar(&a.scalars[SC_MAX], m);
+        if (s_wrap) atomicOr(&a.scalars[SC_WRAP], 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// state management
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_reset(uint32_t* count, unsigned long long* key, double* steps, uint32_t npix,
+                        uint32_t* scalars) {
+    const unsigned long long init = ((unsigned long long)f32_sortable(-1.0f) << 32) | 0xFFFFFFFFull;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        count[p] = 0u;   // :687
+        steps[p] = 0.;   // :690
+        key[p] = init;   // zbuf = -1.0, :693
+    }
+    if (blockIdx.x == 0 && threadIdx.x < SC_COUNT) scalars[threadIdx.x] = 0u;  // max = 0, :694
+}
+
+__global__ void k_zbuf_out(const unsigned long long* key, float* out, uint32_t npix) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x)
+        out[p] = sortable_f32((uint32_t)(key[p] >> 32));
+}
+
+__global__ void k_zbuf_in(const float* z, unsigned long long* key, uint32_t npix) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x)
+        key[p] = ((unsigned long long)f32_sortable(z[p] + 0.0f) << 32) | 0xFFFFFFFFull;
+}
+
+// Runtime::merge (:708-738)
+__global__ void __launch_bounds__(256) k_merge(uint32_t* count, unsigned long long* key, double* steps,
+                                               const uint32_t* ocount, const unsigned long long* okey,
+                                               const double* osteps, uint32_t npix, uint32_t* scalars) {
+    uint32_t local_max = 0;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const uint32_t merged = count[p] + ocount[p];  // wrapping, :719
+        count[p] = merged;
+        local_max = merged > local_max ? merged : local_max;  // :721-723
+        const unsigned long long ok = okey[p];
+        if ((uint32_t)(ok >> 32) > (uint32_t)(key[p] >> 32)) {  // strict: self wins ties, :728
+            steps[p] = osteps[p];
+            key[p] = ok;
+        }
+    }
+    __shared__ uint32_t s_tmp[4];
+    const uint32_t m = block_max_u32(local_max, s_tmp);
+    if (threadIdx.x == 0 && m) raise_scalar(&scalars[SC_MAX], m);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// colorize (:841-904)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t as_u16(double v) {  // Rust `as u16`: saturating, NaN -> 0
+    if (!(v == v)) return 0;
+    if (v <= 0.) return 0;
+    if (v >= 65535.) return 65535;
+    return (uint16_t)(uint32_t)v;
+}
+__device__ __forceinline__ uint16_t as_u16_f32(float v) {
+    if (!(v == v)) return 0;
+    if (v <= 0.f) return 0;
+    if (v >= 65535.f) return 65535;
+    return (uint16_t)(uint32_t)v;
+}
+
+// ln(c) for an integer-valued u32 c: table of host-libm values where it exists (bit-identical to the
+// oracle/reference on the same host), device log beyond it (<= 1 ulp).
+__device__ __forceinline__ double ln_u32(uint32_t c, const double* lut, uint32_t lut_len) {
+    const uint32_t k = c - 1u;  // c == 0 (u32 wrap of count+1) -> huge index -> log(0) = -inf
+    return (k < lut_len) ? lut[k] : log((double)c);
+}
+
+__global__ void __launch_bounds__(256) k_colorize_gas(const uint32_t* count, const double* steps,
+                                                      const uint32_t* scalars, const double* lut,
+                                                      uint32_t lut_len, const PaletteParams pal,
+                                                      double b_offset, double b_factor, int transparent,
+                                                      uint32_t npix, ushort4* out) {
+    __shared__ double s_pal[(SAR_PALETTE_MAX + 1) * 3];
+    for (uint32_t k = threadIdx.x; k < (pal.len + 1) * 3; k += blockDim.x) s_pal[k] = pal.rgb[k / 3][k % 3];
+    __syncthreads();
+    const uint32_t rmax = scalars[SC_WRAP] ? 0xFFFFFFFFu : scalars[SC_MAX];
+    const double ln_base = ln_u32(rmax + 1u, lut, lut_len);  // ln(max + 1), :860
+    const double count_f64 = (double)pal.len;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        // Palette::interpolate (:442-472)
+        double v = steps[p];
+        if (v < 0.) v = 0.;
+        else if (v >= 1.) v = 0.999999;
+        v = v * count_f64;
+        const double fl = floor(v);
+        uint32_t n = (fl == fl) ? (uint32_t)fl : 0u;
+        if (n >= pal.len) n = pal.len - 1;  // unreachable for non-NaN
+        const double t = v - fl;            // == v % 1. for v >= 0 (exact)
+        const double t1 = 1.0 - t;
+        const double* c1 = &s_pal[n * 3];
+        const double* c2 = &s_pal[(n + 1) * 3];
+        const double r = sqrt(c2[0] * t + c1[0] * t1);
+        const double g = sqrt(c2[1] * t + c1[1] * t1);
+        const double b = sqrt(c2[2] * t + c1[2] * t1);
+        // factor = ln(count+1) / ln(max+1)  (f64::log(self, base), :860)
+        const double factor = ln_u32(count[p] + 1u, lut, lut_len) / ln_base;
+        ushort4 o;
+        o.x = as_u16((r * factor + b_offset) * b_factor * 65535.);
+        o.y = as_u16((g * factor + b_offset) * b_factor * 65535.);
+        o.z = as_u16((b * factor + b_offset) * b_factor * 65535.);
+        o.w = transparent ? as_u16(factor * 65535.) : (uint16_t)65535;
+        out[p] = o;
+    }
+}
+
+// fold (max, min) over zbuf != -1.0 with seeds (0.0, f32::MAX) (:877-882); the sortable image turns
+// f32 max/min into u32 atomics.
+__global__ void k_zrange_init(uint32_t* scalars) {
+    scalars[SC_ZMAX] = f32_sortable(0.0f);
+    scalars[SC_ZMIN] = f32_sortable(3.40282346638528859811704183484516925e+38f);
+}
+__global__ void __launch_bounds__(256) k_zrange(const unsigned long long* key, uint32_t npix, uint32_t* scalars) {
+    const uint32_t unset = f32_sortable(-1.0f);
+    uint32_t mx = f32_sortable(0.0f);
+    uint32_t mn = f32_sortable(3.40282346638528859811704183484516925e+38f);
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const uint32_t s = (uint32_t)(key[p] >> 32);
+        if (s != unset) {
+            mx = s > mx ? s : mx;
+            mn = s < mn ? s : mn;
+        }
+    }
+    __shared__ uint32_t s_tmp[4];
+    mx = block_max_u32(mx, s_tmp);
+    mn = block_min_u32(mn, s_tmp);
+    if (threadIdx.x == 0) {
+        atomicMax(&scalars[SC_ZMAX], mx);
+        atomicMin(&scalars[SC_ZMIN], mn);
+    }
+}
+__global__ void __launch_bounds__(256) k_colorize_depth(const unsigned long long* key, const uint32_t* scalars,
+                                                        uint32_t npix, ushort4* out) {
+    const float zmax = sortable_f32(scalars[SC_ZMAX]);
+    const float zmin = sortable_f32(scalars[SC_ZMIN]);
+    const float diff = zmax - zmin;  // :883
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        float z = sortable_f32((uint32_t)(key[p] >> 32));
+        if (z == -1.0f) z = 0.0f;
+        else z = __fdiv_rn(z - zmin, diff);  // f32 reverse lerp, :893
+        const uint16_t v = as_u16_f32(z * 65535.0f);
+        ushort4 o;
+        o.x = v; o.y = v; o.z = v; o.w = 65535;
+        out[p] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// multi-GPU exchange (merge folded in rank order, expressed as MAX / SUM reductions)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long exch_key(unsigned long long key, uint32_t rank) {
+    const unsigned long long k = (key & 0xFFFFFFFF00000000ull) | (unsigned long long)(0xFFFFFFFFu - rank);
+    return (long long)(k ^ 0x8000000000000000ull);  // unsigned order -> signed order
+}
+__global__ void k_exch_export(const unsigned long long* key, uint32_t rank, long long* out, uint32_t npix) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x)
+        out[p] = exch_key(key[p], rank);
+}
+__global__ void k_exch_select(const uint32_t* count, const unsigned long long* key, const double* steps,
+                              uint32_t rank, const long long* reduced, int* out, uint32_t npix) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        out[p] = (int)count[p];
+        const bool mine = exch_key(key[p], rank) == reduced[p];
+        const unsigned long long bits = mine ? (unsigned long long)__double_as_longlong(steps[p]) : 0ull;
+        out[(size_t)npix + 2 * (size_t)p] = (int)(uint32_t)bits;
+        out[(size_t)npix + 2 * (size_t)p + 1] = (int)(uint32_t)(bits >> 32);
+    }
+}
+__global__ void __launch_bounds__(256) k_exch_import(uint32_t* count, unsigned long long* key, double* steps,
+                                                     const long long* reduced, const int* sum, uint32_t npix,
+                                                     uint32_t* scalars) {
+    uint32_t local_max = 0;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)sum[p];
+        count[p] = c;
+        local_max = c > local_max ? c : local_max;
+        const unsigned long long k = (unsigned long long)reduced[p] ^ 0x8000000000000000ull;
+        key[p] = k | 0xFFFFFFFFull;
+        const unsigned long long bits = (unsigned long long)(uint32_t)sum[(size_t)npix + 2 * (size_t)p] |
+                                        ((unsigned long long)(uint32_t)sum[(size_t)npix + 2 * (size_t)p + 1] << 32);
+        steps[p] = __longlong_as_double((long long)bits);
+    }
+    __shared__ uint32_t s_tmp[4];
+    const uint32_t m = block_max_u32(local_max, s_tmp);
+    if (threadIdx.x == 0 && m) raise_scalar(&scalars[SC_MAX], m);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launch wrappers (called from sar_runtime.cpp)
+// ---------------------------------------------------------------------------------------------------
+static inline uint32_t grid_for(uint32_t n, uint32_t block, uint32_t cap) {
+    uint32_t g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    return g ? g : 1;
+}
+
+void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode, hipStream_t s) {
+    const uint32_t grid = (a.n_jobs + block - 1) / block;
+    if (xcd_local) {
+        if (mode == 2) hipLaunchKernelGGL((k_iterate<true, 2>), dim3(grid), dim3(block), 0, s, a);
+        else if (mode == 1) hipLaunchKernelGGL((k_iterate<true, 1>), dim3(grid), dim3(block), 0, s, a);
+        else hipLaunchKernelGGL((k_iterate<true, 0>), dim3(grid), dim3(block), 0, s, a);
+    } else {
+        if (mode == 2) hipLaunchKernelGGL((k_iterate<false, 2>), dim3(grid), dim3(block), 0, s, a);
+        else if (mode == 1) hipLaunchKernelGGL((k_iterate<false, 1>), dim3(grid), dim3(block), 0, s, a);
+        else hipLaunchKernelGGL((k_iterate<false, 0>), dim3(grid), dim3(block), 0, s, a);
+    }
+}
+
+void launch_fold_resolve(const FoldArgs& a, hipStream_t s) {
+    const uint32_t grid = (a.npix + FOLD_PIX - 1) / FOLD_PIX;
+    hipLaunchKernelGGL(k_fold_resolve, dim3(grid), dim3(256), 0, s, a);
+}
+
+void launch_reset(uint32_t* count, unsigned long long* key, double* steps, uint32_t npix, uint32_t* scalars,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(k_reset, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, count, key, steps, npix, scalars);
+}
+void launch_zbuf_out(const unsigned long long* key, float* out, uint32_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_zbuf_out, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, key, out, npix);
+}
+void launch_zbuf_in(const float* z, unsigned long long* key, uint32_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_zbuf_in, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, z, key, npix);
+}
+void launch_merge(uint32_t* count, unsigned long long* key, double* steps, const uint32_t* ocount,
+                  const unsigned long long* okey, const double* osteps, uint32_t npix, uint32_t* scalars,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(k_merge, dim3(grid_for(npix, 256, 2048)), dim3(256), 0, s, count, key, steps, ocount, okey,
+                       osteps, npix, scalars);
+}
+void launch_colorize_gas(const uint32_t* count, const double* steps, const uint32_t* scalars, const double* lut,
+                         uint32_t lut_len, const PaletteParams& pal, double b_offset, double b_factor,
+                         int transparent, uint32_t npix, void* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_colorize_gas, dim3(grid_for(npix, 256, 8192)), dim3(256), 0, s, count, steps, scalars, lut,
+                       lut_len, pal, b_offset, b_factor, transparent, npix, (ushort4*)out);
+}
+void launch_colorize_depth(const unsigned long long* key, uint32_t* scalars, uint32_t npix, void* out,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(k_zrange_init, dim3(1), dim3(1), 0, s, scalars);
+    hipLaunchKernelGGL(k_zrange, dim3(grid_for(npix, 256, 1024)), dim3(256), 0, s, key, npix, scalars);
+    hipLaunchKernelGGL(k_colorize_depth, dim3(grid_for(npix, 256, 8192)), dim3(256), 0, s, key, scalars, npix,
+                       (ushort4*)out);
+}
+void launch_exch_export(const unsigned long long* key, uint32_t rank, void* out, uint32_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_export, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, key, rank, (long long*)out,
+                       npix);
+}
+void launch_exch_select(const uint32_t* count, const unsigned long long* key, const double* steps, uint32_t rank,
+                        const void* reduced, void* out, uint32_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_select, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, count, key, steps, rank,
+                       (const long long*)reduced, (int*)out, npix);
+}
+void launch_exch_import(uint32_t* count, unsigned long long* key, double* steps, const void* reduced,
+                        const void* sum, uint32_t npix, uint32_t* scalars, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_import, dim3(grid_for(npix, 256, 2048)), dim3(256), 0, s, count, key, steps,
+                       (const long long*)reduced, (const int*)sum, npix, scalars);
+}
+
+}  // namespace sar

@@ -1,0 +1,31 @@
+// sar_launch.hpp — host-callable launch wrappers implemented in sar_kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "sar_internal.hpp"
+
+namespace sar {
+
+// mode: 2 = full path (count + depth key); 1 = count only, 0 = arithmetic only (measurement variants)
+void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode, hipStream_t s);
+void launch_fold_resolve(const FoldArgs& a, hipStream_t s);
+void launch_reset(uint32_t* count, unsigned long long* key, double* steps, uint32_t npix, uint32_t* scalars,
+                  hipStream_t s);
+void launch_zbuf_out(const unsigned long long* key, float* out, uint32_t npix, hipStream_t s);
+void launch_zbuf_in(const float* z, unsigned long long* key, uint32_t npix, hipStream_t s);
+void launch_merge(uint32_t* count, unsigned long long* key, double* steps, const uint32_t* ocount,
+                  const unsigned long long* okey, const double* osteps, uint32_t npix, uint32_t* scalars,
+                  hipStream_t s);
+void launch_colorize_gas(const uint32_t* count, const double* steps, const uint32_t* scalars, const double* lut,
+                         uint32_t lut_len, const PaletteParams& pal, double b_offset, double b_factor,
+                         int transparent, uint32_t npix, void* out, hipStream_t s);
+void launch_colorize_depth(const unsigned long long* key, uint32_t* scalars, uint32_t npix, void* out,
+                           hipStream_t s);
+void launch_exch_export(const unsigned long long* key, uint32_t rank, void* out, uint32_t npix, hipStream_t s);
+void launch_exch_select(const uint32_t* count, const unsigned long long* key, const double* steps, uint32_t rank,
+                        const void* reduced, void* out, uint32_t npix, hipStream_t s);
+void launch_exch_import(uint32_t* count, unsigned long long* key, double* steps, const void* reduced,
+                        const void* sum, uint32_t npix, uint32_t* scalars, hipStream_t s);
+
+}  // namespace sar

@@ -1,0 +1,747 @@
+// sar_runtime.cpp — the C ABI over the HIP kernels: Runtime, render, merge, colorize, the
+// ParallelRenderer mirror and the multi-GPU exchange helpers (include/sar.h).
+//
+// Host logic only (allocation, chunking, argument blocks, stream ordering); all arithmetic on image
+// data happens in sar_kernels.hip. There is no CPU fallback: without a HIP device every entry point
+// that touches a runtime returns SAR_ERR_NO_DEVICE.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "sar_launch.hpp"
+
+using namespace sar;
+
+#define HIP_TRY(expr)                                                                 \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorOutOfMemory) ? SAR_ERR_OOM : SAR_ERR_HIP;           \
+        }                                                                             \
+    } while (0)
+
+#define SAR_TRY(expr)                    \
+    do {                                 \
+        int s_ = (expr);                 \
+        if (s_ != SAR_OK) return s_;     \
+    } while (0)
+
+namespace {
+
+struct Span {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+constexpr uint32_t kDefaultBlock = 256;
+constexpr uint32_t kDefaultCkptStride = 64;
+constexpr uint64_t kCkptBytesCap = 24ull << 30;  // checkpoint scratch per launch chunk (HBM is 288 GB)
+
+// ln(k+1) for k < kLnLutEntries, computed once per process with the host libm — the same function
+// the oracle (and the reference, through Rust's f64::ln) calls on this machine.
+const double* host_ln_lut() {
+    static std::vector<double> lut;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        lut.resize(kLnLutEntries);
+        for (uint32_t k = 0; k < kLnLutEntries; ++k) lut[k] = std::log(static_cast<double>(k + 1u));
+    });
+    return lut.data();
+}
+
+}  // namespace
+
+struct sar_runtime {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t W = 0, H = 0, npix = 0;
+    uint32_t sm_count = 0;
+
+    // persistent state (Runtime, reference src/lib.rs:631-646)
+    uint32_t* d_count = nullptr;            // count
+    unsigned long long* d_key = nullptr;    // hi: sortable(zbuf), lo: 0xFFFFFFFF between launches
+    double* d_steps = nullptr;              // steps
+    uint32_t* d_scalars = nullptr;          // max + flags + depth range
+    Rng rng;
+
+    // scratch bins the iterate kernel accumulates into (zero between launches)
+    uint32_t copies = 0;
+    uint32_t* d_scratch_count = nullptr;
+    unsigned long long* d_scratch_key = nullptr;
+
+    // staging
+    double* h_starts = nullptr;  // pinned
+    double* d_starts = nullptr;
+    size_t starts_cap = 0;       // doubles
+    hipEvent_t starts_copied = nullptr;
+    bool starts_pending = false;
+    double* d_ckpt = nullptr;
+    size_t ckpt_cap = 0;         // doubles
+    double* d_lnlut = nullptr;
+    void* d_rgba = nullptr;
+    float* d_ztmp = nullptr;
+
+    // tuning
+    uint32_t block_threads = kDefaultBlock;
+    uint32_t ckpt_stride = kDefaultCkptStride;
+    uint32_t bins_mode = 0;     // 0 default, 1 single copy + agent-scope atomics, 2 per-XCD copies
+    uint32_t measure_mode = 0;  // 0 full path, 1 count only, 2 arithmetic only
+    uint32_t debug_chunk_jobs = 0;  // test hook: cap on jobs per launch chunk (0 = none)
+
+    // timing
+    bool timing = false;
+    std::vector<Span> iter_spans, fold_spans;
+    size_t iter_used = 0, fold_used = 0;
+    Span colorize_span, merge_span;
+    bool colorize_timed = false, merge_timed = false;
+    uint64_t last_iterations = 0;
+};
+
+struct sar_renderer {
+    int device = 0;
+    uint32_t units = 0;
+    uint64_t seed = 0;
+    sar_runtime* rt = nullptr;
+};
+
+namespace {
+
+int free_device_buffers(sar_runtime* rt) {
+    if (rt->d_count) hipFree(rt->d_count);
+    if (rt->d_key) hipFree(rt->d_key);
+    if (rt->d_steps) hipFree(rt->d_steps);
+    if (rt->d_scratch_count) hipFree(rt->d_scratch_count);
+    if (rt->d_scratch_key) hipFree(rt->d_scratch_key);
+    if (rt->d_rgba) hipFree(rt->d_rgba);
+    if (rt->d_ztmp) hipFree(rt->d_ztmp);
+    rt->d_count = nullptr;
+    rt->d_key = nullptr;
+    rt->d_steps = nullptr;
+    rt->d_scratch_count = nullptr;
+    rt->d_scratch_key = nullptr;
+    rt->d_rgba = nullptr;
+    rt->d_ztmp = nullptr;
+    rt->copies = 0;
+    return SAR_OK;
+}
+
+int alloc_image_buffers(sar_runtime* rt, uint32_t w, uint32_t h) {
+    const uint64_t npix64 = static_cast<uint64_t>(w) * h;
+    if (w == 0 || h == 0) { set_error("zero image dimension"); return SAR_ERR_INVALID; }
+    if (npix64 > 0x7fffffffull) { set_error("width*height exceeds 2^31-1"); return SAR_ERR_RANGE; }
+    free_device_buffers(rt);
+    rt->W = w;
+    rt->H = h;
+    rt->npix = static_cast<uint32_t>(npix64);
+    HIP_TRY(hipMalloc(&rt->d_count, npix64 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&rt->d_key, npix64 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&rt->d_steps, npix64 * sizeof(double)));
+    return SAR_OK;
+}
+
+int ensure_scratch(sar_runtime* rt, uint32_t copies) {
+    if (rt->copies == copies && rt->d_scratch_count) return SAR_OK;
+    if (rt->d_scratch_count) hipFree(rt->d_scratch_count);
+    if (rt->d_scratch_key) hipFree(rt->d_scratch_key);
+    rt->d_scratch_count = nullptr;
+    rt->d_scratch_key = nullptr;
+    const size_t n = static_cast<size_t>(copies) * rt->npix;
+    HIP_TRY(hipMalloc(&rt->d_scratch_count, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&rt->d_scratch_key, n * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(rt->d_scratch_count, 0, n * sizeof(uint32_t), rt->stream));
+    HIP_TRY(hipMemsetAsync(rt->d_scratch_key, 0, n * sizeof(unsigned long long), rt->stream));
+    rt->copies = copies;
+    return SAR_OK;
+}
+
+int do_reset(sar_runtime* rt) {
+    launch_reset(rt->d_count, rt->d_key, rt->d_steps, rt->npix, rt->d_scalars, rt->stream);
+    HIP_TRY(hipGetLastError());
+    return SAR_OK;
+}
+
+void span_begin(sar_runtime* rt, std::vector<Span>& spans, size_t& used) {
+    if (!rt->timing) return;
+    if (used == spans.size()) {
+        Span s;
+        hipEventCreate(&s.a);
+        hipEventCreate(&s.b);
+        spans.push_back(s);
+    }
+    hipEventRecord(spans[used].a, rt->stream);
+}
+void span_end(sar_runtime* rt, std::vector<Span>& spans, size_t& used) {
+    if (!rt->timing) return;
+    hipEventRecord(spans[used].b, rt->stream);
+    ++used;
+}
+void single_begin(sar_runtime* rt, Span& s) {
+    if (!rt->timing) return;
+    if (!s.a) { hipEventCreate(&s.a); hipEventCreate(&s.b); }
+    hipEventRecord(s.a, rt->stream);
+}
+void single_end(sar_runtime* rt, Span& s, bool& flag) {
+    if (!rt->timing) return;
+    hipEventRecord(s.b, rt->stream);
+    flag = true;
+}
+
+void fill_map_params(const sar_config& cfg, MapParams& p) {
+    for (int k = 0; k < 10; ++k) {
+        p.cx[k] = cfg.coeff_x[k];
+        p.cy[k] = cfg.coeff_y[k];
+        p.cz[k] = cfg.coeff_z[k];
+    }
+    // the reference's sum starts as `0. + 1.*c0` (src/lib.rs:589-597): identical to c0 except that a
+    // -0.0 coefficient becomes +0.0
+    p.cx[0] = 0. + 1. * cfg.coeff_x[0];
+    p.cy[0] = 0. + 1. * cfg.coeff_y[0];
+    p.cz[0] = 0. + 1. * cfg.coeff_z[0];
+    rotation_matrix(cfg, p.m);                 // :755
+    p.sin_v = std::sin(cfg.angle);             // :756
+    p.cos_v = std::cos(cfg.angle);             // :757
+    p.ccx = cfg.center_camera[0];
+    p.ccy = cfg.center_camera[1];
+    p.ccz = cfg.center_camera[2];
+    p.width = static_cast<double>(cfg.width);   // :760
+    p.height = static_cast<double>(cfg.height); // :762
+    p.half_height = p.height / 2.;              // `height / 2.` of :786
+    p.width_scaled = p.width * cfg.scale;       // :763
+    p.scale_adjusted_mid = 0.5 / cfg.scale;     // :764
+}
+
+void fill_ct_params(const sar_config& cfg, ColorTransformParams& ct) {
+    ct.kind = cfg.color_transform;
+    ct._pad = 0;
+    ct.offset = cfg.ct_offset;
+    ct.factor = cfg.ct_factor;
+    ct.ccx = cfg.center_camera[0];
+    ct.ccy = cfg.center_camera[1];
+}
+
+int check_cfg_matches(const sar_config* cfg, const sar_runtime* rt) {
+    SAR_TRY(validate(cfg));
+    if (!rt) { set_error("runtime is NULL"); return SAR_ERR_INVALID; }
+    if (cfg->width != rt->W || cfg->height != rt->H) {
+        set_error("config is %ux%u but the runtime holds %ux%u", cfg->width, cfg->height, rt->W, rt->H);
+        return SAR_ERR_DIM_MISMATCH;
+    }
+    return SAR_OK;
+}
+
+// Runs n_jobs trajectories of `iters` counted iterations each; starts is AoS [n_jobs][3] on the host.
+// Sequential semantics (job-major, iteration-minor). Launch chunks keep job*iters + t inside 32 bits
+// and the checkpoint scratch inside kCkptBytesCap; chunk boundaries fall on whole jobs, and a later
+// chunk only replaces a depth winner with a strictly greater z, exactly like a later render call.
+int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters,
+                   const double* starts) {
+    rt->last_iterations = 0;
+    rt->iter_used = 0;
+    rt->fold_used = 0;
+    if (n_jobs == 0 || iters == 0) return SAR_OK;
+    if (iters > kMaxChunkOrdinals) {
+        set_error("%llu iterations per job exceed the 32-bit visit ordinal of one launch",
+                  static_cast<unsigned long long>(iters));
+        return SAR_ERR_RANGE;
+    }
+    HIP_TRY(hipSetDevice(rt->device));
+
+    const uint32_t C = rt->ckpt_stride;
+    const uint64_t n_ckpt = (iters + C - 1) / C;
+    uint64_t chunk_jobs = kMaxChunkOrdinals / iters;
+    const uint64_t by_mem = kCkptBytesCap / (n_ckpt * 24ull);
+    if (by_mem < chunk_jobs) chunk_jobs = by_mem ? by_mem : 1;
+    if (rt->debug_chunk_jobs && rt->debug_chunk_jobs < chunk_jobs) chunk_jobs = rt->debug_chunk_jobs;
+    if (chunk_jobs > n_jobs) chunk_jobs = n_jobs;
+    if (chunk_jobs > rt->block_threads) chunk_jobs -= chunk_jobs % rt->block_threads;
+
+    // bins: per-XCD scratch copies pay off once there is enough work to amortise folding 8 copies
+    uint32_t bins = rt->bins_mode;
+    if (bins == 0) bins = 1;
+    const bool xcd_local = (bins == 2);
+    SAR_TRY(ensure_scratch(rt, xcd_local ? 8u : 1u));
+
+    // start points: one pinned staging buffer, laid out as consecutive per-chunk SoA blocks
+    const size_t need = static_cast<size_t>(n_jobs) * 3;
+    if (rt->starts_pending) {
+        HIP_TRY(hipEventSynchronize(rt->starts_copied));
+        rt->starts_pending = false;
+    }
+    if (need > rt->starts_cap) {
+        if (rt->h_starts) hipHostFree(rt->h_starts);
+        if (rt->d_starts) hipFree(rt->d_starts);
+        rt->h_starts = nullptr;
+        rt->d_starts = nullptr;
+        rt->starts_cap = 0;
+        HIP_TRY(hipHostMalloc(&rt->h_starts, need * sizeof(double), hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&rt->d_starts, need * sizeof(double)));
+        rt->starts_cap = need;
+    }
+    for (uint64_t off = 0; off < n_jobs; off += chunk_jobs) {
+        const uint64_t m = (n_jobs - off < chunk_jobs) ? n_jobs - off : chunk_jobs;
+        double* blk = rt->h_starts + off * 3;
+        for (uint64_t k = 0; k < m; ++k) {
+            blk[k] = starts[(off + k) * 3 + 0];
+            blk[m + k] = starts[(off + k) * 3 + 1];
+            blk[2 * m + k] = starts[(off + k) * 3 + 2];
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(rt->d_starts, rt->h_starts, need * sizeof(double), hipMemcpyHostToDevice, rt->stream));
+    HIP_TRY(hipEventRecord(rt->starts_copied, rt->stream));
+    rt->starts_pending = true;
+
+    const size_t ckpt_need = static_cast<size_t>(n_ckpt) * 3 * chunk_jobs;
+    if (ckpt_need > rt->ckpt_cap) {
+        if (rt->d_ckpt) hipFree(rt->d_ckpt);
+        rt->d_ckpt = nullptr;
+        rt->ckpt_cap = 0;
+        HIP_TRY(hipMalloc(&rt->d_ckpt, ckpt_need * sizeof(double)));
+        rt->ckpt_cap = ckpt_need;
+    }
+
+    IterArgs ia;
+    std::memset(&ia, 0, sizeof(ia));
+    fill_map_params(*cfg, ia.p);
+    ia.iters = iters;
+    ia.width = rt->W;
+    ia.npix = rt->npix;
+    ia.ckpt_stride = C;
+    ia.scratch_count = rt->d_scratch_count;
+    ia.scratch_key = rt->d_scratch_key;
+    ia.ckpt = rt->d_ckpt;
+
+    FoldArgs fa;
+    std::memset(&fa, 0, sizeof(fa));
+    fa.p = ia.p;
+    fill_ct_params(*cfg, fa.ct);
+    fa.iters = iters;
+    fa.npix = rt->npix;
+    fa.ckpt_stride = C;
+    fa.copies = rt->copies;
+    fa.count = rt->d_count;
+    fa.key = rt->d_key;
+    fa.steps = rt->d_steps;
+    fa.scratch_count = rt->d_scratch_count;
+    fa.scratch_key = rt->d_scratch_key;
+    fa.ckpt = rt->d_ckpt;
+    fa.scalars = rt->d_scalars;
+
+    const int mode = rt->measure_mode == 0 ? 2 : (rt->measure_mode == 1 ? 1 : 0);
+    for (uint64_t off = 0; off < n_jobs; off += chunk_jobs) {
+        const uint32_t m = static_cast<uint32_t>((n_jobs - off < chunk_jobs) ? n_jobs - off : chunk_jobs);
+        ia.n_jobs = m;
+        ia.starts = rt->d_starts + off * 3;
+        fa.n_jobs = m;
+        span_begin(rt, rt->iter_spans, rt->iter_used);
+        launch_iterate(ia, rt->block_threads, xcd_local, mode, rt->stream);
+        span_end(rt, rt->iter_spans, rt->iter_used);
+        span_begin(rt, rt->fold_spans, rt->fold_used);
+        launch_fold_resolve(fa, rt->stream);
+        span_end(rt, rt->fold_spans, rt->fold_used);
+    }
+    HIP_TRY(hipGetLastError());
+    rt->last_iterations = static_cast<uint64_t>(n_jobs) * iters;
+    return SAR_OK;
+}
+
+int do_colorize(const sar_config* cfg, sar_runtime* rt, void* out_dev) {
+    HIP_TRY(hipSetDevice(rt->device));
+    single_begin(rt, rt->colorize_span);
+    if (cfg->render_kind == SAR_RENDER_GAS) {
+        PaletteParams pal;
+        std::memset(&pal, 0, sizeof(pal));
+        pal.len = cfg->palette_len;
+        for (uint32_t k = 0; k < cfg->palette_len; ++k)
+            for (int ch = 0; ch < 3; ++ch) pal.rgb[k][ch] = cfg->palette_rgb[k][ch];
+        for (int ch = 0; ch < 3; ++ch)  // Palette::new duplicates the last entry (:416-418)
+            pal.rgb[cfg->palette_len][ch] = cfg->palette_rgb[cfg->palette_len - 1][ch];
+        launch_colorize_gas(rt->d_count, rt->d_steps, rt->d_scalars, rt->d_lnlut, kLnLutEntries, pal,
+                            cfg->brightness_offset, cfg->brightness_factor, cfg->transparent ? 1 : 0, rt->npix,
+                            out_dev, rt->stream);
+    } else {
+        launch_colorize_depth(rt->d_key, rt->d_scalars, rt->npix, out_dev, rt->stream);
+    }
+    single_end(rt, rt->colorize_span, rt->colorize_timed);
+    HIP_TRY(hipGetLastError());
+    return SAR_OK;
+}
+
+int ensure_rgba(sar_runtime* rt) {
+    if (!rt->d_rgba) HIP_TRY(hipMalloc(&rt->d_rgba, static_cast<size_t>(rt->npix) * 8));
+    return SAR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sar_device_count(int* out_count) {
+    if (!out_count) return SAR_ERR_INVALID;
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out_count = 0;
+        set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return SAR_ERR_NO_DEVICE;
+    }
+    *out_count = n;
+    return SAR_OK;
+}
+
+int sar_runtime_new(const sar_config* cfg, int device, sar_runtime** out) {
+    if (!out) return SAR_ERR_INVALID;
+    *out = nullptr;
+    SAR_TRY(validate(cfg));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (this library has no CPU fallback)");
+        return SAR_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return SAR_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(device));
+    sar_runtime* rt = new (std::nothrow) sar_runtime();
+    if (!rt) return SAR_ERR_OOM;
+    rt->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) rt->sm_count = static_cast<uint32_t>(prop.multiProcessorCount);
+    int st = SAR_OK;
+    auto fail = [&](int code) { sar_runtime_free(rt); return code; };
+    if (hipStreamCreateWithFlags(&rt->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(SAR_ERR_HIP); }
+    rt->own_stream = true;
+    if (hipEventCreateWithFlags(&rt->starts_copied, hipEventDisableTiming) != hipSuccess) return fail(SAR_ERR_HIP);
+    if (hipMalloc(&rt->d_scalars, SC_COUNT * sizeof(uint32_t)) != hipSuccess) return fail(SAR_ERR_OOM);
+    if (hipMalloc(&rt->d_lnlut, kLnLutEntries * sizeof(double)) != hipSuccess) return fail(SAR_ERR_OOM);
+    if (hipMemcpyAsync(rt->d_lnlut, host_ln_lut(), kLnLutEntries * sizeof(double), hipMemcpyHostToDevice, rt->stream) != hipSuccess)
+        return fail(SAR_ERR_HIP);
+    if ((st = alloc_image_buffers(rt, cfg->width, cfg->height)) != SAR_OK) return fail(st);
+    if ((st = do_reset(rt)) != SAR_OK) return fail(st);
+    rt->rng.seed(cfg->seed);
+    if (hipStreamSynchronize(rt->stream) != hipSuccess) return fail(SAR_ERR_HIP);
+    *out = rt;
+    return SAR_OK;
+}
+
+int sar_runtime_free(sar_runtime* rt) {
+    if (!rt) return SAR_OK;
+    hipSetDevice(rt->device);
+    if (rt->stream) hipStreamSynchronize(rt->stream);
+    free_device_buffers(rt);
+    if (rt->d_scalars) hipFree(rt->d_scalars);
+    if (rt->d_lnlut) hipFree(rt->d_lnlut);
+    if (rt->d_starts) hipFree(rt->d_starts);
+    if (rt->h_starts) hipHostFree(rt->h_starts);
+    if (rt->d_ckpt) hipFree(rt->d_ckpt);
+    if (rt->starts_copied) hipEventDestroy(rt->starts_copied);
+    for (auto& s : rt->iter_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    for (auto& s : rt->fold_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    if (rt->colorize_span.a) { hipEventDestroy(rt->colorize_span.a); hipEventDestroy(rt->colorize_span.b); }
+    if (rt->merge_span.a) { hipEventDestroy(rt->merge_span.a); hipEventDestroy(rt->merge_span.b); }
+    if (rt->own_stream && rt->stream) hipStreamDestroy(rt->stream);
+    delete rt;
+    return SAR_OK;
+}
+
+int sar_runtime_reset(sar_runtime* rt) {
+    if (!rt) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    return do_reset(rt);
+}
+
+int sar_runtime_set_width_height(sar_runtime* rt, uint32_t width, uint32_t height) {
+    if (!rt) return SAR_ERR_INVALID;
+    if (rt->W == width && rt->H == height) return SAR_OK;  // :668
+    HIP_TRY(hipSetDevice(rt->device));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    SAR_TRY(alloc_image_buffers(rt, width, height));
+    return do_reset(rt);
+}
+
+int sar_runtime_seed(sar_runtime* rt, uint64_t seed) {
+    if (!rt) return SAR_ERR_INVALID;
+    rt->rng.seed(seed);
+    return SAR_OK;
+}
+
+int sar_runtime_merge(sar_runtime* dst, const sar_runtime* src) {
+    if (!dst || !src) return SAR_ERR_INVALID;
+    if (dst->W != src->W || dst->H != src->H) {  // assert_eq! in the reference (:709-710)
+        set_error("merge: %ux%u vs %ux%u", dst->W, dst->H, src->W, src->H);
+        return SAR_ERR_DIM_MISMATCH;
+    }
+    if (dst->device != src->device) { set_error("merge: runtimes live on different devices; use the exchange API"); return SAR_ERR_INVALID; }
+    if (dst == src) { set_error("merge: dst and src are the same runtime"); return SAR_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(dst->device));
+    if (src->stream != dst->stream) HIP_TRY(hipStreamSynchronize(src->stream));
+    single_begin(dst, dst->merge_span);
+    launch_merge(dst->d_count, dst->d_key, dst->d_steps, src->d_count, src->d_key, src->d_steps, dst->npix,
+                 dst->d_scalars, dst->stream);
+    single_end(dst, dst->merge_span, dst->merge_timed);
+    HIP_TRY(hipGetLastError());
+    return SAR_OK;
+}
+
+int sar_runtime_synchronize(sar_runtime* rt) {
+    if (!rt) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    return SAR_OK;
+}
+
+int sar_runtime_dims(const sar_runtime* rt, uint32_t* width, uint32_t* height) {
+    if (!rt || !width || !height) return SAR_ERR_INVALID;
+    *width = rt->W;
+    *height = rt->H;
+    return SAR_OK;
+}
+
+int sar_runtime_set_stream(sar_runtime* rt, void* hip_stream) {
+    if (!rt) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    if (rt->own_stream && rt->stream) hipStreamDestroy(rt->stream);
+    rt->stream = static_cast<hipStream_t>(hip_stream);
+    rt->own_stream = false;
+    return SAR_OK;
+}
+
+int sar_runtime_get_stream(const sar_runtime* rt, void** hip_stream_out) {
+    if (!rt || !hip_stream_out) return SAR_ERR_INVALID;
+    *hip_stream_out = rt->stream;
+    return SAR_OK;
+}
+
+int sar_render(const sar_config* cfg, sar_runtime* rt) {
+    SAR_TRY(check_cfg_matches(cfg, rt));
+    double p0[3];
+    rt->rng.start_point(p0);  // :748
+    return render_chunked(cfg, rt, 1, cfg->iterations, p0);
+}
+
+int sar_render_jobs(const sar_config* cfg, sar_runtime* rt, const double* starts_xyz_host) {
+    SAR_TRY(check_cfg_matches(cfg, rt));
+    if (cfg->jobs_total == 0) { set_error("jobs_total is 0"); return SAR_ERR_INVALID; }
+    const uint64_t per_job = cfg->iterations / cfg->jobs_total;  // :1058
+    std::vector<double> drawn;
+    if (!starts_xyz_host) {
+        drawn.resize(static_cast<size_t>(cfg->jobs_total) * 3);
+        for (uint32_t k = 0; k < cfg->jobs_total; ++k) rt->rng.start_point(&drawn[3 * static_cast<size_t>(k)]);
+        starts_xyz_host = drawn.data();
+    }
+    return render_chunked(cfg, rt, cfg->jobs_total, per_job, starts_xyz_host);
+}
+
+int sar_render_job_range(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters_per_job,
+                         const double* starts_xyz_host) {
+    SAR_TRY(check_cfg_matches(cfg, rt));
+    if (n_jobs && !starts_xyz_host) { set_error("starts_xyz_host is NULL"); return SAR_ERR_INVALID; }
+    return render_chunked(cfg, rt, n_jobs, iters_per_job, starts_xyz_host);
+}
+
+int sar_colorize_device(const sar_config* cfg, sar_runtime* rt, void* rgba_out_dev) {
+    SAR_TRY(check_cfg_matches(cfg, rt));
+    if (!rgba_out_dev) return SAR_ERR_INVALID;
+    return do_colorize(cfg, rt, rgba_out_dev);
+}
+
+int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host) {
+    SAR_TRY(check_cfg_matches(cfg, rt));
+    if (!rgba_out_host) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    SAR_TRY(ensure_rgba(rt));
+    SAR_TRY(do_colorize(cfg, rt, rt->d_rgba));
+    HIP_TRY(hipMemcpyAsync(rgba_out_host, rt->d_rgba, static_cast<size_t>(rt->npix) * 8, hipMemcpyDeviceToHost, rt->stream));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    return SAR_OK;
+}
+
+int sar_runtime_count(sar_runtime* rt, uint32_t* out_host) {
+    if (!rt || !out_host) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    HIP_TRY(hipMemcpyAsync(out_host, rt->d_count, static_cast<size_t>(rt->npix) * 4, hipMemcpyDeviceToHost, rt->stream));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    return SAR_OK;
+}
+
+int sar_runtime_steps(sar_runtime* rt, double* out_host) {
+    if (!rt || !out_host) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    HIP_TRY(hipMemcpyAsync(out_host, rt->d_steps, static_cast<size_t>(rt->npix) * 8, hipMemcpyDeviceToHost, rt->stream));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    return SAR_OK;
+}
+
+int sar_runtime_zbuf(sar_runtime* rt, float* out_host) {
+    if (!rt || !out_host) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    if (!rt->d_ztmp) HIP_TRY(hipMalloc(&rt->d_ztmp, static_cast<size_t>(rt->npix) * 4));
+    launch_zbuf_out(rt->d_key, rt->d_ztmp, rt->npix, rt->stream);
+    HIP_TRY(hipMemcpyAsync(out_host, rt->d_ztmp, static_cast<size_t>(rt->npix) * 4, hipMemcpyDeviceToHost, rt->stream));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    return SAR_OK;
+}
+
+int sar_runtime_max(sar_runtime* rt, uint32_t* out_max) {
+    if (!rt || !out_max) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    uint32_t sc[SC_COUNT];
+    HIP_TRY(hipMemcpyAsync(sc, rt->d_scalars, sizeof(sc), hipMemcpyDeviceToHost, rt->stream));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    *out_max = sc[SC_WRAP] ? 0xFFFFFFFFu : sc[SC_MAX];
+    return SAR_OK;
+}
+
+int sar_runtime_load(sar_runtime* rt, const uint32_t* count_host, const double* steps_host,
+                     const float* zbuf_host, uint32_t max) {
+    if (!rt || !count_host || !steps_host || !zbuf_host) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    if (!rt->d_ztmp) HIP_TRY(hipMalloc(&rt->d_ztmp, static_cast<size_t>(rt->npix) * 4));
+    HIP_TRY(hipMemcpyAsync(rt->d_count, count_host, static_cast<size_t>(rt->npix) * 4, hipMemcpyHostToDevice, rt->stream));
+    HIP_TRY(hipMemcpyAsync(rt->d_steps, steps_host, static_cast<size_t>(rt->npix) * 8, hipMemcpyHostToDevice, rt->stream));
+    HIP_TRY(hipMemcpyAsync(rt->d_ztmp, zbuf_host, static_cast<size_t>(rt->npix) * 4, hipMemcpyHostToDevice, rt->stream));
+    launch_zbuf_in(rt->d_ztmp, rt->d_key, rt->npix, rt->stream);
+    uint32_t sc[SC_COUNT] = {0};
+    sc[SC_MAX] = max;
+    HIP_TRY(hipMemcpyAsync(rt->d_scalars, sc, sizeof(sc), hipMemcpyHostToDevice, rt->stream));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    return SAR_OK;
+}
+
+int sar_runtime_exchange_export(sar_runtime* rt, uint32_t rank, void* key_i64_out_dev) {
+    if (!rt || !key_i64_out_dev) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    launch_exch_export(rt->d_key, rank, key_i64_out_dev, rt->npix, rt->stream);
+    HIP_TRY(hipGetLastError());
+    return SAR_OK;
+}
+
+int sar_runtime_exchange_select(sar_runtime* rt, uint32_t rank, const void* key_i64_reduced_dev,
+                                void* sum_i32_out_dev) {
+    if (!rt || !key_i64_reduced_dev || !sum_i32_out_dev) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    launch_exch_select(rt->d_count, rt->d_key, rt->d_steps, rank, key_i64_reduced_dev, sum_i32_out_dev, rt->npix,
+                       rt->stream);
+    HIP_TRY(hipGetLastError());
+    return SAR_OK;
+}
+
+int sar_runtime_exchange_import(sar_runtime* rt, const void* key_i64_reduced_dev, const void* sum_i32_reduced_dev) {
+    if (!rt || !key_i64_reduced_dev || !sum_i32_reduced_dev) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    launch_exch_import(rt->d_count, rt->d_key, rt->d_steps, key_i64_reduced_dev, sum_i32_reduced_dev, rt->npix,
+                       rt->d_scalars, rt->stream);
+    HIP_TRY(hipGetLastError());
+    return SAR_OK;
+}
+
+// ---- ParallelRenderer mirror ------------------------------------------------------------------------
+
+int sar_renderer_new(int device, uint32_t units, uint64_t seed, sar_renderer** out) {
+    if (!out) return SAR_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (this library has no CPU fallback)");
+        return SAR_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range", device); return SAR_ERR_INVALID; }
+    sar_renderer* r = new (std::nothrow) sar_renderer();
+    if (!r) return SAR_ERR_OOM;
+    r->device = device;
+    r->seed = seed;
+    if (units == 0) {
+        // the chip's lane count: one trajectory per SIMD lane (CUs x 4 SIMDs x 64 lanes), the role
+        // available_parallelism() plays at src/lib.rs:920-922
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete r; return SAR_ERR_HIP; }
+        units = static_cast<uint32_t>(prop.multiProcessorCount) * 4u * 64u;
+    }
+    r->units = units;
+    *out = r;
+    return SAR_OK;
+}
+
+int sar_renderer_num_units(const sar_renderer* r, uint32_t* out_units) {
+    if (!r || !out_units) return SAR_ERR_INVALID;
+    *out_units = r->units;
+    return SAR_OK;
+}
+
+int sar_renderer_shutdown(sar_renderer* r) {
+    if (!r) return SAR_OK;
+    if (r->rt) sar_runtime_free(r->rt);
+    delete r;
+    return SAR_OK;
+}
+
+int sar_renderer_runtime(sar_renderer* r, sar_runtime** out_borrowed) {
+    if (!r || !out_borrowed) return SAR_ERR_INVALID;
+    *out_borrowed = r->rt;
+    return r->rt ? SAR_OK : SAR_ERR_INVALID;
+}
+
+int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_per_unit, uint16_t* rgba_out_host) {
+    if (!r) return SAR_ERR_INVALID;
+    SAR_TRY(validate(cfg));
+    if (jobs_per_unit == 0) { set_error("jobs_per_unit is 0"); return SAR_ERR_INVALID; }
+    const uint64_t total_jobs = static_cast<uint64_t>(r->units) * jobs_per_unit;  // :1062
+    if (total_jobs > 0xFFFFFFFFull) { set_error("units*jobs_per_unit exceeds 2^32-1"); return SAR_ERR_RANGE; }
+    if (!r->rt) {
+        sar_config c0 = *cfg;
+        c0.seed = r->seed;
+        SAR_TRY(sar_runtime_new(&c0, r->device, &r->rt));
+    }
+    sar_runtime* rt = r->rt;
+    SAR_TRY(sar_runtime_set_width_height(rt, cfg->width, cfg->height));  // :950
+    SAR_TRY(sar_runtime_reset(rt));                                       // :951
+    const uint64_t per_job = cfg->iterations / r->units / jobs_per_unit;  // :1058
+    std::vector<double> starts(static_cast<size_t>(total_jobs) * 3);
+    for (uint64_t k = 0; k < total_jobs; ++k) rt->rng.start_point(&starts[3 * static_cast<size_t>(k)]);
+    SAR_TRY(render_chunked(cfg, rt, static_cast<uint32_t>(total_jobs), per_job, starts.data()));
+    if (rgba_out_host) return sar_colorize(cfg, rt, rgba_out_host);  // :1080
+    return SAR_OK;
+}
+
+// ---- measurement --------------------------------------------------------------------------------------
+
+int sar_runtime_enable_timing(sar_runtime* rt, int enabled) {
+    if (!rt) return SAR_ERR_INVALID;
+    rt->timing = enabled != 0;
+    return SAR_OK;
+}
+
+int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
+    if (!rt || !out) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    std::memset(out, 0, sizeof(*out));
+    float ms = 0.f;
+    for (size_t k = 0; k < rt->iter_used; ++k)
+        if (hipEventElapsedTime(&ms, rt->iter_spans[k].a, rt->iter_spans[k].b) == hipSuccess) out->iterate_ms += ms;
+    for (size_t k = 0; k < rt->fold_used; ++k)
+        if (hipEventElapsedTime(&ms, rt->fold_spans[k].a, rt->fold_spans[k].b) == hipSuccess) out->resolve_ms += ms;
+    if (rt->colorize_timed && hipEventElapsedTime(&ms, rt->colorize_span.a, rt->colorize_span.b) == hipSuccess) out->colorize_ms = ms;
+    if (rt->merge_timed && hipEventElapsedTime(&ms, rt->merge_span.a, rt->merge_span.b) == hipSuccess) out->merge_ms = ms;
+    out->iterate_launches = static_cast<uint32_t>(rt->iter_used);
+    out->iterations_counted = rt->last_iterations;
+    return SAR_OK;
+}
+
+int sar_runtime_set_tuning(sar_runtime* rt, uint32_t block_threads, uint32_t checkpoint_stride, uint32_t variant) {
+    if (!rt) return SAR_ERR_INVALID;
+    if (block_threads) {
+        if (block_threads % 64 || block_threads > 256) { set_error("block_threads must be 64, 128, 192 or 256"); return SAR_ERR_INVALID; }
+        rt->block_threads = block_threads;
+    }
+    if (checkpoint_stride) rt->ckpt_stride = checkpoint_stride;
+    rt->bins_mode = variant & 0xFu;
+    rt->measure_mode = (variant >> 4) & 0xFu;
+    rt->debug_chunk_jobs = variant >> 8;  // test hook: forces multi-chunk launches
+    if (rt->bins_mode > 2 || rt->measure_mode > 2) { set_error("unknown variant 0x%x", variant); return SAR_ERR_INVALID; }
+    return SAR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+"""Generates the committed fixtures under tests/golden/ (run in the build container; never on the GPU box).
+
+  kat.json            known-answer vectors of the CPU oracle. Nothing in the reference's own test-suite
+                      pins this path (its only test is a doc-test that constructs a Config), so these are
+                      oracle-emitted; the values listed in SURVEY.md §8c were produced independently by a
+                      separate throw-away restatement (gcc AND AMD-clang) and agree bit for bit — the
+                      script asserts that agreement before writing.
+  ref_png_stats.json  statistics of the one artefact the reference ships, media/poisson-saturne.png
+                      (README.md:72-73: `-i1000000000 -b -0.25`, 1920x1080, OS-random seed): bounding box,
+                      non-zero fraction and a 96x54 block-mean thumbnail per channel. Data derived from a
+                      data file; used for the statistical pin of the oracle.
+
+    python tests/golden/make_golden.py [--png /root/reference/media/poisson-saturne.png]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+
+
+def hexes(v):
+    return [float.hex(float(x)) for x in v]
+
+
+def kat():
+    out = {}
+    ps, ss = O.poisson_saturne(), O.solar_sail()
+    p0 = np.array([0.05, 0.031, 0.077])
+    out["poisson_iter"] = {str(n): hexes(O.iterate(ps, p0, n)) for n in (1, 1000, 1001000)}
+    q0 = np.array([0.025, 0.0155, 0.0385])
+    out["solar_iter"] = {str(n): hexes(O.iterate(ss, q0, n)) for n in (1, 1000)}
+    out["poisson_matrix"] = hexes(O.rotation_matrix(ps).ravel())
+    out["solar_matrix"] = hexes(O.rotation_matrix(ss).ravel())
+    # SURVEY.md §8c session values (independent restatement) — must agree
+    assert out["poisson_iter"]["1"] == ["-0x1.4d66b288f62a8p-6", "0x1.2fdb737366f52p-3", "-0x1.007e66211707fp-1"]
+    assert out["poisson_iter"]["1001000"] == ["0x1.3f5a9c613ab36p-2", "0x1.d454faad0974fp-3", "-0x1.071b380ea3f9bp-3"]
+    assert out["solar_iter"]["1000"] == ["0x1.09450fdb8bfb7p-4", "-0x1.2b75c30ac8523p-3", "0x1.4ce662c2471fcp-3"]
+    assert out["poisson_matrix"][0] == "-0x1.926334438a872p-4" and out["poisson_matrix"][8] == "0x1.80efcaa45292bp-3"
+    assert out["solar_matrix"][0] == "-0x1.34d3ccaa576adp-1"
+
+    c = O.poisson_saturne()
+    c.width = c.height = 512
+    rt = O.Runtime(512, 512)
+    O.render(c, rt, p0, 10_000_000)
+    out["c1_512"] = {
+        "p0": hexes(p0), "iterations": 10_000_000,
+        "in_bounds": int(rt.count.sum()), "touched": int((rt.count > 0).sum()), "max": rt.max,
+        "depth_set": int((rt.zbuf != -1).sum()),
+        "count_fnv": f"{O.fnv1a64(rt.count):016x}", "zbuf_fnv": f"{O.fnv1a64(rt.zbuf):016x}",
+        "steps_fnv": f"{O.fnv1a64(rt.steps):016x}",
+    }
+    assert out["c1_512"]["count_fnv"] == "52a35a7e05fd92db" and out["c1_512"]["max"] == 5673
+    assert out["c1_512"]["zbuf_fnv"] == "b69ddb65be9314f5" and out["c1_512"]["steps_fnv"] == "21fff5b92fa0204d"
+    c.transparent = 0
+    out["c1_512"]["rgba_fnv"] = f"{O.fnv1a64(O.colorize(c, rt)):016x}"
+    c.transparent = 1
+    out["c1_512"]["rgba_transparent_fnv"] = f"{O.fnv1a64(O.colorize(c, rt)):016x}"
+    rt.reset()
+    starts = np.stack([p0 * (k + 1) / 4 for k in range(4)])
+    O.render_jobs(c, rt, starts, 2_500_000)
+    out["c1_512_4jobs"] = {"touched": int((rt.count > 0).sum()), "max": rt.max,
+                           "count_fnv": f"{O.fnv1a64(rt.count):016x}", "zbuf_fnv": f"{O.fnv1a64(rt.zbuf):016x}",
+                           "steps_fnv": f"{O.fnv1a64(rt.steps):016x}"}
+    assert out["c1_512_4jobs"]["count_fnv"] == "ae9cc71e6ceb683a" and out["c1_512_4jobs"]["max"] == 5743
+
+    # solar-sail, depth path, with diverging jobs (seeded stream)
+    s = O.solar_sail()
+    s.width, s.height, s.scale, s.render_kind = 450, 500, 1.0, O.SAR_RENDER_DEPTH
+    st = O.start_points(2024, 0, 64)
+    rs = O.Runtime(450, 500)
+    O.render_jobs(s, rs, st, 20000)
+    out["solar_450x500_64jobs"] = {
+        "seed": 2024, "jobs": 64, "iters_per_job": 20000, "count00": int(rs.count[0, 0]), "max": rs.max,
+        "count_fnv": f"{O.fnv1a64(rs.count):016x}", "zbuf_fnv": f"{O.fnv1a64(rs.zbuf):016x}",
+        "steps_fnv": f"{O.fnv1a64(rs.steps):016x}", "depth_rgba_fnv": f"{O.fnv1a64(O.colorize(s, rs)):016x}",
+    }
+    # start-point stream
+    out["start_points_seed1"] = [hexes(r) for r in O.start_points(1, 0, 3)]
+    out["start_points_seed1_skip5"] = [hexes(r) for r in O.start_points(1, 5, 2)]
+    # palette / colour transform spot values
+    pal = {}
+    for v in (-0.5, 0.0, 0.123456789, 0.5, 0.999999, 1.0, 7.0):
+        rgb = np.empty(3)
+        O.lib().sar_oracle_palette(O.C.byref(ps), v, rgb.ctypes.data_as(O.C.POINTER(O.C.c_double)))
+        pal[repr(v)] = hexes(rgb)
+    out["palette_default"] = pal
+    return out
+
+
+def decode_png16(path):
+    """Minimal PNG decoder (non-interlaced, 8/16-bit, colour types 0/2/6): PIL flattens 16-bit RGB to 8."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, hdr = 8, [], None
+    while pos < len(data):
+        ln, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + ln]
+        if typ == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat.append(body)
+        pos += 12 + ln
+    w, h, depth, ctype, _, _, interlace = hdr
+    assert interlace == 0 and depth in (8, 16)
+    ch = {0: 1, 2: 3, 6: 4}[ctype]
+    bpp = ch * depth // 8
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, 1 + w * bpp)
+    out = np.zeros((h, w * bpp), dtype=np.uint8)
+    prev = np.zeros(w * bpp, dtype=np.int32)
+    for y in range(h):
+        f, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        cur = np.zeros(w * bpp, dtype=np.int32)
+        if f == 0:
+            cur = line
+        elif f == 2:
+            cur = (line + prev) & 255
+        elif f == 1:
+            cur = line.copy()
+            for k in range(bpp, w * bpp):
+                cur[k] = (cur[k] + cur[k - bpp]) & 255
+        elif f in (3, 4):
+            for k in range(w * bpp):
+                a = cur[k - bpp] if k >= bpp else 0
+                b = prev[k]
+                c = prev[k - bpp] if k >= bpp else 0
+                if f == 3:
+                    pred = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[k] = (line[k] + pred) & 255
+        out[y] = cur
+        prev = cur
+    if depth == 16:
+        return out.reshape(h, w, ch, 2).astype(np.uint16)[..., 0] << 8 | out.reshape(h, w, ch, 2)[..., 1]
+    return out.reshape(h, w, ch)
+
+
+def png_stats(path):
+    im = decode_png16(path)
+    h, w = im.shape[:2]
+    rgb = im[..., :3].astype(np.float64)
+    nz = rgb.sum(axis=2) > 0
+    ys, xs = np.where(nz)
+    bh, bw = 20, 20
+    thumb = rgb.reshape(h // bh, bh, w // bw, bw, 3).mean(axis=(1, 3))
+    return {
+        "source": "reference media/poisson-saturne.png (README.md:72-73: -i1000000000 -b -0.25)",
+        "width": int(w), "height": int(h), "mode": str(im.dtype),
+        "bbox_x": [int(xs.min()), int(xs.max())], "bbox_y": [int(ys.min()), int(ys.max())],
+        "nonzero_fraction": float(nz.mean()),
+        "channel_mean": [float(v) for v in rgb.mean(axis=(0, 1))],
+        "thumb_block": [bh, bw],
+        "thumb": np.round(thumb).astype(int).tolist(),
+    }
+
+
+if __name__ == "__main__":
+    with open(os.path.join(HERE, "kat.json"), "w") as f:
+        json.dump(kat(), f, indent=1)
+    png = "/root/reference/media/poisson-saturne.png"
+    if "--png" in sys.argv:
+        png = sys.argv[sys.argv.index("--png") + 1]
+    if os.path.exists(png):
+        with open(os.path.join(HERE, "ref_png_stats.json"), "w") as f:
+            json.dump(png_stats(png), f)
+    print("wrote fixtures to", HERE)

@@ -1,0 +1,306 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the
+CPU oracle on the same explicit start points.
+
+Bar: bit-exact for count / max (integer), bit-exact for zbuf and steps (the device executes the
+reference's fp64 op sequence, no FMA), bit-exact RGBA16 for colorize wherever ln() comes from the
+host-libm table (count+1 <= 2^20), <= 1 LSB beyond it (device log, <= 1 ulp)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view({4: np.uint32, 8: np.uint64}[a.dtype.itemsize])
+
+
+def assert_state_equal(rt, ort, what=""):
+    cnt = rt.count()
+    np.testing.assert_array_equal(cnt, ort.count, err_msg=f"count {what}")
+    assert rt.max() == ort.max, f"max {what}"
+    np.testing.assert_array_equal(_bits(rt.zbuf()), _bits(ort.zbuf), err_msg=f"zbuf {what}")
+    np.testing.assert_array_equal(_bits(rt.steps()), _bits(ort.steps), err_msg=f"steps {what}")
+
+
+def _cfg(sar, preset, **kw):
+    return getattr(sar.Config, preset)(**kw)
+
+
+def test_c1_single_trajectory_matches_golden_and_oracle(sar, oracle, gpu):
+    """BASELINE config 1: poisson-saturne, 1e7 iterations, 512x512, one trajectory (render semantics)."""
+    import json, os
+    cfg = _cfg(sar, "poisson_saturne", iterations=10_000_000, width=512, height=512, jobs_total=1)
+    p0 = np.array([[0.05, 0.031, 0.077]])
+    rt = sar.Runtime(cfg)
+    sar.render_jobs(cfg, rt, p0)
+    ort = oracle.Runtime(512, 512)
+    oracle.render(cfg.c, ort, p0[0], 10_000_000)
+    assert_state_equal(rt, ort, "C1")
+    golden = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))["c1_512"]
+    assert f"{oracle.fnv1a64(rt.count()):016x}" == golden["count_fnv"]
+    assert f"{oracle.fnv1a64(rt.zbuf()):016x}" == golden["zbuf_fnv"]
+    assert f"{oracle.fnv1a64(rt.steps()):016x}" == golden["steps_fnv"]
+    assert rt.max() == golden["max"]
+    # colorize (gas, both alpha modes) — exact
+    for transparent in (0, 1):
+        c2 = cfg.replace(transparent=transparent)
+        np.testing.assert_array_equal(sar.colorize(c2, rt), oracle.colorize(c2.c, ort))
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("block", [64, 256])
+def test_many_jobs_bit_exact(sar, oracle, gpu, variant, block):
+    """Thousands of short trajectories: exercises depth ties, the checkpoint resolve and both bin layouts."""
+    jobs, n = 4096, 1500
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=384, height=320, jobs_total=jobs, seed=11)
+    starts = sar.start_points(11, 0, jobs)
+    rt = sar.Runtime(cfg)
+    rt.set_tuning(block_threads=block, checkpoint_stride=64, variant=variant)
+    sar.render_jobs(cfg, rt, starts)
+    ort = oracle.Runtime(384, 320)
+    oracle.render_jobs(cfg.c, ort, starts, n)
+    assert_state_equal(rt, ort, f"variant={variant} block={block}")
+    np.testing.assert_array_equal(sar.colorize(cfg, rt), oracle.colorize(cfg.c, ort))
+
+
+@pytest.mark.parametrize("stride", [1, 7, 64, 100000])
+def test_checkpoint_stride_does_not_change_results(sar, oracle, gpu, stride):
+    jobs, n = 512, 700
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=200, height=160, jobs_total=jobs)
+    starts = sar.start_points(3, 0, jobs)
+    rt = sar.Runtime(cfg)
+    rt.set_tuning(checkpoint_stride=stride)
+    sar.render_jobs(cfg, rt, starts)
+    ort = oracle.Runtime(200, 160)
+    oracle.render_jobs(cfg.c, ort, starts, n)
+    assert_state_equal(rt, ort, f"stride={stride}")
+
+
+def test_solar_sail_divergent_jobs_and_depth(sar, oracle, gpu):
+    """~38 % of solar-sail start points blow up to NaN: those jobs only feed count[0] (and only that)."""
+    jobs, n = 2048, 1200
+    cfg = _cfg(sar, "solar_sail", iterations=jobs * n, width=360, height=400, jobs_total=jobs,
+               render_kind=sar.SAR_RENDER_DEPTH, scale=1.0)
+    starts = sar.start_points(5, 0, jobs)
+    rt = sar.Runtime(cfg)
+    sar.render_jobs(cfg, rt, starts)
+    ort = oracle.Runtime(360, 400)
+    oracle.render_jobs(cfg.c, ort, starts, n)
+    assert ort.count[0, 0] > 100 * n, "expected many divergent jobs in this sample"
+    assert_state_equal(rt, ort, "solar-sail")
+    np.testing.assert_array_equal(sar.colorize(cfg, rt), oracle.colorize(cfg.c, ort))      # depth image
+    gas = cfg.replace(render_kind=sar.SAR_RENDER_GAS)
+    np.testing.assert_array_equal(sar.colorize(gas, rt), oracle.colorize(gas.c, ort))      # gas image
+    lib17 = cfg.replace(scale=1.7, angle=0.7)                                                # library scale, rotated
+    rt.reset(); ort.reset()
+    sar.render_jobs(lib17, rt, starts)
+    oracle.render_jobs(lib17.c, ort, starts, n)
+    assert_state_equal(rt, ort, "solar-sail scale 1.7 angle 0.7")
+
+
+def test_render_accumulates_across_calls_and_reset(sar, oracle, gpu):
+    """render on a non-reset Runtime continues the image (src/lib.rs:742-744); earlier calls win depth ties."""
+    jobs, n = 256, 900
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=160, height=160, jobs_total=jobs)
+    s1, s2 = sar.start_points(1, 0, jobs), sar.start_points(2, 0, jobs)
+    rt = sar.Runtime(cfg)
+    ort = oracle.Runtime(160, 160)
+    sar.render_jobs(cfg, rt, s1); oracle.render_jobs(cfg.c, ort, s1, n)
+    sar.render_jobs(cfg, rt, s2); oracle.render_jobs(cfg.c, ort, s2, n)
+    assert_state_equal(rt, ort, "two calls")
+    # the same 2*jobs trajectories in ONE call are the same sequential render
+    rt2 = sar.Runtime(cfg)
+    both = cfg.replace(iterations=2 * jobs * n, jobs_total=2 * jobs)
+    sar.render_jobs(both, rt2, np.concatenate([s1, s2]))
+    assert_state_equal(rt2, ort, "one call")
+    rt.reset(); ort.reset()
+    assert_state_equal(rt, ort, "after reset")
+    assert rt.max() == 0
+
+
+def test_launch_chunking_is_invisible(sar, oracle, gpu):
+    """Forcing many launch chunks (test hook) must not change a bit: chunk boundaries fall on whole jobs and
+    later chunks only win with a strictly greater depth."""
+    jobs, n = 1000, 600
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=128, height=128, jobs_total=jobs)
+    starts = sar.start_points(9, 0, jobs)
+    ort = oracle.Runtime(128, 128)
+    oracle.render_jobs(cfg.c, ort, starts, n)
+    for cap in (1, 64, 333):
+        rt = sar.Runtime(cfg)
+        rt.set_tuning(block_threads=64, variant=1 | (cap << 8))
+        sar.render_jobs(cfg, rt, starts)
+        assert_state_equal(rt, ort, f"chunk cap {cap}")
+
+
+def test_merge_matches_reference_semantics(sar, oracle, gpu):
+    jobs, n = 300, 800
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=96, height=96, jobs_total=jobs)
+    sa, sb = sar.start_points(21, 0, jobs), sar.start_points(22, 0, jobs)
+    ra, rb = sar.Runtime(cfg), sar.Runtime(cfg)
+    oa, ob = oracle.Runtime(96, 96), oracle.Runtime(96, 96)
+    sar.render_jobs(cfg, ra, sa); sar.render_jobs(cfg, rb, sb)
+    oracle.render_jobs(cfg.c, oa, sa, n); oracle.render_jobs(cfg.c, ob, sb, n)
+    ra.merge(rb)
+    assert oracle.merge(oa, ob) == 0
+    assert_state_equal(ra, oa, "merge")
+    # merge == rendering both job lists in sequence for count/zbuf; steps may differ only on depth ties
+    # (merge keeps self on ties, like the reference) — here checked against the oracle's merge above.
+    other = sar.Runtime(cfg.replace(width=64, height=64))
+    with pytest.raises(sar.SarError) as e:
+        ra.merge(other)
+    assert e.value.status == 2  # SAR_ERR_DIM_MISMATCH (assert_eq! in the reference)
+
+
+def test_load_roundtrip_and_wrapping_merge(sar, oracle, gpu):
+    """u32 counts wrap like the release build (src/lib.rs:719); max follows the merged values only."""
+    w = h = 8
+    cfg = _cfg(sar, "poisson_saturne", width=w, height=h)
+    rng = np.random.default_rng(0)
+    ca = rng.integers(0, 2**32, size=(h, w), dtype=np.uint64).astype(np.uint32)
+    cb = rng.integers(0, 2**32, size=(h, w), dtype=np.uint64).astype(np.uint32)
+    za = rng.uniform(-1, 1, size=(h, w)).astype(np.float32); za[0, :3] = -1.0
+    zb = rng.uniform(-1, 1, size=(h, w)).astype(np.float32); zb[0, 1:4] = -1.0; zb[1, 0] = za[1, 0]
+    sa, sb = rng.uniform(-1, 2, size=(h, w)), rng.uniform(-1, 2, size=(h, w))
+    ra, rb = sar.Runtime(cfg), sar.Runtime(cfg)
+    ra.load(ca, sa, za, 17); rb.load(cb, sb, zb, 99)
+    np.testing.assert_array_equal(ra.count(), ca)
+    np.testing.assert_array_equal(_bits(ra.zbuf()), _bits(za))
+    np.testing.assert_array_equal(_bits(ra.steps()), _bits(sa))
+    assert ra.max() == 17
+    oa, ob = oracle.Runtime(w, h), oracle.Runtime(w, h)
+    oa.count[:] = ca; oa.steps[:] = sa; oa.zbuf[:] = za; oa.set_max(17)
+    ob.count[:] = cb; ob.steps[:] = sb; ob.zbuf[:] = zb; ob.set_max(99)
+    ra.merge(rb); oracle.merge(oa, ob)
+    assert_state_equal(ra, oa, "wrapping merge")
+
+
+def test_render_parallel_job_split(sar, oracle, gpu):
+    """render_parallel: n = N / units / jobs_per_unit (two floor divisions), units*jobs_per_unit jobs,
+    start points from the renderer's stream, reset before, colorize after (src/lib.rs:1051-1082)."""
+    units, jpu = 192, 3
+    cfg = _cfg(sar, "poisson_saturne", iterations=1_000_003, width=256, height=192, transparent=0)
+    r = sar.ParallelRenderer(units=units, seed=77)
+    assert r.num_threads() == units
+    img = sar.render_parallel(r, cfg, jpu)
+    n = 1_000_003 // units // jpu
+    starts = oracle.start_points(77, 0, units * jpu)
+    ort = oracle.Runtime(256, 192)
+    oracle.render_jobs(cfg.c, ort, starts, n)
+    np.testing.assert_array_equal(img, oracle.colorize(cfg.c, ort))
+    assert_state_equal(r.runtime(), ort, "render_parallel")
+    # second frame: the runtime is reset, the stream continues (the reference's RNGs persist across frames)
+    img2 = sar.render_parallel(r, cfg.replace(angle=0.5), jpu)
+    starts2 = oracle.start_points(77, units * jpu, units * jpu)
+    ort.reset()
+    c2 = cfg.replace(angle=0.5)
+    oracle.render_jobs(c2.c, ort, starts2, n)
+    np.testing.assert_array_equal(img2, oracle.colorize(c2.c, ort))
+    r.shutdown()
+    assert sar.ParallelRenderer().num_threads() % 256 == 0  # default: CUs*4*64 lanes
+
+
+def test_render_single_draws_from_seeded_stream(sar, oracle, gpu):
+    cfg = _cfg(sar, "poisson_saturne", iterations=200_000, width=128, height=128, seed=5)
+    rt = sar.Runtime(cfg)
+    sar.render(cfg, rt)
+    sar.render(cfg, rt)
+    starts = oracle.start_points(5, 0, 2)
+    ort = oracle.Runtime(128, 128)
+    oracle.render(cfg.c, ort, starts[0], 200_000)
+    oracle.render(cfg.c, ort, starts[1], 200_000)
+    assert_state_equal(rt, ort, "render x2")
+
+
+def test_edge_cases(sar, oracle, gpu):
+    cfg = _cfg(sar, "poisson_saturne", iterations=0, width=33, height=17, jobs_total=5)
+    rt = sar.Runtime(cfg)
+    sar.render_jobs(cfg, rt)                      # zero iterations: nothing changes
+    assert rt.count().sum() == 0 and rt.max() == 0
+    assert np.all(rt.zbuf() == -1.0) and np.all(rt.steps() == 0.0)
+    img = sar.colorize(cfg, rt)                   # max == 0: ln(1)/ln(1) = NaN -> 0 (src/lib.rs:860-869)
+    ort = oracle.Runtime(33, 17)
+    np.testing.assert_array_equal(img, oracle.colorize(cfg.c, ort))
+    d = cfg.replace(render_kind=sar.SAR_RENDER_DEPTH)
+    np.testing.assert_array_equal(sar.colorize(d, rt), oracle.colorize(d.c, ort))
+    # iterations < jobs: per-job count floors to zero
+    few = cfg.replace(iterations=4, jobs_total=5)
+    sar.render_jobs(few, rt)
+    assert rt.count().sum() == 0
+    # 1x1 image, ragged job count (not a multiple of the wave size)
+    tiny = _cfg(sar, "poisson_saturne", iterations=77 * 130, width=1, height=1, jobs_total=77)
+    rt1 = sar.Runtime(tiny)
+    st = sar.start_points(1, 0, 77)
+    sar.render_jobs(tiny, rt1, st)
+    o1 = oracle.Runtime(1, 1)
+    oracle.render_jobs(tiny.c, o1, st, 130)
+    assert_state_equal(rt1, o1, "1x1")
+    # config / runtime size mismatch is an error, not UB
+    with pytest.raises(sar.SarError):
+        sar.render(cfg.replace(width=34), rt)
+    with pytest.raises(sar.SarError):
+        sar.Runtime(cfg.replace(palette_len=0))
+    # zoomed / rotated view with most points out of bounds (previous_point must still advance, :793)
+    zoom = _cfg(sar, "poisson_saturne", iterations=300 * 500, width=80, height=60, jobs_total=300,
+                scale=6.0, angle=2.2)
+    rz, oz = sar.Runtime(zoom), oracle.Runtime(80, 60)
+    sz = sar.start_points(4, 0, 300)
+    sar.render_jobs(zoom, rz, sz); oracle.render_jobs(zoom.c, oz, sz, 500)
+    assert 0 < oz.count.sum() < 300 * 500
+    assert_state_equal(rz, oz, "zoom")
+    np.testing.assert_array_equal(sar.colorize(zoom, rz), oracle.colorize(zoom.c, oz))
+
+
+def test_custom_palette_and_brightness(sar, oracle, gpu):
+    pal = np.array([[0.1, 0.9, 0.3], [0.8, 0.2, 0.6], [0.4, 0.4, 1.0]])
+    cfg = _cfg(sar, "poisson_saturne", iterations=64 * 2000, width=96, height=64, jobs_total=64,
+               palette_rgb=pal, brightness_offset=-0.25, brightness_factor=2.0, transparent=1)
+    st = sar.start_points(8, 0, 64)
+    rt, ort = sar.Runtime(cfg), oracle.Runtime(96, 64)
+    sar.render_jobs(cfg, rt, st); oracle.render_jobs(cfg.c, ort, st, 2000)
+    np.testing.assert_array_equal(sar.colorize(cfg, rt), oracle.colorize(cfg.c, ort))
+
+
+def test_colorize_beyond_ln_table_within_one_lsb(sar, oracle, gpu):
+    """count+1 > 2^20 uses the device log (<= 1 ulp): RGBA16 may differ by at most 1 LSB there."""
+    w = h = 16
+    cfg = _cfg(sar, "poisson_saturne", width=w, height=h, transparent=1)
+    rng = np.random.default_rng(3)
+    cnt = rng.integers(2**20, 2**31, size=(h, w), dtype=np.uint64).astype(np.uint32)
+    cnt[0, 0] = 2**32 - 1                         # count+1 wraps to 0 -> ln(0) = -inf
+    steps = rng.uniform(-0.2, 1.2, size=(h, w)); steps[0, 1] = np.nan
+    z = rng.uniform(-1, 1, size=(h, w)).astype(np.float32)
+    rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
+    mx = int(cnt[1:].max())
+    rt.load(cnt, steps, z, mx)
+    ort.count[:] = cnt; ort.steps[:] = steps; ort.zbuf[:] = z; ort.set_max(mx)
+    a, b = sar.colorize(cfg, rt).astype(np.int64), oracle.colorize(cfg.c, ort).astype(np.int64)
+    assert np.abs(a - b).max() <= 1
+
+
+def test_device_sqrt_div_are_correctly_rounded(sar, oracle, gpu):
+    """The colour transform's sqrt and division must be IEEE-exact on the device: drive them through the
+    depth-winner path with an image so coarse that almost every visit is a winner candidate."""
+    jobs, n = 1024, 400
+    for preset in ("poisson_saturne", "solar_sail"):
+        cfg = _cfg(sar, preset, iterations=jobs * n, width=1024, height=1024, jobs_total=jobs, scale=1.0)
+        st = sar.start_points(31, 0, jobs)
+        rt, ort = sar.Runtime(cfg), oracle.Runtime(1024, 1024)
+        sar.render_jobs(cfg, rt, st); oracle.render_jobs(cfg.c, ort, st, n)
+        assert (ort.zbuf != -1).sum() > 50_000
+        assert_state_equal(rt, ort, preset)
+
+
+def test_deterministic_across_runs(sar, gpu):
+    jobs, n = 8192, 500
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=512, height=512, jobs_total=jobs)
+    st = sar.start_points(1, 0, jobs)
+    outs = []
+    for _ in range(2):
+        rt = sar.Runtime(cfg)
+        sar.render_jobs(cfg, rt, st)
+        outs.append((rt.count(), rt.zbuf(), rt.steps(), rt.max()))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        np.testing.assert_array_equal(_bits(a), _bits(b))
+    assert outs[0][3] == outs[1][3]
