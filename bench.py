@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — attractor iterations/second of the MI355X iterate/accumulate path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one whole frame of BASELINE.json configs[1] on every GPU: reset the runtime (as every
+render_parallel frame does, reference src/lib.rs:950-951), iterate/accumulate 1e9 counted attractor
+iterations of poisson-saturne into a 2048x2048 runtime (start points uploaded inside the step), then —
+for N>1 — the depth/count exchange over RCCL, and colorize to an RGBA16 image in device memory.
+Scaling is WEAK: every GPU renders its own 1e9 iterations of a (N x 1e9)-iteration frame.
+
+One JSON line on rank 0; see DESIGN.md "Measurement" for how each field is derived.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH = HEIGHT = 2048
+ITERS_PER_GPU = 1_000_000_000
+DEFAULT_JOBS = 131072            # trajectories per GPU (2 waves per SIMD); n = floor(1e9 / jobs)
+ALG_BYTES_PER_ITER = 12.0 + 12.0 * 0.0055   # count RMW 8 B + zbuf read 4 B + win-rate * 12 B
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(seconds_hint: float):
+    """The oracle's render_parallel-shaped port (threads + private buffers + serial merge + serial
+    colorize) on this box's host cores. Reported beside the GPU number, never part of it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cfg = O.poisson_saturne()
+    cfg.width, cfg.height, cfg.transparent = WIDTH, HEIGHT, 0
+    # the full C2 frame when the host gets through it in the time hint (~2e7 it/s/thread), else a cut
+    est_rate = 2.0e7 * threads
+    iters = ITERS_PER_GPU if ITERS_PER_GPU / est_rate <= seconds_hint else int(est_rate * seconds_hint)
+    cfg.iterations = iters
+    secs, done, _ = O.render_parallel(cfg, threads, 12, 1, want_image=True)
+    return {
+        "value": done / secs, "unit": "iterations/s", "cores": threads, "kind": "port",
+        "sample": f"poisson-saturne {WIDTH}x{HEIGHT}, {done} iterations, {threads} threads x 12 jobs/thread, "
+                  f"private buffers + serial merge + serial colorize ({secs:.2f} s); C restatement of the "
+                  "reference (clang -O3 -ffp-contract=off), not rustc output",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--jobs", type=int, default=DEFAULT_JOBS, help="trajectories per GPU")
+    ap.add_argument("--iters", type=float, default=ITERS_PER_GPU, help="counted iterations per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=lambda s: int(s, 0), default=0)
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--stride", type=int, default=0)
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import strange_attractor_renderer_amd as S
+    from strange_attractor_renderer_amd.distributed import exchange_merge
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        a.gpus = world
+    if not torch.cuda.is_available() or S.device_count() <= 0:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    jobs = a.jobs
+    iters_gpu = int(a.iters)
+    n = iters_gpu // jobs
+    # global frame: world*jobs trajectories of n iterations; this rank owns jobs [rank*jobs, (rank+1)*jobs)
+    cfg = S.Config.poisson_saturne(iterations=n * jobs * world, width=WIDTH, height=HEIGHT,
+                                   jobs_total=jobs * world, transparent=0, seed=1)
+    starts = S.start_points(1, rank * jobs, jobs)
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        rt = S.Runtime(cfg, device=local_rank)
+        rt.set_stream(stream.cuda_stream)
+        rt.enable_timing(True)
+        rt.set_tuning(block_threads=a.block, checkpoint_stride=a.stride, variant=a.variant)
+        npix = WIDTH * HEIGHT
+        rgba = torch.empty(npix * 4, dtype=torch.int16, device="cuda")
+        if world > 1:
+            key = torch.empty(npix, dtype=torch.int64, device="cuda")
+            sums = torch.empty(3 * npix, dtype=torch.int32, device="cuda")
+
+        def step():
+            rt.reset()
+            S.render_job_range(cfg, rt, n, starts)
+            if world > 1:
+                # Runtime::merge folded in rank order as two collectives over xGMI:
+                # depth keys (z, lowest rank wins ties) -> all-reduce MAX; counts + winner's steps -> reduce SUM
+                exchange_merge(rt, rank, dist, key, sums, dst=0)
+            if rank == 0:
+                S.colorize_device(cfg, rt, rgba.data_ptr())
+
+        def fence():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(a.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        iter_ms = fold_ms = 0.0
+        launches = 0
+        for _ in range(a.steps):
+            step()
+            if rank == 0:
+                pass
+        fence()
+        elapsed = time.perf_counter() - t0
+        # device-side duration of the dominant kernel, from HIP events recorded on the launch stream
+        # (one more un-timed step so that reading the events does not perturb the timed region)
+        step()
+        torch.cuda.synchronize()
+        tm = rt.last_timing()
+        iter_ms, fold_ms, launches = tm.iterate_ms, tm.resolve_ms, tm.iterate_launches
+        col_ms = tm.colorize_ms
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+    counted = n * jobs * world * a.steps
+    value = counted / elapsed
+    if rank == 0:
+        kern_s = iter_ms * 1e-3 / max(launches, 1)
+        ach = ALG_BYTES_PER_ITER * (n * jobs / max(launches, 1)) / kern_s / 1e9
+        out = {
+            "metric": "attractor iterations/sec at 1e9 iters, 2048x2048 buffer (poisson-saturne), per-GPU frame",
+            "value": value, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: poisson-saturne, 1e9 iterations per GPU, 2048x2048, "
+                                   "Gas colorize to RGBA16 in HBM", "jobs_per_gpu": jobs,
+                       "iterations_per_job": n, "counted_iterations_per_step": n * jobs * world,
+                       "warmup_iterations_per_job_uncounted": 1000,
+                       "parallelism": f"trajectories sharded over {world} GPU(s)"
+                                      + ("; all-reduce MAX (depth keys) + reduce SUM (count, steps) over RCCL" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_iterate", "kernel_ms": kern_s * 1e3,
+                         "alg_bytes_per_iteration": ALG_BYTES_PER_ITER,
+                         "note": "scatter state lives in L2/Infinity Cache; co-bound is fp64 VALU "
+                                 "(88 unfused flops/iteration => ~4e11 it/s), see DESIGN.md"},
+            "kernel_ms": {"iterate": iter_ms, "fold_resolve": fold_ms, "colorize": col_ms},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+"""CPU: the C-ABI library loads, exports everything include/sar.h declares, agrees with the ctypes mirror on
+the struct layout, and its host-side logic (presets, setup math, start-point stream, validation, error
+behaviour) matches the oracle / the reference's data. No compute calls: there is no GPU here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sar.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sar_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(sar):
+    from strange_attractor_renderer_amd import _abi
+    lib = sar.load_library()
+    names = declared_functions()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/sar.h but not exported by libsar_hip.so"
+    assert sorted(_abi.PROTOTYPES) == names, "ctypes prototypes and header declarations differ"
+    assert lib.sar_abi_version() == 1
+
+
+def test_struct_layout_matches_c(sar):
+    from strange_attractor_renderer_amd._abi import SarConfig, SarTiming
+    fields = ["iterations", "width", "render_kind", "angle", "coeff_x", "coeff_z", "palette_len", "palette_rgb",
+              "brightness_offset", "center_camera", "rotation_axis", "rotation_angle", "scale", "color_transform",
+              "ct_offset", "seed", "jobs_total"]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "sar.h"\nint main(void){\n'
+    prog += 'printf("%zu %zu\\n", sizeof(sar_config), sizeof(sar_timing));\n'
+    for f in fields:
+        prog += f'printf("%zu\\n", offsetof(sar_config, {f}));\n'
+    prog += "return 0;}\n"
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe],
+                       check=True)  # the header must be plain C
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == C.sizeof(SarConfig) and int(out[1]) == C.sizeof(SarTiming)
+    for f, off in zip(fields, out[2:]):
+        assert getattr(SarConfig, f).offset == int(off), f
+
+
+def test_presets_are_the_reference_values(sar, oracle):
+    assert bytes(sar.Config.poisson_saturne().c) == bytes(oracle.poisson_saturne())
+    assert bytes(sar.Config.solar_sail().c) == bytes(oracle.solar_sail())
+    c = sar.Config.poisson_saturne()
+    # Config::new defaults (src/lib.rs:289-307)
+    assert (c.iterations, c.width, c.height, c.transparent, c.angle, c.silent) == (10_000_000, 1920, 1080, 1, 0.0, 1)
+    assert c.render_kind == sar.SAR_RENDER_GAS and c.palette_len == 6
+    assert c.brightness_offset == -0.15 and c.brightness_factor == 5.0 / 3.0
+    assert c.center_camera[2] == -0.366 + 0.12 and c.scale == 1.0
+    s = sar.Config.solar_sail()
+    assert s.scale == 1.7 and s.color_transform == sar.SAR_CT_ADJUSTED_VELOCITY
+    assert (s.ct_offset, s.ct_factor) == (0.8, -0.2)
+    # `Config { iterations: 100_000_000, ..Config::poisson_saturne() }` (the reference's only doc-test, :9-15)
+    d = sar.Config.poisson_saturne(iterations=100_000_000)
+    assert d.iterations == 100_000_000 and d.width == 1920
+    d.validate()
+
+
+def test_setup_math_matches_oracle_bit_for_bit(sar, oracle):
+    for mk_s, mk_o in ((sar.Config.poisson_saturne, oracle.poisson_saturne), (sar.Config.solar_sail, oracle.solar_sail)):
+        a = mk_s().rotation_matrix()
+        b = oracle.rotation_matrix(mk_o())
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    for seed, first, n in ((0, 0, 7), (1, 5, 2), (2**63 + 12345, 1000, 33)):
+        assert np.array_equal(sar.start_points(seed, first, n), oracle.start_points(seed, first, n))
+
+
+def test_validation_and_error_reporting(sar):
+    lib = sar.load_library()
+    for bad in (dict(width=0), dict(height=0), dict(render_kind=7), dict(color_transform=5), dict(palette_len=0),
+                dict(palette_len=16), dict(attractor_kind=3), dict(width=65536, height=65536)):
+        with pytest.raises(sar.SarError) as e:
+            sar.Config.poisson_saturne(**bad).validate()
+        assert e.value.status in (1, 6)
+    assert lib.sar_config_validate(None) == 1
+    assert lib.sar_config_poisson_saturne(None) == 1
+    assert lib.sar_status_string(2).decode() == "runtime dimensions differ"
+    assert lib.sar_status_string(12345).decode() == "unknown status"
+    assert lib.sar_runtime_free(None) == 0 and lib.sar_renderer_shutdown(None) == 0
+    assert lib.sar_runtime_reset(None) == 1 and lib.sar_runtime_merge(None, None) == 1
+
+
+def test_no_device_is_an_error_not_a_fallback(sar):
+    if sar.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(sar.SarError) as e:
+        sar.Runtime(sar.Config.poisson_saturne(width=8, height=8))
+    assert e.value.status == 3  # SAR_ERR_NO_DEVICE
+    with pytest.raises(sar.SarError) as e:
+        sar.ParallelRenderer()
+    assert e.value.status == 3
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under the product package may import, link or load it."""
+    pkg = os.path.join(ROOT, "strange_attractor_renderer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle_lib" not in text and "libsar_oracle" not in text and "sar_oracle" not in text, f
+    out = subprocess.run(["ldd", os.path.join(pkg, "libsar_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+def test_missing_library_fails_loudly(sar):
+    from strange_attractor_renderer_amd import _abi
+    with pytest.raises(_abi.SarLibraryMissing):
+        _abi.load_library("/nonexistent/libsar_hip.so")
