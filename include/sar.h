@@ -214,13 +214,16 @@ int sar_renderer_runtime(sar_renderer* r, sar_runtime** out_borrowed);
 /* ---- measurement ----------------------------------------------------------------------------------- */
 int sar_runtime_enable_timing(sar_runtime* rt, int enabled);
 int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
-/* Tuning knobs (0 keeps the default): lanes per workgroup of the iterate kernel and checkpoint
- * stride (iterations between trajectory checkpoints used by the payload resolve).
- * variant: bits 0-3 scratch-bin layout (0 default, 1 one copy + agent-scope atomics, 2 one copy per
- * XCD + L2-local atomics); bits 4-7 measurement-only kernels (0 full path, 1 count only, 2 arithmetic
- * only — results are NOT the render); bits 8-31 test hook: cap on jobs per launch chunk. */
-int sar_runtime_set_tuning(sar_runtime* rt, uint32_t block_threads, uint32_t checkpoint_stride,
-                           uint32_t variant);
+/* Tuning / test options by name (value 0 restores the default unless noted):
+ *   "block_threads"      lanes per workgroup of the iterate kernel (64, 128, 192, 256)
+ *   "checkpoint_stride"  iterations between trajectory checkpoints used by the payload resolve
+ *   "path"               accumulate path: 0 default (= 3 when the image fits), 1 one global atomic per
+ *                        visit at agent scope, 2 the same into one scratch copy per XCD, 3 LDS-binned records
+ *   "bin_shift"          log2(pixels per bin) of the binned path (12..15)
+ *   "splits"             workgroups per bin in the record-accumulate kernel (1..16)
+ *   "measure"            measurement-only kernels: 1 count only, 2 arithmetic only (results are NOT the render)
+ *   "debug_chunk_jobs"   test hook: cap on jobs per launch chunk */
+int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value);
 
 #ifdef __cplusplus
 }

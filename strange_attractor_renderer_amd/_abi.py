@@ -115,7 +115,7 @@ PROTOTYPES = {
     "sar_renderer_runtime": (C.c_int, [_vp, _P(_vp)]),
     "sar_runtime_enable_timing": (C.c_int, [_vp, C.c_int]),
     "sar_runtime_last_timing": (C.c_int, [_vp, _P(SarTiming)]),
-    "sar_runtime_set_tuning": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "sar_runtime_set_option": (C.c_int, [_vp, C.c_char_p, C.c_uint64]),
 }
 
 LIB_NAME = "libsar_hip.so"

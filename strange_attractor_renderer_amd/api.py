@@ -223,9 +223,18 @@ class Runtime:
         return Timing(t.iterate_ms, t.resolve_ms, t.colorize_ms, t.merge_ms, t.iterate_launches,
                       t.iterations_counted)
 
-    def set_tuning(self, block_threads: int = 0, checkpoint_stride: int = 0, variant: int = 0):
-        _check(_lib().sar_runtime_set_tuning(self._h, block_threads, checkpoint_stride, variant),
-               "sar_runtime_set_tuning")
+    def set_option(self, name: str, value: int):
+        _check(_lib().sar_runtime_set_option(self._h, name.encode(), int(value)), f"sar_runtime_set_option({name})")
+
+    def set_tuning(self, block_threads: int = 0, checkpoint_stride: int = 0, variant: int = 0, **more):
+        """Convenience over set_option. variant: bits 0-3 path, bits 4-7 measure, bits 8+ debug_chunk_jobs."""
+        self.set_option("block_threads", block_threads)
+        self.set_option("checkpoint_stride", checkpoint_stride)
+        self.set_option("path", variant & 0xF)
+        self.set_option("measure", (variant >> 4) & 0xF)
+        self.set_option("debug_chunk_jobs", variant >> 8)
+        for k, v in more.items():
+            self.set_option(k, v)
 
     def stream(self) -> int:
         s = C.c_void_p()

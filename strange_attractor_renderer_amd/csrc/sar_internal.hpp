@@ -58,6 +58,27 @@ struct IterArgs {
     double* ckpt;              // [n_ckpt][3][n_jobs]
 };
 
+// Binned variant of the iterate kernel (see sar_kernels.hip: k_iterate_binned).
+struct BinIterArgs {
+    IterArgs it;                 // scratch_count unused here (counts travel as records)
+    uint32_t bin_shift;          // log2(pixels per bin)
+    uint32_t n_bins;             // B = ceil(npix / bin_px) <= kMaxBins
+    uint32_t chunks_per_wave;    // arena capacity of one wave, in 64-byte chunks
+    uint32_t n_waves;            // launched waves (= heads stride)
+    void* arena;                 // [n_waves][chunks_per_wave] 64-byte chunks {prev, n, 28 x u16}
+    uint32_t* heads;             // [n_bins][n_waves] last chunk of each (bin, wave) list, or kNoChunk
+    uint32_t* zhint;             // [8][npix] per-XCD lower bound of the sortable depth already binned
+    unsigned long long* nan_count;  // iterations of diverged (NaN) trajectories: all land on pixel (0,0)
+};
+
+struct BinAccArgs {
+    uint32_t bin_shift, n_bins, chunks_per_wave, n_waves;
+    uint32_t npix, splits, _pad0, _pad1;
+    const void* arena;
+    const uint32_t* heads;
+    uint32_t* scratch_count;     // [splits][npix], fully overwritten
+};
+
 struct FoldArgs {
     MapParams p;
     ColorTransformParams ct;
@@ -65,7 +86,10 @@ struct FoldArgs {
     uint32_t n_jobs;
     uint32_t npix;
     uint32_t ckpt_stride;
-    uint32_t copies;
+    uint32_t copies;             // scratch_count copies
+    uint32_t key_copies;         // scratch_key copies
+    uint32_t _pad;
+    unsigned long long* nan_count;  // nullable; added to pixel 0 and cleared
     uint32_t* count;                 // persistent [npix]
     unsigned long long* key;         // persistent [npix]: hi = sortable(zbuf), lo = 0xFFFFFFFF
     double* steps;                   // persistent [npix]
@@ -98,5 +122,9 @@ static inline uint32_t f32_sortable_host(float f) {
 
 constexpr uint32_t kLnLutEntries = 1u << 20;  // ln(k+1), k < 2^20, host libm (exact parity with the oracle)
 constexpr uint64_t kMaxChunkOrdinals = 0xFFFFFFFEull;
+constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
+constexpr uint32_t kChunkRecords = 28;   // u16 records per 64-byte chunk (8-byte header)
+constexpr uint32_t kMaxBins = 1024;      // LDS staging is 64 B per bin per wave
+constexpr uint32_t kMaxBinPx = 32768;    // phase-2 LDS histogram: 4 B per pixel of the bin
 
 }  // namespace sar

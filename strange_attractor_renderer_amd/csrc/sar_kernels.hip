@@ -212,6 +212,265 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_iterate_binned — the hot loop without a global atomic per visit
+// ---------------------------------------------------------------------------------------------------
+// Measured on MI355X: the chip retires ~2.1e10 scattered global atomics per second whatever their
+// scope or width, while the fp64 arithmetic of this loop alone runs at ~3.6e11 iterations/s. So a
+// visit must not cost a global atomic. Here every visit becomes a 2-byte RECORD instead:
+//
+//   * the image is cut into B bins of 2^bin_shift consecutive pixels; a record is the pixel's offset
+//     inside its bin (u16);
+//   * each WAVE owns B staging buffers of 28 records in LDS (64 B per bin: counter, link, 28 x u16);
+//     a visit takes a slot with one LDS atomic (ds_add_rtn) and writes its u16 there;
+//   * the lane that takes the last slot copies the 28 records + {link to the previous chunk of this
+//     (wave, bin), count} as ONE 64-byte chunk to the wave's private arena in HBM — position from a
+//     wave-local cursor, so no global atomic and nothing to wait for — and resets the buffer;
+//   * k_bin_accumulate later walks the per-(bin, wave) chunk lists and histograms them in LDS.
+//
+// Depth: the 64-bit key atomic-max survives only for visits that can still win. Each XCD keeps a
+// private array of depth hints (a lower bound of the best sortable z this XCD has already sent for
+// the pixel, plain loads/stores served by the XCD's own L2); a visit is sent iff its z is >= the
+// hint. The hint read is issued one iteration ahead of its use, so its latency hides behind the next
+// iteration's arithmetic. A stale or lost hint only costs an extra atomic, never a wrong result.
+template <bool DEPTH>
+__global__ void __launch_bounds__(256) k_iterate_binned(const BinIterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t B = a.n_bins;
+    uint32_t* const cnt = smem + (threadIdx.x >> 6) * (B * 16u);  // [B] fill counters
+    uint32_t* const prv = cnt + B;                                  // [B] previous chunk of this (wave, bin)
+    unsigned short* const rec = (unsigned short*)(prv + B);        // [B][28] staged records
+    for (uint32_t b = lane; b < B; b += 64u) {
+        cnt[b] = 0u;
+        prv[b] = kNoChunk;
+    }
+
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t wave = job >> 6;
+    bool alive = job < a.it.n_jobs;
+
+    MapParams p = a.it.p;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) p.cz[k] = vgpr_pin(p.cz[k]);  // this kernel needs more SGPRs for its loops
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p.m[k] = vgpr_pin(p.m[k]);
+    p.sin_v = vgpr_pin(p.sin_v);
+    p.cos_v = vgpr_pin(p.cos_v);
+    p.ccx = vgpr_pin(p.ccx);
+    p.ccy = vgpr_pin(p.ccy);
+    p.ccz = vgpr_pin(p.ccz);
+    p.width = vgpr_pin(p.width);
+    p.height = vgpr_pin(p.height);
+    p.half_height = vgpr_pin(p.half_height);
+    p.width_scaled = vgpr_pin(p.width_scaled);
+    p.scale_adjusted_mid = vgpr_pin(p.scale_adjusted_mid);
+
+    double x = 0., y = 0., z = 0.;
+    if (alive) {
+        x = a.it.starts[job];
+        y = a.it.starts[a.it.n_jobs + job];
+        z = a.it.starts[2u * a.it.n_jobs + job];
+        for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);  // warm-up (:750-752)
+    }
+
+    uint4* const arena = (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * 4u;  // 4 x uint4 per chunk
+    uint32_t cursor = 0;  // wave-uniform: next free chunk of this wave's arena
+    uint32_t* const zhint = a.zhint + (size_t)xcc_id() * a.it.npix;
+    unsigned long long* const key = a.it.scratch_key;
+
+    const uint32_t n = (uint32_t)a.it.iters;
+    const uint32_t lo_base = 0xFFFFFFFFu - job * n;
+    const uint32_t C = a.it.ckpt_stride;
+    const size_t cs = a.it.n_jobs;
+    const uint32_t bin_mask = (1u << a.bin_shift) - 1u;
+
+    // depth candidate of the previous iteration, waiting for its hint
+    bool pv = false;
+    uint32_t p_idx = 0, p_zkey = 0, p_lo = 0, p_hint = 0;
+    // visit of the previous iteration, waiting for its LDS slot (requested one iteration ahead so that
+    // the LDS round trip hides behind the arithmetic)
+    bool b_have = false;
+    uint32_t b_bin = 0, b_slot = 0;
+    unsigned short b_local = 0;
+
+    // Places the pending visit. Slots are handed out consecutively per bin, so slot = 28*gen + pos says
+    // which refill generation of the 28-record buffer the record belongs to. Trip g of the loop writes
+    // generation g; the lane holding pos 27 copies the full buffer out as one chunk and takes 28 off the
+    // counter; lanes of generation g+1 with pos < 27 can then write at once (their buffer was emptied a
+    // few instructions earlier, LDS operations of a wave execute in order). More than one trip is only
+    // needed when a lane holds pos 27 of a later generation, i.e. ~29+ lanes hit one bin at once.
+    auto finish_visit = [&]() {
+        bool pend = b_have;
+        const uint32_t gen = b_slot / kChunkRecords;
+        const uint32_t pos = b_slot - gen * kChunkRecords;
+        unsigned short* const dstrec = rec + b_bin * kChunkRecords;
+        for (uint32_t g = 0; __ballot(pend); ++g) {
+            const bool mine = pend && gen == g;
+            if (mine) dstrec[pos] = b_local;
+            const bool flusher = mine && pos == kChunkRecords - 1u;
+            const unsigned long long fb = __ballot(flusher);
+            if (fb) {
+                if (flusher) {
+                    const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
+                                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
+                    const uint2* r = (const uint2*)dstrec;  // 56 B, 8-byte aligned
+                    const uint2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
+                    uint4* dst = arena + (size_t)chunk * 4u;
+                    dst[0] = make_uint4(prv[b_bin], kChunkRecords, r0.x, r0.y);
+                    dst[1] = make_uint4(r1.x, r1.y, r2.x, r2.y);
+                    dst[2] = make_uint4(r3.x, r3.y, r4.x, r4.y);
+                    dst[3] = make_uint4(r5.x, r5.y, r6.x, r6.y);
+                    prv[b_bin] = chunk;
+                    __hip_atomic_fetch_sub(&cnt[b_bin], kChunkRecords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                cursor += (uint32_t)__popcll(fb);
+            }
+            const bool early = pend && gen == g + 1u && pos < kChunkRecords - 1u;
+            if (early) dstrec[pos] = b_local;
+            pend = pend && !(mine || early);
+        }
+    };
+
+    uint32_t t = 0;
+    double* ck = a.it.ckpt + job;
+    while (t < n) {
+        if (alive) {  // checkpoint: the state BEFORE iteration t
+            ck[0] = x;
+            ck[cs] = y;
+            ck[2 * cs] = z;
+        }
+        ck += 3 * cs;
+        const uint32_t tend = (n - t > C) ? t + C : n;
+        for (; t < tend; ++t) {
+            bool inb = false;
+            uint32_t idx = 0;
+            double z2 = 0.;
+            if (alive) {
+                next_point(p, x, y, z);  // :770
+                if (x != x) {
+                    // absorbing NaN state (see k_iterate): this and all remaining iterations hit pixel (0,0)
+                    alive = false;
+                    atomicAdd(a.nan_count, (unsigned long long)(n - t));
+                } else {
+                    double sx, sy, sz;
+                    screen_space(p, x, y, z, sx, sy, sz);  // :773
+                    const double ax = sx + p.ccx;
+                    const double az = sz + p.ccy;
+                    const double x2 = ax * p.cos_v + az * p.sin_v;  // :776-779
+                    z2 = ax * p.sin_v - az * p.cos_v;
+                    const double fi = (p.scale_adjusted_mid - x2) * p.width_scaled;   // :783
+                    const double fj = p.half_height - (sy + p.ccz) * p.width_scaled;  // :786
+                    inb = !(fi >= p.width || fj >= p.height || fi < 0. || fj < 0.);    // :789
+                    if (inb) {
+                        const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;
+                        const uint32_t j = (fj == fj) ? (uint32_t)fj : 0u;
+                        idx = j * a.it.width + i;
+                    }
+                }
+            }
+
+            if (DEPTH) {
+                // (1) settle the previous iteration's depth candidate: its hint has had a whole
+                //     iteration of arithmetic to arrive
+                if (pv && p_zkey >= p_hint) {
+                    atomicMax(key + p_idx, ((unsigned long long)p_zkey << 32) | (unsigned long long)p_lo);
+                    if (p_zkey > p_hint) zhint[p_idx] = p_zkey;
+                }
+                // (2) this iteration's candidate: strict `>` against the initial -1.0 (:693, :821)
+                pv = false;
+                if (inb) {
+                    float zf = (float)z2;  // `z2 as f32`
+                    if (zf > -1.0f) {
+                        zf = zf + 0.0f;  // -0.0 -> +0.0: integer order == float order
+                        pv = true;
+                        p_idx = idx;
+                        p_zkey = f32_sortable(zf);
+                        p_lo = lo_base - t;
+                        p_hint = zhint[idx];
+                    }
+                }
+            }
+
+            // (3) the visits (:807-812) as staged records: place the previous one, request a slot for this one
+            finish_visit();
+            b_have = inb;
+            if (inb) {
+                b_bin = idx >> a.bin_shift;
+                b_local = (unsigned short)(idx & bin_mask);
+                b_slot = atomicAdd(&cnt[b_bin], 1u);  // ds_add_rtn_u32
+            }
+        }
+    }
+    finish_visit();
+    if (DEPTH) {
+        if (pv && p_zkey >= p_hint) {
+            atomicMax(key + p_idx, ((unsigned long long)p_zkey << 32) | (unsigned long long)p_lo);
+            if (p_zkey > p_hint) zhint[p_idx] = p_zkey;
+        }
+    }
+
+    // flush the partly filled buffers and publish the list heads
+    for (uint32_t b0 = 0; b0 < B; b0 += 64u) {
+        const uint32_t b = b0 + lane;
+        const uint32_t have = (b < B) ? cnt[b] : 0u;
+        const bool flusher = have != 0u;
+        const unsigned long long fb = __ballot(flusher);
+        uint32_t head = (b < B) ? prv[b] : kNoChunk;
+        if (flusher) {
+            const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
+            const uint2* r = (const uint2*)(rec + b * kChunkRecords);
+            const uint2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
+            uint4* dst = arena + (size_t)chunk * 4u;
+            dst[0] = make_uint4(head, have, r0.x, r0.y);
+            dst[1] = make_uint4(r1.x, r1.y, r2.x, r2.y);
+            dst[2] = make_uint4(r3.x, r3.y, r4.x, r4.y);
+            dst[3] = make_uint4(r5.x, r5.y, r6.x, r6.y);
+            head = chunk;
+        }
+        cursor += (uint32_t)__popcll(fb);
+        if (b < B) a.heads[(size_t)b * a.n_waves + wave] = head;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_bin_accumulate — records -> per-pixel hit counts, in LDS
+// ---------------------------------------------------------------------------------------------------
+// grid (B, splits): block (b, s) owns bin b and the waves w with w % splits == s. Every thread walks
+// whole (bin, wave) chunk lists (64-byte loads, newest chunk first) and adds the records into the
+// bin's LDS histogram with LDS atomics; the histogram is then written — plainly, fully — as copy s of
+// the scratch count bins, which k_fold_resolve sums into Runtime::count.
+__global__ void __launch_bounds__(256) k_bin_accumulate(const BinAccArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    const uint32_t b = blockIdx.x, s = blockIdx.y;
+    const uint32_t bin_px = 1u << a.bin_shift;
+    for (uint32_t k = threadIdx.x; k < bin_px; k += blockDim.x) hist[k] = 0u;
+    __syncthreads();
+    const uint4* arena = (const uint4*)a.arena;
+    for (uint32_t w = s + a.splits * threadIdx.x; w < a.n_waves; w += a.splits * blockDim.x) {
+        uint32_t chunk = a.heads[(size_t)b * a.n_waves + w];
+        const uint4* base = arena + (size_t)w * a.chunks_per_wave * 4u;
+        while (chunk != kNoChunk) {
+            const uint4* c = base + (size_t)chunk * 4u;
+            const uint4 q0 = c[0], q1 = c[1], q2 = c[2], q3 = c[3];
+            const uint32_t nrec = q0.y;
+            const uint32_t words[14] = {q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+            for (uint32_t r = 0; r < 14u; ++r) {
+                if (2u * r < nrec) atomicAdd(&hist[words[r] & 0xFFFFu], 1u);
+                if (2u * r + 1u < nrec) atomicAdd(&hist[words[r] >> 16], 1u);
+            }
+            chunk = q0.x;
+        }
+    }
+    __syncthreads();
+    const uint32_t px0 = b << a.bin_shift;
+    uint32_t* out = a.scratch_count + (size_t)s * a.npix;
+    for (uint32_t k = threadIdx.x; k < bin_px; k += blockDim.x)
+        if (px0 + k < a.npix) out[px0 + k] = hist[k];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // block-level reductions (result valid in thread 0)
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t block_max_u32(uint32_t v, uint32_t* s_tmp /* [4] */) {
@@ -272,9 +531,16 @@ __global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) {
         for (uint32_t c = 0; c < a.copies; ++c) {
             const size_t o = (size_t)c * a.npix + px;
             const uint32_t sc = a.scratch_count[o];
-            const unsigned long long sk = a.scratch_key[o];
             if (sc) { add += sc; a.scratch_count[o] = 0; }
+        }
+        for (uint32_t c = 0; c < a.key_copies; ++c) {
+            const size_t o = (size_t)c * a.npix + px;
+            const unsigned long long sk = a.scratch_key[o];
             if (sk) { kbest = sk > kbest ? sk : kbest; a.scratch_key[o] = 0; }
+        }
+        if (px == 0 && a.nan_count) {  // diverged trajectories: every iteration after the NaN hits (0,0)
+            add += *a.nan_count;
+            *a.nan_count = 0;
         }
         if (add) {
             // count += hits, wrapping like the release build (:811); if the u32 wraps, the reference's
@@ -529,6 +795,26 @@ void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode,
         else if (mode == 1) hipLaunchKernelGGL((k_iterate<false, 1>), dim3(grid), dim3(block), 0, s, a);
         else hipLaunchKernelGGL((k_iterate<false, 0>), dim3(grid), dim3(block), 0, s, a);
     }
+}
+
+void launch_iterate_binned(const BinIterArgs& a, uint32_t block, bool depth, hipStream_t s) {
+    const uint32_t grid = (a.it.n_jobs + block - 1) / block;
+    const size_t lds = (size_t)(block / 64u) * a.n_bins * 64u;
+    if (depth) hipLaunchKernelGGL((k_iterate_binned<true>), dim3(grid), dim3(block), lds, s, a);
+    else hipLaunchKernelGGL((k_iterate_binned<false>), dim3(grid), dim3(block), lds, s, a);
+}
+
+void launch_bin_accumulate(const BinAccArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)4u << a.bin_shift;
+    hipLaunchKernelGGL(k_bin_accumulate, dim3(a.n_bins, a.splits), dim3(256), lds, s, a);
+}
+
+int binned_kernel_attributes() {
+    // both kernels need more dynamic LDS than the 64 KiB default window
+    hipError_t e = hipFuncSetAttribute((const void*)k_iterate_binned<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_binned<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return (int)e;
 }
 
 void launch_fold_resolve(const FoldArgs& a, hipStream_t s) {

@@ -69,9 +69,18 @@ struct sar_runtime {
     Rng rng;
 
     // scratch bins the iterate kernel accumulates into (zero between launches)
-    uint32_t copies = 0;
+    uint32_t copies = 0;      // scratch_count copies
+    uint32_t key_copies = 0;  // scratch_key copies
     uint32_t* d_scratch_count = nullptr;
     unsigned long long* d_scratch_key = nullptr;
+
+    // binned path: per-wave record arenas, list heads, per-XCD depth hints, NaN iteration counter
+    void* d_arena = nullptr;
+    size_t arena_cap = 0;  // bytes
+    uint32_t* d_heads = nullptr;
+    size_t heads_cap = 0;  // entries
+    uint32_t* d_zhint = nullptr;
+    unsigned long long* d_nan_count = nullptr;
 
     // staging
     double* h_starts = nullptr;  // pinned
@@ -88,9 +97,12 @@ struct sar_runtime {
     // tuning
     uint32_t block_threads = kDefaultBlock;
     uint32_t ckpt_stride = kDefaultCkptStride;
-    uint32_t bins_mode = 0;     // 0 default, 1 single copy + agent-scope atomics, 2 per-XCD copies
+    uint32_t bins_mode = 0;     // 0 default (binned when eligible), 1 one copy + agent-scope atomics,
+                                // 2 one copy per XCD + L2-local atomics, 3 LDS-binned records
     uint32_t measure_mode = 0;  // 0 full path, 1 count only, 2 arithmetic only
     uint32_t debug_chunk_jobs = 0;  // test hook: cap on jobs per launch chunk (0 = none)
+    uint32_t bin_shift = 0;         // 0 = automatic
+    uint32_t splits = 0;            // 0 = automatic
 
     // timing
     bool timing = false;
@@ -118,6 +130,8 @@ int free_device_buffers(sar_runtime* rt) {
     if (rt->d_scratch_key) hipFree(rt->d_scratch_key);
     if (rt->d_rgba) hipFree(rt->d_rgba);
     if (rt->d_ztmp) hipFree(rt->d_ztmp);
+    if (rt->d_zhint) hipFree(rt->d_zhint);
+    rt->d_zhint = nullptr;
     rt->d_count = nullptr;
     rt->d_key = nullptr;
     rt->d_steps = nullptr;
@@ -126,6 +140,7 @@ int free_device_buffers(sar_runtime* rt) {
     rt->d_rgba = nullptr;
     rt->d_ztmp = nullptr;
     rt->copies = 0;
+    rt->key_copies = 0;
     return SAR_OK;
 }
 
@@ -143,22 +158,62 @@ int alloc_image_buffers(sar_runtime* rt, uint32_t w, uint32_t h) {
     return SAR_OK;
 }
 
-int ensure_scratch(sar_runtime* rt, uint32_t copies) {
-    if (rt->copies == copies && rt->d_scratch_count) return SAR_OK;
-    if (rt->d_scratch_count) hipFree(rt->d_scratch_count);
-    if (rt->d_scratch_key) hipFree(rt->d_scratch_key);
-    rt->d_scratch_count = nullptr;
-    rt->d_scratch_key = nullptr;
-    const size_t n = static_cast<size_t>(copies) * rt->npix;
-    HIP_TRY(hipMalloc(&rt->d_scratch_count, n * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&rt->d_scratch_key, n * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(rt->d_scratch_count, 0, n * sizeof(uint32_t), rt->stream));
-    HIP_TRY(hipMemsetAsync(rt->d_scratch_key, 0, n * sizeof(unsigned long long), rt->stream));
-    rt->copies = copies;
+int ensure_scratch(sar_runtime* rt, uint32_t copies, uint32_t key_copies) {
+    if (rt->copies != copies || !rt->d_scratch_count) {
+        if (rt->d_scratch_count) hipFree(rt->d_scratch_count);
+        rt->d_scratch_count = nullptr;
+        rt->copies = 0;
+        const size_t n = static_cast<size_t>(copies) * rt->npix;
+        HIP_TRY(hipMalloc(&rt->d_scratch_count, n * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(rt->d_scratch_count, 0, n * sizeof(uint32_t), rt->stream));
+        rt->copies = copies;
+    }
+    if (rt->key_copies != key_copies || !rt->d_scratch_key) {
+        if (rt->d_scratch_key) hipFree(rt->d_scratch_key);
+        rt->d_scratch_key = nullptr;
+        rt->key_copies = 0;
+        const size_t n = static_cast<size_t>(key_copies) * rt->npix;
+        HIP_TRY(hipMalloc(&rt->d_scratch_key, n * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(rt->d_scratch_key, 0, n * sizeof(unsigned long long), rt->stream));
+        rt->key_copies = key_copies;
+    }
+    return SAR_OK;
+}
+
+// Bin geometry of the LDS-binned path: bins of 2^shift consecutive pixels, at most kMaxBins of them.
+struct BinGeometry {
+    uint32_t shift = 0, bins = 0, block = 0, splits = 0;
+    bool ok = false;
+};
+BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift, uint32_t want_splits) {
+    BinGeometry g;
+    uint32_t px = 4096;
+    while (px < kMaxBinPx && static_cast<uint64_t>(px) * 256u < npix) px <<= 1;
+    if (want_shift) px = 1u << want_shift;
+    g.bins = (npix + px - 1) / px;
+    if (g.bins > kMaxBins) return g;
+    while ((1u << g.shift) < px) ++g.shift;
+    const uint32_t waves_fit = (160u * 1024u) / (g.bins * 64u);
+    uint32_t block = want_block;
+    if (block > waves_fit * 64u) block = waves_fit * 64u;
+    if (block == 0) return g;
+    g.block = block;
+    g.splits = 2048u / g.bins;
+    if (g.splits < 1) g.splits = 1;
+    if (g.splits > 16) g.splits = 16;
+    if (want_splits) g.splits = want_splits;
+    g.ok = true;
+    return g;
+}
+
+int clear_hints(sar_runtime* rt) {
+    // hints are lower bounds of depths already accumulated; anything that can lower zbuf voids them
+    if (rt->d_zhint) HIP_TRY(hipMemsetAsync(rt->d_zhint, 0, static_cast<size_t>(rt->npix) * 8u * sizeof(uint32_t), rt->stream));
     return SAR_OK;
 }
 
 int do_reset(sar_runtime* rt) {
+    SAR_TRY(clear_hints(rt));
     launch_reset(rt->d_count, rt->d_key, rt->d_steps, rt->npix, rt->d_scalars, rt->stream);
     HIP_TRY(hipGetLastError());
     return SAR_OK;
@@ -250,20 +305,30 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
     }
     HIP_TRY(hipSetDevice(rt->device));
 
+    // which accumulate path: LDS-binned records (default) or one global atomic per visit
+    const BinGeometry geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits);
+    bool binned = (rt->bins_mode == 0 || rt->bins_mode == 3) && rt->measure_mode != 2 && geo.ok;
+    if (rt->bins_mode == 3 && !geo.ok) {
+        set_error("the binned path needs width*height <= %u pixels", kMaxBins * kMaxBinPx);
+        return SAR_ERR_RANGE;
+    }
+    const bool xcd_local = (rt->bins_mode == 2);
+    const uint32_t block = binned ? geo.block : rt->block_threads;
+
     const uint32_t C = rt->ckpt_stride;
     const uint64_t n_ckpt = (iters + C - 1) / C;
+    const uint64_t chunks_per_wave = (iters * 64ull + kChunkRecords - 1) / kChunkRecords + geo.bins;
     uint64_t chunk_jobs = kMaxChunkOrdinals / iters;
-    const uint64_t by_mem = kCkptBytesCap / (n_ckpt * 24ull);
+    // scratch per job: checkpoints (24 B each) + its share of the wave's record arena (binned path)
+    const uint64_t bytes_per_job = n_ckpt * 24ull + (binned ? chunks_per_wave : 0ull);
+    const uint64_t by_mem = kCkptBytesCap / bytes_per_job;
     if (by_mem < chunk_jobs) chunk_jobs = by_mem ? by_mem : 1;
     if (rt->debug_chunk_jobs && rt->debug_chunk_jobs < chunk_jobs) chunk_jobs = rt->debug_chunk_jobs;
     if (chunk_jobs > n_jobs) chunk_jobs = n_jobs;
-    if (chunk_jobs > rt->block_threads) chunk_jobs -= chunk_jobs % rt->block_threads;
+    if (chunk_jobs > block) chunk_jobs -= chunk_jobs % block;
+    if (binned && chunks_per_wave > 0xFFFFFFF0ull) binned = false;
 
-    // bins: per-XCD scratch copies pay off once there is enough work to amortise folding 8 copies
-    uint32_t bins = rt->bins_mode;
-    if (bins == 0) bins = 1;
-    const bool xcd_local = (bins == 2);
-    SAR_TRY(ensure_scratch(rt, xcd_local ? 8u : 1u));
+    SAR_TRY(ensure_scratch(rt, binned ? geo.splits : (xcd_local ? 8u : 1u), (!binned && xcd_local) ? 8u : 1u));
 
     // start points: one pinned staging buffer, laid out as consecutive per-chunk SoA blocks
     const size_t need = static_cast<size_t>(n_jobs) * 3;
@@ -303,6 +368,38 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
         rt->ckpt_cap = ckpt_need;
     }
 
+    const uint32_t max_waves = static_cast<uint32_t>(((chunk_jobs + block - 1) / block) * (block / 64u));
+    if (binned) {
+        static std::once_flag attr_once;
+        static int attr_status = 0;
+        std::call_once(attr_once, [] { attr_status = binned_kernel_attributes(); });
+        if (attr_status != 0) { set_error("hipFuncSetAttribute(max dynamic LDS) failed: %d", attr_status); return SAR_ERR_HIP; }
+        const size_t arena_need = static_cast<size_t>(max_waves) * chunks_per_wave * 64u;
+        if (arena_need > rt->arena_cap) {
+            if (rt->d_arena) hipFree(rt->d_arena);
+            rt->d_arena = nullptr;
+            rt->arena_cap = 0;
+            HIP_TRY(hipMalloc(&rt->d_arena, arena_need));
+            rt->arena_cap = arena_need;
+        }
+        const size_t heads_need = static_cast<size_t>(max_waves) * geo.bins;
+        if (heads_need > rt->heads_cap) {
+            if (rt->d_heads) hipFree(rt->d_heads);
+            rt->d_heads = nullptr;
+            rt->heads_cap = 0;
+            HIP_TRY(hipMalloc(&rt->d_heads, heads_need * sizeof(uint32_t)));
+            rt->heads_cap = heads_need;
+        }
+        if (!rt->d_zhint) {
+            HIP_TRY(hipMalloc(&rt->d_zhint, static_cast<size_t>(rt->npix) * 8u * sizeof(uint32_t)));
+            SAR_TRY(clear_hints(rt));
+        }
+        if (!rt->d_nan_count) {
+            HIP_TRY(hipMalloc(&rt->d_nan_count, sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, sizeof(unsigned long long), rt->stream));
+        }
+    }
+
     IterArgs ia;
     std::memset(&ia, 0, sizeof(ia));
     fill_map_params(*cfg, ia.p);
@@ -322,6 +419,8 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
     fa.npix = rt->npix;
     fa.ckpt_stride = C;
     fa.copies = rt->copies;
+    fa.key_copies = rt->key_copies;
+    fa.nan_count = binned ? rt->d_nan_count : nullptr;
     fa.count = rt->d_count;
     fa.key = rt->d_key;
     fa.steps = rt->d_steps;
@@ -336,12 +435,44 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
         ia.n_jobs = m;
         ia.starts = rt->d_starts + off * 3;
         fa.n_jobs = m;
-        span_begin(rt, rt->iter_spans, rt->iter_used);
-        launch_iterate(ia, rt->block_threads, xcd_local, mode, rt->stream);
-        span_end(rt, rt->iter_spans, rt->iter_used);
-        span_begin(rt, rt->fold_spans, rt->fold_used);
-        launch_fold_resolve(fa, rt->stream);
-        span_end(rt, rt->fold_spans, rt->fold_used);
+        if (binned) {
+            BinIterArgs ba;
+            std::memset(&ba, 0, sizeof(ba));
+            ba.it = ia;
+            ba.bin_shift = geo.shift;
+            ba.n_bins = geo.bins;
+            ba.chunks_per_wave = static_cast<uint32_t>(chunks_per_wave);
+            ba.n_waves = ((m + block - 1) / block) * (block / 64u);
+            ba.arena = rt->d_arena;
+            ba.heads = rt->d_heads;
+            ba.zhint = rt->d_zhint;
+            ba.nan_count = rt->d_nan_count;
+            span_begin(rt, rt->iter_spans, rt->iter_used);
+            launch_iterate_binned(ba, block, mode == 2, rt->stream);
+            span_end(rt, rt->iter_spans, rt->iter_used);
+            BinAccArgs ca;
+            std::memset(&ca, 0, sizeof(ca));
+            ca.bin_shift = geo.shift;
+            ca.n_bins = geo.bins;
+            ca.chunks_per_wave = ba.chunks_per_wave;
+            ca.n_waves = ba.n_waves;
+            ca.npix = rt->npix;
+            ca.splits = geo.splits;
+            ca.arena = rt->d_arena;
+            ca.heads = rt->d_heads;
+            ca.scratch_count = rt->d_scratch_count;
+            span_begin(rt, rt->fold_spans, rt->fold_used);
+            launch_bin_accumulate(ca, rt->stream);
+            launch_fold_resolve(fa, rt->stream);
+            span_end(rt, rt->fold_spans, rt->fold_used);
+        } else {
+            span_begin(rt, rt->iter_spans, rt->iter_used);
+            launch_iterate(ia, block, xcd_local, mode, rt->stream);
+            span_end(rt, rt->iter_spans, rt->iter_used);
+            span_begin(rt, rt->fold_spans, rt->fold_used);
+            launch_fold_resolve(fa, rt->stream);
+            span_end(rt, rt->fold_spans, rt->fold_used);
+        }
     }
     HIP_TRY(hipGetLastError());
     rt->last_iterations = static_cast<uint64_t>(n_jobs) * iters;
@@ -435,6 +566,9 @@ int sar_runtime_free(sar_runtime* rt) {
     if (rt->d_starts) hipFree(rt->d_starts);
     if (rt->h_starts) hipHostFree(rt->h_starts);
     if (rt->d_ckpt) hipFree(rt->d_ckpt);
+    if (rt->d_arena) hipFree(rt->d_arena);
+    if (rt->d_heads) hipFree(rt->d_heads);
+    if (rt->d_nan_count) hipFree(rt->d_nan_count);
     if (rt->starts_copied) hipEventDestroy(rt->starts_copied);
     for (auto& s : rt->iter_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto& s : rt->fold_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
@@ -603,6 +737,7 @@ int sar_runtime_load(sar_runtime* rt, const uint32_t* count_host, const double* 
     HIP_TRY(hipMemcpyAsync(rt->d_steps, steps_host, static_cast<size_t>(rt->npix) * 8, hipMemcpyHostToDevice, rt->stream));
     HIP_TRY(hipMemcpyAsync(rt->d_ztmp, zbuf_host, static_cast<size_t>(rt->npix) * 4, hipMemcpyHostToDevice, rt->stream));
     launch_zbuf_in(rt->d_ztmp, rt->d_key, rt->npix, rt->stream);
+    SAR_TRY(clear_hints(rt));
     uint32_t sc[SC_COUNT] = {0};
     sc[SC_MAX] = max;
     HIP_TRY(hipMemcpyAsync(rt->d_scalars, sc, sizeof(sc), hipMemcpyHostToDevice, rt->stream));
@@ -730,17 +865,33 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
     return SAR_OK;
 }
 
-int sar_runtime_set_tuning(sar_runtime* rt, uint32_t block_threads, uint32_t checkpoint_stride, uint32_t variant) {
-    if (!rt) return SAR_ERR_INVALID;
-    if (block_threads) {
-        if (block_threads % 64 || block_threads > 256) { set_error("block_threads must be 64, 128, 192 or 256"); return SAR_ERR_INVALID; }
-        rt->block_threads = block_threads;
+int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
+    if (!rt || !name) return SAR_ERR_INVALID;
+    const uint32_t v = static_cast<uint32_t>(value);
+    if (!std::strcmp(name, "block_threads")) {
+        if (v == 0) { rt->block_threads = kDefaultBlock; return SAR_OK; }
+        if (v % 64 || v > 256) { set_error("block_threads must be 64, 128, 192 or 256"); return SAR_ERR_INVALID; }
+        rt->block_threads = v;
+    } else if (!std::strcmp(name, "checkpoint_stride")) {
+        rt->ckpt_stride = v ? v : kDefaultCkptStride;
+    } else if (!std::strcmp(name, "path")) {
+        if (v > 3) { set_error("path must be 0..3"); return SAR_ERR_INVALID; }
+        rt->bins_mode = v;
+    } else if (!std::strcmp(name, "bin_shift")) {
+        if (v && (v < 12 || v > 15)) { set_error("bin_shift must be 12..15"); return SAR_ERR_INVALID; }
+        rt->bin_shift = v;
+    } else if (!std::strcmp(name, "splits")) {
+        if (v > 16) { set_error("splits must be 1..16"); return SAR_ERR_INVALID; }
+        rt->splits = v;
+    } else if (!std::strcmp(name, "measure")) {
+        if (v > 2) { set_error("measure must be 0..2"); return SAR_ERR_INVALID; }
+        rt->measure_mode = v;
+    } else if (!std::strcmp(name, "debug_chunk_jobs")) {
+        rt->debug_chunk_jobs = v;
+    } else {
+        set_error("unknown option '%s'", name);
+        return SAR_ERR_INVALID;
     }
-    if (checkpoint_stride) rt->ckpt_stride = checkpoint_stride;
-    rt->bins_mode = variant & 0xFu;
-    rt->measure_mode = (variant >> 4) & 0xFu;
-    rt->debug_chunk_jobs = variant >> 8;  // test hook: forces multi-chunk launches
-    if (rt->bins_mode > 2 || rt->measure_mode > 2) { set_error("unknown variant 0x%x", variant); return SAR_ERR_INVALID; }
     return SAR_OK;
 }
 

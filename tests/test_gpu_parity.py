@@ -48,7 +48,7 @@ def test_c1_single_trajectory_matches_golden_and_oracle(sar, oracle, gpu):
         np.testing.assert_array_equal(sar.colorize(c2, rt), oracle.colorize(c2.c, ort))
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("block", [64, 256])
 def test_many_jobs_bit_exact(sar, oracle, gpu, variant, block):
     """Thousands of short trajectories: exercises depth ties, the checkpoint resolve and both bin layouts."""
@@ -127,11 +127,12 @@ def test_launch_chunking_is_invisible(sar, oracle, gpu):
     starts = sar.start_points(9, 0, jobs)
     ort = oracle.Runtime(128, 128)
     oracle.render_jobs(cfg.c, ort, starts, n)
-    for cap in (1, 64, 333):
-        rt = sar.Runtime(cfg)
-        rt.set_tuning(block_threads=64, variant=1 | (cap << 8))
-        sar.render_jobs(cfg, rt, starts)
-        assert_state_equal(rt, ort, f"chunk cap {cap}")
+    for variant in (1, 3):
+        for cap in (1, 64, 333):
+            rt = sar.Runtime(cfg)
+            rt.set_tuning(block_threads=64, variant=variant | (cap << 8))
+            sar.render_jobs(cfg, rt, starts)
+            assert_state_equal(rt, ort, f"variant {variant} chunk cap {cap}")
 
 
 def test_merge_matches_reference_semantics(sar, oracle, gpu):
@@ -290,6 +291,20 @@ def test_device_sqrt_div_are_correctly_rounded(sar, oracle, gpu):
         sar.render_jobs(cfg, rt, st); oracle.render_jobs(cfg.c, ort, st, n)
         assert (ort.zbuf != -1).sum() > 50_000
         assert_state_equal(rt, ort, preset)
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (3000, 2500), (4096, 4096), (8192, 6000)])
+def test_bin_geometries(sar, oracle, gpu, size):
+    """Image sizes that exercise every bin geometry of the LDS-binned path (ragged last bin, 512+ bins, and
+    the > 32 Mpx fallback to the atomic path)."""
+    w, h = size
+    jobs, n = 2048, 300
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=w, height=h, jobs_total=jobs)
+    st = sar.start_points(13, 0, jobs)
+    rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
+    sar.render_jobs(cfg, rt, st)
+    oracle.render_jobs(cfg.c, ort, st, n)
+    assert_state_equal(rt, ort, f"{w}x{h}")
 
 
 def test_deterministic_across_runs(sar, gpu):

@@ -12,10 +12,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import strange_attractor_renderer_amd as S  # noqa: E402
 
 
-def run(cfg, starts, block, stride, variant, reps=2):
+def run(cfg, starts, block, stride, variant, reps=2, **more):
     rt = S.Runtime(cfg)
     rt.enable_timing(True)
-    rt.set_tuning(block_threads=block, checkpoint_stride=stride, variant=variant)
+    rt.set_tuning(block_threads=block, checkpoint_stride=stride, variant=variant, **more)
     best = None
     for _ in range(reps):
         rt.reset()
@@ -42,6 +42,8 @@ if __name__ == "__main__":
     ap.add_argument("--variants", type=lambda s: int(s, 0), nargs="+",
                     default=[0x01, 0x02, 0x11, 0x12, 0x21])
     ap.add_argument("--stride", type=int, nargs="+", default=[64])
+    ap.add_argument("--bin-shift", type=int, nargs="+", default=[0])
+    ap.add_argument("--splits", type=int, nargs="+", default=[0])
     ap.add_argument("--out", default="gpurun_out/perf_explore.jsonl")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
@@ -52,9 +54,10 @@ if __name__ == "__main__":
             starts = S.start_points(1, 0, jobs)
             for block in a.blocks:
                 for variant in a.variants:
-                    for stride in a.stride:
-                        r = run(cfg, starts, block, stride, variant)
+                    for stride, bs, sp in [(x, y, z) for x in a.stride for y in a.bin_shift for z in a.splits]:
+                        r = run(cfg, starts, block, stride, variant, bin_shift=bs, splits=sp)
                         r.update(jobs=jobs, block=block, variant=hex(variant), stride=stride, size=a.size,
+                                 bin_shift=bs, splits=sp,
                                  preset=a.preset,
                                  git_per_s_kernel=r["iters"] / r["iter_ms"] / 1e6,
                                  git_per_s_wall=r["iters"] / r["wall_ms"] / 1e6)
