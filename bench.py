@@ -26,6 +26,22 @@ ITERS_PER_GPU = 1_000_000_000
 DEFAULT_JOBS = 131072            # trajectories per GPU (2 waves per SIMD); n = floor(1e9 / jobs)
 ALG_BYTES_PER_ITER = 12.0 + 12.0 * 0.0055   # count RMW 8 B + zbuf read 4 B + win-rate * 12 B
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_OPS_PER_ITER = 88           # unfused fp64 ops per counted iteration; FMA is not allowed
+FP64_PEAK_OPS = 78.6e12 / 2      # MI355X vector fp64 78.6 TFLOP/s counts an FMA as 2 -> 39.3e12 unfused op/s
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*.json):
+    (2*FETCH_SIZE + WRITE_SIZE) * 1024, the guide's gfx950 correction (FETCH_SIZE reads 1/2 of a coalesced stream)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))["k_iterate_binned"]
+        return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
 
 
 def cpu_baseline(seconds_hint: float):
@@ -161,11 +177,14 @@ def main():
                        "parallelism": f"trajectories sharded over {world} GPU(s)"
                                       + ("; all-reduce MAX (depth keys) + reduce SUM (count, steps) over RCCL" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_iterate", "kernel_ms": kern_s * 1e3,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
+                         "kernel": "k_iterate_binned", "kernel_ms": kern_s * 1e3,
                          "alg_bytes_per_iteration": ALG_BYTES_PER_ITER,
-                         "note": "scatter state lives in L2/Infinity Cache; co-bound is fp64 VALU "
-                                 "(88 unfused flops/iteration => ~4e11 it/s), see DESIGN.md"},
+                         "valu_frac": FP64_OPS_PER_ITER * (n * jobs / max(launches, 1)) / kern_s / FP64_PEAK_OPS,
+                         "note": "judged roofline per SURVEY 8(d) is HBM with 12.07 algorithmic B/iteration; the "
+                                 "kernel's binding resource is fp64 VALU issue (88 unfused ops/iteration, no FMA "
+                                 "allowed): valu_frac = 88*it/s / 39.3e12 op/s. traffic = PMC bytes/launch "
+                                 "(profiles/), below the algorithmic bytes because the scatter state lives in LDS/L2"},
             "kernel_ms": {"iterate": iter_ms, "fold_resolve": fold_ms, "colorize": col_ms},
         }
         if world == 1 and not a.no_cpu_baseline:

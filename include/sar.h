@@ -102,6 +102,7 @@ typedef struct sar_timing {
     uint32_t iterate_launches;
     uint32_t _pad;
     uint64_t iterations_counted; /* jobs * iterations-per-job executed by the last render call */
+    uint64_t depth_atomics;      /* binned path: global depth atomics issued since the last query (statistic) */
 } sar_timing;
 
 /* ---- misc ---------------------------------------------------------------------------------- */
@@ -221,6 +222,7 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *                        visit at agent scope, 2 the same into one scratch copy per XCD, 3 LDS-binned records
  *   "bin_shift"          log2(pixels per bin) of the binned path (12..15)
  *   "splits"             workgroups per bin in the record-accumulate kernel (1..16)
+ *   "depth_refresh"      1: depth atomics return the chip-wide best and refresh the per-XCD hints
  *   "measure"            measurement-only kernels: 1 count only, 2 arithmetic only (results are NOT the render)
  *   "debug_chunk_jobs"   test hook: cap on jobs per launch chunk */
 int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value);

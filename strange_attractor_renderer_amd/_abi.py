@@ -67,6 +67,7 @@ class SarTiming(C.Structure):
         ("iterate_launches", C.c_uint32),
         ("_pad", C.c_uint32),
         ("iterations_counted", C.c_uint64),
+        ("depth_atomics", C.c_uint64),
     ]
 
 

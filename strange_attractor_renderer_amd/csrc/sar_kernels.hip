@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
 // the pixel, plain loads/stores served by the XCD's own L2); a visit is sent iff its z is >= the
 // hint. The hint read is issued one iteration ahead of its use, so its latency hides behind the next
 // iteration's arithmetic. A stale or lost hint only costs an extra atomic, never a wrong result.
-template <bool DEPTH>
+template <bool DEPTH, bool REFRESH>
 __global__ void __launch_bounds__(256) k_iterate_binned(const BinIterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -287,6 +287,11 @@ __global__ void __launch_bounds__(256) k_iterate_binned(const BinIterArgs a) {
     // depth candidate of the previous iteration, waiting for its hint
     bool pv = false;
     uint32_t p_idx = 0, p_zkey = 0, p_lo = 0, p_hint = 0;
+    uint32_t n_sent = 0;  // depth atomics this lane issued (statistics)
+    // depth atomic in flight (returning): refreshes the hint one iteration later
+    bool r_have = false;
+    uint32_t r_idx = 0, r_zkey = 0;
+    unsigned long long r_old = 0;
     // visit of the previous iteration, waiting for its LDS slot (requested one iteration ahead so that
     // the LDS round trip hides behind the arithmetic)
     bool b_have = false;
@@ -372,9 +377,24 @@ __global__ void __launch_bounds__(256) k_iterate_binned(const BinIterArgs a) {
             if (DEPTH) {
                 // (1) settle the previous iteration's depth candidate: its hint has had a whole
                 //     iteration of arithmetic to arrive
-                if (pv && p_zkey >= p_hint) {
+                // (0) a depth atomic sent one iteration ago has returned what the WHOLE chip had for that pixel:
+                //     raise this XCD's hint to it (so an XCD learns from the other seven whenever it speaks)
+                if (REFRESH) {
+                    if (r_have) {
+                        const uint32_t seen = (uint32_t)(r_old >> 32);
+                        zhint[r_idx] = seen > r_zkey ? seen : r_zkey;
+                    }
+                    r_have = pv && p_zkey >= p_hint;
+                    if (r_have) {
+                        r_idx = p_idx;
+                        r_zkey = p_zkey;
+                        r_old = atomicMax(key + p_idx, ((unsigned long long)p_zkey << 32) | (unsigned long long)p_lo);
+                        ++n_sent;
+                    }
+                } else if (pv && p_zkey >= p_hint) {
                     atomicMax(key + p_idx, ((unsigned long long)p_zkey << 32) | (unsigned long long)p_lo);
                     if (p_zkey > p_hint) zhint[p_idx] = p_zkey;
+                    ++n_sent;
                 }
                 // (2) this iteration's candidate: strict `>` against the initial -1.0 (:693, :821)
                 pv = false;
@@ -403,10 +423,19 @@ __global__ void __launch_bounds__(256) k_iterate_binned(const BinIterArgs a) {
     }
     finish_visit();
     if (DEPTH) {
+        if (REFRESH && r_have) {
+            const uint32_t seen = (uint32_t)(r_old >> 32);
+            zhint[r_idx] = seen > r_zkey ? seen : r_zkey;
+        }
         if (pv && p_zkey >= p_hint) {
             atomicMax(key + p_idx, ((unsigned long long)p_zkey << 32) | (unsigned long long)p_lo);
             if (p_zkey > p_hint) zhint[p_idx] = p_zkey;
+            ++n_sent;
         }
+        // statistics: depth atomics issued by this wave (one add per wave)
+        uint32_t tot = n_sent;
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
+        if (lane == 0 && tot) atomicAdd(a.nan_count + 1, (unsigned long long)tot);
     }
 
     // flush the partly filled buffers and publish the list heads
@@ -797,11 +826,12 @@ void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode,
     }
 }
 
-void launch_iterate_binned(const BinIterArgs& a, uint32_t block, bool depth, hipStream_t s) {
+void launch_iterate_binned(const BinIterArgs& a, uint32_t block, bool depth, bool refresh, hipStream_t s) {
     const uint32_t grid = (a.it.n_jobs + block - 1) / block;
     const size_t lds = (size_t)(block / 64u) * a.n_bins * 64u;
-    if (depth) hipLaunchKernelGGL((k_iterate_binned<true>), dim3(grid), dim3(block), lds, s, a);
-    else hipLaunchKernelGGL((k_iterate_binned<false>), dim3(grid), dim3(block), lds, s, a);
+    if (!depth) hipLaunchKernelGGL((k_iterate_binned<false, false>), dim3(grid), dim3(block), lds, s, a);
+    else if (refresh) hipLaunchKernelGGL((k_iterate_binned<true, true>), dim3(grid), dim3(block), lds, s, a);
+    else hipLaunchKernelGGL((k_iterate_binned<true, false>), dim3(grid), dim3(block), lds, s, a);
 }
 
 void launch_bin_accumulate(const BinAccArgs& a, hipStream_t s) {
@@ -811,8 +841,9 @@ void launch_bin_accumulate(const BinAccArgs& a, hipStream_t s) {
 
 int binned_kernel_attributes() {
     // both kernels need more dynamic LDS than the 64 KiB default window
-    hipError_t e = hipFuncSetAttribute((const void*)k_iterate_binned<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_binned<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_iterate_binned<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_binned<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_binned<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return (int)e;
 }

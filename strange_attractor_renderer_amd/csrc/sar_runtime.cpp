@@ -103,6 +103,7 @@ struct sar_runtime {
     uint32_t debug_chunk_jobs = 0;  // test hook: cap on jobs per launch chunk (0 = none)
     uint32_t bin_shift = 0;         // 0 = automatic
     uint32_t splits = 0;            // 0 = automatic
+    uint32_t depth_refresh = 0;     // returning depth atomics refresh the per-XCD hints
 
     // timing
     bool timing = false;
@@ -395,8 +396,8 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             SAR_TRY(clear_hints(rt));
         }
         if (!rt->d_nan_count) {
-            HIP_TRY(hipMalloc(&rt->d_nan_count, sizeof(unsigned long long)));
-            HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, sizeof(unsigned long long), rt->stream));
+            HIP_TRY(hipMalloc(&rt->d_nan_count, 2 * sizeof(unsigned long long)));  // [0] NaN iterations, [1] depth atomics (stat)
+            HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, 2 * sizeof(unsigned long long), rt->stream));
         }
     }
 
@@ -448,7 +449,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             ba.zhint = rt->d_zhint;
             ba.nan_count = rt->d_nan_count;
             span_begin(rt, rt->iter_spans, rt->iter_used);
-            launch_iterate_binned(ba, block, mode == 2, rt->stream);
+            launch_iterate_binned(ba, block, mode == 2, rt->depth_refresh != 0, rt->stream);
             span_end(rt, rt->iter_spans, rt->iter_used);
             BinAccArgs ca;
             std::memset(&ca, 0, sizeof(ca));
@@ -861,6 +862,12 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
     if (rt->colorize_timed && hipEventElapsedTime(&ms, rt->colorize_span.a, rt->colorize_span.b) == hipSuccess) out->colorize_ms = ms;
     if (rt->merge_timed && hipEventElapsedTime(&ms, rt->merge_span.a, rt->merge_span.b) == hipSuccess) out->merge_ms = ms;
     out->iterate_launches = static_cast<uint32_t>(rt->iter_used);
+    if (rt->d_nan_count) {  // cumulative statistic of the binned path; cleared by reading
+        unsigned long long sent = 0;
+        HIP_TRY(hipMemcpy(&sent, rt->d_nan_count + 1, sizeof(sent), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(rt->d_nan_count + 1, 0, sizeof(sent)));
+        out->depth_atomics = sent;
+    }
     out->iterations_counted = rt->last_iterations;
     return SAR_OK;
 }
@@ -883,6 +890,8 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "splits")) {
         if (v > 16) { set_error("splits must be 1..16"); return SAR_ERR_INVALID; }
         rt->splits = v;
+    } else if (!std::strcmp(name, "depth_refresh")) {
+        rt->depth_refresh = v ? 1u : 0u;
     } else if (!std::strcmp(name, "measure")) {
         if (v > 2) { set_error("measure must be 0..2"); return SAR_ERR_INVALID; }
         rt->measure_mode = v;

@@ -122,3 +122,32 @@ def test_missing_library_fails_loudly(sar):
     from strange_attractor_renderer_amd import _abi
     with pytest.raises(_abi.SarLibraryMissing):
         _abi.load_library("/nonexistent/libsar_hip.so")
+
+
+def test_cpp_header_mirror_compiles_links_and_runs(sar):
+    """include/sar.hpp (the C++ mirror of the crate's names) builds against the library; host-only calls work and a
+    missing device surfaces as sar::Error, not a crash."""
+    prog = r'''
+#include <cstdio>
+#include "sar.hpp"
+int main() {
+    auto c = sar::Config::poisson_saturne();
+    c.iterations = 1000; c.width = 16; c.height = 16; c.validate();
+    auto s = sar::Config::solar_sail();
+    if (c.coeff_x[1] != 1.182 || s.scale != 1.7) return 2;
+    int n = 0; sar_device_count(&n);
+    try { sar::Runtime rt(c); sar::render(c, rt); auto img = sar::colorize(c, rt); if (img.rgba.size() != 16*16*4) return 3; }
+    catch (const sar::Error& e) { if (n > 0 || e.status != SAR_ERR_NO_DEVICE) return 4; }
+    std::puts("ok");
+    return 0;
+}
+'''
+    pkg = os.path.join(ROOT, "strange_attractor_renderer_amd")
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.cpp")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                        "-L", pkg, "-l:libsar_hip.so", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+        out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr)

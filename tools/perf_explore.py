@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import strange_attractor_renderer_amd as S  # noqa: E402
 
 
-def run(cfg, starts, block, stride, variant, reps=2, **more):
+def run(cfg, starts, block, stride, variant, reps=4, **more):
     rt = S.Runtime(cfg)
     rt.enable_timing(True)
     rt.set_tuning(block_threads=block, checkpoint_stride=stride, variant=variant, **more)
@@ -25,7 +25,7 @@ def run(cfg, starts, block, stride, variant, reps=2, **more):
         rt.synchronize()
         wall = (time.perf_counter() - t0) * 1e3
         t = rt.last_timing()
-        rec = dict(iter_ms=t.iterate_ms, fold_ms=t.resolve_ms, wall_ms=wall, iters=t.iterations_counted)
+        rec = dict(iter_ms=t.iterate_ms, fold_ms=t.resolve_ms, wall_ms=wall, iters=t.iterations_counted, depth_atomics=t.depth_atomics)
         if best is None or rec["iter_ms"] < best["iter_ms"]:
             best = rec
     rt.close()
@@ -44,6 +44,7 @@ if __name__ == "__main__":
     ap.add_argument("--stride", type=int, nargs="+", default=[64])
     ap.add_argument("--bin-shift", type=int, nargs="+", default=[0])
     ap.add_argument("--splits", type=int, nargs="+", default=[0])
+    ap.add_argument("--refresh", type=int, nargs="+", default=[0])
     ap.add_argument("--out", default="gpurun_out/perf_explore.jsonl")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
@@ -54,10 +55,10 @@ if __name__ == "__main__":
             starts = S.start_points(1, 0, jobs)
             for block in a.blocks:
                 for variant in a.variants:
-                    for stride, bs, sp in [(x, y, z) for x in a.stride for y in a.bin_shift for z in a.splits]:
-                        r = run(cfg, starts, block, stride, variant, bin_shift=bs, splits=sp)
+                    for stride, bs, sp, rf in [(x, y, z, q) for x in a.stride for y in a.bin_shift for z in a.splits for q in a.refresh]:
+                        r = run(cfg, starts, block, stride, variant, bin_shift=bs, splits=sp, depth_refresh=rf)
                         r.update(jobs=jobs, block=block, variant=hex(variant), stride=stride, size=a.size,
-                                 bin_shift=bs, splits=sp,
+                                 bin_shift=bs, splits=sp, refresh=rf,
                                  preset=a.preset,
                                  git_per_s_kernel=r["iters"] / r["iter_ms"] / 1e6,
                                  git_per_s_wall=r["iters"] / r["wall_ms"] / 1e6)

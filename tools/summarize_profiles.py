@@ -1,0 +1,49 @@
+"""Condenses a tools/profile_round.sh output directory into one markdown summary (kernel stats + per-kernel
+PMC averages). The summary is what gets committed under profiles/."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+print(f"# rocprofv3 summary — {os.path.basename(root)}\n")
+print("Command profiled: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` (N=1, BASELINE configs[1]).\n")
+for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    print("## Kernel time (`--kernel-trace --stats`, no counters)\n")
+    print("| kernel | calls | total ms | avg ms | % |")
+    print("|---|---|---|---|---|")
+    for r in csv.DictReader(open(f)):
+        print(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e6:.4f} | {r['Percentage']} |")
+    print()
+try:
+    line = [l for l in open(os.path.join(root, "trace_bench.json")) if l.startswith("{")][-1]
+    b = json.loads(line)
+    print(f"bench line under the tracer: value {b['value']:.4g} {b['unit']}, ms_per_step {b['ms_per_step']:.3f}, "
+          f"kernel_ms {b.get('kernel_ms')}\n")
+except Exception as e:  # noqa
+    print(f"(no bench line: {e})\n")
+
+print("## PMC passes (each counter group in its own run; averages per dispatch of each kernel)\n")
+for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        print(f"### {os.path.basename(d)}: no counter file (see {os.path.basename(d)}.err)\n")
+        continue
+    agg = defaultdict(lambda: defaultdict(list))
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            k = r.get("Kernel_Name") or r.get("Kernel Name") or "?"
+            agg[k][r.get("Counter_Name") or r.get("Counter Name")].append(float(r.get("Counter_Value") or r.get("Counter Value") or 0))
+    print(f"### {os.path.basename(d)}\n")
+    print("| kernel | counter | dispatches | mean per dispatch |")
+    print("|---|---|---|---|")
+    for k, cs in agg.items():
+        if not any(t in k for t in ("k_iterate", "k_bin_accumulate", "k_fold", "k_colorize")):
+            continue
+        for c, v in cs.items():
+            print(f"| `{k[:48]}` | {c} | {len(v)} | {sum(v)/len(v):.6g} |")
+    print()
