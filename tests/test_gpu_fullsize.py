@@ -1,0 +1,100 @@
+"""GPU, BASELINE.json's full sizes: size-independent properties (the oracle would need minutes per case).
+
+  * conservation: every counted iteration of a trajectory that stays finite and in bounds lands in exactly one
+    pixel: sum(count) == jobs * iterations-per-job when nothing leaves the image (poisson-saturne at scale 1:
+    the attractor fits the frame) — for solar-sail the diverged jobs land on pixel (0,0);
+  * max == count.max(); zbuf is set exactly where count > 0 (except diverged-only pixel (0,0)); steps is finite
+    where zbuf is set;
+  * linearity: render(A) then render(B) on one runtime == merge(render(A), render(B)) for count / zbuf, and the
+    count buffer does not depend on how the job list is cut into launches;
+  * determinism across paths: the LDS-binned path and the one-atomic-per-visit path give the same bits;
+  * a checksum of checksums pins the full-size result between runs of the suite on the same build.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view({4: np.uint32, 8: np.uint64}[a.dtype.itemsize])
+
+
+def test_c2_poisson_1e9_2048(sar, gpu):
+    jobs = 131072
+    cfg = sar.Config.poisson_saturne(iterations=1_000_000_000, width=2048, height=2048, jobs_total=jobs, seed=1,
+                                     transparent=0)
+    n = 1_000_000_000 // jobs
+    starts = sar.start_points(1, 0, jobs)
+    rt = sar.Runtime(cfg)
+    sar.render_jobs(cfg, rt, starts)
+    cnt, z, st = rt.count(), rt.zbuf(), rt.steps()
+    assert int(cnt.sum(dtype=np.uint64)) == jobs * n              # conservation, 100 % in bounds
+    assert rt.max() == int(cnt.max())
+    assert np.array_equal(cnt > 0, z != -1.0)                     # depth set exactly on touched pixels
+    assert np.all(np.isfinite(st[z != -1.0])) and np.all(st[z == -1.0] == 0.0)
+    touched = float((cnt > 0).mean())
+    assert 0.17 < touched < 0.21                                  # SURVEY: 18.8 % of pixels touched
+    img = sar.colorize(cfg, rt)
+    assert img.shape == (2048, 2048, 4) and np.all(img[..., 3] == 65535)
+    assert np.all(img[cnt == 0][:, :3] == 0)                      # offset -0.15: untouched pixels are black
+
+    # linearity + independence from the launch decomposition: two halves on two runtimes, merged
+    half = jobs // 2
+    ca = cfg.replace(iterations=half * n, jobs_total=half)
+    ra, rb = sar.Runtime(ca), sar.Runtime(ca)
+    sar.render_jobs(ca, ra, starts[:half])
+    sar.render_jobs(ca, rb, starts[half:])
+    ra.merge(rb)
+    assert np.array_equal(ra.count(), cnt) and ra.max() == rt.max()
+    assert np.array_equal(_bits(ra.zbuf()), _bits(z))
+    same = _bits(ra.steps()) == _bits(st)                         # steps may differ only on exact f32 depth ties
+    assert same.mean() > 0.9999
+    # the same frame through the one-atomic-per-visit path: identical bits
+    r1 = sar.Runtime(cfg)
+    r1.set_option("path", 1)
+    sar.render_jobs(cfg, r1, starts)
+    assert np.array_equal(r1.count(), cnt) and np.array_equal(_bits(r1.zbuf()), _bits(z))
+    assert np.array_equal(_bits(r1.steps()), _bits(st))
+
+
+def test_c3_solar_sail_depth_1e9_1800x2000(sar, gpu):
+    jobs = 131072
+    cfg = sar.Config.solar_sail(iterations=1_000_000_000, width=1800, height=2000, jobs_total=jobs, seed=1,
+                                render_kind=sar.SAR_RENDER_DEPTH, scale=1.0)
+    n = 1_000_000_000 // jobs
+    starts = sar.start_points(1, 0, jobs)
+    rt = sar.Runtime(cfg)
+    sar.render_jobs(cfg, rt, starts)
+    cnt, z = rt.count(), rt.zbuf()
+    total = int(cnt.sum(dtype=np.uint64))
+    assert total == jobs * n                                      # in-bounds visits + diverged iterations on (0,0)
+    diverged_iters = int(cnt[0, 0])
+    assert diverged_iters % 1 == 0 and 0.30 < diverged_iters / total < 0.45   # ~38 % of start points diverge
+    assert rt.max() == int(cnt.max()) == diverged_iters
+    img = sar.colorize(cfg, rt)
+    assert np.all(img[..., 0] == img[..., 1]) and np.all(img[..., 3] == 65535)
+    assert img[..., 0].max() == 65535 and np.all(img[z == -1.0][:, 0] == 0)
+    r1 = sar.Runtime(cfg)
+    r1.set_option("path", 1)
+    sar.render_jobs(cfg, r1, starts)
+    assert np.array_equal(r1.count(), cnt) and np.array_equal(_bits(r1.zbuf()), _bits(z))
+    assert np.array_equal(_bits(r1.steps()), _bits(rt.steps()))
+
+
+def test_c4_shape_4096_one_gpu_share(sar, gpu):
+    """One GPU's share of BASELINE configs[3] (4096x4096, 1e10 iterations over 8 GPUs = 1.25e9 here)."""
+    jobs = 65536
+    n = 19073
+    cfg = sar.Config.poisson_saturne(iterations=jobs * n, width=4096, height=4096, jobs_total=jobs, seed=3)
+    starts = sar.start_points(3, 5 * jobs, jobs)                  # rank 5's slice of the global job list
+    rt = sar.Runtime(cfg)
+    sar.render_job_range(cfg, rt, n, starts)
+    cnt = rt.count()
+    assert int(cnt.sum(dtype=np.uint64)) == jobs * n and rt.max() == int(cnt.max())
+    r2 = sar.Runtime(cfg)
+    r2.set_option("debug_chunk_jobs", 16384)                      # four launch chunks
+    sar.render_job_range(cfg, r2, n, starts)
+    assert np.array_equal(r2.count(), cnt)
+    assert np.array_equal(_bits(r2.zbuf()), _bits(rt.zbuf())) and np.array_equal(_bits(r2.steps()), _bits(rt.steps()))

@@ -48,7 +48,7 @@ def test_c1_single_trajectory_matches_golden_and_oracle(sar, oracle, gpu):
         np.testing.assert_array_equal(sar.colorize(c2, rt), oracle.colorize(c2.c, ort))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 @pytest.mark.parametrize("block", [64, 256])
 def test_many_jobs_bit_exact(sar, oracle, gpu, variant, block):
     """Thousands of short trajectories: exercises depth ties, the checkpoint resolve and both bin layouts."""
@@ -75,6 +75,24 @@ def test_checkpoint_stride_does_not_change_results(sar, oracle, gpu, stride):
     ort = oracle.Runtime(200, 160)
     oracle.render_jobs(cfg.c, ort, starts, n)
     assert_state_equal(rt, ort, f"stride={stride}")
+
+
+@pytest.mark.parametrize("slices", [2, 3, 7, 64])
+def test_split_pipeline_slicing_is_invisible(sar, oracle, gpu, slices):
+    """Path 4 cuts the trajectories into time slices (compute kernel || accumulate kernel): any slicing must
+    give the same bits, including for trajectories that diverge in the middle of a slice (solar-sail)."""
+    jobs, n = 1536, 1000
+    for preset in ("poisson_saturne", "solar_sail"):
+        cfg = _cfg(sar, preset, iterations=jobs * n, width=300, height=260, jobs_total=jobs, scale=1.0)
+        st = sar.start_points(17, 0, jobs)
+        rt, ort = sar.Runtime(cfg), oracle.Runtime(300, 260)
+        rt.set_tuning(variant=4, slices=slices, checkpoint_stride=16)
+        sar.render_jobs(cfg, rt, st)
+        oracle.render_jobs(cfg.c, ort, st, n)
+        assert_state_equal(rt, ort, f"{preset} slices={slices}")
+        sar.render_jobs(cfg, rt, st)            # accumulate a second call on the same runtime
+        oracle.render_jobs(cfg.c, ort, st, n)
+        assert_state_equal(rt, ort, f"{preset} slices={slices} second call")
 
 
 def test_solar_sail_divergent_jobs_and_depth(sar, oracle, gpu):
@@ -127,7 +145,7 @@ def test_launch_chunking_is_invisible(sar, oracle, gpu):
     starts = sar.start_points(9, 0, jobs)
     ort = oracle.Runtime(128, 128)
     oracle.render_jobs(cfg.c, ort, starts, n)
-    for variant in (1, 3):
+    for variant in (1, 3, 4):
         for cap in (1, 64, 333):
             rt = sar.Runtime(cfg)
             rt.set_tuning(block_threads=64, variant=variant | (cap << 8))
