@@ -220,11 +220,9 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *   "checkpoint_stride"  iterations between trajectory checkpoints used by the payload resolve
  *   "path"               accumulate path: 0 default (= 3 when the image fits), 1 one global atomic per
  *                        visit at agent scope, 2 the same into one scratch copy per XCD, 3 LDS-binned records
- *                        in one fused kernel, 4 compute kernel || LDS-binning kernel over time slices
- *   "batch"              path 3: iterations whose visits are accumulated together per lane (1, 2, 4, 8; default 4)
- *   "slices"             time slices of path 4 (default 8)
  *   "bin_shift"          log2(pixels per bin) of the binned path (12..15)
  *   "splits"             workgroups per bin in the record-accumulate kernel (1..16)
+ *   "acc_threads"        threads per block of the record-accumulate kernel (256, 512, 1024)
  *   "depth_refresh"      1: depth atomics return the chip-wide best and refresh the per-XCD hints
  *   "measure"            measurement-only kernels: 1 count only, 2 arithmetic only (results are NOT the render)
  *   "debug_chunk_jobs"   test hook: cap on jobs per launch chunk */

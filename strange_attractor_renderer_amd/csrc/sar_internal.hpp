@@ -71,37 +71,6 @@ struct BinIterArgs {
     unsigned long long* nan_count;  // iterations of diverged (NaN) trajectories: all land on pixel (0,0)
 };
 
-// Split pipeline (compute kernel || accumulate kernel over time slices of the trajectories).
-struct VisitArgs {
-    MapParams p;
-    uint64_t iters;            // counted iterations per job (whole render)
-    uint32_t n_jobs;
-    uint32_t width;
-    uint32_t t0, t1;           // this slice: iterations [t0, t1)
-    uint32_t ckpt_stride;      // t0 is a multiple of it
-    uint32_t first;            // 1: read start points and run the 1000 warm-up iterations; 0: resume from `state`
-    const double* starts;      // [3][n_jobs]
-    double* state;             // [3][n_jobs] trajectory state between slices (x = NaN: diverged)
-    void* visits;              // uint2 [t1 - t0][n_jobs]: {pixel index or kNoPixel, sortable(z as f32) or 0}
-    double* ckpt;              // [n_ckpt][3][n_jobs]
-    unsigned long long* nan_count;
-};
-
-struct AccVisitArgs {
-    uint64_t iters;
-    uint32_t n_jobs, npix;
-    uint32_t t0, t1;
-    uint32_t bin_shift, n_bins, chunks_per_wave, n_waves;
-    uint32_t first, last;      // first: fresh staging buffers; last: flush partial buffers and publish list heads
-    const void* visits;
-    void* arena;
-    uint32_t* heads;
-    uint32_t* zhint;
-    unsigned long long* scratch_key;
-    uint32_t* wave_state;      // [n_waves][n_bins*16 + 16]: LDS staging image + arena cursor between slices
-    unsigned long long* stats; // [1] depth atomics issued
-};
-
 struct BinAccArgs {
     uint32_t bin_shift, n_bins, chunks_per_wave, n_waves;
     uint32_t npix, splits, _pad0, _pad1;
@@ -154,7 +123,6 @@ static inline uint32_t f32_sortable_host(float f) {
 constexpr uint32_t kLnLutEntries = 1u << 20;  // ln(k+1), k < 2^20, host libm (exact parity with the oracle)
 constexpr uint64_t kMaxChunkOrdinals = 0xFFFFFFFEull;
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
-constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
 constexpr uint32_t kChunkRecords = 28;   // u16 records per 64-byte chunk (8-byte header)
 constexpr uint32_t kMaxBins = 1024;      // LDS staging is 64 B per bin per wave
 constexpr uint32_t kMaxBinPx = 32768;    // phase-2 LDS histogram: 4 B per pixel of the bin

@@ -463,508 +463,6 @@ __global__ void __launch_bounds__(256) k_iterate_binned(const BinIterArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_iterate_batched — k_iterate_binned with the accumulate work batched over U iterations per lane
-// ---------------------------------------------------------------------------------------------------
-// Kernel traces of the split pipeline showed that the arithmetic of an iteration costs ~0.47 us per
-// wave pair and the record staging + depth hints ~1 us of mostly serialized LDS / memory round trips
-// per visit. One trajectory cannot run ahead of itself, but its VISITS can wait: the lane computes U
-// iterations back to back, then
-//   (1) settles the depth candidates of the previous batch (hints requested a whole batch ago),
-//   (2) places the previous batch's records — all U buffer write / copy-out sequences are ISSUED first
-//       (LDS executes a wave's operations in order, so a copy-out read issued before a later write sees
-//       the old contents) and the chunk stores follow after ONE LDS wait,
-//   (3) requests U LDS slots and U depth hints for the batch just computed.
-// So U LDS round trips and U hint loads are in flight together and a full batch of arithmetic hides them.
-template <int U, bool DEPTH>
-__global__ void __launch_bounds__(256) k_iterate_batched(const BinIterArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t B = a.n_bins;
-    uint32_t* const cnt = smem + (threadIdx.x >> 6) * (B * 16u);
-    uint32_t* const prv = cnt + B;
-    unsigned short* const rec = (unsigned short*)(prv + B);
-    for (uint32_t b = lane; b < B; b += 64u) {
-        cnt[b] = 0u;
-        prv[b] = kNoChunk;
-    }
-    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t wave = job >> 6;
-    bool alive = job < a.it.n_jobs;
-
-    MapParams p = a.it.p;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) p.cz[k] = vgpr_pin(p.cz[k]);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) p.m[k] = vgpr_pin(p.m[k]);
-    p.sin_v = vgpr_pin(p.sin_v);
-    p.cos_v = vgpr_pin(p.cos_v);
-    p.ccx = vgpr_pin(p.ccx);
-    p.ccy = vgpr_pin(p.ccy);
-    p.ccz = vgpr_pin(p.ccz);
-    p.width = vgpr_pin(p.width);
-    p.height = vgpr_pin(p.height);
-    p.half_height = vgpr_pin(p.half_height);
-    p.width_scaled = vgpr_pin(p.width_scaled);
-    p.scale_adjusted_mid = vgpr_pin(p.scale_adjusted_mid);
-
-    double x = 0., y = 0., z = 0.;
-    if (alive) {
-        x = a.it.starts[job];
-        y = a.it.starts[a.it.n_jobs + job];
-        z = a.it.starts[2u * a.it.n_jobs + job];
-        for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);  // warm-up (:750-752)
-    }
-    uint4* const arena = (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * 4u;
-    uint32_t cursor = 0;
-    uint32_t* const zhint = a.zhint + (size_t)xcc_id() * a.it.npix;
-    unsigned long long* const key = a.it.scratch_key;
-    const uint32_t n = (uint32_t)a.it.iters;
-    const uint32_t lo_base = 0xFFFFFFFFu - job * n;
-    const uint32_t C = a.it.ckpt_stride;  // a multiple of U (host guarantees)
-    const size_t cs = a.it.n_jobs;
-    const uint32_t bin_mask = (1u << a.bin_shift) - 1u;
-
-    // previous batch: visits waiting for their LDS slot / depth hint
-    uint32_t q_idx[U], q_zkey[U], q_slot[U], q_hint[U];
-    bool q_have[U], q_cand[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        q_idx[u] = q_zkey[u] = q_slot[u] = q_hint[u] = 0u;
-        q_have[u] = q_cand[u] = false;
-    }
-    uint32_t q_t0 = 0;
-    uint32_t n_sent = 0;
-
-    // one 64-byte chunk: {previous chunk of this (wave, bin), 28, records}
-    auto store_chunk = [&](uint32_t chunk, uint32_t prev, const uint2 (&r)[7]) {
-        uint4* dst = arena + (size_t)chunk * 4u;
-        dst[0] = make_uint4(prev, kChunkRecords, r[0].x, r[0].y);
-        dst[1] = make_uint4(r[1].x, r[1].y, r[2].x, r[2].y);
-        dst[2] = make_uint4(r[3].x, r[3].y, r[4].x, r[4].y);
-        dst[3] = make_uint4(r[5].x, r[5].y, r[6].x, r[6].y);
-    };
-
-    auto settle_batch = [&]() {
-        // (1) depth candidates of the previous batch
-        if (DEPTH) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (q_cand[u] && q_zkey[u] >= q_hint[u]) {
-                    atomicMax(key + q_idx[u], ((unsigned long long)q_zkey[u] << 32) |
-                                                  (unsigned long long)(lo_base - (q_t0 + (uint32_t)u)));
-                    if (q_zkey[u] > q_hint[u]) zhint[q_idx[u]] = q_zkey[u];
-                    ++n_sent;
-                }
-            }
-        }
-        // (2) records of the previous batch. slot = 28*gen + pos (see k_iterate_binned::finish_visit).
-        uint2 fr[U][7];
-        uint32_t f_prev[U], f_chunk[U];
-        bool f_on[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t bin = q_idx[u] >> a.bin_shift;
-            const unsigned short local = (unsigned short)(q_idx[u] & bin_mask);
-            const uint32_t gen = q_slot[u] / kChunkRecords;
-            const uint32_t pos = q_slot[u] - gen * kChunkRecords;
-            unsigned short* const dstrec = rec + bin * kChunkRecords;
-            f_on[u] = false;
-            f_prev[u] = f_chunk[u] = 0u;
-            bool pend = q_have[u];
-            const bool mine = pend && gen == 0u;
-            if (mine) dstrec[pos] = local;
-            const bool flusher = mine && pos == kChunkRecords - 1u;
-            const unsigned long long fb = __ballot(flusher);
-            if (fb) {
-                if (flusher) {  // issue the copy-out reads now, store after the common LDS wait below
-                    f_on[u] = true;
-                    f_chunk[u] = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
-                    const uint2* r = (const uint2*)dstrec;
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) fr[u][k] = r[k];
-                    f_prev[u] = prv[bin];
-                    prv[bin] = f_chunk[u];
-                    __hip_atomic_fetch_sub(&cnt[bin], kChunkRecords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                cursor += (uint32_t)__popcll(fb);
-            }
-            const bool early = pend && gen == 1u && pos < kChunkRecords - 1u;
-            if (early) dstrec[pos] = local;
-            pend = pend && !(mine || early);
-            // rare: ~29+ lanes of this wave hit one bin in one request -> later generations, in order
-            for (uint32_t g = 1; __ballot(pend); ++g) {
-                const bool mine2 = pend && gen == g;
-                if (mine2) dstrec[pos] = local;
-                const bool fl2 = mine2 && pos == kChunkRecords - 1u;
-                const unsigned long long fb2 = __ballot(fl2);
-                if (fb2) {
-                    if (fl2) {
-                        const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb2 >> 32),
-                                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)fb2, 0u));
-                        const uint2* r = (const uint2*)dstrec;
-                        uint2 t7[7];
-#pragma unroll
-                        for (int k = 0; k < 7; ++k) t7[k] = r[k];
-                        store_chunk(chunk, prv[bin], t7);
-                        prv[bin] = chunk;
-                        __hip_atomic_fetch_sub(&cnt[bin], kChunkRecords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    cursor += (uint32_t)__popcll(fb2);
-                }
-                const bool early2 = pend && gen == g + 1u && pos < kChunkRecords - 1u;
-                if (early2) dstrec[pos] = local;
-                pend = pend && !(mine2 || early2);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (f_on[u]) store_chunk(f_chunk[u], f_prev[u], fr[u]);
-    };
-
-    double* ck = a.it.ckpt + job;
-    for (uint32_t tb = 0; tb < n; tb += U) {
-        if (tb % C == 0u) {  // checkpoint: the state BEFORE iteration tb
-            if (alive) {
-                ck[0] = x;
-                ck[cs] = y;
-                ck[2 * cs] = z;
-            }
-            ck += 3 * cs;
-        }
-        uint32_t v_idx[U], v_zkey[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            v_idx[u] = kNoPixel;
-            v_zkey[u] = 0u;
-            const uint32_t t = tb + (uint32_t)u;
-            if (alive && t < n) {
-                next_point(p, x, y, z);  // :770
-                if (x != x) {
-                    alive = false;  // absorbing NaN state: this and all remaining iterations hit pixel (0,0)
-                    atomicAdd(a.nan_count, (unsigned long long)(n - t));
-                } else {
-                    double sx, sy, sz;
-                    screen_space(p, x, y, z, sx, sy, sz);  // :773
-                    const double ax = sx + p.ccx;
-                    const double az = sz + p.ccy;
-                    const double x2 = ax * p.cos_v + az * p.sin_v;  // :776-779
-                    const double z2 = ax * p.sin_v - az * p.cos_v;
-                    const double fi = (p.scale_adjusted_mid - x2) * p.width_scaled;   // :783
-                    const double fj = p.half_height - (sy + p.ccz) * p.width_scaled;  // :786
-                    if (!(fi >= p.width || fj >= p.height || fi < 0. || fj < 0.)) {    // :789
-                        const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;
-                        const uint32_t j = (fj == fj) ? (uint32_t)fj : 0u;
-                        v_idx[u] = j * a.it.width + i;
-                        float zf = (float)z2;  // `z2 as f32`
-                        if (zf > -1.0f) {      // strict `>` against the initial -1.0 (:693, :821); NaN fails
-                            zf = zf + 0.0f;    // -0.0 -> +0.0
-                            v_zkey[u] = f32_sortable(zf);
-                        }
-                    }
-                }
-            }
-        }
-        settle_batch();
-        // (3) requests for the batch just computed
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            q_idx[u] = v_idx[u];
-            q_zkey[u] = v_zkey[u];
-            q_have[u] = v_idx[u] != kNoPixel;
-            q_cand[u] = DEPTH && q_have[u] && v_zkey[u] != 0u;
-            if (q_have[u]) q_slot[u] = atomicAdd(&cnt[v_idx[u] >> a.bin_shift], 1u);  // ds_add_rtn_u32
-            if (q_cand[u]) q_hint[u] = zhint[v_idx[u]];
-        }
-        q_t0 = tb;
-    }
-    settle_batch();
-    if (DEPTH) {
-        uint32_t tot = n_sent;
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
-        if (lane == 0 && tot) atomicAdd(a.nan_count + 1, (unsigned long long)tot);
-    }
-    // flush the partly filled buffers and publish the list heads
-    for (uint32_t b0 = 0; b0 < B; b0 += 64u) {
-        const uint32_t b = b0 + lane;
-        const uint32_t have = (b < B) ? cnt[b] : 0u;
-        const bool flusher = have != 0u;
-        const unsigned long long fb = __ballot(flusher);
-        uint32_t head = (b < B) ? prv[b] : kNoChunk;
-        if (flusher) {
-            const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
-                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
-            const uint2* r = (const uint2*)(rec + b * kChunkRecords);
-            const uint2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
-            uint4* dst = arena + (size_t)chunk * 4u;
-            dst[0] = make_uint4(head, have, r0.x, r0.y);
-            dst[1] = make_uint4(r1.x, r1.y, r2.x, r2.y);
-            dst[2] = make_uint4(r3.x, r3.y, r4.x, r4.y);
-            dst[3] = make_uint4(r5.x, r5.y, r6.x, r6.y);
-            head = chunk;
-        }
-        cursor += (uint32_t)__popcll(fb);
-        if (b < B) a.heads[(size_t)b * a.n_waves + wave] = head;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// split pipeline: k_visits (pure fp64 compute, streams visits to HBM) || k_accumulate_visits (bins them)
-// ---------------------------------------------------------------------------------------------------
-// rocprof of k_iterate_binned: waves sit in s_waitcnt 45 % of their cycles (LDS round trips of the
-// staging, hint loads queued behind chunk stores on the in-order vmcnt) and only 2 waves per SIMD are
-// resident (LDS staging), while more trajectories would cost 1000 warm-up iterations each. So the two
-// halves run as two kernels on two streams over time slices of the trajectories:
-//   k_visits             per lane: the exact iteration arithmetic, one coalesced 8-byte store per visit
-//                        {pixel, sortable depth}, checkpoints; nothing in its loop waits on memory;
-//   k_accumulate_visits  per lane: reads visits back (prefetched a trip ahead), stages records in LDS and
-//                        sends depth candidates exactly like k_iterate_binned, 8 visits per lane per trip;
-//                        its stalls are filled by k_visits' waves on the same SIMDs.
-// Slice s+1 of k_visits overlaps slice s of k_accumulate_visits (two visit buffers, stream events).
-__global__ void __launch_bounds__(256) k_visits(const VisitArgs a) {
-    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    if (job >= a.n_jobs) return;
-    MapParams p = a.p;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) p.cz[k] = vgpr_pin(p.cz[k]);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) p.m[k] = vgpr_pin(p.m[k]);
-    p.sin_v = vgpr_pin(p.sin_v);
-    p.cos_v = vgpr_pin(p.cos_v);
-    p.ccx = vgpr_pin(p.ccx);
-    p.ccy = vgpr_pin(p.ccy);
-    p.ccz = vgpr_pin(p.ccz);
-    p.width = vgpr_pin(p.width);
-    p.height = vgpr_pin(p.height);
-    p.half_height = vgpr_pin(p.half_height);
-    p.width_scaled = vgpr_pin(p.width_scaled);
-    p.scale_adjusted_mid = vgpr_pin(p.scale_adjusted_mid);
-
-    const size_t cs = a.n_jobs;
-    double x, y, z;
-    bool alive = true;
-    if (a.first) {
-        x = a.starts[job];
-        y = a.starts[cs + job];
-        z = a.starts[2 * cs + job];
-        for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);  // warm-up (:750-752)
-    } else {
-        x = a.state[job];
-        y = a.state[cs + job];
-        z = a.state[2 * cs + job];
-        alive = !(x != x);  // diverged in an earlier slice (its remaining iterations are already counted)
-    }
-    const uint32_t n = (uint32_t)a.iters;
-    const uint32_t C = a.ckpt_stride;
-    uint2* out = (uint2*)a.visits + job;
-    double* ck = a.ckpt + (size_t)(a.t0 / C) * 3 * cs + job;
-    uint32_t t = a.t0;
-    while (t < a.t1) {
-        if (alive) {  // checkpoint: the state BEFORE iteration t
-            ck[0] = x;
-            ck[cs] = y;
-            ck[2 * cs] = z;
-        }
-        ck += 3 * cs;
-        const uint32_t tend = (a.t1 - t > C) ? t + C : a.t1;
-        for (; t < tend; ++t) {
-            uint2 v = make_uint2(kNoPixel, 0u);
-            if (alive) {
-                next_point(p, x, y, z);  // :770
-                if (x != x) {
-                    alive = false;  // absorbing NaN state: this and all remaining iterations hit pixel (0,0)
-                    atomicAdd(a.nan_count, (unsigned long long)(n - t));
-                } else {
-                    double sx, sy, sz;
-                    screen_space(p, x, y, z, sx, sy, sz);  // :773
-                    const double ax = sx + p.ccx;
-                    const double az = sz + p.ccy;
-                    const double x2 = ax * p.cos_v + az * p.sin_v;  // :776-779
-                    const double z2 = ax * p.sin_v - az * p.cos_v;
-                    const double fi = (p.scale_adjusted_mid - x2) * p.width_scaled;   // :783
-                    const double fj = p.half_height - (sy + p.ccz) * p.width_scaled;  // :786
-                    if (!(fi >= p.width || fj >= p.height || fi < 0. || fj < 0.)) {    // :789
-                        const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;
-                        const uint32_t j = (fj == fj) ? (uint32_t)fj : 0u;
-                        v.x = j * a.width + i;
-                        float zf = (float)z2;  // `z2 as f32`
-                        if (zf > -1.0f) {      // strict `>` against the initial -1.0 (:693, :821); NaN fails
-                            zf = zf + 0.0f;    // -0.0 -> +0.0
-                            v.y = f32_sortable(zf);
-                        }
-                    }
-                }
-            }
-            *out = v;
-            out += cs;
-        }
-    }
-    a.state[job] = alive ? x : __longlong_as_double(0x7ff8000000000000ll);
-    a.state[cs + job] = y;
-    a.state[2 * cs + job] = z;
-}
-
-constexpr int ACC_U = 8;  // visits per lane per trip of k_accumulate_visits
-
-__global__ void __launch_bounds__(256) k_accumulate_visits(const AccVisitArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t B = a.n_bins;
-    uint32_t* const img = smem + (threadIdx.x >> 6) * (B * 16u);
-    uint32_t* const cnt = img;       // [B] fill counters
-    uint32_t* const prv = cnt + B;   // [B] previous chunk of this (wave, bin)
-    unsigned short* const rec = (unsigned short*)(prv + B);  // [B][28] staged records
-    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t wave = job >> 6;
-    const bool valid = job < a.n_jobs;
-    uint32_t* const wstate = a.wave_state + (size_t)wave * (B * 16u + 16u);
-    uint32_t cursor = 0;
-    if (a.first) {
-        for (uint32_t b = lane; b < B; b += 64u) {
-            cnt[b] = 0u;
-            prv[b] = kNoChunk;
-        }
-    } else {
-        for (uint32_t k = lane; k < B * 16u; k += 64u) img[k] = wstate[k];
-        cursor = wstate[B * 16u];
-    }
-    uint4* const arena = (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * 4u;
-    uint32_t* const zhint = a.zhint + (size_t)xcc_id() * a.npix;
-    unsigned long long* const key = a.scratch_key;
-    const uint32_t n = (uint32_t)a.iters;
-    const uint32_t lo_base = 0xFFFFFFFFu - job * n;
-    const uint32_t bin_mask = (1u << a.bin_shift) - 1u;
-    const size_t cs = a.n_jobs;
-    const uint2* src = (const uint2*)a.visits + job;
-
-    // places one staged record (see k_iterate_binned::finish_visit for the generation logic)
-    auto place = [&](bool have, uint32_t bin, uint32_t slot, unsigned short local) {
-        bool pend = have;
-        const uint32_t gen = slot / kChunkRecords;
-        const uint32_t pos = slot - gen * kChunkRecords;
-        unsigned short* const dstrec = rec + bin * kChunkRecords;
-        for (uint32_t g = 0; __ballot(pend); ++g) {
-            const bool mine = pend && gen == g;
-            if (mine) dstrec[pos] = local;
-            const bool flusher = mine && pos == kChunkRecords - 1u;
-            const unsigned long long fb = __ballot(flusher);
-            if (fb) {
-                if (flusher) {
-                    const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
-                                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
-                    const uint2* r = (const uint2*)dstrec;
-                    const uint2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
-                    uint4* dst = arena + (size_t)chunk * 4u;
-                    dst[0] = make_uint4(prv[bin], kChunkRecords, r0.x, r0.y);
-                    dst[1] = make_uint4(r1.x, r1.y, r2.x, r2.y);
-                    dst[2] = make_uint4(r3.x, r3.y, r4.x, r4.y);
-                    dst[3] = make_uint4(r5.x, r5.y, r6.x, r6.y);
-                    prv[bin] = chunk;
-                    __hip_atomic_fetch_sub(&cnt[bin], kChunkRecords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                cursor += (uint32_t)__popcll(fb);
-            }
-            const bool early = pend && gen == g + 1u && pos < kChunkRecords - 1u;
-            if (early) dstrec[pos] = local;
-            pend = pend && !(mine || early);
-        }
-    };
-
-    uint2 nxt[ACC_U];  // visits of the next trip (prefetched)
-    uint32_t c_idx[ACC_U], c_zkey[ACC_U], c_hint[ACC_U], c_slot[ACC_U];  // previous trip, waiting for hint / slot
-    bool c_have[ACC_U], c_cand[ACC_U];
-#pragma unroll
-    for (int u = 0; u < ACC_U; ++u) {
-        c_have[u] = false;
-        c_cand[u] = false;
-        c_idx[u] = c_zkey[u] = c_hint[u] = c_slot[u] = 0;
-        const uint32_t t = a.t0 + (uint32_t)u;
-        nxt[u] = (valid && t < a.t1) ? src[(size_t)u * cs] : make_uint2(kNoPixel, 0u);
-    }
-    uint32_t n_sent = 0;
-    uint32_t tprev = a.t0;  // first iteration of the trip held in c_*
-    for (uint32_t tb = a.t0; tb < a.t1; tb += ACC_U) {
-        // (1) depth candidates of the previous trip: their hints were requested a whole trip ago
-#pragma unroll
-        for (int u = 0; u < ACC_U; ++u) {
-            if (c_cand[u] && c_zkey[u] >= c_hint[u]) {
-                atomicMax(key + c_idx[u], ((unsigned long long)c_zkey[u] << 32) | (unsigned long long)(lo_base - (tprev + (uint32_t)u)));
-                if (c_zkey[u] > c_hint[u]) zhint[c_idx[u]] = c_zkey[u];
-                ++n_sent;
-            }
-        }
-        // (2) this trip's visits arrive from the prefetch; start the prefetch of the next trip
-        uint2 cur[ACC_U];
-#pragma unroll
-        for (int u = 0; u < ACC_U; ++u) cur[u] = nxt[u];
-#pragma unroll
-        for (int u = 0; u < ACC_U; ++u) {
-            const uint32_t t = tb + ACC_U + (uint32_t)u;
-            nxt[u] = (valid && t < a.t1) ? src[(size_t)(t - a.t0) * cs] : make_uint2(kNoPixel, 0u);
-        }
-        // (3) place the previous trip's records (their LDS slots were requested a trip ago)
-#pragma unroll
-        for (int u = 0; u < ACC_U; ++u)
-            place(c_have[u], c_idx[u] >> a.bin_shift, c_slot[u], (unsigned short)(c_idx[u] & bin_mask));
-        // (4) request slots and hints for this trip
-#pragma unroll
-        for (int u = 0; u < ACC_U; ++u) {
-            c_idx[u] = cur[u].x;
-            c_zkey[u] = cur[u].y;
-            c_have[u] = cur[u].x != kNoPixel;
-            c_cand[u] = c_have[u] && cur[u].y != 0u;
-            if (c_have[u]) c_slot[u] = atomicAdd(&cnt[c_idx[u] >> a.bin_shift], 1u);
-            if (c_cand[u]) c_hint[u] = zhint[c_idx[u]];
-        }
-        tprev = tb;
-    }
-#pragma unroll
-    for (int u = 0; u < ACC_U; ++u) {
-        if (c_cand[u] && c_zkey[u] >= c_hint[u]) {
-            atomicMax(key + c_idx[u], ((unsigned long long)c_zkey[u] << 32) | (unsigned long long)(lo_base - (tprev + (uint32_t)u)));
-            if (c_zkey[u] > c_hint[u]) zhint[c_idx[u]] = c_zkey[u];
-            ++n_sent;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < ACC_U; ++u)
-        place(c_have[u], c_idx[u] >> a.bin_shift, c_slot[u], (unsigned short)(c_idx[u] & bin_mask));
-    {
-        uint32_t tot = n_sent;
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
-        if (lane == 0 && tot) atomicAdd(a.stats + 1, (unsigned long long)tot);
-    }
-
-    if (!a.last) {  // park the staging buffers and the cursor for the next slice
-        for (uint32_t k = lane; k < B * 16u; k += 64u) wstate[k] = img[k];
-        if (lane == 0) wstate[B * 16u] = cursor;
-        return;
-    }
-    // last slice: flush the partly filled buffers and publish the list heads
-    for (uint32_t b0 = 0; b0 < B; b0 += 64u) {
-        const uint32_t b = b0 + lane;
-        const uint32_t have = (b < B) ? cnt[b] : 0u;
-        const bool flusher = have != 0u;
-        const unsigned long long fb = __ballot(flusher);
-        uint32_t head = (b < B) ? prv[b] : kNoChunk;
-        if (flusher) {
-            const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
-                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
-            const uint2* r = (const uint2*)(rec + b * kChunkRecords);
-            const uint2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
-            uint4* dst = arena + (size_t)chunk * 4u;
-            dst[0] = make_uint4(head, have, r0.x, r0.y);
-            dst[1] = make_uint4(r1.x, r1.y, r2.x, r2.y);
-            dst[2] = make_uint4(r3.x, r3.y, r4.x, r4.y);
-            dst[3] = make_uint4(r5.x, r5.y, r6.x, r6.y);
-            head = chunk;
-        }
-        cursor += (uint32_t)__popcll(fb);
-        if (b < B) a.heads[(size_t)b * a.n_waves + wave] = head;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // k_bin_accumulate — records -> per-pixel hit counts, in LDS
 // ---------------------------------------------------------------------------------------------------
 // grid (B, splits): block (b, s) owns bin b and the waves w with w % splits == s. Every thread walks
@@ -1336,37 +834,10 @@ void launch_iterate_binned(const BinIterArgs& a, uint32_t block, bool depth, boo
     else hipLaunchKernelGGL((k_iterate_binned<true, false>), dim3(grid), dim3(block), lds, s, a);
 }
 
-int launch_iterate_batched(const BinIterArgs& a, uint32_t block, uint32_t batch, bool depth, hipStream_t s) {
-    const uint32_t grid = (a.it.n_jobs + block - 1) / block;
-    const size_t lds = (size_t)(block / 64u) * a.n_bins * 64u;
-#define SAR_LAUNCH_BATCHED(UU)                                                                                   \
-    if (depth) hipLaunchKernelGGL((k_iterate_batched<UU, true>), dim3(grid), dim3(block), lds, s, a);            \
-    else hipLaunchKernelGGL((k_iterate_batched<UU, false>), dim3(grid), dim3(block), lds, s, a)
-    switch (batch) {
-        case 2: SAR_LAUNCH_BATCHED(2); break;
-        case 4: SAR_LAUNCH_BATCHED(4); break;
-        case 8: SAR_LAUNCH_BATCHED(8); break;
-        default: return 1;
-    }
-#undef SAR_LAUNCH_BATCHED
-    return 0;
-}
-
-void launch_visits(const VisitArgs& a, uint32_t block, hipStream_t s) {
-    const uint32_t grid = (a.n_jobs + block - 1) / block;
-    hipLaunchKernelGGL(k_visits, dim3(grid), dim3(block), 0, s, a);
-}
-
-void launch_accumulate_visits(const AccVisitArgs& a, uint32_t block, hipStream_t s) {
-    const uint32_t grid = (a.n_jobs + block - 1) / block;
-    const size_t lds = (size_t)(block / 64u) * a.n_bins * 64u;
-    hipLaunchKernelGGL(k_accumulate_visits, dim3(grid), dim3(block), lds, s, a);
-}
-
-void launch_bin_accumulate(const BinAccArgs& a, hipStream_t s) {
+void launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, hipStream_t s) {
     const size_t lds = (size_t)4u << a.bin_shift;
     // one block per CU fits when the histogram needs > 64 KiB: use all 1024 threads for its list walks then
-    const uint32_t threads = lds > 64u * 1024u ? 1024u : 256u;
+    if (threads == 0) threads = lds > 64u * 1024u ? 1024u : 256u;
     hipLaunchKernelGGL(k_bin_accumulate, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a);
 }
 
@@ -1376,14 +847,6 @@ int binned_kernel_attributes() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_binned<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_binned<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_accumulate_visits, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#define SAR_ATTR_BATCHED(UU)                                                                                                                              \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_batched<UU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_batched<UU, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-    SAR_ATTR_BATCHED(2);
-    SAR_ATTR_BATCHED(4);
-    SAR_ATTR_BATCHED(8);
-#undef SAR_ATTR_BATCHED
     return (int)e;
 }
 

@@ -10,10 +10,7 @@ namespace sar {
 // mode: 2 = full path (count + depth key); 1 = count only, 0 = arithmetic only (measurement variants)
 void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode, hipStream_t s);
 void launch_iterate_binned(const BinIterArgs& a, uint32_t block, bool depth, bool refresh, hipStream_t s);
-int launch_iterate_batched(const BinIterArgs& a, uint32_t block, uint32_t batch, bool depth, hipStream_t s);
-void launch_visits(const VisitArgs& a, uint32_t block, hipStream_t s);
-void launch_accumulate_visits(const AccVisitArgs& a, uint32_t block, hipStream_t s);
-void launch_bin_accumulate(const BinAccArgs& a, hipStream_t s);
+void launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, hipStream_t s);
 int binned_kernel_attributes();
 void launch_fold_resolve(const FoldArgs& a, hipStream_t s);
 void launch_reset(uint32_t* count, unsigned long long* key, double* steps, uint32_t npix, uint32_t* scalars,

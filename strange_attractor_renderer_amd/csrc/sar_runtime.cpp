@@ -38,7 +38,6 @@ struct Span {
 
 constexpr uint32_t kDefaultBlock = 256;
 constexpr uint32_t kDefaultCkptStride = 64;
-constexpr uint32_t kDefaultBatch = 4;
 constexpr uint64_t kCkptBytesCap = 24ull << 30;  // checkpoint scratch per launch chunk (HBM is 288 GB)
 
 // ln(k+1) for k < kLnLutEntries, computed once per process with the host libm — the same function
@@ -83,16 +82,6 @@ struct sar_runtime {
     uint32_t* d_zhint = nullptr;
     unsigned long long* d_nan_count = nullptr;
 
-    // split pipeline: second stream, visit buffers, trajectory state, parked staging buffers
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_k1[2] = {nullptr, nullptr}, ev_k2[2] = {nullptr, nullptr};
-    void* d_visits[2] = {nullptr, nullptr};
-    size_t visits_cap = 0;  // bytes per buffer
-    double* d_state = nullptr;
-    size_t state_cap = 0;   // doubles
-    uint32_t* d_wave_state = nullptr;
-    size_t wave_state_cap = 0;  // words
-
     // staging
     double* h_starts = nullptr;  // pinned
     double* d_starts = nullptr;
@@ -115,8 +104,7 @@ struct sar_runtime {
     uint32_t bin_shift = 0;         // 0 = automatic
     uint32_t splits = 0;            // 0 = automatic
     uint32_t depth_refresh = 0;     // returning depth atomics refresh the per-XCD hints
-    uint32_t slices = 0;            // split pipeline: time slices per launch chunk (0 = automatic)
-    uint32_t batch = 0;             // fused binned kernel: iterations batched per lane (0 = default, 1 = unbatched)
+    uint32_t acc_threads = 0;       // threads per k_bin_accumulate block (0 = automatic)
 
     // timing
     bool timing = false;
@@ -319,10 +307,8 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
 
     // which accumulate path: LDS-binned records (default) or one global atomic per visit
     const BinGeometry geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits);
-    bool binned = (rt->bins_mode == 0 || rt->bins_mode >= 3) && rt->measure_mode != 2 && geo.ok;
-    // path 4 (default when eligible): compute kernel || accumulate kernel over time slices; path 3: one fused kernel
-    bool split = binned && rt->bins_mode == 4 && rt->measure_mode == 0;
-    if (rt->bins_mode >= 3 && !geo.ok) {
+    bool binned = (rt->bins_mode == 0 || rt->bins_mode == 3) && rt->measure_mode != 2 && geo.ok;
+    if (rt->bins_mode == 3 && !geo.ok) {
         set_error("the binned path needs width*height <= %u pixels", kMaxBins * kMaxBinPx);
         return SAR_ERR_RANGE;
     }
@@ -334,13 +320,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
     const uint64_t chunks_per_wave = (iters * 64ull + kChunkRecords - 1) / kChunkRecords + geo.bins;
     uint64_t chunk_jobs = kMaxChunkOrdinals / iters;
     // scratch per job: checkpoints (24 B each) + its share of the wave's record arena (binned path)
-    // split pipeline: S time slices of L iterations (a multiple of the checkpoint stride), two visit buffers
-    uint32_t n_slices = rt->slices ? rt->slices : 8u;
-    uint64_t slice_len = ((iters + n_slices - 1) / n_slices + C - 1) / C * C;
-    if (slice_len == 0) slice_len = C;
-    n_slices = static_cast<uint32_t>((iters + slice_len - 1) / slice_len);
-    if (n_slices < 2) split = false;  // nothing to overlap
-    const uint64_t bytes_per_job = n_ckpt * 24ull + (binned ? chunks_per_wave : 0ull) + (split ? 2ull * slice_len * 8ull + 24ull : 0ull);
+    const uint64_t bytes_per_job = n_ckpt * 24ull + (binned ? chunks_per_wave : 0ull);
     const uint64_t by_mem = kCkptBytesCap / bytes_per_job;
     if (by_mem < chunk_jobs) chunk_jobs = by_mem ? by_mem : 1;
     if (rt->debug_chunk_jobs && rt->debug_chunk_jobs < chunk_jobs) chunk_jobs = rt->debug_chunk_jobs;
@@ -431,42 +411,6 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, 2 * sizeof(unsigned long long), rt->stream));
         }
     }
-    if (split) {
-        if (!rt->stream2) {
-            HIP_TRY(hipStreamCreateWithFlags(&rt->stream2, hipStreamNonBlocking));
-            for (int k = 0; k < 2; ++k) {
-                HIP_TRY(hipEventCreateWithFlags(&rt->ev_k1[k], hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&rt->ev_k2[k], hipEventDisableTiming));
-            }
-        }
-        const size_t vbytes = static_cast<size_t>(slice_len) * chunk_jobs * 8u;
-        if (vbytes > rt->visits_cap) {
-            for (int k = 0; k < 2; ++k) {
-                if (rt->d_visits[k]) hipFree(rt->d_visits[k]);
-                rt->d_visits[k] = nullptr;
-            }
-            rt->visits_cap = 0;
-            HIP_TRY(hipMalloc(&rt->d_visits[0], vbytes));
-            HIP_TRY(hipMalloc(&rt->d_visits[1], vbytes));
-            rt->visits_cap = vbytes;
-        }
-        if (chunk_jobs * 3 > rt->state_cap) {
-            if (rt->d_state) hipFree(rt->d_state);
-            rt->d_state = nullptr;
-            rt->state_cap = 0;
-            HIP_TRY(hipMalloc(&rt->d_state, chunk_jobs * 3 * sizeof(double)));
-            rt->state_cap = chunk_jobs * 3;
-        }
-        const size_t ws_need = static_cast<size_t>(max_waves) * (geo.bins * 16u + 16u);
-        if (ws_need > rt->wave_state_cap) {
-            if (rt->d_wave_state) hipFree(rt->d_wave_state);
-            rt->d_wave_state = nullptr;
-            rt->wave_state_cap = 0;
-            HIP_TRY(hipMalloc(&rt->d_wave_state, ws_need * sizeof(uint32_t)));
-            rt->wave_state_cap = ws_need;
-        }
-    }
-
     IterArgs ia;
     std::memset(&ia, 0, sizeof(ia));
     fill_map_params(*cfg, ia.p);
@@ -502,70 +446,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
         ia.n_jobs = m;
         ia.starts = rt->d_starts + off * 3;
         fa.n_jobs = m;
-        if (binned && split) {
-            const uint32_t n_waves = ((m + block - 1) / block) * (block / 64u);
-            VisitArgs va;
-            std::memset(&va, 0, sizeof(va));
-            va.p = ia.p;
-            va.iters = iters;
-            va.n_jobs = m;
-            va.width = rt->W;
-            va.ckpt_stride = C;
-            va.starts = ia.starts;
-            va.state = rt->d_state;
-            va.ckpt = rt->d_ckpt;
-            va.nan_count = rt->d_nan_count;
-            AccVisitArgs aa;
-            std::memset(&aa, 0, sizeof(aa));
-            aa.iters = iters;
-            aa.n_jobs = m;
-            aa.npix = rt->npix;
-            aa.bin_shift = geo.shift;
-            aa.n_bins = geo.bins;
-            aa.chunks_per_wave = static_cast<uint32_t>(chunks_per_wave);
-            aa.n_waves = n_waves;
-            aa.arena = rt->d_arena;
-            aa.heads = rt->d_heads;
-            aa.zhint = rt->d_zhint;
-            aa.scratch_key = rt->d_scratch_key;
-            aa.wave_state = rt->d_wave_state;
-            aa.stats = rt->d_nan_count;
-            span_begin(rt, rt->iter_spans, rt->iter_used);
-            for (uint32_t sl = 0; sl < n_slices; ++sl) {
-                const int buf = static_cast<int>(sl & 1u);
-                const uint32_t t0 = static_cast<uint32_t>(sl * slice_len);
-                const uint32_t t1 = static_cast<uint32_t>((sl + 1 == n_slices) ? iters : (sl + 1) * slice_len);
-                if (sl >= 2) HIP_TRY(hipStreamWaitEvent(rt->stream, rt->ev_k2[buf], 0));  // visit buffer free again
-                va.t0 = aa.t0 = t0;
-                va.t1 = aa.t1 = t1;
-                va.first = aa.first = (sl == 0);
-                aa.last = (sl + 1 == n_slices);
-                va.visits = rt->d_visits[buf];
-                aa.visits = rt->d_visits[buf];
-                launch_visits(va, 256, rt->stream);
-                HIP_TRY(hipEventRecord(rt->ev_k1[buf], rt->stream));
-                HIP_TRY(hipStreamWaitEvent(rt->stream2, rt->ev_k1[buf], 0));
-                launch_accumulate_visits(aa, block, rt->stream2);
-                HIP_TRY(hipEventRecord(rt->ev_k2[buf], rt->stream2));
-            }
-            HIP_TRY(hipStreamWaitEvent(rt->stream, rt->ev_k2[(n_slices - 1) & 1u], 0));
-            span_end(rt, rt->iter_spans, rt->iter_used);
-            BinAccArgs ca;
-            std::memset(&ca, 0, sizeof(ca));
-            ca.bin_shift = geo.shift;
-            ca.n_bins = geo.bins;
-            ca.chunks_per_wave = aa.chunks_per_wave;
-            ca.n_waves = n_waves;
-            ca.npix = rt->npix;
-            ca.splits = splits;
-            ca.arena = rt->d_arena;
-            ca.heads = rt->d_heads;
-            ca.scratch_count = rt->d_scratch_count;
-            span_begin(rt, rt->fold_spans, rt->fold_used);
-            launch_bin_accumulate(ca, rt->stream);
-            launch_fold_resolve(fa, rt->stream);
-            span_end(rt, rt->fold_spans, rt->fold_used);
-        } else if (binned) {
+        if (binned) {
             BinIterArgs ba;
             std::memset(&ba, 0, sizeof(ba));
             ba.it = ia;
@@ -577,15 +458,8 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             ba.heads = rt->d_heads;
             ba.zhint = rt->d_zhint;
             ba.nan_count = rt->d_nan_count;
-            // batched accumulate (default) needs the checkpoint stride to be a multiple of the batch
-            uint32_t batch = rt->batch ? rt->batch : kDefaultBatch;
-            while (batch > 1 && (C % batch) != 0) batch >>= 1;
             span_begin(rt, rt->iter_spans, rt->iter_used);
-            if (batch > 1 && !rt->depth_refresh) {
-                if (launch_iterate_batched(ba, block, batch, mode == 2, rt->stream) != 0) { set_error("bad batch"); return SAR_ERR_INVALID; }
-            } else {
-                launch_iterate_binned(ba, block, mode == 2, rt->depth_refresh != 0, rt->stream);
-            }
+            launch_iterate_binned(ba, block, mode == 2, rt->depth_refresh != 0, rt->stream);
             span_end(rt, rt->iter_spans, rt->iter_used);
             BinAccArgs ca;
             std::memset(&ca, 0, sizeof(ca));
@@ -599,7 +473,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             ca.heads = rt->d_heads;
             ca.scratch_count = rt->d_scratch_count;
             span_begin(rt, rt->fold_spans, rt->fold_used);
-            launch_bin_accumulate(ca, rt->stream);
+            launch_bin_accumulate(ca, rt->acc_threads, rt->stream);
             launch_fold_resolve(fa, rt->stream);
             span_end(rt, rt->fold_spans, rt->fold_used);
         } else {
@@ -706,14 +580,6 @@ int sar_runtime_free(sar_runtime* rt) {
     if (rt->d_arena) hipFree(rt->d_arena);
     if (rt->d_heads) hipFree(rt->d_heads);
     if (rt->d_nan_count) hipFree(rt->d_nan_count);
-    for (int k = 0; k < 2; ++k) {
-        if (rt->d_visits[k]) hipFree(rt->d_visits[k]);
-        if (rt->ev_k1[k]) hipEventDestroy(rt->ev_k1[k]);
-        if (rt->ev_k2[k]) hipEventDestroy(rt->ev_k2[k]);
-    }
-    if (rt->d_state) hipFree(rt->d_state);
-    if (rt->d_wave_state) hipFree(rt->d_wave_state);
-    if (rt->stream2) hipStreamDestroy(rt->stream2);
     if (rt->starts_copied) hipEventDestroy(rt->starts_copied);
     for (auto& s : rt->iter_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto& s : rt->fold_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
@@ -1026,7 +892,7 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "checkpoint_stride")) {
         rt->ckpt_stride = v ? v : kDefaultCkptStride;
     } else if (!std::strcmp(name, "path")) {
-        if (v > 4) { set_error("path must be 0..4"); return SAR_ERR_INVALID; }
+        if (v > 3) { set_error("path must be 0..3"); return SAR_ERR_INVALID; }
         rt->bins_mode = v;
     } else if (!std::strcmp(name, "bin_shift")) {
         if (v && (v < 12 || v > 15)) { set_error("bin_shift must be 12..15"); return SAR_ERR_INVALID; }
@@ -1034,14 +900,11 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "splits")) {
         if (v > 16) { set_error("splits must be 1..16"); return SAR_ERR_INVALID; }
         rt->splits = v;
+    } else if (!std::strcmp(name, "acc_threads")) {
+        if (v && v != 256 && v != 512 && v != 1024) { set_error("acc_threads must be 256, 512 or 1024"); return SAR_ERR_INVALID; }
+        rt->acc_threads = v;
     } else if (!std::strcmp(name, "depth_refresh")) {
         rt->depth_refresh = v ? 1u : 0u;
-    } else if (!std::strcmp(name, "batch")) {
-        if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8) { set_error("batch must be 0, 1, 2, 4 or 8"); return SAR_ERR_INVALID; }
-        rt->batch = v;
-    } else if (!std::strcmp(name, "slices")) {
-        if (v > 64) { set_error("slices must be <= 64"); return SAR_ERR_INVALID; }
-        rt->slices = v;
     } else if (!std::strcmp(name, "measure")) {
         if (v > 2) { set_error("measure must be 0..2"); return SAR_ERR_INVALID; }
         rt->measure_mode = v;

@@ -1,0 +1,60 @@
+"""The `sequence` angle iterator (reference src/bin/main.rs:107-176) and the frame-per-GPU driver."""
+import math
+
+import numpy as np
+import pytest
+
+from strange_attractor_renderer_amd.sequence import angle_iter, frames
+
+
+def test_default_sweeps_frame_counts_and_names():
+    f1 = frames(0.0, 360.0, 1.0, "attractor")
+    assert len(f1) == 360                                   # curr + 0.5 < 360  ->  curr = 0..359
+    assert f1[0] == (0, 0.0, "attractor000") and f1[-1][2] == "attractor359"
+    assert f1[90][1] == 90.0 * math.pi / 180.0              # degrees -> radians only in the sweep branch
+    f2 = frames(0.0, 360.0, 0.5, "out/solar.png")           # the subcommand's default step
+    assert len(f2) == 720 and f2[1][2] == "out/solar001.png" and f2[-1][2] == "out/solar719.png"
+    assert f2[-1][1] == 359.5 * math.pi / 180.0
+    f3 = frames(10.0, 13.0, 1.0, "a")                        # count = 2.5 -> 1 digit
+    assert [n for _, _, n in f3] == ["a0", "a1", "a2"] and len(f3) == 3
+    f4 = frames(0.0, 2.4, 1.0, "a")                          # count = 1.9 -> `as usize` 1 -> no digits: both frames "a"
+    assert [n for _, _, n in f4] == ["a", "a"]
+    assert len(frames(0.0, 1.5, 1.0, "a")) == 1                # 1 + 0.5 < 1.5 is false
+
+
+def test_single_image_fallback_passes_angle_unconverted():
+    # the plain --angle path builds AngleIter::new(angle, angle, 1., name): one frame, value NOT converted
+    assert list(angle_iter(220.0, 220.0, 1.0, "attractor")) == [(220.0, "attractor")]
+    assert list(angle_iter(5.0, 1.0, 1.0, "x")) == [(5.0, "x")]
+
+
+def test_float_accumulation_matches_rust_loop():
+    got = [a for a, _ in angle_iter(0.0, 1.0, 0.1, "f")]
+    curr, want = 0.0, []
+    while curr + 0.05 < 1.0:
+        want.append(curr * math.pi / 180.0)
+        curr += 0.1
+    assert got == want and len(got) == 10
+
+
+@pytest.mark.gpu
+def test_sequence_frames_match_oracle_and_do_not_depend_on_world_size(sar, oracle, gpu):
+    from strange_attractor_renderer_amd.sequence import render_sequence
+    cfg = sar.Config.solar_sail(iterations=400_000, width=180, height=200, scale=1.0, transparent=0,
+                                render_kind=sar.SAR_RENDER_DEPTH)
+    units, jpt, seed = 128, 2, 9
+    whole = render_sequence(cfg, 0.0, 4.0, 1.0, units=units, jobs_per_thread=jpt, seed=seed)
+    assert [k for k, _, _ in whole] == [0, 1, 2, 3]
+    parts = {}
+    for r in range(2):                                       # two "GPUs": frames 0,2 and 1,3
+        for k, name, img in render_sequence(cfg, 0.0, 4.0, 1.0, units=units, jobs_per_thread=jpt, seed=seed,
+                                            rank=r, world=2):
+            parts[k] = img
+    n = 400_000 // units // jpt
+    for k, name, img in whole:
+        assert name == f"attractor{k}"
+        np.testing.assert_array_equal(img, parts[k])
+        c = cfg.replace(angle=k * math.pi / 180.0)
+        ort = oracle.Runtime(180, 200)
+        oracle.render_jobs(c.c, ort, oracle.start_points(seed, k * units * jpt, units * jpt), n)
+        np.testing.assert_array_equal(img, oracle.colorize(c.c, ort))

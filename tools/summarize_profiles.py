@@ -25,6 +25,7 @@ try:
 except Exception as e:  # noqa
     print(f"(no bench line: {e})\n")
 
+pmc_json = {}
 print("## PMC passes (each counter group in its own run; averages per dispatch of each kernel)\n")
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(d):
@@ -44,6 +45,11 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     for k, cs in agg.items():
         if not any(t in k for t in ("k_iterate", "k_bin_accumulate", "k_fold", "k_colorize")):
             continue
+        short = next(t for t in ("k_iterate_binned", "k_iterate_batched", "k_iterate", "k_bin_accumulate", "k_fold_resolve", "k_colorize_gas", "k_colorize") if t in k)
         for c, v in cs.items():
             print(f"| `{k[:48]}` | {c} | {len(v)} | {sum(v)/len(v):.6g} |")
+            pmc_json.setdefault(short, {})[c] = sum(v) / len(v)
     print()
+
+if len(sys.argv) > 2:
+    json.dump(pmc_json, open(sys.argv[2], "w"), indent=1, sort_keys=True)
