@@ -57,11 +57,23 @@ def cpu_baseline(seconds_hint: float):
     iters = ITERS_PER_GPU if ITERS_PER_GPU / est_rate <= seconds_hint else int(est_rate * seconds_hint)
     cfg.iterations = iters
     secs, done, _ = O.render_parallel(cfg, threads, 12, 1, want_image=True)
+    # `--single-thread` semantics (render + colorize on one core, src/bin/main.rs:483-490) on a shorter sample
+    import time as _t
+    import numpy as _np
+    st_iters = 100_000_000
+    rt = O.Runtime(WIDTH, HEIGHT)
+    t0 = _t.perf_counter()
+    O.render(cfg, rt, _np.array([0.05, 0.031, 0.077]), st_iters)
+    O.colorize(cfg, rt)
+    st_secs = _t.perf_counter() - t0
     return {
         "value": done / secs, "unit": "iterations/s", "cores": threads, "kind": "port",
         "sample": f"poisson-saturne {WIDTH}x{HEIGHT}, {done} iterations, {threads} threads x 12 jobs/thread, "
-                  f"private buffers + serial merge + serial colorize ({secs:.2f} s); C restatement of the "
+                  f"private buffers + serial merge + serial colorize ({secs:.2f} s, of which the serial merge of "
+                  f"{threads} buffer sets dominates on many-core hosts); C restatement of the "
                   "reference (clang -O3 -ffp-contract=off), not rustc output",
+        "single_thread": {"value": st_iters / st_secs, "unit": "iterations/s",
+                          "sample": f"one trajectory, {st_iters} iterations + colorize ({st_secs:.2f} s)"},
     }
 
 
@@ -74,6 +86,10 @@ def main():
     ap.add_argument("--iters", type=float, default=ITERS_PER_GPU, help="counted iterations per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo only "
+                    "to exercise the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--check", action="store_true", help="N>1: verify the merged count buffer against the sum of "
+                    "the per-rank buffers (debug; not timed)")
     ap.add_argument("--variant", type=lambda s: int(s, 0), default=0)
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--stride", type=int, default=0)
@@ -93,13 +109,16 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available() or S.device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     jobs = a.jobs
     iters_gpu = int(a.iters)
@@ -139,6 +158,19 @@ def main():
         for _ in range(a.warmup):
             step()
         fence()
+        if world > 1 and a.check:
+            # each rank's own (un-merged) count summed over ranks must equal the merged count on rank 0
+            rt.reset()
+            S.render_job_range(cfg, rt, n, starts)
+            own = torch.from_numpy(rt.count().astype(np.int64)).cuda()
+            exchange_merge(rt, rank, dist, key, sums, dst=0)
+            dist.reduce(own, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                merged = rt.count().astype(np.int64)
+                assert np.array_equal(merged, own.cpu().numpy() % (1 << 32)), "merged count != sum of rank counts"
+                assert int(merged.sum()) == n * jobs * world
+                print(f"[check] merged count over {world} ranks == sum of per-rank counts == {n * jobs * world}", file=sys.stderr)
+            fence()
         t0 = time.perf_counter()
         iter_ms = fold_ms = 0.0
         launches = 0
@@ -175,9 +207,11 @@ def main():
                        "iterations_per_job": n, "counted_iterations_per_step": n * jobs * world,
                        "warmup_iterations_per_job_uncounted": 1000,
                        "parallelism": f"trajectories sharded over {world} GPU(s)"
-                                      + ("; all-reduce MAX (depth keys) + reduce SUM (count, steps) over RCCL" if world > 1 else "")},
+                                      + (f"; all-reduce MAX (depth keys) + reduce SUM (count, steps) over "
+                                         f"{'RCCL/xGMI' if a.backend == 'nccl' else a.backend}" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
+                         "frac": ach / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic_bytes() if (iters_gpu == ITERS_PER_GPU and jobs == DEFAULT_JOBS) else None,
                          "kernel": "k_iterate_binned", "kernel_ms": kern_s * 1e3,
                          "alg_bytes_per_iteration": ALG_BYTES_PER_ITER,
                          "valu_frac": FP64_OPS_PER_ITER * (n * jobs / max(launches, 1)) / kern_s / FP64_PEAK_OPS,

@@ -151,3 +151,18 @@ int main() {
                         "-L", pkg, "-l:libsar_hip.so", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
         out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr)
+
+
+def test_rust_binding_source_declares_every_abi_function():
+    """bindings/rust is source-only (no Rust toolchain here); at least keep it in step with the header."""
+    rs = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+    declared = set(re.findall(r"pub fn (sar_[a-z0-9_]+)\s*\(", rs))
+    assert declared == set(declared_functions())
+    # field order of the #[repr(C)] mirror == the ctypes mirror == the C header
+    from strange_attractor_renderer_amd._abi import SarConfig, SarTiming
+    body = rs[rs.index("pub struct SarConfig {"):]
+    body = body[:body.index("}")]
+    assert re.findall(r"pub (\w+):", body) == [f for f, _ in SarConfig._fields_]
+    body = rs[rs.index("pub struct SarTiming {"):]
+    body = body[:body.index("}")]
+    assert re.findall(r"pub (\w+):", body) == [f for f, _ in SarTiming._fields_]
