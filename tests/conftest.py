@@ -24,6 +24,9 @@ def oracle():
 def sar():
     """The product package with libsar_hip.so loaded (fails loudly if it is not built)."""
     import strange_attractor_renderer_amd as S
+    from strange_attractor_renderer_amd import _abi, build
+    if not os.path.exists(_abi.LIB_PATH):
+        build.build_library()          # same recipe as __graft_entry__.build(); the product itself never builds lazily
     S.load_library()
     return S
 
