@@ -66,8 +66,14 @@ def cpu_baseline(seconds_hint: float):
     O.render(cfg, rt, _np.array([0.05, 0.031, 0.077]), st_iters)
     O.colorize(cfg, rt)
     st_secs = _t.perf_counter() - t0
+    few = None
+    if threads > 16:  # the serial merge scales with the thread count: also show a 16-thread run of the same frame
+        s16, d16, _ = O.render_parallel(cfg, 16, 12, 1, want_image=True)
+        few = {"value": d16 / s16, "unit": "iterations/s", "cores": 16,
+               "sample": f"same frame on 16 threads x 12 jobs/thread ({s16:.2f} s)"}
     return {
         "value": done / secs, "unit": "iterations/s", "cores": threads, "kind": "port",
+        "fewer_threads": few,
         "sample": f"poisson-saturne {WIDTH}x{HEIGHT}, {done} iterations, {threads} threads x 12 jobs/thread, "
                   f"private buffers + serial merge + serial colorize ({secs:.2f} s, of which the serial merge of "
                   f"{threads} buffer sets dominates on many-core hosts); C restatement of the "
