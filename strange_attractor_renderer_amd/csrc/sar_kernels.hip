@@ -473,6 +473,13 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     const uint32_t b = blockIdx.x, s = blockIdx.y;
     const uint32_t bin_px = 1u << a.bin_shift;
+    // Most bins of a frame are empty (the attractor covers a band of the image): a block with no chunk at all
+    // leaves its partial histogram untouched — the scratch copies are all-zero between launches because
+    // k_fold_resolve clears what it reads.
+    int any = 0;
+    for (uint32_t w = s + a.splits * threadIdx.x; w < a.n_waves; w += a.splits * blockDim.x)
+        any |= a.heads[(size_t)b * a.n_waves + w] != kNoChunk;
+    if (!__syncthreads_or(any)) return;
     for (uint32_t k = threadIdx.x; k < bin_px; k += blockDim.x) hist[k] = 0u;
     __syncthreads();
     const uint4* arena = (const uint4*)a.arena;
@@ -846,7 +853,7 @@ int binned_kernel_attributes() {
     hipError_t e = hipFuncSetAttribute((const void*)k_iterate_binned<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_binned<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_binned<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     return (int)e;
 }
 
