@@ -31,14 +31,15 @@ FP64_PEAK_OPS = 78.6e12 / 2      # MI355X vector fp64 78.6 TFLOP/s counts an FMA
 
 
 def pmc_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*.json):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r*_pmc.json):
     (2*FETCH_SIZE + WRITE_SIZE) * 1024, the guide's gfx950 correction (FETCH_SIZE reads 1/2 of a coalesced stream)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
         return None
     try:
-        d = json.load(open(files[-1]))["k_iterate_binned"]
+        d = json.load(open(files[-1]))
+        d = d.get("k_iterate_lean") or d["k_iterate_binned"]
         return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
     except Exception:
         return None
@@ -218,7 +219,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic_bytes() if (iters_gpu == ITERS_PER_GPU and jobs == DEFAULT_JOBS) else None,
-                         "kernel": "k_iterate_binned", "kernel_ms": kern_s * 1e3,
+                         "kernel": "k_iterate_lean", "kernel_ms": kern_s * 1e3,
                          "alg_bytes_per_iteration": ALG_BYTES_PER_ITER,
                          "valu_frac": FP64_OPS_PER_ITER * (n * jobs / max(launches, 1)) / kern_s / FP64_PEAK_OPS,
                          "note": "judged roofline per SURVEY 8(d) is HBM with 12.07 algorithmic B/iteration; the "

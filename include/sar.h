@@ -223,7 +223,6 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *   "bin_shift"          log2(pixels per bin) of the binned path (12..15)
  *   "splits"             workgroups per bin in the record-accumulate kernel (1..16)
  *   "acc_threads"        threads per block of the record-accumulate kernel (256, 512, 1024)
- *   "depth_refresh"      1: depth atomics return the chip-wide best and refresh the per-XCD hints
  *   "measure"            measurement-only kernels: 1 count only, 2 arithmetic only (results are NOT the render)
  *   "debug_chunk_jobs"   test hook: cap on jobs per launch chunk */
 int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value);

@@ -58,7 +58,7 @@ struct IterArgs {
     double* ckpt;              // [n_ckpt][3][n_jobs]
 };
 
-// Binned variant of the iterate kernel (see sar_kernels.hip: k_iterate_binned).
+// LDS-binned iterate kernel (see sar_kernels.hip: k_iterate_lean).
 struct BinIterArgs {
     IterArgs it;                 // scratch_count unused here (counts travel as records)
     uint32_t bin_shift;          // log2(pixels per bin)
@@ -67,7 +67,7 @@ struct BinIterArgs {
     uint32_t n_waves;            // launched waves (= heads stride)
     void* arena;                 // [n_waves][chunks_per_wave] 64-byte chunks {prev, n, 28 x u16}
     uint32_t* heads;             // [n_bins][n_waves] last chunk of each (bin, wave) list, or kNoChunk
-    uint32_t* zhint;             // [8][npix] per-XCD lower bound of the sortable depth already binned
+    unsigned short* zhint;       // [8][npix] per-XCD depth hints (16-bit fixed point, see depth_q16)
     unsigned long long* nan_count;  // iterations of diverged (NaN) trajectories: all land on pixel (0,0)
 };
 

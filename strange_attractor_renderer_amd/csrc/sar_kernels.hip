@@ -39,6 +39,19 @@ __device__ __forceinline__ float sortable_f32(uint32_t s) {
     return __uint_as_float(b);
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Depth hints are 16-bit fixed point: q(z) = clamp(floor((z + 1) * 2^14), 0, 65535). Every step is monotone
+// non-decreasing in z, so q(a) < q(b) implies a < b: a visit whose q is below the stored q of an already-sent
+// visit cannot win the depth test. 6e-5 resolution over z in [-1, 3) passes ~as few visits as an exact hint,
+// at half the footprint — the hint arrays then stay L2-resident (scattered 4-byte loads run at 2.65e11/s out
+// of a 2 MiB region and at 0.8e11/s out of 16 MiB on this chip, tools/ubench).
+__device__ __forceinline__ uint32_t depth_q16(float zf) {
+    const float s = (zf + 1.0f) * 16384.0f;
+    const uint32_t q = (uint32_t)fminf(fmaxf(s, 0.0f), 65535.0f);
+    return q;
+}
+
 // Forces a wave-uniform value into a VGPR (opaque to the optimiser, no instruction emitted).
 __device__ __forceinline__ double vgpr_pin(double v) {
     asm volatile("" : "+v"(v));
@@ -212,7 +225,7 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_iterate_binned — the hot loop without a global atomic per visit
+// k_iterate_lean — the hot loop without a global atomic per visit
 // ---------------------------------------------------------------------------------------------------
 // Measured on MI355X: the chip retires ~2.1e10 scattered global atomics per second whatever their
 // scope or width, while the fp64 arithmetic of this loop alone runs at ~3.6e11 iterations/s. So a
@@ -232,18 +245,30 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
 // the pixel, plain loads/stores served by the XCD's own L2); a visit is sent iff its z is >= the
 // hint. The hint read is issued one iteration ahead of its use, so its latency hides behind the next
 // iteration's arithmetic. A stale or lost hint only costs an extra atomic, never a wrong result.
-template <bool DEPTH, bool REFRESH>
-__global__ void __launch_bounds__(256) k_iterate_binned(const BinIterArgs a) {
+//
+// Control flow: the per-visit operations are issued unconditionally with a select on the ADDRESS instead
+// of a branch (every `if` around an LDS or memory operation costs s_and_saveexec / s_cbranch_execz / s_or):
+//   * a lane without a visit requests its slot from a private dummy counter and writes its record to
+//     a private scratch slot (cnt[B + lane], rec[B*28 + lane]);
+//   * the hint of a lane without a depth candidate is loaded from element 0;
+//   * only the two rare-per-lane events keep a wave-level branch: "some lane filled a buffer" (copy-out,
+//     which also places the records that overflowed into the next buffer generation) and "some lane
+//     has a depth candidate that passes its hint" (the 64-bit atomic max).
+constexpr uint32_t kLeanWaveLds(uint32_t bins) { return bins * 64u + 384u; }  // bytes of LDS per wave
+
+template <bool DEPTH>
+__global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t B = a.n_bins;
-    uint32_t* const cnt = smem + (threadIdx.x >> 6) * (B * 16u);  // [B] fill counters
-    uint32_t* const prv = cnt + B;                                  // [B] previous chunk of this (wave, bin)
-    unsigned short* const rec = (unsigned short*)(prv + B);        // [B][28] staged records
-    for (uint32_t b = lane; b < B; b += 64u) {
-        cnt[b] = 0u;
-        prv[b] = kNoChunk;
-    }
+    char* const wbase = (char*)smem + (threadIdx.x >> 6) * kLeanWaveLds(B);
+    unsigned short* const rec = (unsigned short*)wbase;            // [B][28] staged records + 64 scratch slots
+    uint32_t* const cnt = (uint32_t*)(wbase + B * 56u + 128u);     // [B] fill counters + 64 dummy counters
+    uint32_t* const prv = cnt + B + 64u;                           // [B] previous chunk of this (wave, bin)
+    for (uint32_t b = lane; b < B + 64u; b += 64u) cnt[b] = 0u;
+    for (uint32_t b = lane; b < B; b += 64u) prv[b] = kNoChunk;
+    const uint32_t trash = B * kChunkRecords + lane;  // this lane's scratch record slot
+    const uint32_t dummy = B + lane;                   // this lane's dummy counter
 
     const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t wave = job >> 6;
@@ -251,7 +276,7 @@ __global__ void __launch_bounds__(256) k_iterate_binned(const BinIterArgs a) {
 
     MapParams p = a.it.p;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) p.cz[k] = vgpr_pin(p.cz[k]);  // this kernel needs more SGPRs for its loops
+    for (int k = 0; k < 10; ++k) p.cz[k] = vgpr_pin(p.cz[k]);
 #pragma unroll
     for (int k = 0; k < 9; ++k) p.m[k] = vgpr_pin(p.m[k]);
     p.sin_v = vgpr_pin(p.sin_v);
@@ -273,9 +298,9 @@ __global__ void __launch_bounds__(256) k_iterate_binned(const BinIterArgs a) {
         for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);  // warm-up (:750-752)
     }
 
-    uint4* const arena = (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * 4u;  // 4 x uint4 per chunk
+    uint4* const arena = (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * 4u;
     uint32_t cursor = 0;  // wave-uniform: next free chunk of this wave's arena
-    uint32_t* const zhint = a.zhint + (size_t)xcc_id() * a.it.npix;
+    unsigned short* const zhint = a.zhint + (size_t)xcc_id() * a.it.npix;
     unsigned long long* const key = a.it.scratch_key;
 
     const uint32_t n = (uint32_t)a.it.iters;
@@ -284,77 +309,137 @@ __global__ void __launch_bounds__(256) k_iterate_binned(const BinIterArgs a) {
     const size_t cs = a.it.n_jobs;
     const uint32_t bin_mask = (1u << a.bin_shift) - 1u;
 
-    // depth candidate of the previous iteration, waiting for its hint
-    bool pv = false;
-    uint32_t p_idx = 0, p_zkey = 0, p_lo = 0, p_hint = 0;
-    uint32_t n_sent = 0;  // depth atomics this lane issued (statistics)
-    // depth atomic in flight (returning): refreshes the hint one iteration later
-    bool r_have = false;
-    uint32_t r_idx = 0, r_zkey = 0;
-    unsigned long long r_old = 0;
-    // visit of the previous iteration, waiting for its LDS slot (requested one iteration ahead so that
-    // the LDS round trip hides behind the arithmetic)
-    bool b_have = false;
-    uint32_t b_bin = 0, b_slot = 0;
-    unsigned short b_local = 0;
+    bool pv = false;  // depth candidate of the previous iteration, waiting for its hint
+    uint32_t p_idx = 0, p_zkey = 0, p_lo = 0, p_hint = 0, p_q = 0, n_sent = 0;
+    bool b_have = false;  // visit of the previous iteration, waiting for its LDS slot
+    uint32_t b_bin = 0, b_slot = 0, b_local = 0;
 
-    // Places the pending visit. Slots are handed out consecutively per bin, so slot = 28*gen + pos says
-    // which refill generation of the 28-record buffer the record belongs to. Trip g of the loop writes
-    // generation g; the lane holding pos 27 copies the full buffer out as one chunk and takes 28 off the
-    // counter; lanes of generation g+1 with pos < 27 can then write at once (their buffer was emptied a
-    // few instructions earlier, LDS operations of a wave execute in order). More than one trip is only
-    // needed when a lane holds pos 27 of a later generation, i.e. ~29+ lanes hit one bin at once.
-    auto finish_visit = [&]() {
-        bool pend = b_have;
+    // copy one full staging buffer out as a 64-byte chunk {previous chunk, 28, records} (immediate form, rare path)
+    auto flush_full = [&](uint32_t bin, uint32_t chunk) {
+        const uint2* r = (const uint2*)(rec + bin * kChunkRecords);  // 56 B, 8-byte aligned
+        const uint2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
+        u32x4* dst = (u32x4*)(arena + (size_t)chunk * 4u);
+        __builtin_nontemporal_store((u32x4){prv[bin], kChunkRecords, r0.x, r0.y}, dst + 0);
+        __builtin_nontemporal_store((u32x4){r1.x, r1.y, r2.x, r2.y}, dst + 1);
+        __builtin_nontemporal_store((u32x4){r3.x, r3.y, r4.x, r4.y}, dst + 2);
+        __builtin_nontemporal_store((u32x4){r5.x, r5.y, r6.x, r6.y}, dst + 3);
+        prv[bin] = chunk;
+        __hip_atomic_fetch_sub(&cnt[bin], kChunkRecords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    // The common copy-out is split over two iterations: the lane that filled a buffer ISSUES the LDS reads
+    // (and frees the buffer: LDS executes a wave's operations in order, so later writes cannot overtake
+    // them) and keeps the 64 bytes in registers; the global stores go out one iteration later, when the
+    // reads have long returned — no s_waitcnt sits between a read and its store any more.
+    bool f_on = false;
+    uint32_t f_chunk = 0, f_prev = 0;
+    uint2 f0 = {0, 0}, f1 = {0, 0}, f2 = {0, 0}, f3 = {0, 0}, f4 = {0, 0}, f5 = {0, 0}, f6 = {0, 0};
+    auto flush_store_pending = [&]() {
+        if (f_on) {
+            u32x4* dst = (u32x4*)(arena + (size_t)f_chunk * 4u);
+            __builtin_nontemporal_store((u32x4){f_prev, kChunkRecords, f0.x, f0.y}, dst + 0);
+            __builtin_nontemporal_store((u32x4){f1.x, f1.y, f2.x, f2.y}, dst + 1);
+            __builtin_nontemporal_store((u32x4){f3.x, f3.y, f4.x, f4.y}, dst + 2);
+            __builtin_nontemporal_store((u32x4){f5.x, f5.y, f6.x, f6.y}, dst + 3);
+        }
+        f_on = false;
+    };
+
+    // Places the pending record. slot = 28*gen + pos (slots are handed out consecutively per bin, so the
+    // quotient says which refill generation of the 28-record buffer a record belongs to). The generation-0 write is unconditional (scratch slot for lanes without one); everything
+    // else only exists when some lane filled a buffer in the same slot request.
+    auto place_visit = [&]() {
+        flush_store_pending();
         const uint32_t gen = b_slot / kChunkRecords;
         const uint32_t pos = b_slot - gen * kChunkRecords;
-        unsigned short* const dstrec = rec + b_bin * kChunkRecords;
-        for (uint32_t g = 0; __ballot(pend); ++g) {
-            const bool mine = pend && gen == g;
-            if (mine) dstrec[pos] = b_local;
-            const bool flusher = mine && pos == kChunkRecords - 1u;
-            const unsigned long long fb = __ballot(flusher);
-            if (fb) {
-                if (flusher) {
-                    const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
-                                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
-                    const uint2* r = (const uint2*)dstrec;  // 56 B, 8-byte aligned
-                    const uint2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
-                    uint4* dst = arena + (size_t)chunk * 4u;
-                    dst[0] = make_uint4(prv[b_bin], kChunkRecords, r0.x, r0.y);
-                    dst[1] = make_uint4(r1.x, r1.y, r2.x, r2.y);
-                    dst[2] = make_uint4(r3.x, r3.y, r4.x, r4.y);
-                    dst[3] = make_uint4(r5.x, r5.y, r6.x, r6.y);
-                    prv[b_bin] = chunk;
-                    __hip_atomic_fetch_sub(&cnt[b_bin], kChunkRecords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                cursor += (uint32_t)__popcll(fb);
+        const uint32_t at = b_bin * kChunkRecords + pos;
+        const bool w0 = b_have && gen == 0u;
+        rec[w0 ? at : trash] = (unsigned short)b_local;
+        const bool fl = w0 && pos == kChunkRecords - 1u;
+        const unsigned long long fb = __ballot(fl);
+        if (fb) {
+            if (fl) {
+                const uint2* r = (const uint2*)(rec + b_bin * kChunkRecords);
+                f0 = r[0]; f1 = r[1]; f2 = r[2]; f3 = r[3]; f4 = r[4]; f5 = r[5]; f6 = r[6];
+                f_prev = prv[b_bin];
+                f_chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
+                f_on = true;
+                prv[b_bin] = f_chunk;
+                __hip_atomic_fetch_sub(&cnt[b_bin], kChunkRecords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            const bool early = pend && gen == g + 1u && pos < kChunkRecords - 1u;
-            if (early) dstrec[pos] = b_local;
-            pend = pend && !(mine || early);
+            cursor += (uint32_t)__popcll(fb);
+            // records that overflowed into the next generation of a buffer that was just emptied
+            const bool e1 = b_have && gen == 1u && pos < kChunkRecords - 1u;
+            rec[e1 ? at : trash] = (unsigned short)b_local;
+            bool pend = b_have && gen >= 1u && !e1;  // a later generation's pos 27, or generation >= 2: rare
+            for (uint32_t g = 1; __ballot(pend); ++g) {
+                const bool mine = pend && gen == g;
+                if (mine) rec[at] = (unsigned short)b_local;
+                const bool fl2 = mine && pos == kChunkRecords - 1u;
+                const unsigned long long fb2 = __ballot(fl2);
+                if (fb2) {
+                    if (fl2) flush_full(b_bin, cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb2 >> 32),
+                                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)fb2, 0u)));
+                    cursor += (uint32_t)__popcll(fb2);
+                }
+                const bool early = pend && gen == g + 1u && pos < kChunkRecords - 1u;
+                if (early) rec[at] = (unsigned short)b_local;
+                pend = pend && !(mine || early);
+            }
         }
+    };
+
+    // Depth candidates go through two filters before they cost a global atomic (the chip retires only
+    // ~2.1e10 of those per second):
+    //   stage 1  this XCD's private 16-bit hint (L2-resident, loaded one iteration ahead);
+    //   stage 2  the chip-wide 64-bit key itself, read at device scope one iteration after stage 1 passed
+    //            (~5 % of the visits): the atomic is sent only if this visit beats what ANY XCD has sent —
+    //            and the private hint learns the chip-wide depth on the way.
+    bool gv = false;  // stage-2 candidate waiting for the chip-wide key
+    uint32_t g_idx = 0, g_q = 0;
+    unsigned long long g_mine = 0, g_cur = 0;
+    auto settle_depth = [&]() {
+        if (gv) {
+            if (g_mine > g_cur) {
+                atomicMax(key + g_idx, g_mine);
+                ++n_sent;
+            }
+            const uint32_t seen = (uint32_t)(g_cur >> 32);  // 0 while nobody has sent this pixel
+            const uint32_t qs = seen ? depth_q16(sortable_f32(seen)) : 0u;
+            zhint[g_idx] = (unsigned short)(qs > g_q ? qs : g_q);
+        }
+        gv = pv && p_q >= p_hint;
+        if (gv) {
+            g_idx = p_idx;
+            g_q = p_q;
+            g_mine = ((unsigned long long)p_zkey << 32) | (unsigned long long)p_lo;
+            g_cur = __hip_atomic_load(key + p_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto drain_depth = [&]() {
+        settle_depth();  // moves the last stage-1 candidate to stage 2
+        pv = false;
+        settle_depth();  // settles it
     };
 
     uint32_t t = 0;
     double* ck = a.it.ckpt + job;
     while (t < n) {
         if (alive) {  // checkpoint: the state BEFORE iteration t
-            ck[0] = x;
-            ck[cs] = y;
-            ck[2 * cs] = z;
+            __builtin_nontemporal_store(x, ck);
+            __builtin_nontemporal_store(y, ck + cs);
+            __builtin_nontemporal_store(z, ck + 2 * cs);
         }
         ck += 3 * cs;
         const uint32_t tend = (n - t > C) ? t + C : n;
         for (; t < tend; ++t) {
             bool inb = false;
             uint32_t idx = 0;
-            double z2 = 0.;
+            float zf = -2.0f;
             if (alive) {
                 next_point(p, x, y, z);  // :770
                 if (x != x) {
-                    // absorbing NaN state (see k_iterate): this and all remaining iterations hit pixel (0,0)
-                    alive = false;
+                    alive = false;  // absorbing NaN state: this and all remaining iterations hit pixel (0,0)
                     atomicAdd(a.nan_count, (unsigned long long)(n - t));
                 } else {
                     double sx, sy, sz;
@@ -362,78 +447,43 @@ __global__ void __launch_bounds__(256) k_iterate_binned(const BinIterArgs a) {
                     const double ax = sx + p.ccx;
                     const double az = sz + p.ccy;
                     const double x2 = ax * p.cos_v + az * p.sin_v;  // :776-779
-                    z2 = ax * p.sin_v - az * p.cos_v;
+                    const double z2 = ax * p.sin_v - az * p.cos_v;
                     const double fi = (p.scale_adjusted_mid - x2) * p.width_scaled;   // :783
                     const double fj = p.half_height - (sy + p.ccz) * p.width_scaled;  // :786
                     inb = !(fi >= p.width || fj >= p.height || fi < 0. || fj < 0.);    // :789
-                    if (inb) {
-                        const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;
-                        const uint32_t j = (fj == fj) ? (uint32_t)fj : 0u;
-                        idx = j * a.it.width + i;
-                    }
+                    const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;  // Rust `as u32`: NaN -> 0
+                    const uint32_t j = (fj == fj) ? (uint32_t)fj : 0u;
+                    idx = inb ? j * a.it.width + i : 0u;
+                    zf = (float)z2;  // `z2 as f32`
                 }
             }
 
             if (DEPTH) {
-                // (1) settle the previous iteration's depth candidate: its hint has had a whole
-                //     iteration of arithmetic to arrive
-                // (0) a depth atomic sent one iteration ago has returned what the WHOLE chip had for that pixel:
-                //     raise this XCD's hint to it (so an XCD learns from the other seven whenever it speaks)
-                if (REFRESH) {
-                    if (r_have) {
-                        const uint32_t seen = (uint32_t)(r_old >> 32);
-                        zhint[r_idx] = seen > r_zkey ? seen : r_zkey;
-                    }
-                    r_have = pv && p_zkey >= p_hint;
-                    if (r_have) {
-                        r_idx = p_idx;
-                        r_zkey = p_zkey;
-                        r_old = atomicMax(key + p_idx, ((unsigned long long)p_zkey << 32) | (unsigned long long)p_lo);
-                        ++n_sent;
-                    }
-                } else if (pv && p_zkey >= p_hint) {
-                    atomicMax(key + p_idx, ((unsigned long long)p_zkey << 32) | (unsigned long long)p_lo);
-                    if (p_zkey > p_hint) zhint[p_idx] = p_zkey;
-                    ++n_sent;
-                }
-                // (2) this iteration's candidate: strict `>` against the initial -1.0 (:693, :821)
-                pv = false;
-                if (inb) {
-                    float zf = (float)z2;  // `z2 as f32`
-                    if (zf > -1.0f) {
-                        zf = zf + 0.0f;  // -0.0 -> +0.0: integer order == float order
-                        pv = true;
-                        p_idx = idx;
-                        p_zkey = f32_sortable(zf);
-                        p_lo = lo_base - t;
-                        p_hint = zhint[idx];
-                    }
-                }
+                settle_depth();  // the previous iteration's candidate: its hint had a whole iteration to arrive
+                // this iteration's candidate: strict `>` against the initial -1.0 (:693, :821); NaN fails
+                const bool cand = inb && zf > -1.0f;
+                const float zc = zf + 0.0f;  // -0.0 -> +0.0: integer order == float order
+                p_zkey = f32_sortable(zc);
+                p_q = depth_q16(zc);
+                p_idx = idx;
+                p_lo = lo_base - t;
+                p_hint = zhint[cand ? idx : 0u];
+                pv = cand;
             }
 
-            // (3) the visits (:807-812) as staged records: place the previous one, request a slot for this one
-            finish_visit();
+            // the visits (:807-812) as staged records: place the previous one, request a slot for this one
+            place_visit();
             b_have = inb;
-            if (inb) {
-                b_bin = idx >> a.bin_shift;
-                b_local = (unsigned short)(idx & bin_mask);
-                b_slot = atomicAdd(&cnt[b_bin], 1u);  // ds_add_rtn_u32
-            }
+            b_bin = idx >> a.bin_shift;
+            b_local = idx & bin_mask;
+            b_slot = atomicAdd(&cnt[inb ? b_bin : dummy], 1u);  // ds_add_rtn_u32
         }
     }
-    finish_visit();
+    place_visit();
+    flush_store_pending();
     if (DEPTH) {
-        if (REFRESH && r_have) {
-            const uint32_t seen = (uint32_t)(r_old >> 32);
-            zhint[r_idx] = seen > r_zkey ? seen : r_zkey;
-        }
-        if (pv && p_zkey >= p_hint) {
-            atomicMax(key + p_idx, ((unsigned long long)p_zkey << 32) | (unsigned long long)p_lo);
-            if (p_zkey > p_hint) zhint[p_idx] = p_zkey;
-            ++n_sent;
-        }
-        // statistics: depth atomics issued by this wave (one add per wave)
-        uint32_t tot = n_sent;
+        drain_depth();
+        uint32_t tot = n_sent;  // statistics: depth atomics issued by this wave
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
         if (lane == 0 && tot) atomicAdd(a.nan_count + 1, (unsigned long long)tot);
     }
@@ -833,12 +883,13 @@ void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode,
     }
 }
 
-void launch_iterate_binned(const BinIterArgs& a, uint32_t block, bool depth, bool refresh, hipStream_t s) {
+uint32_t lean_wave_lds_bytes(uint32_t bins) { return kLeanWaveLds(bins); }
+
+void launch_iterate_lean(const BinIterArgs& a, uint32_t block, bool depth, hipStream_t s) {
     const uint32_t grid = (a.it.n_jobs + block - 1) / block;
-    const size_t lds = (size_t)(block / 64u) * a.n_bins * 64u;
-    if (!depth) hipLaunchKernelGGL((k_iterate_binned<false, false>), dim3(grid), dim3(block), lds, s, a);
-    else if (refresh) hipLaunchKernelGGL((k_iterate_binned<true, true>), dim3(grid), dim3(block), lds, s, a);
-    else hipLaunchKernelGGL((k_iterate_binned<true, false>), dim3(grid), dim3(block), lds, s, a);
+    const size_t lds = (size_t)(block / 64u) * kLeanWaveLds(a.n_bins);
+    if (depth) hipLaunchKernelGGL((k_iterate_lean<true>), dim3(grid), dim3(block), lds, s, a);
+    else hipLaunchKernelGGL((k_iterate_lean<false>), dim3(grid), dim3(block), lds, s, a);
 }
 
 void launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, hipStream_t s) {
@@ -850,9 +901,8 @@ void launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, hipStream_t s)
 
 int binned_kernel_attributes() {
     // both kernels need more dynamic LDS than the 64 KiB default window
-    hipError_t e = hipFuncSetAttribute((const void*)k_iterate_binned<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_binned<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_binned<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_iterate_lean<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     return (int)e;
 }

@@ -79,7 +79,7 @@ struct sar_runtime {
     size_t arena_cap = 0;  // bytes
     uint32_t* d_heads = nullptr;
     size_t heads_cap = 0;  // entries
-    uint32_t* d_zhint = nullptr;
+    unsigned short* d_zhint = nullptr;
     unsigned long long* d_nan_count = nullptr;
 
     // staging
@@ -103,7 +103,6 @@ struct sar_runtime {
     uint32_t debug_chunk_jobs = 0;  // test hook: cap on jobs per launch chunk (0 = none)
     uint32_t bin_shift = 0;         // 0 = automatic
     uint32_t splits = 0;            // 0 = automatic
-    uint32_t depth_refresh = 0;     // returning depth atomics refresh the per-XCD hints
     uint32_t acc_threads = 0;       // threads per k_bin_accumulate block (0 = automatic)
 
     // timing
@@ -195,7 +194,7 @@ BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift
     g.bins = (npix + px - 1) / px;
     if (g.bins > kMaxBins) return g;
     while ((1u << g.shift) < px) ++g.shift;
-    const uint32_t waves_fit = (160u * 1024u) / (g.bins * 64u);
+    const uint32_t waves_fit = (160u * 1024u) / lean_wave_lds_bytes(g.bins);
     uint32_t block = want_block;
     if (block > waves_fit * 64u) block = waves_fit * 64u;
     if (block == 0) return g;
@@ -208,7 +207,7 @@ BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift
 
 int clear_hints(sar_runtime* rt) {
     // hints are lower bounds of depths already accumulated; anything that can lower zbuf voids them
-    if (rt->d_zhint) HIP_TRY(hipMemsetAsync(rt->d_zhint, 0, static_cast<size_t>(rt->npix) * 8u * sizeof(uint32_t), rt->stream));
+    if (rt->d_zhint) HIP_TRY(hipMemsetAsync(rt->d_zhint, 0, static_cast<size_t>(rt->npix) * 8u * sizeof(unsigned short), rt->stream));
     return SAR_OK;
 }
 
@@ -403,7 +402,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             rt->heads_cap = heads_need;
         }
         if (!rt->d_zhint) {
-            HIP_TRY(hipMalloc(&rt->d_zhint, static_cast<size_t>(rt->npix) * 8u * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(&rt->d_zhint, static_cast<size_t>(rt->npix) * 8u * sizeof(unsigned short)));
             SAR_TRY(clear_hints(rt));
         }
         if (!rt->d_nan_count) {
@@ -459,7 +458,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             ba.zhint = rt->d_zhint;
             ba.nan_count = rt->d_nan_count;
             span_begin(rt, rt->iter_spans, rt->iter_used);
-            launch_iterate_binned(ba, block, mode == 2, rt->depth_refresh != 0, rt->stream);
+            launch_iterate_lean(ba, block, mode == 2, rt->stream);
             span_end(rt, rt->iter_spans, rt->iter_used);
             BinAccArgs ca;
             std::memset(&ca, 0, sizeof(ca));
@@ -903,8 +902,6 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "acc_threads")) {
         if (v && v != 256 && v != 512 && v != 1024) { set_error("acc_threads must be 256, 512 or 1024"); return SAR_ERR_INVALID; }
         rt->acc_threads = v;
-    } else if (!std::strcmp(name, "depth_refresh")) {
-        rt->depth_refresh = v ? 1u : 0u;
     } else if (!std::strcmp(name, "measure")) {
         if (v > 2) { set_error("measure must be 0..2"); return SAR_ERR_INVALID; }
         rt->measure_mode = v;

@@ -44,7 +44,6 @@ if __name__ == "__main__":
     ap.add_argument("--stride", type=int, nargs="+", default=[64])
     ap.add_argument("--bin-shift", type=int, nargs="+", default=[0])
     ap.add_argument("--splits", type=int, nargs="+", default=[0])
-    ap.add_argument("--refresh", type=int, nargs="+", default=[0])
     ap.add_argument("--acc-threads", type=int, nargs="+", default=[0])
     ap.add_argument("--out", default="gpurun_out/perf_explore.jsonl")
     a = ap.parse_args()
@@ -56,10 +55,10 @@ if __name__ == "__main__":
             starts = S.start_points(1, 0, jobs)
             for block in a.blocks:
                 for variant in a.variants:
-                    for stride, bs, sp, rf, at in [(x, y, z, q, w) for x in a.stride for y in a.bin_shift for z in a.splits for q in a.refresh for w in a.acc_threads]:
-                        r = run(cfg, starts, block, stride, variant, bin_shift=bs, splits=sp, depth_refresh=rf, acc_threads=at)
+                    for stride, bs, sp, at in [(x, y, z, w) for x in a.stride for y in a.bin_shift for z in a.splits for w in a.acc_threads]:
+                        r = run(cfg, starts, block, stride, variant, bin_shift=bs, splits=sp, acc_threads=at)
                         r.update(jobs=jobs, block=block, variant=hex(variant), stride=stride, size=a.size,
-                                 bin_shift=bs, splits=sp, refresh=rf, acc_threads=at,
+                                 bin_shift=bs, splits=sp, acc_threads=at,
                                  preset=a.preset,
                                  git_per_s_kernel=r["iters"] / r["iter_ms"] / 1e6,
                                  git_per_s_wall=r["iters"] / r["wall_ms"] / 1e6)

@@ -45,7 +45,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     for k, cs in agg.items():
         if not any(t in k for t in ("k_iterate", "k_bin_accumulate", "k_fold", "k_colorize")):
             continue
-        short = next(t for t in ("k_iterate_binned", "k_iterate_batched", "k_iterate", "k_bin_accumulate", "k_fold_resolve", "k_colorize_gas", "k_colorize") if t in k)
+        short = next(t for t in ("k_iterate_lean", "k_iterate_binned", "k_iterate", "k_bin_accumulate", "k_fold_resolve", "k_colorize_gas", "k_colorize") if t in k)
         for c, v in cs.items():
             print(f"| `{k[:48]}` | {c} | {len(v)} | {sum(v)/len(v):.6g} |")
             pmc_json.setdefault(short, {})[c] = sum(v) / len(v)
