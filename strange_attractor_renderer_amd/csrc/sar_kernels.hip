@@ -254,27 +254,259 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
 //   * only the two rare-per-lane events keep a wave-level branch: "some lane filled a buffer" (copy-out,
 //     which also places the records that overflowed into the next buffer generation) and "some lane
 //     has a depth candidate that passes its hint" (the 64-bit atomic max).
-constexpr uint32_t kLeanWaveLds(uint32_t bins) { return bins * 64u + 384u; }  // bytes of LDS per wave
+// LDS per wave: B buffers of R records + B counters + B links + 64 scratch records + 64 dummy counters
+// per-XCD hint arrays: an even number of 16-bit entries each, so that the dword holding a hint is aligned
+__host__ __device__ constexpr size_t kHintStride(uint32_t npix) { return ((size_t)npix + 1u) & ~(size_t)1u; }
+constexpr uint32_t kLeanWaveLds(uint32_t bins, uint32_t R) { return bins * (2u * R + 8u) + 384u; }
+constexpr uint32_t kChunkQuads(uint32_t R) { return (8u + 2u * R) / 16u; }  // 16-byte quads per chunk: R = 12, 20, 28
 
-template <bool DEPTH>
-__global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t B = a.n_bins;
-    char* const wbase = (char*)smem + (threadIdx.x >> 6) * kLeanWaveLds(B);
-    unsigned short* const rec = (unsigned short*)wbase;            // [B][28] staged records + 64 scratch slots
-    uint32_t* const cnt = (uint32_t*)(wbase + B * 56u + 128u);     // [B] fill counters + 64 dummy counters
-    uint32_t* const prv = cnt + B + 64u;                           // [B] previous chunk of this (wave, bin)
-    for (uint32_t b = lane; b < B + 64u; b += 64u) cnt[b] = 0u;
-    for (uint32_t b = lane; b < B; b += 64u) prv[b] = kNoChunk;
-    const uint32_t trash = B * kChunkRecords + lane;  // this lane's scratch record slot
-    const uint32_t dummy = B + lane;                   // this lane's dummy counter
+// Everything a wave needs to turn a stream of visits into staged records + depth candidates. One visit
+// per lane per step(); all per-visit state lives in registers, the staging buffers in the wave's LDS slice.
+template <bool DEPTH, uint32_t R>
+struct Stager {
+    static constexpr uint32_t Q = kChunkQuads(R);  // 16-byte quads per chunk
+    unsigned short* rec;  // [B][R] staged records + 64 scratch slots
+    uint32_t* cnt;        // [B] fill counters + 64 dummy counters
+    uint32_t* prv;        // [B] previous chunk of this (wave, bin)
+    uint32_t trash, dummy, lane, n_bins;
+    uint4* arena;         // this wave's chunk arena
+    uint32_t cursor;      // wave-uniform: next free chunk
+    unsigned short* zhint;
+    unsigned long long* key;
+    uint32_t bin_shift, bin_mask, lo_base;
+    bool pv;              // depth candidate of the previous visit, waiting for its hint
+    uint32_t p_idx, p_zkey, p_lo, p_hint, p_q, n_sent;
+    bool gv;              // stage-2 candidate waiting for the chip-wide key
+    uint32_t g_idx, g_q;
+    unsigned long long g_mine, g_cur;
+    bool b_have;          // previous visit, waiting for its LDS slot
+    uint32_t b_bin, b_slot, b_local;
+    bool f_on;            // a filled buffer whose 2R bytes sit in registers, waiting to be stored
+    uint32_t f_chunk, f_prev;
+    uint2 fpend[R / 4u];
 
-    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t wave = job >> 6;
-    bool alive = job < a.it.n_jobs;
+    __device__ __forceinline__ void init(char* wbase, uint32_t bins, uint32_t lane_, uint4* arena_, unsigned short* zhint_,
+                                         unsigned long long* key_, uint32_t shift, uint32_t lo_base_) {
+        n_bins = bins;
+        lane = lane_;
+        rec = (unsigned short*)wbase;
+        cnt = (uint32_t*)(wbase + bins * 2u * R + 128u);
+        prv = cnt + bins + 64u;
+        for (uint32_t b = lane; b < bins + 64u; b += 64u) cnt[b] = 0u;
+        for (uint32_t b = lane; b < bins; b += 64u) prv[b] = kNoChunk;
+        trash = bins * R + lane;
+        dummy = bins + lane;
+        arena = arena_;
+        cursor = 0;
+        zhint = zhint_;
+        key = key_;
+        bin_shift = shift;
+        bin_mask = (1u << shift) - 1u;
+        lo_base = lo_base_;
+        pv = gv = b_have = f_on = false;
+        p_idx = p_zkey = p_lo = p_hint = p_q = n_sent = 0;
+        g_idx = g_q = 0;
+        g_mine = g_cur = 0;
+        b_bin = b_slot = b_local = 0;
+        f_chunk = f_prev = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < R / 4u; ++k) fpend[k] = make_uint2(0u, 0u);
+    }
 
-    MapParams p = a.it.p;
+    // one chunk: {previous chunk of this (wave, bin), record count, records}
+    __device__ __forceinline__ void store_chunk(uint32_t chunk, uint32_t prev, uint32_t count, const uint2 (&f)[R / 4u]) {
+        uint32_t w[4u * Q];
+        w[0] = prev;
+        w[1] = count;
+#pragma unroll
+        for (uint32_t k = 0; k < R / 4u; ++k) {
+            w[2u + 2u * k] = f[k].x;
+            w[3u + 2u * k] = f[k].y;
+        }
+        u32x4* dst = (u32x4*)(arena + (size_t)chunk * Q);
+#pragma unroll
+        for (uint32_t q = 0; q < Q; ++q)  // streamed once, read once: keep them out of the L2 the hints live in
+            __builtin_nontemporal_store((u32x4){w[4u * q], w[4u * q + 1u], w[4u * q + 2u], w[4u * q + 3u]}, dst + q);
+    }
+    // immediate copy-out (rare path)
+    __device__ __forceinline__ void flush_full(uint32_t bin, uint32_t chunk) {
+        const uint2* r = (const uint2*)(rec + bin * R);  // 2R bytes, 8-byte aligned
+        uint2 f[R / 4u];
+#pragma unroll
+        for (uint32_t k = 0; k < R / 4u; ++k) f[k] = r[k];
+        store_chunk(chunk, prv[bin], R, f);
+        prv[bin] = chunk;
+        __hip_atomic_fetch_sub(&cnt[bin], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // The common copy-out is split: the lane that filled a buffer ISSUES the LDS reads (and frees the buffer:
+    // LDS executes a wave's operations in order, so later writes cannot overtake them); the global stores go
+    // out later in the step, when the reads have long returned.
+    __device__ __forceinline__ void flush_store_pending() {
+        if (f_on) store_chunk(f_chunk, f_prev, R, fpend);
+        f_on = false;
+    }
+
+    // Places the pending record. slot = R*gen + pos: slots are handed out consecutively per bin, so the
+    // quotient says which refill generation of the R-record buffer a record belongs to. The generation-0
+    // write is unconditional (scratch slot for lanes without one); everything else only exists when some lane
+    // filled a buffer in the same slot request.
+    __device__ __forceinline__ void place_visit() {
+        const uint32_t gen = b_slot / R;
+        const uint32_t pos = b_slot - gen * R;
+        const uint32_t at = b_bin * R + pos;
+        const bool w0 = b_have && gen == 0u;
+        rec[w0 ? at : trash] = (unsigned short)b_local;
+        const bool fl = w0 && pos == R - 1u;
+        const unsigned long long fb = __ballot(fl);
+        if (fb) {
+            if (fl) {
+                const uint2* r = (const uint2*)(rec + b_bin * R);
+#pragma unroll
+                for (uint32_t k = 0; k < R / 4u; ++k) fpend[k] = r[k];
+                f_prev = prv[b_bin];
+                f_chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
+                f_on = true;
+                prv[b_bin] = f_chunk;
+                __hip_atomic_fetch_sub(&cnt[b_bin], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            cursor += (uint32_t)__popcll(fb);
+            // records that overflowed into the next generation of a buffer that was just emptied
+            const bool e1 = b_have && gen == 1u && pos < R - 1u;
+            rec[e1 ? at : trash] = (unsigned short)b_local;
+            bool pend = b_have && gen >= 1u && !e1;  // a later generation's last slot, or generation >= 2: rare
+            for (uint32_t g = 1; __ballot(pend); ++g) {
+                const bool mine = pend && gen == g;
+                if (mine) rec[at] = (unsigned short)b_local;
+                const bool fl2 = mine && pos == R - 1u;
+                const unsigned long long fb2 = __ballot(fl2);
+                if (fb2) {
+                    if (fl2) flush_full(b_bin, cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb2 >> 32),
+                                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)fb2, 0u)));
+                    cursor += (uint32_t)__popcll(fb2);
+                }
+                const bool early = pend && gen == g + 1u && pos < R - 1u;
+                if (early) rec[at] = (unsigned short)b_local;
+                pend = pend && !(mine || early);
+            }
+        }
+    }
+
+    // Depth candidates go through two filters before they cost a global atomic (the chip retires only
+    // ~2.1e10 of those per second):
+    //   stage 1  this XCD's private 16-bit hint (L2-resident, loaded one visit ahead);
+    //   stage 2  the chip-wide 64-bit key itself, read at device scope one visit after stage 1 passed
+    //            (~5 % of the visits): the atomic is sent only if this visit beats what ANY XCD has sent —
+    //            and the private hint learns the chip-wide depth on the way.
+    __device__ __forceinline__ void settle_depth() {
+        if (gv) {
+            if (g_mine > g_cur) {
+                atomicMax(key + g_idx, g_mine);
+                ++n_sent;
+            }
+            const uint32_t seen = (uint32_t)(g_cur >> 32);  // 0 while nobody has sent this pixel
+            const uint32_t qs = seen ? depth_q16(sortable_f32(seen)) : 0u;
+            zhint[g_idx] = (unsigned short)(qs > g_q ? qs : g_q);
+        }
+        // p_hint is the raw dword holding this pixel's hint and its neighbour's: it is unpacked only HERE, one
+        // visit after the load was issued. (Unpacking next to the load makes the compiler wait for the load at
+        // the bottom of the loop — vmcnt(0) every iteration — instead of letting it fly across the map arithmetic.)
+        const uint32_t hint = (p_idx & 1u) ? (p_hint >> 16) : (p_hint & 0xFFFFu);
+        gv = pv && p_q >= hint;
+        if (gv) {
+            g_idx = p_idx;
+            g_q = p_q;
+            g_mine = ((unsigned long long)p_zkey << 32) | (unsigned long long)p_lo;
+            g_cur = __hip_atomic_load(key + p_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // One visit of this lane: inb = the iteration landed inside the image at pixel idx with depth zf
+    // (reference src/lib.rs:807-834); t = iteration number (for the visit ordinal).
+    __device__ __forceinline__ void step(bool inb, uint32_t idx, float zf, uint32_t t) {
+        // the previous visit's record first: pure LDS work that gives the hint load more time to arrive
+        place_visit();
+        if (DEPTH) {
+            settle_depth();  // the previous visit's candidate: its hint was requested a whole step ago
+            // this visit's candidate: strict `>` against the initial -1.0 (:693, :821); NaN fails
+            const bool cand = inb && zf > -1.0f;
+            const float zc = zf + 0.0f;  // -0.0 -> +0.0: integer order == float order
+            p_zkey = f32_sortable(zc);
+            p_q = depth_q16(zc);
+            p_idx = idx;
+            p_lo = lo_base - t;
+            p_hint = *(const uint32_t*)(zhint + (cand ? (idx & ~1u) : 0u));
+            pv = cand;
+        }
+        // chunk stores of a buffer that filled up (their LDS reads were issued by place_visit above), then this
+        // visit's slot request
+        flush_store_pending();
+        b_have = inb;
+        b_bin = idx >> bin_shift;
+        b_local = idx & bin_mask;
+        b_slot = atomicAdd(&cnt[inb ? b_bin : dummy], 1u);  // ds_add_rtn_u32
+    }
+
+    // After the last visit: settle what is in flight, flush the partly filled buffers, publish the list heads.
+    __device__ __forceinline__ void finish(uint32_t* heads, uint32_t n_waves, uint32_t wave, unsigned long long* stats) {
+        place_visit();
+        flush_store_pending();
+        if (DEPTH) {
+            settle_depth();  // moves the last stage-1 candidate to stage 2
+            pv = false;
+            settle_depth();  // settles it
+            uint32_t tot = n_sent;  // statistics: depth atomics issued by this wave
+            for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
+            if (lane == 0 && tot) atomicAdd(stats + 1, (unsigned long long)tot);
+        }
+        for (uint32_t b0 = 0; b0 < n_bins; b0 += 64u) {
+            const uint32_t b = b0 + lane;
+            const uint32_t have = (b < n_bins) ? cnt[b] : 0u;
+            const bool flusher = have != 0u;
+            const unsigned long long fb = __ballot(flusher);
+            uint32_t head = (b < n_bins) ? prv[b] : kNoChunk;
+            if (flusher) {
+                const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
+                                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
+                const uint2* r = (const uint2*)(rec + b * R);
+                uint2 f[R / 4u];
+#pragma unroll
+                for (uint32_t k = 0; k < R / 4u; ++k) f[k] = r[k];
+                store_chunk(chunk, head, have, f);
+                head = chunk;
+            }
+            cursor += (uint32_t)__popcll(fb);
+            if (b < n_bins) heads[(size_t)b * n_waves + wave] = head;
+        }
+    }
+};
+
+// One iteration of render's loop body up to the visit (reference src/lib.rs:770-802): advances the point and
+// reports whether the iteration landed inside the image, at which pixel, and its depth as f32. Returns false
+// when the trajectory has just become NaN (absorbing: this and every remaining iteration hit pixel (0,0)).
+__device__ __forceinline__ bool iterate_once(const MapParams& p, uint32_t width, double& x, double& y, double& z,
+                                             bool& inb, uint32_t& idx, float& zf) {
+    next_point(p, x, y, z);  // :770
+    if (x != x) return false;
+    double sx, sy, sz;
+    screen_space(p, x, y, z, sx, sy, sz);  // :773
+    const double ax = sx + p.ccx;          // center_camera.x with screen_space.x
+    const double az = sz + p.ccy;          // center_camera.y with screen_space.z (:776-779)
+    const double x2 = ax * p.cos_v + az * p.sin_v;
+    const double z2 = ax * p.sin_v - az * p.cos_v;
+    const double fi = (p.scale_adjusted_mid - x2) * p.width_scaled;   // :783
+    const double fj = p.half_height - (sy + p.ccz) * p.width_scaled;  // :786
+    inb = !(fi >= p.width || fj >= p.height || fi < 0. || fj < 0.);    // :789
+    const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;  // Rust `as u32`: NaN -> 0
+    const uint32_t j = (fj == fj) ? (uint32_t)fj : 0u;
+    idx = inb ? j * width + i : 0u;
+    zf = (float)z2;  // `z2 as f32`
+    return true;
+}
+
+__device__ __forceinline__ void pin_map_params(MapParams& p) {
+    // 30 coefficients + 9 matrix entries + 10 projection constants are 98 SGPRs as kernel arguments — more than
+    // the scalar file holds next to pointers and exec masks (the compiler then spills SGPRs to VGPR lanes inside
+    // the loop). The x/y coefficients stay scalar operands; the rest is pinned into (plentiful) VGPRs.
 #pragma unroll
     for (int k = 0; k < 10; ++k) p.cz[k] = vgpr_pin(p.cz[k]);
 #pragma unroll
@@ -289,7 +521,26 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     p.half_height = vgpr_pin(p.half_height);
     p.width_scaled = vgpr_pin(p.width_scaled);
     p.scale_adjusted_mid = vgpr_pin(p.scale_adjusted_mid);
+}
 
+template <bool DEPTH, uint32_t R>
+__global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t wave = job >> 6;
+    bool alive = job < a.it.n_jobs;
+    const uint32_t n = (uint32_t)a.it.iters;
+
+    Stager<DEPTH, R> st;
+    // visit ordinal = job*n + t (job-major, iteration-minor == the sequential order of the reference); the key's
+    // low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie
+    st.init((char*)smem + (threadIdx.x >> 6) * kLeanWaveLds(a.n_bins, R), a.n_bins, lane,
+            (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkQuads(R),
+            a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.bin_shift, 0xFFFFFFFFu - job * n);
+
+    MapParams p = a.it.p;
+    pin_map_params(p);
     double x = 0., y = 0., z = 0.;
     if (alive) {
         x = a.it.starts[job];
@@ -297,135 +548,12 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
         z = a.it.starts[2u * a.it.n_jobs + job];
         for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);  // warm-up (:750-752)
     }
-
-    uint4* const arena = (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * 4u;
-    uint32_t cursor = 0;  // wave-uniform: next free chunk of this wave's arena
-    unsigned short* const zhint = a.zhint + (size_t)xcc_id() * a.it.npix;
-    unsigned long long* const key = a.it.scratch_key;
-
-    const uint32_t n = (uint32_t)a.it.iters;
-    const uint32_t lo_base = 0xFFFFFFFFu - job * n;
     const uint32_t C = a.it.ckpt_stride;
     const size_t cs = a.it.n_jobs;
-    const uint32_t bin_mask = (1u << a.bin_shift) - 1u;
-
-    bool pv = false;  // depth candidate of the previous iteration, waiting for its hint
-    uint32_t p_idx = 0, p_zkey = 0, p_lo = 0, p_hint = 0, p_q = 0, n_sent = 0;
-    bool b_have = false;  // visit of the previous iteration, waiting for its LDS slot
-    uint32_t b_bin = 0, b_slot = 0, b_local = 0;
-
-    // copy one full staging buffer out as a 64-byte chunk {previous chunk, 28, records} (immediate form, rare path)
-    auto flush_full = [&](uint32_t bin, uint32_t chunk) {
-        const uint2* r = (const uint2*)(rec + bin * kChunkRecords);  // 56 B, 8-byte aligned
-        const uint2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
-        u32x4* dst = (u32x4*)(arena + (size_t)chunk * 4u);
-        __builtin_nontemporal_store((u32x4){prv[bin], kChunkRecords, r0.x, r0.y}, dst + 0);
-        __builtin_nontemporal_store((u32x4){r1.x, r1.y, r2.x, r2.y}, dst + 1);
-        __builtin_nontemporal_store((u32x4){r3.x, r3.y, r4.x, r4.y}, dst + 2);
-        __builtin_nontemporal_store((u32x4){r5.x, r5.y, r6.x, r6.y}, dst + 3);
-        prv[bin] = chunk;
-        __hip_atomic_fetch_sub(&cnt[bin], kChunkRecords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-
-    // The common copy-out is split over two iterations: the lane that filled a buffer ISSUES the LDS reads
-    // (and frees the buffer: LDS executes a wave's operations in order, so later writes cannot overtake
-    // them) and keeps the 64 bytes in registers; the global stores go out one iteration later, when the
-    // reads have long returned — no s_waitcnt sits between a read and its store any more.
-    bool f_on = false;
-    uint32_t f_chunk = 0, f_prev = 0;
-    uint2 f0 = {0, 0}, f1 = {0, 0}, f2 = {0, 0}, f3 = {0, 0}, f4 = {0, 0}, f5 = {0, 0}, f6 = {0, 0};
-    auto flush_store_pending = [&]() {
-        if (f_on) {
-            u32x4* dst = (u32x4*)(arena + (size_t)f_chunk * 4u);
-            __builtin_nontemporal_store((u32x4){f_prev, kChunkRecords, f0.x, f0.y}, dst + 0);
-            __builtin_nontemporal_store((u32x4){f1.x, f1.y, f2.x, f2.y}, dst + 1);
-            __builtin_nontemporal_store((u32x4){f3.x, f3.y, f4.x, f4.y}, dst + 2);
-            __builtin_nontemporal_store((u32x4){f5.x, f5.y, f6.x, f6.y}, dst + 3);
-        }
-        f_on = false;
-    };
-
-    // Places the pending record. slot = 28*gen + pos (slots are handed out consecutively per bin, so the
-    // quotient says which refill generation of the 28-record buffer a record belongs to). The generation-0 write is unconditional (scratch slot for lanes without one); everything
-    // else only exists when some lane filled a buffer in the same slot request.
-    auto place_visit = [&]() {
-        flush_store_pending();
-        const uint32_t gen = b_slot / kChunkRecords;
-        const uint32_t pos = b_slot - gen * kChunkRecords;
-        const uint32_t at = b_bin * kChunkRecords + pos;
-        const bool w0 = b_have && gen == 0u;
-        rec[w0 ? at : trash] = (unsigned short)b_local;
-        const bool fl = w0 && pos == kChunkRecords - 1u;
-        const unsigned long long fb = __ballot(fl);
-        if (fb) {
-            if (fl) {
-                const uint2* r = (const uint2*)(rec + b_bin * kChunkRecords);
-                f0 = r[0]; f1 = r[1]; f2 = r[2]; f3 = r[3]; f4 = r[4]; f5 = r[5]; f6 = r[6];
-                f_prev = prv[b_bin];
-                f_chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
-                f_on = true;
-                prv[b_bin] = f_chunk;
-                __hip_atomic_fetch_sub(&cnt[b_bin], kChunkRecords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            cursor += (uint32_t)__popcll(fb);
-            // records that overflowed into the next generation of a buffer that was just emptied
-            const bool e1 = b_have && gen == 1u && pos < kChunkRecords - 1u;
-            rec[e1 ? at : trash] = (unsigned short)b_local;
-            bool pend = b_have && gen >= 1u && !e1;  // a later generation's pos 27, or generation >= 2: rare
-            for (uint32_t g = 1; __ballot(pend); ++g) {
-                const bool mine = pend && gen == g;
-                if (mine) rec[at] = (unsigned short)b_local;
-                const bool fl2 = mine && pos == kChunkRecords - 1u;
-                const unsigned long long fb2 = __ballot(fl2);
-                if (fb2) {
-                    if (fl2) flush_full(b_bin, cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb2 >> 32),
-                                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)fb2, 0u)));
-                    cursor += (uint32_t)__popcll(fb2);
-                }
-                const bool early = pend && gen == g + 1u && pos < kChunkRecords - 1u;
-                if (early) rec[at] = (unsigned short)b_local;
-                pend = pend && !(mine || early);
-            }
-        }
-    };
-
-    // Depth candidates go through two filters before they cost a global atomic (the chip retires only
-    // ~2.1e10 of those per second):
-    //   stage 1  this XCD's private 16-bit hint (L2-resident, loaded one iteration ahead);
-    //   stage 2  the chip-wide 64-bit key itself, read at device scope one iteration after stage 1 passed
-    //            (~5 % of the visits): the atomic is sent only if this visit beats what ANY XCD has sent —
-    //            and the private hint learns the chip-wide depth on the way.
-    bool gv = false;  // stage-2 candidate waiting for the chip-wide key
-    uint32_t g_idx = 0, g_q = 0;
-    unsigned long long g_mine = 0, g_cur = 0;
-    auto settle_depth = [&]() {
-        if (gv) {
-            if (g_mine > g_cur) {
-                atomicMax(key + g_idx, g_mine);
-                ++n_sent;
-            }
-            const uint32_t seen = (uint32_t)(g_cur >> 32);  // 0 while nobody has sent this pixel
-            const uint32_t qs = seen ? depth_q16(sortable_f32(seen)) : 0u;
-            zhint[g_idx] = (unsigned short)(qs > g_q ? qs : g_q);
-        }
-        gv = pv && p_q >= p_hint;
-        if (gv) {
-            g_idx = p_idx;
-            g_q = p_q;
-            g_mine = ((unsigned long long)p_zkey << 32) | (unsigned long long)p_lo;
-            g_cur = __hip_atomic_load(key + p_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    auto drain_depth = [&]() {
-        settle_depth();  // moves the last stage-1 candidate to stage 2
-        pv = false;
-        settle_depth();  // settles it
-    };
-
     uint32_t t = 0;
     double* ck = a.it.ckpt + job;
     while (t < n) {
-        if (alive) {  // checkpoint: the state BEFORE iteration t
+        if (alive) {  // checkpoint: the state BEFORE iteration t (coalesced 512-B rows per wave)
             __builtin_nontemporal_store(x, ck);
             __builtin_nontemporal_store(y, ck + cs);
             __builtin_nontemporal_store(z, ck + 2 * cs);
@@ -436,80 +564,149 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
             bool inb = false;
             uint32_t idx = 0;
             float zf = -2.0f;
+            if (alive && !iterate_once(p, a.it.width, x, y, z, inb, idx, zf)) {
+                // absorbing NaN state: this and all remaining iterations pass the bounds test (:789), land on pixel
+                // (0,0) (:800-802) and never win the depth test — add them in one go
+                alive = false;
+                inb = false;
+                atomicAdd(a.nan_count, (unsigned long long)(n - t));
+            }
+            st.step(inb, idx, zf, t);
+        }
+    }
+    st.finish(a.heads, a.n_waves, wave, a.nan_count);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_iterate_ws: the same work as k_iterate_lean, split between two kinds of waves of one workgroup.
+//   waves 0..3  "map waves": own 64 trajectories each, run the fp64 map + projection (88 unfused DP
+//               operations per iteration) and write one 8-byte visit per lane into an LDS ring;
+//   waves 4..7  "record waves": wave 4+k drains the ring of wave k through the Stager (LDS slot request,
+//               record placement, chunk copy-out, depth filter).
+// In k_iterate_lean one wave does both, so its DP pipe idles whenever the wave waits for an LDS atomic
+// return or a hint load; here the SIMD always has a map wave to issue DP instructions from.
+// Ring protocol (per wave pair; LDS executes one wave's operations in issue order, and both counters are
+// single-writer): the map wave writes slot t % D then head = t + 1; the record wave reads slot c % D then
+// writes tail = c + 1. Every spin is bounded: a protocol failure raises stats[2] and ends the kernel
+// instead of hanging the device.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kWsRingDepth = 8;                                   // iterations in flight per wave pair
+constexpr uint32_t kWsRingBytes = 64u + kWsRingDepth * 64u * 8u;       // {head, tail, abort} + visits
+constexpr uint32_t kWsPairs = 4;                                       // wave pairs per workgroup
+constexpr uint32_t kWsSpinLimit = 1u << 22;
+constexpr uint32_t kWsNoVisit = 0xFFFFFFFFu;
+constexpr uint32_t kWsBlockLds(uint32_t bins, uint32_t R) { return kWsPairs * (kWsRingBytes + kLeanWaveLds(bins, R)); }
+
+template <bool DEPTH, uint32_t R>
+__global__ void __launch_bounds__(512, 2) k_iterate_ws(const BinIterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = threadIdx.x >> 6;   // 0..7
+    const uint32_t pair = w & 3u;
+    const bool map_wave = w < kWsPairs;
+    const uint32_t job = blockIdx.x * (kWsPairs * 64u) + pair * 64u + lane;
+    const uint32_t wave = job >> 6;        // the pair's index in the launch: arena slice and list heads
+    const uint32_t n = (uint32_t)a.it.iters;
+
+    char* ring = (char*)smem + pair * kWsRingBytes;
+    volatile uint32_t* head = (volatile uint32_t*)ring;         // visits published by the map wave
+    volatile uint32_t* tail = (volatile uint32_t*)(ring + 16);  // visits consumed by the record wave
+    volatile uint32_t* quit = (volatile uint32_t*)(ring + 32);
+    uint2* slots = (uint2*)(ring + 64);
+    if (map_wave && lane == 0) {
+        *head = 0u;
+        *tail = 0u;
+        *quit = 0u;
+    }
+    __syncthreads();
+
+    if (map_wave) {
+        bool alive = job < a.it.n_jobs;
+        MapParams p = a.it.p;
+        pin_map_params(p);
+        double x = 0., y = 0., z = 0.;
+        if (alive) {
+            x = a.it.starts[job];
+            y = a.it.starts[a.it.n_jobs + job];
+            z = a.it.starts[2u * a.it.n_jobs + job];
+            for (int k = 0; k < 1000; ++k) next_point(p, x, y, z);  // warm-up (:750-752)
+        }
+        const uint32_t C = a.it.ckpt_stride;
+        const size_t cs = a.it.n_jobs;
+        uint32_t t = 0, seen_tail = 0;
+        double* ck = a.it.ckpt + job;
+        while (t < n) {
             if (alive) {
-                next_point(p, x, y, z);  // :770
-                if (x != x) {
-                    alive = false;  // absorbing NaN state: this and all remaining iterations hit pixel (0,0)
+                __builtin_nontemporal_store(x, ck);
+                __builtin_nontemporal_store(y, ck + cs);
+                __builtin_nontemporal_store(z, ck + 2 * cs);
+            }
+            ck += 3 * cs;
+            const uint32_t tend = (n - t > C) ? t + C : n;
+            for (; t < tend; ++t) {
+                bool inb = false;
+                uint32_t idx = 0;
+                float zf = -2.0f;
+                if (alive && !iterate_once(p, a.it.width, x, y, z, inb, idx, zf)) {
+                    alive = false;
+                    inb = false;
                     atomicAdd(a.nan_count, (unsigned long long)(n - t));
-                } else {
-                    double sx, sy, sz;
-                    screen_space(p, x, y, z, sx, sy, sz);  // :773
-                    const double ax = sx + p.ccx;
-                    const double az = sz + p.ccy;
-                    const double x2 = ax * p.cos_v + az * p.sin_v;  // :776-779
-                    const double z2 = ax * p.sin_v - az * p.cos_v;
-                    const double fi = (p.scale_adjusted_mid - x2) * p.width_scaled;   // :783
-                    const double fj = p.half_height - (sy + p.ccz) * p.width_scaled;  // :786
-                    inb = !(fi >= p.width || fj >= p.height || fi < 0. || fj < 0.);    // :789
-                    const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;  // Rust `as u32`: NaN -> 0
-                    const uint32_t j = (fj == fj) ? (uint32_t)fj : 0u;
-                    idx = inb ? j * a.it.width + i : 0u;
-                    zf = (float)z2;  // `z2 as f32`
+                }
+                if (t - seen_tail >= kWsRingDepth) {  // ring full as far as this wave knows: look again
+                    uint32_t spins = 0;
+                    for (;;) {
+                        seen_tail = __builtin_amdgcn_readfirstlane(*tail);
+                        if (t - seen_tail < kWsRingDepth) break;
+                        if (++spins > kWsSpinLimit || *quit) {
+                            if (lane == 0) {
+                                *quit = 1u;
+                                atomicAdd(a.nan_count + 2, 1ull);
+                            }
+                            return;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                slots[(t % kWsRingDepth) * 64u + lane] = make_uint2(inb ? idx : kWsNoVisit, __float_as_uint(zf));
+                asm volatile("" ::: "memory");  // compiler order only: the LDS itself keeps a wave's operations in order
+                if (lane == 0) *head = t + 1u;
+            }
+        }
+        return;
+    }
+
+    // record wave
+    Stager<DEPTH, R> st;
+    st.init((char*)smem + kWsPairs * kWsRingBytes + pair * kLeanWaveLds(a.n_bins, R), a.n_bins, lane,
+            (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkQuads(R),
+            a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.bin_shift, 0xFFFFFFFFu - job * n);
+    uint32_t c = 0;
+    while (c < n) {
+        uint32_t h = __builtin_amdgcn_readfirstlane(*head);
+        if (h == c) {
+            uint32_t spins = 0;
+            for (;;) {
+                __builtin_amdgcn_s_sleep(2);
+                h = __builtin_amdgcn_readfirstlane(*head);
+                if (h != c) break;
+                if (++spins > kWsSpinLimit || *quit) {
+                    if (lane == 0) {
+                        *quit = 1u;
+                        atomicAdd(a.nan_count + 2, 1ull);
+                    }
+                    return;
                 }
             }
-
-            if (DEPTH) {
-                settle_depth();  // the previous iteration's candidate: its hint had a whole iteration to arrive
-                // this iteration's candidate: strict `>` against the initial -1.0 (:693, :821); NaN fails
-                const bool cand = inb && zf > -1.0f;
-                const float zc = zf + 0.0f;  // -0.0 -> +0.0: integer order == float order
-                p_zkey = f32_sortable(zc);
-                p_q = depth_q16(zc);
-                p_idx = idx;
-                p_lo = lo_base - t;
-                p_hint = zhint[cand ? idx : 0u];
-                pv = cand;
-            }
-
-            // the visits (:807-812) as staged records: place the previous one, request a slot for this one
-            place_visit();
-            b_have = inb;
-            b_bin = idx >> a.bin_shift;
-            b_local = idx & bin_mask;
-            b_slot = atomicAdd(&cnt[inb ? b_bin : dummy], 1u);  // ds_add_rtn_u32
+        }
+        asm volatile("" ::: "memory");
+        for (; c < h; ++c) {
+            const uint2 v = slots[(c % kWsRingDepth) * 64u + lane];
+            asm volatile("" ::: "memory");
+            if (lane == 0) *tail = c + 1u;  // issued after the read: the slot is free once the map wave sees this
+            st.step(v.x != kWsNoVisit, v.x, __uint_as_float(v.y), c);
         }
     }
-    place_visit();
-    flush_store_pending();
-    if (DEPTH) {
-        drain_depth();
-        uint32_t tot = n_sent;  // statistics: depth atomics issued by this wave
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
-        if (lane == 0 && tot) atomicAdd(a.nan_count + 1, (unsigned long long)tot);
-    }
-
-    // flush the partly filled buffers and publish the list heads
-    for (uint32_t b0 = 0; b0 < B; b0 += 64u) {
-        const uint32_t b = b0 + lane;
-        const uint32_t have = (b < B) ? cnt[b] : 0u;
-        const bool flusher = have != 0u;
-        const unsigned long long fb = __ballot(flusher);
-        uint32_t head = (b < B) ? prv[b] : kNoChunk;
-        if (flusher) {
-            const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
-                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
-            const uint2* r = (const uint2*)(rec + b * kChunkRecords);
-            const uint2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
-            uint4* dst = arena + (size_t)chunk * 4u;
-            dst[0] = make_uint4(head, have, r0.x, r0.y);
-            dst[1] = make_uint4(r1.x, r1.y, r2.x, r2.y);
-            dst[2] = make_uint4(r3.x, r3.y, r4.x, r4.y);
-            dst[3] = make_uint4(r5.x, r5.y, r6.x, r6.y);
-            head = chunk;
-        }
-        cursor += (uint32_t)__popcll(fb);
-        if (b < B) a.heads[(size_t)b * a.n_waves + wave] = head;
-    }
+    st.finish(a.heads, a.n_waves, wave, a.nan_count);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -519,7 +716,9 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
 // whole (bin, wave) chunk lists (64-byte loads, newest chunk first) and adds the records into the
 // bin's LDS histogram with LDS atomics; the histogram is then written — plainly, fully — as copy s of
 // the scratch count bins, which k_fold_resolve sums into Runtime::count.
+template <uint32_t R>
 __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
+    constexpr uint32_t Q = kChunkQuads(R);
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     const uint32_t b = blockIdx.x, s = blockIdx.y;
     const uint32_t bin_px = 1u << a.bin_shift;
@@ -535,18 +734,25 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     const uint4* arena = (const uint4*)a.arena;
     for (uint32_t w = s + a.splits * threadIdx.x; w < a.n_waves; w += a.splits * blockDim.x) {
         uint32_t chunk = a.heads[(size_t)b * a.n_waves + w];
-        const uint4* base = arena + (size_t)w * a.chunks_per_wave * 4u;
+        const uint4* base = arena + (size_t)w * a.chunks_per_wave * Q;
         while (chunk != kNoChunk) {
-            const uint4* c = base + (size_t)chunk * 4u;
-            const uint4 q0 = c[0], q1 = c[1], q2 = c[2], q3 = c[3];
-            const uint32_t nrec = q0.y;
-            const uint32_t words[14] = {q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            const uint4* c = base + (size_t)chunk * Q;
+            uint32_t words[4u * Q];
 #pragma unroll
-            for (uint32_t r = 0; r < 14u; ++r) {
-                if (2u * r < nrec) atomicAdd(&hist[words[r] & 0xFFFFu], 1u);
-                if (2u * r + 1u < nrec) atomicAdd(&hist[words[r] >> 16], 1u);
+            for (uint32_t q = 0; q < Q; ++q) {
+                const uint4 v = c[q];
+                words[4u * q] = v.x;
+                words[4u * q + 1u] = v.y;
+                words[4u * q + 2u] = v.z;
+                words[4u * q + 3u] = v.w;
             }
-            chunk = q0.x;
+            const uint32_t nrec = words[1];
+#pragma unroll
+            for (uint32_t r = 0; r < R / 2u; ++r) {
+                if (2u * r < nrec) atomicAdd(&hist[words[2u + r] & 0xFFFFu], 1u);
+                if (2u * r + 1u < nrec) atomicAdd(&hist[words[2u + r] >> 16], 1u);
+            }
+            chunk = words[0];
         }
     }
     __syncthreads();
@@ -883,27 +1089,69 @@ void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode,
     }
 }
 
-uint32_t lean_wave_lds_bytes(uint32_t bins) { return kLeanWaveLds(bins); }
+uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records) { return kLeanWaveLds(bins, records); }
+uint32_t chunk_bytes(uint32_t records) { return kChunkQuads(records) * 16u; }
 
-void launch_iterate_lean(const BinIterArgs& a, uint32_t block, bool depth, hipStream_t s) {
+int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, bool depth, hipStream_t s) {
     const uint32_t grid = (a.it.n_jobs + block - 1) / block;
-    const size_t lds = (size_t)(block / 64u) * kLeanWaveLds(a.n_bins);
-    if (depth) hipLaunchKernelGGL((k_iterate_lean<true>), dim3(grid), dim3(block), lds, s, a);
-    else hipLaunchKernelGGL((k_iterate_lean<false>), dim3(grid), dim3(block), lds, s, a);
+    const size_t lds = (size_t)(block / 64u) * kLeanWaveLds(a.n_bins, records);
+#define SAR_LAUNCH_LEAN(RR)                                                                                \
+    if (depth) hipLaunchKernelGGL((k_iterate_lean<true, RR>), dim3(grid), dim3(block), lds, s, a);         \
+    else hipLaunchKernelGGL((k_iterate_lean<false, RR>), dim3(grid), dim3(block), lds, s, a)
+    switch (records) {
+        case 12: SAR_LAUNCH_LEAN(12u); break;
+        case 20: SAR_LAUNCH_LEAN(20u); break;
+        case 28: SAR_LAUNCH_LEAN(28u); break;
+        default: return 1;
+    }
+#undef SAR_LAUNCH_LEAN
+    return 0;
 }
 
-void launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, hipStream_t s) {
+uint32_t ws_block_lds_bytes(uint32_t bins, uint32_t records) { return kWsBlockLds(bins, records); }
+
+int launch_iterate_ws(const BinIterArgs& a, uint32_t records, bool depth, hipStream_t s) {
+    const uint32_t grid = (a.it.n_jobs + kWsPairs * 64u - 1) / (kWsPairs * 64u);
+    const size_t lds = kWsBlockLds(a.n_bins, records);
+#define SAR_LAUNCH_WS(RR)                                                                          \
+    if (depth) hipLaunchKernelGGL((k_iterate_ws<true, RR>), dim3(grid), dim3(512), lds, s, a);     \
+    else hipLaunchKernelGGL((k_iterate_ws<false, RR>), dim3(grid), dim3(512), lds, s, a)
+    switch (records) {
+        case 12: SAR_LAUNCH_WS(12u); break;
+        case 20: SAR_LAUNCH_WS(20u); break;
+        case 28: SAR_LAUNCH_WS(28u); break;
+        default: return 1;
+    }
+#undef SAR_LAUNCH_WS
+    return 0;
+}
+
+int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, hipStream_t s) {
     const size_t lds = (size_t)4u << a.bin_shift;
     // one block per CU fits when the histogram needs > 64 KiB: use all 1024 threads for its list walks then
     if (threads == 0) threads = lds > 64u * 1024u ? 1024u : 256u;
-    hipLaunchKernelGGL(k_bin_accumulate, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a);
+    switch (records) {
+        case 12: hipLaunchKernelGGL(k_bin_accumulate<12u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
+        case 20: hipLaunchKernelGGL(k_bin_accumulate<20u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
+        case 28: hipLaunchKernelGGL(k_bin_accumulate<28u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
+        default: return 1;
+    }
+    return 0;
 }
 
 int binned_kernel_attributes() {
     // both kernels need more dynamic LDS than the 64 KiB default window
-    hipError_t e = hipFuncSetAttribute((const void*)k_iterate_lean<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    hipError_t e = hipSuccess;
+#define SAR_ATTR(RR)                                                                                                                                   \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<true, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<false, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_ws<true, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_ws<false, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)
+    SAR_ATTR(12u);
+    SAR_ATTR(20u);
+    SAR_ATTR(28u);
+#undef SAR_ATTR
     return (int)e;
 }
 

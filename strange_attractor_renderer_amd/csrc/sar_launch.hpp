@@ -9,9 +9,12 @@ namespace sar {
 
 // mode: 2 = full path (count + depth key); 1 = count only, 0 = arithmetic only (measurement variants)
 void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode, hipStream_t s);
-uint32_t lean_wave_lds_bytes(uint32_t bins);
-void launch_iterate_lean(const BinIterArgs& a, uint32_t block, bool depth, hipStream_t s);
-void launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, hipStream_t s);
+uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records);
+uint32_t chunk_bytes(uint32_t records);
+int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, bool depth, hipStream_t s);
+uint32_t ws_block_lds_bytes(uint32_t bins, uint32_t records);
+int launch_iterate_ws(const BinIterArgs& a, uint32_t records, bool depth, hipStream_t s);
+int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, hipStream_t s);
 int binned_kernel_attributes();
 void launch_fold_resolve(const FoldArgs& a, hipStream_t s);
 void launch_reset(uint32_t* count, unsigned long long* key, double* steps, uint32_t npix, uint32_t* scalars,

@@ -104,6 +104,7 @@ struct sar_runtime {
     uint32_t bin_shift = 0;         // 0 = automatic
     uint32_t splits = 0;            // 0 = automatic
     uint32_t acc_threads = 0;       // threads per k_bin_accumulate block (0 = automatic)
+    uint32_t chunk_records = 0;     // records per chunk (0 = default 28; 12 / 20 shrink the LDS staging per wave)
 
     // timing
     bool timing = false;
@@ -186,7 +187,7 @@ struct BinGeometry {
     uint32_t shift = 0, bins = 0, block = 0, splits = 0;
     bool ok = false;
 };
-BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift, uint32_t want_splits) {
+BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift, uint32_t want_splits, uint32_t records) {
     BinGeometry g;
     uint32_t px = 4096;
     while (px < kMaxBinPx && static_cast<uint64_t>(px) * 256u < npix) px <<= 1;
@@ -194,7 +195,7 @@ BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift
     g.bins = (npix + px - 1) / px;
     if (g.bins > kMaxBins) return g;
     while ((1u << g.shift) < px) ++g.shift;
-    const uint32_t waves_fit = (160u * 1024u) / lean_wave_lds_bytes(g.bins);
+    const uint32_t waves_fit = (160u * 1024u) / lean_wave_lds_bytes(g.bins, records);
     uint32_t block = want_block;
     if (block > waves_fit * 64u) block = waves_fit * 64u;
     if (block == 0) return g;
@@ -205,9 +206,22 @@ BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift
     return g;
 }
 
+// k_iterate_ws raises stats[2] when one of its bounded ring waits ran out (a protocol failure, never expected):
+// every entry point that hands results to the host checks it after its stream synchronisation.
+int check_device_fault(sar_runtime* rt) {
+    if (!rt->d_nan_count || rt->bins_mode != 4) return SAR_OK;
+    unsigned long long faults = 0;
+    HIP_TRY(hipMemcpy(&faults, rt->d_nan_count + 2, sizeof(faults), hipMemcpyDeviceToHost));
+    if (faults) {
+        set_error("k_iterate_ws: %llu ring waits timed out; the buffers of this runtime are invalid", faults);
+        return SAR_ERR_HIP;
+    }
+    return SAR_OK;
+}
+
 int clear_hints(sar_runtime* rt) {
     // hints are lower bounds of depths already accumulated; anything that can lower zbuf voids them
-    if (rt->d_zhint) HIP_TRY(hipMemsetAsync(rt->d_zhint, 0, static_cast<size_t>(rt->npix) * 8u * sizeof(unsigned short), rt->stream));
+    if (rt->d_zhint) HIP_TRY(hipMemsetAsync(rt->d_zhint, 0, (static_cast<size_t>(rt->npix) + 2u) * 8u * sizeof(unsigned short), rt->stream));
     return SAR_OK;
 }
 
@@ -305,9 +319,15 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
     HIP_TRY(hipSetDevice(rt->device));
 
     // which accumulate path: LDS-binned records (default) or one global atomic per visit
-    const BinGeometry geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits);
-    bool binned = (rt->bins_mode == 0 || rt->bins_mode == 3) && rt->measure_mode != 2 && geo.ok;
-    if (rt->bins_mode == 3 && !geo.ok) {
+    const bool ws = rt->bins_mode == 4;  // map waves + record waves (k_iterate_ws)
+    const uint32_t R = rt->chunk_records ? rt->chunk_records : (ws ? 20u : kDefaultChunkRecords);
+    BinGeometry geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, R);
+    if (ws && geo.ok) {
+        geo.block = 256;  // trajectories per workgroup (4 map waves)
+        if (ws_block_lds_bytes(geo.bins, R) > 160u * 1024u) geo.ok = false;
+    }
+    bool binned = (rt->bins_mode == 0 || rt->bins_mode >= 3) && rt->measure_mode != 2 && geo.ok;
+    if (rt->bins_mode >= 3 && !geo.ok) {
         set_error("the binned path needs width*height <= %u pixels", kMaxBins * kMaxBinPx);
         return SAR_ERR_RANGE;
     }
@@ -316,7 +336,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
 
     const uint32_t C = rt->ckpt_stride;
     const uint64_t n_ckpt = (iters + C - 1) / C;
-    const uint64_t chunks_per_wave = (iters * 64ull + kChunkRecords - 1) / kChunkRecords + geo.bins;
+    const uint64_t chunks_per_wave = (iters * 64ull + R - 1) / R + geo.bins;
     uint64_t chunk_jobs = kMaxChunkOrdinals / iters;
     // scratch per job: checkpoints (24 B each) + its share of the wave's record arena (binned path)
     const uint64_t bytes_per_job = n_ckpt * 24ull + (binned ? chunks_per_wave : 0ull);
@@ -385,7 +405,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
         static int attr_status = 0;
         std::call_once(attr_once, [] { attr_status = binned_kernel_attributes(); });
         if (attr_status != 0) { set_error("hipFuncSetAttribute(max dynamic LDS) failed: %d", attr_status); return SAR_ERR_HIP; }
-        const size_t arena_need = static_cast<size_t>(max_waves) * chunks_per_wave * 64u;
+        const size_t arena_need = static_cast<size_t>(max_waves) * chunks_per_wave * chunk_bytes(R);
         if (arena_need > rt->arena_cap) {
             if (rt->d_arena) hipFree(rt->d_arena);
             rt->d_arena = nullptr;
@@ -402,12 +422,13 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             rt->heads_cap = heads_need;
         }
         if (!rt->d_zhint) {
-            HIP_TRY(hipMalloc(&rt->d_zhint, static_cast<size_t>(rt->npix) * 8u * sizeof(unsigned short)));
+            HIP_TRY(hipMalloc(&rt->d_zhint, (static_cast<size_t>(rt->npix) + 2u) * 8u * sizeof(unsigned short)));
             SAR_TRY(clear_hints(rt));
         }
         if (!rt->d_nan_count) {
-            HIP_TRY(hipMalloc(&rt->d_nan_count, 2 * sizeof(unsigned long long)));  // [0] NaN iterations, [1] depth atomics (stat)
-            HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, 2 * sizeof(unsigned long long), rt->stream));
+            // [0] NaN iterations, [1] depth atomics (statistic), [2] ring-protocol timeouts of k_iterate_ws
+            HIP_TRY(hipMalloc(&rt->d_nan_count, 3 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, 3 * sizeof(unsigned long long), rt->stream));
         }
     }
     IterArgs ia;
@@ -458,7 +479,8 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             ba.zhint = rt->d_zhint;
             ba.nan_count = rt->d_nan_count;
             span_begin(rt, rt->iter_spans, rt->iter_used);
-            launch_iterate_lean(ba, block, mode == 2, rt->stream);
+            const int bad = ws ? launch_iterate_ws(ba, R, mode == 2, rt->stream) : launch_iterate_lean(ba, block, R, mode == 2, rt->stream);
+            if (bad) { set_error("bad chunk_records"); return SAR_ERR_INVALID; }
             span_end(rt, rt->iter_spans, rt->iter_used);
             BinAccArgs ca;
             std::memset(&ca, 0, sizeof(ca));
@@ -472,7 +494,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             ca.heads = rt->d_heads;
             ca.scratch_count = rt->d_scratch_count;
             span_begin(rt, rt->fold_spans, rt->fold_used);
-            launch_bin_accumulate(ca, rt->acc_threads, rt->stream);
+            launch_bin_accumulate(ca, rt->acc_threads, R, rt->stream);
             launch_fold_resolve(fa, rt->stream);
             span_end(rt, rt->fold_spans, rt->fold_used);
         } else {
@@ -632,6 +654,7 @@ int sar_runtime_synchronize(sar_runtime* rt) {
     if (!rt) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipStreamSynchronize(rt->stream));
+    SAR_TRY(check_device_fault(rt));
     return SAR_OK;
 }
 
@@ -699,6 +722,7 @@ int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host
     SAR_TRY(do_colorize(cfg, rt, rt->d_rgba));
     HIP_TRY(hipMemcpyAsync(rgba_out_host, rt->d_rgba, static_cast<size_t>(rt->npix) * 8, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
+    SAR_TRY(check_device_fault(rt));
     return SAR_OK;
 }
 
@@ -707,6 +731,7 @@ int sar_runtime_count(sar_runtime* rt, uint32_t* out_host) {
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipMemcpyAsync(out_host, rt->d_count, static_cast<size_t>(rt->npix) * 4, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
+    SAR_TRY(check_device_fault(rt));
     return SAR_OK;
 }
 
@@ -715,6 +740,7 @@ int sar_runtime_steps(sar_runtime* rt, double* out_host) {
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipMemcpyAsync(out_host, rt->d_steps, static_cast<size_t>(rt->npix) * 8, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
+    SAR_TRY(check_device_fault(rt));
     return SAR_OK;
 }
 
@@ -725,6 +751,7 @@ int sar_runtime_zbuf(sar_runtime* rt, float* out_host) {
     launch_zbuf_out(rt->d_key, rt->d_ztmp, rt->npix, rt->stream);
     HIP_TRY(hipMemcpyAsync(out_host, rt->d_ztmp, static_cast<size_t>(rt->npix) * 4, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
+    SAR_TRY(check_device_fault(rt));
     return SAR_OK;
 }
 
@@ -734,6 +761,7 @@ int sar_runtime_max(sar_runtime* rt, uint32_t* out_max) {
     uint32_t sc[SC_COUNT];
     HIP_TRY(hipMemcpyAsync(sc, rt->d_scalars, sizeof(sc), hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
+    SAR_TRY(check_device_fault(rt));
     *out_max = sc[SC_WRAP] ? 0xFFFFFFFFu : sc[SC_MAX];
     return SAR_OK;
 }
@@ -862,6 +890,7 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
     if (!rt || !out) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipStreamSynchronize(rt->stream));
+    SAR_TRY(check_device_fault(rt));
     std::memset(out, 0, sizeof(*out));
     float ms = 0.f;
     for (size_t k = 0; k < rt->iter_used; ++k)
@@ -891,7 +920,7 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "checkpoint_stride")) {
         rt->ckpt_stride = v ? v : kDefaultCkptStride;
     } else if (!std::strcmp(name, "path")) {
-        if (v > 3) { set_error("path must be 0..3"); return SAR_ERR_INVALID; }
+        if (v > 4) { set_error("path must be 0..4"); return SAR_ERR_INVALID; }
         rt->bins_mode = v;
     } else if (!std::strcmp(name, "bin_shift")) {
         if (v && (v < 12 || v > 15)) { set_error("bin_shift must be 12..15"); return SAR_ERR_INVALID; }
@@ -899,6 +928,9 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "splits")) {
         if (v > 16) { set_error("splits must be 1..16"); return SAR_ERR_INVALID; }
         rt->splits = v;
+    } else if (!std::strcmp(name, "chunk_records")) {
+        if (v && v != 12 && v != 20 && v != 28) { set_error("chunk_records must be 12, 20 or 28"); return SAR_ERR_INVALID; }
+        rt->chunk_records = v;
     } else if (!std::strcmp(name, "acc_threads")) {
         if (v && v != 256 && v != 512 && v != 1024) { set_error("acc_threads must be 256, 512 or 1024"); return SAR_ERR_INVALID; }
         rt->acc_threads = v;

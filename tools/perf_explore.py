@@ -45,6 +45,7 @@ if __name__ == "__main__":
     ap.add_argument("--bin-shift", type=int, nargs="+", default=[0])
     ap.add_argument("--splits", type=int, nargs="+", default=[0])
     ap.add_argument("--acc-threads", type=int, nargs="+", default=[0])
+    ap.add_argument("--records", type=int, nargs="+", default=[0])
     ap.add_argument("--out", default="gpurun_out/perf_explore.jsonl")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
@@ -55,10 +56,10 @@ if __name__ == "__main__":
             starts = S.start_points(1, 0, jobs)
             for block in a.blocks:
                 for variant in a.variants:
-                    for stride, bs, sp, at in [(x, y, z, w) for x in a.stride for y in a.bin_shift for z in a.splits for w in a.acc_threads]:
-                        r = run(cfg, starts, block, stride, variant, bin_shift=bs, splits=sp, acc_threads=at)
+                    for stride, bs, sp, at, rc in [(x, y, z, w, v) for x in a.stride for y in a.bin_shift for z in a.splits for w in a.acc_threads for v in a.records]:
+                        r = run(cfg, starts, block, stride, variant, bin_shift=bs, splits=sp, acc_threads=at, chunk_records=rc)
                         r.update(jobs=jobs, block=block, variant=hex(variant), stride=stride, size=a.size,
-                                 bin_shift=bs, splits=sp, acc_threads=at,
+                                 bin_shift=bs, splits=sp, acc_threads=at, records=rc,
                                  preset=a.preset,
                                  git_per_s_kernel=r["iters"] / r["iter_ms"] / 1e6,
                                  git_per_s_wall=r["iters"] / r["wall_ms"] / 1e6)
