@@ -66,7 +66,7 @@ struct BinIterArgs {
     uint32_t chunks_per_wave;    // arena capacity of one wave, in 64-byte chunks
     uint32_t n_waves;            // launched waves (= heads stride)
     void* arena;                 // [n_waves][chunks_per_wave] chunks {prev, n, R x u16}, R = 12 / 20 / 28
-    uint32_t* heads;             // [n_bins][n_waves] last chunk of each (bin, wave) list, or kNoChunk
+    uint32_t* heads;             // [n_bins][n_waves][kListChains] last chunk of each chain of a (bin, wave) list, or kNoChunk
     unsigned short* zhint;       // [8][npix] per-XCD depth hints (16-bit fixed point, see depth_q16)
     unsigned long long* nan_count;  // iterations of diverged (NaN) trajectories: all land on pixel (0,0)
 };
@@ -122,6 +122,7 @@ static inline uint32_t f32_sortable_host(float f) {
 
 constexpr uint32_t kLnLutEntries = 1u << 20;  // ln(k+1), k < 2^20, host libm (exact parity with the oracle)
 constexpr uint64_t kMaxChunkOrdinals = 0xFFFFFFFEull;
+constexpr uint32_t kListChains = 2;  // interleaved chains per (bin, wave) record list (== kChains of the kernels)
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
 constexpr uint32_t kDefaultChunkRecords = 28;  // u16 records per chunk (8-byte header): 12, 20 or 28 -> 32/48/64-byte chunks
 constexpr uint32_t kMaxBins = 1024;      // LDS staging is 64 B per bin per wave

@@ -320,7 +320,17 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
 
     // which accumulate path: LDS-binned records (default) or one global atomic per visit
     const bool ws = rt->bins_mode == 4;  // map waves + record waves (k_iterate_ws)
-    const uint32_t R = rt->chunk_records ? rt->chunk_records : (ws ? 20u : kDefaultChunkRecords);
+    // records per chunk: the largest of 28/20/12 whose per-wave LDS staging still lets two waves share a SIMD
+    // (8 per CU, 160 KiB): 2 waves/SIMD with 32-byte chunks beat 1 wave/SIMD with 64-byte chunks by 1.4x (4096^2)
+    uint32_t R = rt->chunk_records ? rt->chunk_records : (ws ? 20u : kDefaultChunkRecords);
+    if (!rt->chunk_records && !ws) {
+        const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u);
+        if (probe.ok)
+            for (uint32_t cand : {28u, 20u, 12u}) {
+                R = cand;
+                if (lean_wave_lds_bytes(probe.bins, cand) * 8u <= 160u * 1024u) break;
+            }
+    }
     BinGeometry geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, R);
     if (ws && geo.ok) {
         geo.block = 256;  // trajectories per workgroup (4 map waves)
@@ -350,10 +360,11 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
     const uint32_t max_waves_pre = static_cast<uint32_t>(((chunk_jobs + block - 1) / block) * (block / 64u));
     uint32_t splits = geo.splits;
     if (binned && splits == 0) {
-        // k_bin_accumulate is bound by the dependent-load chain of its (bin, wave) list walks: aim at one
-        // list per thread, and at enough blocks to cover the chip when only a band of bins is populated
-        const uint32_t threads = (4u << geo.shift) > 64u * 1024u ? 1024u : 256u;
-        splits = (max_waves_pre + threads - 1u) / threads;
+        // k_bin_accumulate walks one (bin, wave) list per group of lanes (4, or 2 with 32-byte chunks): aim at one
+        // list per group, and at enough blocks to cover the chip when only a band of bins is populated
+        const uint32_t threads = rt->acc_threads ? rt->acc_threads : 1024u;
+        const uint32_t groups = threads / (R == 12u ? 2u : 4u);
+        splits = (max_waves_pre + groups - 1u) / groups;
         const uint32_t cover = 2048u / geo.bins;
         if (splits < cover) splits = cover;
         if (splits < 1) splits = 1;
@@ -413,7 +424,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             HIP_TRY(hipMalloc(&rt->d_arena, arena_need));
             rt->arena_cap = arena_need;
         }
-        const size_t heads_need = static_cast<size_t>(max_waves) * geo.bins;
+        const size_t heads_need = static_cast<size_t>(max_waves) * geo.bins * kListChains;
         if (heads_need > rt->heads_cap) {
             if (rt->d_heads) hipFree(rt->d_heads);
             rt->d_heads = nullptr;
