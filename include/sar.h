@@ -219,12 +219,13 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *   "block_threads"      lanes per workgroup of the iterate kernel (64, 128, 192, 256)
  *   "checkpoint_stride"  iterations between trajectory checkpoints used by the payload resolve
  *   "path"               accumulate path: 0 default (= 3 when the image fits), 1 one global atomic per
- *                        visit at agent scope, 2 the same into one scratch copy per XCD, 3 LDS-binned records,
- *                        4 LDS-binned records with separate map waves and record waves (k_iterate_ws)
+ *                        visit at agent scope, 2 the same into one scratch copy per XCD, 3 LDS-binned records
  *   "bin_shift"          log2(pixels per bin) of the binned path (12..15)
  *   "splits"             workgroups per bin in the record-accumulate kernel (1..16)
  *   "chunk_records"      u16 records per chunk: 12, 20 or 28 (32/48/64-byte chunks; fewer = less LDS per wave)
  *   "acc_threads"        threads per block of the record-accumulate kernel (256, 512, 1024)
+ *   "timing_accumulate"  1: the spans of successive render calls add up (sar_timing sums, iterate_launches counts
+ *                        them) until sar_runtime_last_timing reads and clears them; 0: last render call only
  *   "measure"            measurement-only kernels: 1 count only, 2 arithmetic only (results are NOT the render)
  *   "debug_chunk_jobs"   test hook: cap on jobs per launch chunk */
 int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value);

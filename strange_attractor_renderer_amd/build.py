@@ -70,7 +70,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for s in SOURCES:
         obj = os.path.join(BUILD_DIR, s + ".o")
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, s), "-o", obj]
+        # SAR_EXTRA_FLAGS: extra compiler flags for timing experiments (e.g. -DSAR_EXPERIMENT_...); never set by the product
+        cmd = [hipcc, *FLAGS, *os.environ.get("SAR_EXTRA_FLAGS", "").split(), "-c", os.path.join(CSRC, s), "-o", obj]
         if s.endswith(".hip"):
             cmd += ["-save-temps=obj"]
         if verbose:

@@ -593,138 +593,6 @@ __global__ void __launch_bounds__(256, R == 12u ? 4 : 2) k_iterate_lean(const Bi
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_iterate_ws: the same work as k_iterate_lean, split between two kinds of waves of one workgroup.
-//   waves 0..3  "map waves": own 64 trajectories each, run the fp64 map + projection (88 unfused DP
-//               operations per iteration) and write one 8-byte visit per lane into an LDS ring;
-//   waves 4..7  "record waves": wave 4+k drains the ring of wave k through the Stager (LDS slot request,
-//               record placement, chunk copy-out, depth filter).
-// In k_iterate_lean one wave does both, so its DP pipe idles whenever the wave waits for an LDS atomic
-// return or a hint load; here the SIMD always has a map wave to issue DP instructions from.
-// Ring protocol (per wave pair; LDS executes one wave's operations in issue order, and both counters are
-// single-writer): the map wave writes slot t % D then head = t + 1; the record wave reads slot c % D then
-// writes tail = c + 1. Every spin is bounded: a protocol failure raises stats[2] and ends the kernel
-// instead of hanging the device.
-// ---------------------------------------------------------------------------------------------------
-constexpr uint32_t kWsRingDepth = 8;                                   // iterations in flight per wave pair
-constexpr uint32_t kWsRingBytes = 64u + kWsRingDepth * 64u * 8u;       // {head, tail, abort} + visits
-constexpr uint32_t kWsPairs = 4;                                       // wave pairs per workgroup
-constexpr uint32_t kWsSpinLimit = 1u << 22;
-constexpr uint32_t kWsNoVisit = 0xFFFFFFFFu;
-constexpr uint32_t kWsBlockLds(uint32_t bins, uint32_t R) { return kWsPairs * (kWsRingBytes + kLeanWaveLds(bins, R)); }
-
-template <bool DEPTH, uint32_t R>
-__global__ void __launch_bounds__(512, 2) k_iterate_ws(const BinIterArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t w = threadIdx.x >> 6;   // 0..7
-    const uint32_t pair = w & 3u;
-    const bool map_wave = w < kWsPairs;
-    const uint32_t job = blockIdx.x * (kWsPairs * 64u) + pair * 64u + lane;
-    const uint32_t wave = job >> 6;        // the pair's index in the launch: arena slice and list heads
-    const uint32_t n = (uint32_t)a.it.iters;
-
-    char* ring = (char*)smem + pair * kWsRingBytes;
-    volatile uint32_t* head = (volatile uint32_t*)ring;         // visits published by the map wave
-    volatile uint32_t* tail = (volatile uint32_t*)(ring + 16);  // visits consumed by the record wave
-    volatile uint32_t* quit = (volatile uint32_t*)(ring + 32);
-    uint2* slots = (uint2*)(ring + 64);
-    if (map_wave && lane == 0) {
-        *head = 0u;
-        *tail = 0u;
-        *quit = 0u;
-    }
-    __syncthreads();
-
-    if (map_wave) {
-        bool alive = job < a.it.n_jobs;
-        MapParams p = a.it.p;
-        pin_map_params(p);
-        double x = 0., y = 0., z = 0.;
-        if (alive) {
-            x = a.it.starts[job];
-            y = a.it.starts[a.it.n_jobs + job];
-            z = a.it.starts[2u * a.it.n_jobs + job];
-            for (int k = 0; k < 1000; ++k) next_point(p, x, y, z);  // warm-up (:750-752)
-        }
-        const uint32_t C = a.it.ckpt_stride;
-        const size_t cs = a.it.n_jobs;
-        uint32_t t = 0, seen_tail = 0;
-        double* ck = a.it.ckpt + job;
-        while (t < n) {
-            if (alive) {
-                __builtin_nontemporal_store(x, ck);
-                __builtin_nontemporal_store(y, ck + cs);
-                __builtin_nontemporal_store(z, ck + 2 * cs);
-            }
-            ck += 3 * cs;
-            const uint32_t tend = (n - t > C) ? t + C : n;
-            for (; t < tend; ++t) {
-                bool inb = false;
-                uint32_t idx = 0;
-                float zf = -2.0f;
-                if (alive && !iterate_once(p, a.it.width, x, y, z, inb, idx, zf)) {
-                    alive = false;
-                    inb = false;
-                    atomicAdd(a.nan_count, (unsigned long long)(n - t));
-                }
-                if (t - seen_tail >= kWsRingDepth) {  // ring full as far as this wave knows: look again
-                    uint32_t spins = 0;
-                    for (;;) {
-                        seen_tail = __builtin_amdgcn_readfirstlane(*tail);
-                        if (t - seen_tail < kWsRingDepth) break;
-                        if (++spins > kWsSpinLimit || *quit) {
-                            if (lane == 0) {
-                                *quit = 1u;
-                                atomicAdd(a.nan_count + 2, 1ull);
-                            }
-                            return;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-                slots[(t % kWsRingDepth) * 64u + lane] = make_uint2(inb ? idx : kWsNoVisit, __float_as_uint(zf));
-                asm volatile("" ::: "memory");  // compiler order only: the LDS itself keeps a wave's operations in order
-                if (lane == 0) *head = t + 1u;
-            }
-        }
-        return;
-    }
-
-    // record wave
-    Stager<DEPTH, R> st;
-    st.init((char*)smem + kWsPairs * kWsRingBytes + pair * kLeanWaveLds(a.n_bins, R), a.n_bins, lane,
-            (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkQuads(R),
-            a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.bin_shift, 0xFFFFFFFFu - job * n);
-    uint32_t c = 0;
-    while (c < n) {
-        uint32_t h = __builtin_amdgcn_readfirstlane(*head);
-        if (h == c) {
-            uint32_t spins = 0;
-            for (;;) {
-                __builtin_amdgcn_s_sleep(2);
-                h = __builtin_amdgcn_readfirstlane(*head);
-                if (h != c) break;
-                if (++spins > kWsSpinLimit || *quit) {
-                    if (lane == 0) {
-                        *quit = 1u;
-                        atomicAdd(a.nan_count + 2, 1ull);
-                    }
-                    return;
-                }
-            }
-        }
-        asm volatile("" ::: "memory");
-        for (; c < h; ++c) {
-            const uint2 v = slots[(c % kWsRingDepth) * 64u + lane];
-            asm volatile("" ::: "memory");
-            if (lane == 0) *tail = c + 1u;  // issued after the read: the slot is free once the map wave sees this
-            st.step(v.x != kWsNoVisit, v.x, __uint_as_float(v.y), c);
-        }
-    }
-    st.finish(a.heads, a.n_waves, wave, a.nan_count);
-}
-
-// ---------------------------------------------------------------------------------------------------
 // k_bin_accumulate — records -> per-pixel hit counts, in LDS
 // ---------------------------------------------------------------------------------------------------
 // grid (B, splits): block (b, s) owns bin b and the waves w with w % splits == s. Every thread walks
@@ -1146,24 +1014,6 @@ int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, 
     return 0;
 }
 
-uint32_t ws_block_lds_bytes(uint32_t bins, uint32_t records) { return kWsBlockLds(bins, records); }
-
-int launch_iterate_ws(const BinIterArgs& a, uint32_t records, bool depth, hipStream_t s) {
-    const uint32_t grid = (a.it.n_jobs + kWsPairs * 64u - 1) / (kWsPairs * 64u);
-    const size_t lds = kWsBlockLds(a.n_bins, records);
-#define SAR_LAUNCH_WS(RR)                                                                          \
-    if (depth) hipLaunchKernelGGL((k_iterate_ws<true, RR>), dim3(grid), dim3(512), lds, s, a);     \
-    else hipLaunchKernelGGL((k_iterate_ws<false, RR>), dim3(grid), dim3(512), lds, s, a)
-    switch (records) {
-        case 12: SAR_LAUNCH_WS(12u); break;
-        case 20: SAR_LAUNCH_WS(20u); break;
-        case 28: SAR_LAUNCH_WS(28u); break;
-        default: return 1;
-    }
-#undef SAR_LAUNCH_WS
-    return 0;
-}
-
 int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, hipStream_t s) {
     const size_t lds = (size_t)4u << a.bin_shift;
     // a list takes a group of 2 or 4 lanes: 1024 threads walk 256..512 lists per block
@@ -1183,8 +1033,6 @@ int binned_kernel_attributes() {
 #define SAR_ATTR(RR)                                                                                                                                   \
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<true, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<false, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_ws<true, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_ws<false, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)
     SAR_ATTR(12u);
     SAR_ATTR(20u);

@@ -12,8 +12,6 @@ void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode,
 uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records);
 uint32_t chunk_bytes(uint32_t records);
 int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, bool depth, hipStream_t s);
-uint32_t ws_block_lds_bytes(uint32_t bins, uint32_t records);
-int launch_iterate_ws(const BinIterArgs& a, uint32_t records, bool depth, hipStream_t s);
 int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, hipStream_t s);
 int binned_kernel_attributes();
 void launch_fold_resolve(const FoldArgs& a, hipStream_t s);

@@ -100,6 +100,7 @@ struct sar_runtime {
     uint32_t bins_mode = 0;     // 0 default (binned when eligible), 1 one copy + agent-scope atomics,
                                 // 2 one copy per XCD + L2-local atomics, 3 LDS-binned records
     uint32_t measure_mode = 0;  // 0 full path, 1 count only, 2 arithmetic only
+    bool timing_accumulate = false;  // spans of successive render calls add up until sar_runtime_last_timing reads them
     uint32_t debug_chunk_jobs = 0;  // test hook: cap on jobs per launch chunk (0 = none)
     uint32_t bin_shift = 0;         // 0 = automatic
     uint32_t splits = 0;            // 0 = automatic
@@ -206,19 +207,6 @@ BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift
     return g;
 }
 
-// k_iterate_ws raises stats[2] when one of its bounded ring waits ran out (a protocol failure, never expected):
-// every entry point that hands results to the host checks it after its stream synchronisation.
-int check_device_fault(sar_runtime* rt) {
-    if (!rt->d_nan_count || rt->bins_mode != 4) return SAR_OK;
-    unsigned long long faults = 0;
-    HIP_TRY(hipMemcpy(&faults, rt->d_nan_count + 2, sizeof(faults), hipMemcpyDeviceToHost));
-    if (faults) {
-        set_error("k_iterate_ws: %llu ring waits timed out; the buffers of this runtime are invalid", faults);
-        return SAR_ERR_HIP;
-    }
-    return SAR_OK;
-}
-
 int clear_hints(sar_runtime* rt) {
     // hints are lower bounds of depths already accumulated; anything that can lower zbuf voids them
     if (rt->d_zhint) HIP_TRY(hipMemsetAsync(rt->d_zhint, 0, (static_cast<size_t>(rt->npix) + 2u) * 8u * sizeof(unsigned short), rt->stream));
@@ -307,9 +295,11 @@ int check_cfg_matches(const sar_config* cfg, const sar_runtime* rt) {
 // chunk only replaces a depth winner with a strictly greater z, exactly like a later render call.
 int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters,
                    const double* starts) {
-    rt->last_iterations = 0;
-    rt->iter_used = 0;
-    rt->fold_used = 0;
+    if (!rt->timing_accumulate) {
+        rt->last_iterations = 0;
+        rt->iter_used = 0;
+        rt->fold_used = 0;
+    }
     if (n_jobs == 0 || iters == 0) return SAR_OK;
     if (iters > kMaxChunkOrdinals) {
         set_error("%llu iterations per job exceed the 32-bit visit ordinal of one launch",
@@ -319,25 +309,32 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
     HIP_TRY(hipSetDevice(rt->device));
 
     // which accumulate path: LDS-binned records (default) or one global atomic per visit
-    const bool ws = rt->bins_mode == 4;  // map waves + record waves (k_iterate_ws)
-    // records per chunk: the largest of 28/20/12 whose per-wave LDS staging still lets two waves share a SIMD
-    // (8 per CU, 160 KiB): 2 waves/SIMD with 32-byte chunks beat 1 wave/SIMD with 64-byte chunks by 1.4x (4096^2)
-    uint32_t R = rt->chunk_records ? rt->chunk_records : (ws ? 20u : kDefaultChunkRecords);
-    if (!rt->chunk_records && !ws) {
+    // records per chunk: the largest of 28/20/12 whose per-wave LDS staging still fits the waves this launch can
+    // use — up to 3 per SIMD (more jobs than that run in rounds), at least 2. Measured at 2048^2, 1e9 iterations:
+    // 131072 jobs 28 records 9.65 ms, 196608 jobs 20 records 9.29 ms; at 4096^2 12 records (2 waves/SIMD) beat
+    // 28 (1 wave/SIMD) by 1.4x.
+    uint32_t R = rt->chunk_records ? rt->chunk_records : kDefaultChunkRecords;
+    if (!rt->chunk_records) {
         const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u);
-        if (probe.ok)
-            for (uint32_t cand : {28u, 20u, 12u}) {
-                R = cand;
-                if (lean_wave_lds_bytes(probe.bins, cand) * 8u <= 160u * 1024u) break;
-            }
+        const uint64_t cus = rt->sm_count ? rt->sm_count : 256u;
+        uint64_t want = (n_jobs + 64u * cus - 1) / (64u * cus);  // waves per CU if all jobs were resident
+        want = want < 8 ? 8 : (want > 12 ? 12 : want);
+        if (probe.ok) {
+            bool found = false;
+            for (uint32_t need : {static_cast<uint32_t>(want), 8u})
+                for (uint32_t cand : {28u, 20u, 12u}) {
+                    if (found) break;
+                    if (lean_wave_lds_bytes(probe.bins, cand) * need <= 160u * 1024u) {
+                        R = cand;
+                        found = true;
+                    }
+                }
+            if (!found) R = 12u;
+        }
     }
     BinGeometry geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, R);
-    if (ws && geo.ok) {
-        geo.block = 256;  // trajectories per workgroup (4 map waves)
-        if (ws_block_lds_bytes(geo.bins, R) > 160u * 1024u) geo.ok = false;
-    }
-    bool binned = (rt->bins_mode == 0 || rt->bins_mode >= 3) && rt->measure_mode != 2 && geo.ok;
-    if (rt->bins_mode >= 3 && !geo.ok) {
+    bool binned = (rt->bins_mode == 0 || rt->bins_mode == 3) && rt->measure_mode != 2 && geo.ok;
+    if (rt->bins_mode == 3 && !geo.ok) {
         set_error("the binned path needs width*height <= %u pixels", kMaxBins * kMaxBinPx);
         return SAR_ERR_RANGE;
     }
@@ -437,9 +434,8 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             SAR_TRY(clear_hints(rt));
         }
         if (!rt->d_nan_count) {
-            // [0] NaN iterations, [1] depth atomics (statistic), [2] ring-protocol timeouts of k_iterate_ws
-            HIP_TRY(hipMalloc(&rt->d_nan_count, 3 * sizeof(unsigned long long)));
-            HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, 3 * sizeof(unsigned long long), rt->stream));
+            HIP_TRY(hipMalloc(&rt->d_nan_count, 2 * sizeof(unsigned long long)));  // [0] NaN iterations, [1] depth atomics (stat)
+            HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, 2 * sizeof(unsigned long long), rt->stream));
         }
     }
     IterArgs ia;
@@ -490,8 +486,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             ba.zhint = rt->d_zhint;
             ba.nan_count = rt->d_nan_count;
             span_begin(rt, rt->iter_spans, rt->iter_used);
-            const int bad = ws ? launch_iterate_ws(ba, R, mode == 2, rt->stream) : launch_iterate_lean(ba, block, R, mode == 2, rt->stream);
-            if (bad) { set_error("bad chunk_records"); return SAR_ERR_INVALID; }
+            if (launch_iterate_lean(ba, block, R, mode == 2, rt->stream) != 0) { set_error("bad chunk_records"); return SAR_ERR_INVALID; }
             span_end(rt, rt->iter_spans, rt->iter_used);
             BinAccArgs ca;
             std::memset(&ca, 0, sizeof(ca));
@@ -665,7 +660,6 @@ int sar_runtime_synchronize(sar_runtime* rt) {
     if (!rt) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipStreamSynchronize(rt->stream));
-    SAR_TRY(check_device_fault(rt));
     return SAR_OK;
 }
 
@@ -733,7 +727,6 @@ int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host
     SAR_TRY(do_colorize(cfg, rt, rt->d_rgba));
     HIP_TRY(hipMemcpyAsync(rgba_out_host, rt->d_rgba, static_cast<size_t>(rt->npix) * 8, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
-    SAR_TRY(check_device_fault(rt));
     return SAR_OK;
 }
 
@@ -742,7 +735,6 @@ int sar_runtime_count(sar_runtime* rt, uint32_t* out_host) {
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipMemcpyAsync(out_host, rt->d_count, static_cast<size_t>(rt->npix) * 4, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
-    SAR_TRY(check_device_fault(rt));
     return SAR_OK;
 }
 
@@ -751,7 +743,6 @@ int sar_runtime_steps(sar_runtime* rt, double* out_host) {
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipMemcpyAsync(out_host, rt->d_steps, static_cast<size_t>(rt->npix) * 8, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
-    SAR_TRY(check_device_fault(rt));
     return SAR_OK;
 }
 
@@ -762,7 +753,6 @@ int sar_runtime_zbuf(sar_runtime* rt, float* out_host) {
     launch_zbuf_out(rt->d_key, rt->d_ztmp, rt->npix, rt->stream);
     HIP_TRY(hipMemcpyAsync(out_host, rt->d_ztmp, static_cast<size_t>(rt->npix) * 4, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
-    SAR_TRY(check_device_fault(rt));
     return SAR_OK;
 }
 
@@ -772,7 +762,6 @@ int sar_runtime_max(sar_runtime* rt, uint32_t* out_max) {
     uint32_t sc[SC_COUNT];
     HIP_TRY(hipMemcpyAsync(sc, rt->d_scalars, sizeof(sc), hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
-    SAR_TRY(check_device_fault(rt));
     *out_max = sc[SC_WRAP] ? 0xFFFFFFFFu : sc[SC_MAX];
     return SAR_OK;
 }
@@ -901,7 +890,6 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
     if (!rt || !out) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipStreamSynchronize(rt->stream));
-    SAR_TRY(check_device_fault(rt));
     std::memset(out, 0, sizeof(*out));
     float ms = 0.f;
     for (size_t k = 0; k < rt->iter_used; ++k)
@@ -918,6 +906,11 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
         out->depth_atomics = sent;
     }
     out->iterations_counted = rt->last_iterations;
+    if (rt->timing_accumulate) {
+        rt->last_iterations = 0;
+        rt->iter_used = 0;
+        rt->fold_used = 0;
+    }
     return SAR_OK;
 }
 
@@ -931,7 +924,7 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "checkpoint_stride")) {
         rt->ckpt_stride = v ? v : kDefaultCkptStride;
     } else if (!std::strcmp(name, "path")) {
-        if (v > 4) { set_error("path must be 0..4"); return SAR_ERR_INVALID; }
+        if (v > 3) { set_error("path must be 0..3"); return SAR_ERR_INVALID; }
         rt->bins_mode = v;
     } else if (!std::strcmp(name, "bin_shift")) {
         if (v && (v < 12 || v > 15)) { set_error("bin_shift must be 12..15"); return SAR_ERR_INVALID; }
@@ -948,6 +941,11 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "measure")) {
         if (v > 2) { set_error("measure must be 0..2"); return SAR_ERR_INVALID; }
         rt->measure_mode = v;
+    } else if (!std::strcmp(name, "timing_accumulate")) {
+        rt->timing_accumulate = v != 0;
+        rt->last_iterations = 0;
+        rt->iter_used = 0;
+        rt->fold_used = 0;
     } else if (!std::strcmp(name, "debug_chunk_jobs")) {
         rt->debug_chunk_jobs = v;
     } else {

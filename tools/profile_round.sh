@@ -25,5 +25,5 @@ run_pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIV
 run_pmc grbm GRBM_GUI_ACTIVE GRBM_COUNT
 rocprofv3 -L 2>/dev/null | grep -E "^\s*(Name|name)|TCC_.*ATOMIC|TCC_EA0" | head -60 > $OUT/counter_names.txt
 cd $GRAFT_REPO_ROOT
-python tools/summarize_profiles.py $OUT > $OUT/SUMMARY.md 2>&1
+python tools/summarize_profiles.py $OUT $OUT/pmc.json > $OUT/SUMMARY.md 2>&1
 cat $OUT/SUMMARY.md

@@ -21,7 +21,7 @@ try:
     line = [l for l in open(os.path.join(root, "trace_bench.json")) if l.startswith("{")][-1]
     b = json.loads(line)
     print(f"bench line under the tracer: value {b['value']:.4g} {b['unit']}, ms_per_step {b['ms_per_step']:.3f}, "
-          f"kernel_ms {b.get('kernel_ms')}\n")
+          f"kernel_ms_per_step {b.get('kernel_ms_per_step')}, roofline.kernel_ms {b['roofline'].get('kernel_ms')}\n")
 except Exception as e:  # noqa
     print(f"(no bench line: {e})\n")
 
