@@ -262,7 +262,11 @@ __host__ __device__ constexpr size_t kHintStride(uint32_t npix) { return ((size_
 // flight — its list walk is a dependent-load chain, bound by memory latency x lists, not by bandwidth.
 constexpr uint32_t kChains = kListChains;
 constexpr uint32_t kLeanWaveLds(uint32_t bins, uint32_t R) { return bins * (2u * R + 4u + 4u * kChains) + 384u; }
-constexpr uint32_t kChunkQuads(uint32_t R) { return (8u + 2u * R) / 16u; }  // 16-byte quads per chunk: R = 12, 20, 28
+constexpr uint32_t kChunkQuads(uint32_t R) { return (8u + 2u * R) / 16u; }  // 16-byte quads of data per chunk: R = 12, 20, 28
+// Chunks never straddle a 64-byte sector of the arena: the 48-byte chunk (R = 20) is laid out on a 64-byte stride.
+// The accumulate kernel's chunk reads are isolated, and an isolated read moves whole sectors (measured, tools/ubench/
+// gather_runs.hip: 3.4 TB/s for 64-byte pieces) — a straddling chunk would cost two.
+constexpr uint32_t kChunkStride(uint32_t R) { return R == 12u ? 2u : 4u; }
 
 // Everything a wave needs to turn a stream of visits into staged records + depth candidates. One visit
 // per lane per step(); all per-visit state lives in registers, the staging buffers in the wave's LDS slice.
@@ -327,7 +331,7 @@ struct Stager {
             w[2u + 2u * k] = f[k].x;
             w[3u + 2u * k] = f[k].y;
         }
-        u32x4* dst = (u32x4*)(arena + (size_t)chunk * Q);
+        u32x4* dst = (u32x4*)(arena + (size_t)chunk * kChunkStride(R));
 #pragma unroll
         for (uint32_t q = 0; q < Q; ++q)  // streamed once, read once: keep them out of the L2 the hints live in
             __builtin_nontemporal_store((u32x4){w[4u * q], w[4u * q + 1u], w[4u * q + 2u], w[4u * q + 3u]}, dst + q);
@@ -551,7 +555,7 @@ __global__ void __launch_bounds__(256, R == 12u ? 4 : 2) k_iterate_lean(const Bi
     // visit ordinal = job*n + t (job-major, iteration-minor == the sequential order of the reference); the key's
     // low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie
     st.init((char*)smem + (threadIdx.x >> 6) * kLeanWaveLds(a.n_bins, R), a.n_bins, lane,
-            (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkQuads(R),
+            (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkStride(R),
             a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.bin_shift, 0xFFFFFFFFu - job * n);
 
     MapParams p = a.it.p;
@@ -627,7 +631,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
         uint32_t chunk[kChains];
 #pragma unroll
         for (uint32_t k = 0; k < kChains; ++k) chunk[k] = a.heads[((size_t)b * a.n_waves + w) * kChains + k];
-        const uint4* base = arena + (size_t)w * a.chunks_per_wave * Q;
+        const uint4* base = arena + (size_t)w * a.chunks_per_wave * kChunkStride(R);
         for (;;) {
             bool live = false;
 #pragma unroll
@@ -637,7 +641,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
 #pragma unroll
             for (uint32_t k = 0; k < kChains; ++k) {
                 v[k] = make_uint4(kNoChunk, 0u, 0u, 0u);
-                if (chunk[k] != kNoChunk && q < Q) v[k] = base[(size_t)chunk[k] * Q + q];
+                if (chunk[k] != kNoChunk && q < Q) v[k] = base[(size_t)chunk[k] * kChunkStride(R) + q];
             }
 #pragma unroll
             for (uint32_t k = 0; k < kChains; ++k) {
@@ -996,7 +1000,7 @@ void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode,
 }
 
 uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records) { return kLeanWaveLds(bins, records); }
-uint32_t chunk_bytes(uint32_t records) { return kChunkQuads(records) * 16u; }
+uint32_t chunk_bytes(uint32_t records) { return kChunkStride(records) * 16u; }
 
 int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, bool depth, hipStream_t s) {
     const uint32_t grid = (a.it.n_jobs + block - 1) / block;
