@@ -136,7 +136,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("SAR_LIBRARY") or LIB_PATH  # SAR_LIBRARY: A/B timing of another build of the same ABI
     if not os.path.exists(p):
         raise SarLibraryMissing(
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -499,13 +499,12 @@ struct Stager {
     }
 };
 
-// One iteration of render's loop body up to the visit (reference src/lib.rs:770-802): advances the point and
-// reports whether the iteration landed inside the image, at which pixel, and its depth as f32. Returns false
-// when the trajectory has just become NaN (absorbing: this and every remaining iteration hit pixel (0,0)).
-__device__ __forceinline__ bool iterate_once(const MapParams& p, uint32_t width, double& x, double& y, double& z,
+// One iteration of render's loop body up to the visit (reference src/lib.rs:770-802), without a branch: advances the
+// point and reports whether the iteration passes the bounds test, the pixel it would land on and its depth as f32.
+// The caller masks the result for lanes whose trajectory has ended (NaN is absorbing: x != x after this call).
+__device__ __forceinline__ void iterate_once(const MapParams& p, uint32_t width, double& x, double& y, double& z,
                                              bool& inb, uint32_t& idx, float& zf) {
     next_point(p, x, y, z);  // :770
-    if (x != x) return false;
     double sx, sy, sz;
     screen_space(p, x, y, z, sx, sy, sz);  // :773
     const double ax = sx + p.ccx;          // center_camera.x with screen_space.x
@@ -514,12 +513,12 @@ __device__ __forceinline__ bool iterate_once(const MapParams& p, uint32_t width,
     const double z2 = ax * p.sin_v - az * p.cos_v;
     const double fi = (p.scale_adjusted_mid - x2) * p.width_scaled;   // :783
     const double fj = p.half_height - (sy + p.ccz) * p.width_scaled;  // :786
-    inb = !(fi >= p.width || fj >= p.height || fi < 0. || fj < 0.);    // :789
-    const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;  // Rust `as u32`: NaN -> 0
+    // :789 — `|` instead of `||`: four compares and three mask ORs, not four nested branches
+    inb = !((int)(fi >= p.width) | (int)(fj >= p.height) | (int)(fi < 0.) | (int)(fj < 0.));
+    const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;  // Rust `as u32`: NaN -> 0 (non-finite coordinates pass :789)
     const uint32_t j = (fj == fj) ? (uint32_t)fj : 0u;
-    idx = inb ? j * width + i : 0u;
+    idx = j * width + i;
     zf = (float)z2;  // `z2 as f32`
-    return true;
 }
 
 __device__ __forceinline__ void pin_map_params(MapParams& p) {
@@ -580,16 +579,19 @@ __global__ void __launch_bounds__(256, R == 12u ? 4 : 2) k_iterate_lean(const Bi
         ck += 3 * cs;
         const uint32_t tend = (n - t > C) ? t + C : n;
         for (; t < tend; ++t) {
-            bool inb = false;
-            uint32_t idx = 0;
-            float zf = -2.0f;
-            if (alive && !iterate_once(p, a.it.width, x, y, z, inb, idx, zf)) {
+            bool inb;
+            uint32_t idx;
+            float zf;
+            iterate_once(p, a.it.width, x, y, z, inb, idx, zf);  // every lane, finished or not: no divergence
+            const bool ended = alive && x != x;
+            if (__ballot(ended)) {
                 // absorbing NaN state: this and all remaining iterations pass the bounds test (:789), land on pixel
                 // (0,0) (:800-802) and never win the depth test — add them in one go
-                alive = false;
-                inb = false;
-                atomicAdd(a.nan_count, (unsigned long long)(n - t));
+                if (ended) atomicAdd(a.nan_count, (unsigned long long)(n - t));
+                alive = alive && !ended;
             }
+            inb = inb && alive;
+            idx = inb ? idx : 0u;
             st.step(inb, idx, zf, t);
         }
     }
