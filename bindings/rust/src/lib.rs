@@ -14,12 +14,17 @@ pub const SAR_ERR_NO_DEVICE: c_int = 3;
 pub const SAR_ERR_HIP: c_int = 4;
 pub const SAR_ERR_OOM: c_int = 5;
 pub const SAR_ERR_RANGE: c_int = 6;
+pub const SAR_ERR_IO: c_int = 7;
 
 pub const SAR_RENDER_GAS: i32 = 0; // RenderKind::Gas   (:233-239)
 pub const SAR_RENDER_DEPTH: i32 = 1; // RenderKind::Depth
 pub const SAR_CT_POISSON_SATURNE: i32 = 0; // color_transforms::poisson_saturne (:520)
 pub const SAR_CT_ADJUSTED_VELOCITY: i32 = 1; // color_transforms::AdjustedVelocity (:507)
 pub const SAR_PALETTE_MAX: usize = 15;
+pub const SAR_FMT_RGBA16: c_int = 0;
+pub const SAR_FMT_RGB16: c_int = 1;
+pub const SAR_FMT_RGBA8: c_int = 2;
+pub const SAR_FMT_RGB8: c_int = 3;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug)]
@@ -105,6 +110,14 @@ extern "C" {
     pub fn sar_colorize(cfg: *const SarConfig, rt: *mut SarRuntime, rgba_out_host: *mut u16) -> c_int; // colorize (:841)
     pub fn sar_colorize_device(cfg: *const SarConfig, rt: *mut SarRuntime, rgba_out_dev: *mut c_void) -> c_int;
 
+    // image export (src/bin/main.rs:40-100)
+    pub fn sar_image_format(transparent: c_int, eight_bit: c_int) -> c_int;
+    pub fn sar_image_bytes(format: c_int, width: u32, height: u32) -> usize;
+    pub fn sar_image_convert_device(rt: *mut SarRuntime, rgba16_dev: *const c_void, format: c_int, out_dev: *mut c_void) -> c_int;
+    pub fn sar_colorize_format(cfg: *const SarConfig, rt: *mut SarRuntime, format: c_int, out_host: *mut c_void) -> c_int;
+    pub fn sar_write_png(path: *const c_char, format: c_int, width: u32, height: u32, pixels: *const c_void) -> c_int;
+    pub fn sar_write_bmp(path: *const c_char, format: c_int, width: u32, height: u32, pixels: *const c_void) -> c_int;
+    pub fn sar_write_pam(path: *const c_char, format: c_int, width: u32, height: u32, pixels: *const c_void) -> c_int;
     pub fn sar_runtime_count(rt: *mut SarRuntime, out_host: *mut u32) -> c_int;
     pub fn sar_runtime_steps(rt: *mut SarRuntime, out_host: *mut f64) -> c_int;
     pub fn sar_runtime_zbuf(rt: *mut SarRuntime, out_host: *mut f32) -> c_int;

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SAR_ABI_VERSION 1
+#define SAR_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -45,7 +45,8 @@ enum {
     SAR_ERR_NO_DEVICE = 3,    /* no HIP device / HIP runtime unavailable */
     SAR_ERR_HIP = 4,          /* a HIP call failed; see sar_last_error() */
     SAR_ERR_OOM = 5,
-    SAR_ERR_RANGE = 6         /* a size exceeds what one launch chunk can order (see sar_render_jobs) */
+    SAR_ERR_RANGE = 6,        /* a size exceeds what one launch chunk can order (see sar_render_jobs) */
+    SAR_ERR_IO = 7            /* an image file could not be created or written (ref: File::create(..).unwrap(), main.rs:103) */
 };
 
 /* ---- closed enums (Rust generics / closures cannot cross a C ABI) ------------------------- */
@@ -172,6 +173,35 @@ int sar_render_job_range(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs
 int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host);
 /* Same, leaving the image in device memory (width*height*8 bytes); stream-ordered, no host sync. */
 int sar_colorize_device(const sar_config* cfg, sar_runtime* rt, void* rgba_out_dev);
+
+/* ---- image export (src/bin/main.rs:40-100, write_image_matches) ------------------------------------ *
+ * The CLI converts FinalImage (RGBA16) by (--transparent, --8bit) before it encodes (:52-57):
+ *   (true,false) RGBA16 as is | (false,false) to_rgb16 | (true,true) to_rgba8 | (false,true) to_rgb8
+ * and writes PNG (default compression, adaptive filter, :84-92), BMP (:71-77) or PAM (:64-70; both need --8bit,
+ * :256-258). The conversions and encoders live in the `image` crate (Cargo.toml: image = "0.25", no lockfile,
+ * not vendored): restated here from its published algorithm — 16 -> 8 bit is ((c + 128) / 257), alpha is
+ * dropped without pre-multiplication — PARITY UNPINNED beyond "the file decodes to these samples".
+ */
+#define SAR_FMT_RGBA16 0
+#define SAR_FMT_RGB16  1
+#define SAR_FMT_RGBA8  2
+#define SAR_FMT_RGB8   3
+/* The format write_image_matches picks for (--transparent, --8bit) (:52-57). */
+int sar_image_format(int transparent, int eight_bit);
+/* Bytes of a width x height image in `format` (0 for an unknown format). */
+size_t sar_image_bytes(int format, uint32_t width, uint32_t height);
+/* RGBA16 (device) -> format (device), stream-ordered on rt's stream; in and out must not overlap. */
+int sar_image_convert_device(sar_runtime* rt, const void* rgba16_dev, int format, void* out_dev);
+/* colorize + conversion on the device, then ONE device-to-host copy of the converted image
+ * (sar_image_bytes(format) bytes: 12 MiB instead of 32 MiB for RGB8 at 2048x2048). Samples are host-endian. */
+int sar_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host);
+/* Encoders (host only; no device needed). `pixels` is a host image in `format`, host-endian samples.
+ * PNG: 8/16-bit RGB(A), zlib default compression, per-row adaptive filter (minimum sum of absolute differences).
+ * BMP / PAM: SAR_FMT_RGBA8 or SAR_FMT_RGB8 only (the CLI requires --8bit for them); BMP 24 bpp BI_RGB or
+ * 32 bpp BI_BITFIELDS (V4 header) bottom-up; PAM "P7" with TUPLTYPE RGB / RGB_ALPHA. */
+int sar_write_png(const char* path, int format, uint32_t width, uint32_t height, const void* pixels);
+int sar_write_bmp(const char* path, int format, uint32_t width, uint32_t height, const void* pixels);
+int sar_write_pam(const char* path, int format, uint32_t width, uint32_t height, const void* pixels);
 
 /* ---- read-back accessors (the reference keeps these fields private, :633-643) ---------------------- */
 int sar_runtime_count(sar_runtime* rt, uint32_t* out_host);   /* width*height */

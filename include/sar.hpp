@@ -87,6 +87,22 @@ inline FinalImage colorize(const Config& config, Runtime& runtime) {
     return img;
 }
 
+// write_image_matches (src/bin/main.rs:40-100): colorize, convert by (transparent, 8bit) on the device, encode by
+// (pam, bmp) — both need 8bit (:256-258) — and replace the extension of `name`. Returns the path written.
+inline std::string write_image_matches(const Config& config, Runtime& runtime, const std::string& name, bool eight_bit = false,
+                                       bool pam = false, bool bmp = false) {
+    if ((pam || bmp) && !eight_bit) throw Error(SAR_ERR_INVALID, "write_image_matches: --pam/--bmp require --8bit");
+    const int format = sar_image_format(config.transparent, eight_bit ? 1 : 0);
+    std::vector<unsigned char> pixels(sar_image_bytes(format, config.width, config.height));
+    check(sar_colorize_format(&config, runtime.handle(), format, pixels.data()), "colorize_format");
+    const size_t dot = name.find_last_of('.'), slash = name.find_last_of('/');
+    const std::string stem = (dot != std::string::npos && (slash == std::string::npos || dot > slash)) ? name.substr(0, dot) : name;
+    const std::string path = stem + (pam ? ".pam" : (bmp ? ".bmp" : ".png"));
+    check((pam ? sar_write_pam : (bmp ? sar_write_bmp : sar_write_png))(path.c_str(), format, config.width, config.height, pixels.data()),
+          "write_image");
+    return path;
+}
+
 class ParallelRenderer {  // :908
 public:
     explicit ParallelRenderer(int device = 0, uint32_t units = 0, uint64_t seed = 0) {

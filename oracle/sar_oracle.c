@@ -264,6 +264,34 @@ void sar_oracle_palette(const sar_config* cfg, double value, double rgb[3]) {
 }
 
 /* ---- a13 / a14: colorize, src/lib.rs:841-904 -------------------------------------------------- */
+/* src/bin/main.rs:52-57; image 0.25 `FromPrimitive<u16> for u8`: ((c + 128) / 257), channels copied in order,
+ * alpha dropped (not pre-multiplied) by to_rgb16 / to_rgb8. */
+static uint8_t oracle_u16_to_u8(uint16_t c) { return (uint8_t)(((uint32_t)c + 128u) / 257u); }
+
+void sar_oracle_convert(int format, uint64_t npix, const uint16_t* rgba16, void* out) {
+    uint16_t* o16 = (uint16_t*)out;
+    uint8_t* o8 = (uint8_t*)out;
+    for (uint64_t p = 0; p < npix; ++p) {
+        const uint16_t* px = rgba16 + 4 * p;
+        switch (format) {
+            case SAR_FMT_RGBA16:
+                for (int c = 0; c < 4; ++c) o16[4 * p + c] = px[c];
+                break;
+            case SAR_FMT_RGB16:
+                for (int c = 0; c < 3; ++c) o16[3 * p + c] = px[c];
+                break;
+            case SAR_FMT_RGBA8:
+                for (int c = 0; c < 4; ++c) o8[4 * p + c] = oracle_u16_to_u8(px[c]);
+                break;
+            case SAR_FMT_RGB8:
+                for (int c = 0; c < 3; ++c) o8[3 * p + c] = oracle_u16_to_u8(px[c]);
+                break;
+            default:
+                break;
+        }
+    }
+}
+
 void sar_oracle_colorize(const sar_config* cfg, const sar_oracle_runtime* rt, uint16_t* rgba) {
     const size_t n = (size_t)rt->width * rt->height;
     const double u16_max = 65535.;

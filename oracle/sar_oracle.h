@@ -62,6 +62,11 @@ void sar_oracle_palette(const sar_config* cfg, double value, double rgb[3]);
 /* colorize, src/lib.rs:841-904; rgba: width*height*4 uint16 */
 void sar_oracle_colorize(const sar_config* cfg, const sar_oracle_runtime* rt, uint16_t* rgba);
 
+/* write_image_matches' format conversion, src/bin/main.rs:52-57 (DynamicImage::to_rgb16 / to_rgba8 / to_rgb8 of the
+ * `image` crate 0.25 — not vendored, version unpinned: its published u16 -> u8 rule ((c + 128) / 257) is restated;
+ * parity unpinned). format: SAR_FMT_*; out holds npix * channels samples of 1 or 2 bytes, host-endian. */
+void sar_oracle_convert(int format, uint64_t npix, const uint16_t* rgba16, void* out);
+
 /* Start-point stream (defined by this project, see include/sar.h sar_start_points). */
 void sar_oracle_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double* xyz);
 

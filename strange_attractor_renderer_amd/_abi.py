@@ -15,6 +15,7 @@ SAR_ERR_NO_DEVICE = 3
 SAR_ERR_HIP = 4
 SAR_ERR_OOM = 5
 SAR_ERR_RANGE = 6
+SAR_ERR_IO = 7
 
 SAR_RENDER_GAS = 0
 SAR_RENDER_DEPTH = 1
@@ -22,6 +23,10 @@ SAR_ATTRACTOR_SPROTT2 = 0
 SAR_CT_POISSON_SATURNE = 0
 SAR_CT_ADJUSTED_VELOCITY = 1
 SAR_PALETTE_MAX = 15
+SAR_FMT_RGBA16 = 0
+SAR_FMT_RGB16 = 1
+SAR_FMT_RGBA8 = 2
+SAR_FMT_RGB8 = 3
 
 
 class SarConfig(C.Structure):
@@ -101,6 +106,13 @@ PROTOTYPES = {
     "sar_render_job_range": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _P(C.c_double)]),
     "sar_colorize": (C.c_int, [_cfg_p, _vp, _P(C.c_uint16)]),
     "sar_colorize_device": (C.c_int, [_cfg_p, _vp, _vp]),
+    "sar_image_format": (C.c_int, [C.c_int, C.c_int]),
+    "sar_image_bytes": (C.c_size_t, [C.c_int, C.c_uint32, C.c_uint32]),
+    "sar_image_convert_device": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "sar_colorize_format": (C.c_int, [_cfg_p, _vp, C.c_int, _vp]),
+    "sar_write_png": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, _vp]),
+    "sar_write_bmp": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, _vp]),
+    "sar_write_pam": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, _vp]),
     "sar_runtime_count": (C.c_int, [_vp, _P(C.c_uint32)]),
     "sar_runtime_steps": (C.c_int, [_vp, _P(C.c_double)]),
     "sar_runtime_zbuf": (C.c_int, [_vp, _P(C.c_float)]),

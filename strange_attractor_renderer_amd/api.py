@@ -16,6 +16,7 @@ There is no CPU fallback: without the library or without a HIP device these call
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -300,6 +301,60 @@ def colorize_device(config: Config, runtime: Runtime, rgba_dev_ptr: int):
     """colorize into a caller-provided device buffer (H*W*8 bytes); stream-ordered, no host sync."""
     _check(_lib().sar_colorize_device(C.byref(config.c), runtime.handle, C.c_void_p(rgba_dev_ptr)),
            "sar_colorize_device")
+
+
+# ---- image export (src/bin/main.rs:40-100) -------------------------------------------------------------------
+_FMT_SHAPE = {_abi.SAR_FMT_RGBA16: (4, np.uint16), _abi.SAR_FMT_RGB16: (3, np.uint16),
+              _abi.SAR_FMT_RGBA8: (4, np.uint8), _abi.SAR_FMT_RGB8: (3, np.uint8)}
+
+
+def image_format(transparent: bool, eight_bit: bool) -> int:
+    """The format ``write_image_matches`` converts to for (--transparent, --8bit) (src/bin/main.rs:52-57)."""
+    return int(_lib().sar_image_format(int(bool(transparent)), int(bool(eight_bit))))
+
+
+def colorize_format(config: Config, runtime: Runtime, fmt: int) -> np.ndarray:
+    """``colorize`` followed by the CLI's format conversion, both on the device; one copy of the converted image."""
+    if fmt not in _FMT_SHAPE:
+        raise ValueError(f"unknown image format {fmt}")
+    ch, dt = _FMT_SHAPE[fmt]
+    out = np.empty((config.c.height, config.c.width, ch), dtype=dt)
+    _check(_lib().sar_colorize_format(C.byref(config.c), runtime.handle, fmt, out.ctypes.data_as(C.c_void_p)),
+           "sar_colorize_format")
+    return out
+
+
+def convert_device(runtime: Runtime, rgba16_dev_ptr: int, fmt: int, out_dev_ptr: int):
+    """RGBA16 -> fmt between two device buffers, ordered on the runtime's stream."""
+    _check(_lib().sar_image_convert_device(runtime.handle, C.c_void_p(rgba16_dev_ptr), fmt, C.c_void_p(out_dev_ptr)),
+           "sar_image_convert_device")
+
+
+def _fmt_of(image: np.ndarray) -> int:
+    for fmt, (ch, dt) in _FMT_SHAPE.items():
+        if image.ndim == 3 and image.shape[2] == ch and image.dtype == dt:
+            return fmt
+    raise ValueError("image must be (H, W, 3|4) of uint8 or uint16")
+
+
+def write_image(image: np.ndarray, path: str, kind: str = "png"):
+    """Encodes a host image (as returned by ``colorize_format``) as PNG, BMP or PAM."""
+    fmt = _fmt_of(image)
+    img = np.ascontiguousarray(image)
+    fn = {"png": _lib().sar_write_png, "bmp": _lib().sar_write_bmp, "pam": _lib().sar_write_pam}[kind]
+    _check(fn(os.fsencode(path), fmt, img.shape[1], img.shape[0], img.ctypes.data_as(C.c_void_p)), f"sar_write_{kind}")
+
+
+def write_image_matches(config: Config, runtime: Runtime, name: str, transparent: bool = False, eight_bit: bool = False,
+                        pam: bool = False, bmp: bool = False) -> str:
+    """``write_image_matches`` (src/bin/main.rs:40-100): convert by (transparent, 8bit), pick the encoder by
+    (pam, bmp) — both need 8bit (:256-258) — and replace the extension of ``name``. Returns the path written."""
+    if (pam or bmp) and not eight_bit:
+        raise ValueError("--pam / --bmp require --8bit (src/bin/main.rs:256-258)")
+    kind = "pam" if pam else ("bmp" if bmp else "png")
+    path = os.path.splitext(name)[0] + "." + kind
+    write_image(colorize_format(config, runtime, image_format(transparent, eight_bit)), path, kind)
+    return path
 
 
 class ParallelRenderer:

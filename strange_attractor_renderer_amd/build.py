@@ -18,7 +18,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libsar_hip.so")
 BUILD_DIR = os.path.join(os.path.dirname(PKG), "build", "sar_hip")
-SOURCES = ["sar_host.cpp", "sar_runtime.cpp", "sar_kernels.hip"]
+SOURCES = ["sar_host.cpp", "sar_export.cpp", "sar_runtime.cpp", "sar_kernels.hip"]
 HEADERS = ["sar_internal.hpp", "sar_launch.hpp", os.path.join("..", "..", "include", "sar.h")]
 ARCH = "gfx950"
 
@@ -83,7 +83,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print("fused-fp64 audit:", {k[:60]: v for k, v in counts.items()})
     tmp = OUT + ".tmp"
-    subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", tmp], check=True)
+    subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-lz", "-o", tmp], check=True)  # zlib: PNG export
     os.replace(tmp, OUT)
     return OUT
 

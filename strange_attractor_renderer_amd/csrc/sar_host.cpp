@@ -123,6 +123,7 @@ const char* sar_status_string(int status) {
         case SAR_ERR_HIP: return "HIP call failed";
         case SAR_ERR_OOM: return "out of memory";
         case SAR_ERR_RANGE: return "size out of range";
+        case SAR_ERR_IO: return "image file could not be written";
         default: return "unknown status";
     }
 }

@@ -988,6 +988,69 @@ static inline uint32_t grid_for(uint32_t n, uint32_t block, uint32_t cap) {
     return g ? g : 1;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_convert — RGBA16 -> RGB16 / RGBA8 / RGB8 (src/bin/main.rs:52-57: DynamicImage::to_rgb16 / to_rgba8 / to_rgb8).
+// image 0.25's channel conversion u16 -> u8 is ((c + 128) / 257) (rounding, exact inverse of c * 257); alpha is
+// dropped, not pre-multiplied. Streaming: 8 B/px in, 3-6 B/px out; four pixels per thread keep stores 4-byte aligned.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t to8(uint32_t c16) { return (c16 + 128u) / 257u; }
+
+template <int FORMAT>
+__global__ void __launch_bounds__(256) k_convert(const ushort4* __restrict__ in, void* __restrict__ out, uint32_t npix) {
+    const uint32_t quads = (npix + 3u) / 4u;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < quads; g += gridDim.x * blockDim.x) {
+        const uint32_t p0 = 4u * g;
+        ushort4 px[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) px[k] = (p0 + k < npix) ? in[p0 + k] : make_ushort4(0, 0, 0, 0);
+        const bool full = p0 + 4u <= npix;
+        if (FORMAT == SAR_FMT_RGB16) {
+            unsigned short* o = (unsigned short*)out + (size_t)p0 * 3u;
+            if (full) {  // 12 u16 = three 8-byte stores
+                uint2* o2 = (uint2*)o;
+                o2[0] = make_uint2(px[0].x | ((uint32_t)px[0].y << 16), px[0].z | ((uint32_t)px[1].x << 16));
+                o2[1] = make_uint2(px[1].y | ((uint32_t)px[1].z << 16), px[2].x | ((uint32_t)px[2].y << 16));
+                o2[2] = make_uint2(px[2].z | ((uint32_t)px[3].x << 16), px[3].y | ((uint32_t)px[3].z << 16));
+            } else {
+                for (uint32_t k = 0; p0 + k < npix; ++k) {
+                    o[3u * k] = px[k].x;
+                    o[3u * k + 1u] = px[k].y;
+                    o[3u * k + 2u] = px[k].z;
+                }
+            }
+        } else if (FORMAT == SAR_FMT_RGBA8) {
+            uint32_t w[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) w[k] = to8(px[k].x) | (to8(px[k].y) << 8) | (to8(px[k].z) << 16) | (to8(px[k].w) << 24);
+            uint32_t* o = (uint32_t*)out + p0;
+            if (full) *(uint4*)o = make_uint4(w[0], w[1], w[2], w[3]);
+            else
+                for (uint32_t k = 0; p0 + k < npix; ++k) o[k] = w[k];
+        } else {  // RGB8: 12 bytes per four pixels
+            unsigned char* o = (unsigned char*)out + (size_t)p0 * 3u;
+            if (full) {
+                uint32_t b[12];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    b[3u * k] = to8(px[k].x);
+                    b[3u * k + 1u] = to8(px[k].y);
+                    b[3u * k + 2u] = to8(px[k].z);
+                }
+                uint32_t* o4 = (uint32_t*)o;
+                o4[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                o4[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+                o4[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+            } else {
+                for (uint32_t k = 0; p0 + k < npix; ++k) {
+                    o[3u * k] = (unsigned char)to8(px[k].x);
+                    o[3u * k + 1u] = (unsigned char)to8(px[k].y);
+                    o[3u * k + 2u] = (unsigned char)to8(px[k].z);
+                }
+            }
+        }
+    }
+}
+
 void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode, hipStream_t s) {
     const uint32_t grid = (a.n_jobs + block - 1) / block;
     if (xcd_local) {
@@ -1081,6 +1144,17 @@ void launch_colorize_depth(const unsigned long long* key, uint32_t* scalars, uin
     hipLaunchKernelGGL(k_colorize_depth, dim3(grid_for(npix, 256, 8192)), dim3(256), 0, s, key, scalars, npix,
                        (ushort4*)out);
 }
+int launch_convert(const void* rgba16, int format, void* out, uint32_t npix, hipStream_t s) {
+    const dim3 grid(grid_for((npix + 3u) / 4u, 256, 8192)), block(256);
+    switch (format) {
+        case SAR_FMT_RGB16: hipLaunchKernelGGL(k_convert<SAR_FMT_RGB16>, grid, block, 0, s, (const ushort4*)rgba16, out, npix); break;
+        case SAR_FMT_RGBA8: hipLaunchKernelGGL(k_convert<SAR_FMT_RGBA8>, grid, block, 0, s, (const ushort4*)rgba16, out, npix); break;
+        case SAR_FMT_RGB8: hipLaunchKernelGGL(k_convert<SAR_FMT_RGB8>, grid, block, 0, s, (const ushort4*)rgba16, out, npix); break;
+        default: return 1;
+    }
+    return 0;
+}
+
 void launch_exch_export(const unsigned long long* key, uint32_t rank, void* out, uint32_t npix, hipStream_t s) {
     hipLaunchKernelGGL(k_exch_export, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, key, rank, (long long*)out,
                        npix);

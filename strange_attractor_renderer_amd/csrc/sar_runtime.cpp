@@ -92,6 +92,7 @@ struct sar_runtime {
     size_t ckpt_cap = 0;         // doubles
     double* d_lnlut = nullptr;
     void* d_rgba = nullptr;
+    void* d_export = nullptr;  // converted image of sar_colorize_format (<= 6 bytes per pixel)
     float* d_ztmp = nullptr;
 
     // tuning
@@ -132,6 +133,8 @@ int free_device_buffers(sar_runtime* rt) {
     if (rt->d_scratch_count) hipFree(rt->d_scratch_count);
     if (rt->d_scratch_key) hipFree(rt->d_scratch_key);
     if (rt->d_rgba) hipFree(rt->d_rgba);
+    if (rt->d_export) hipFree(rt->d_export);
+    rt->d_export = nullptr;
     if (rt->d_ztmp) hipFree(rt->d_ztmp);
     if (rt->d_zhint) hipFree(rt->d_zhint);
     rt->d_zhint = nullptr;
@@ -726,6 +729,39 @@ int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host
     SAR_TRY(ensure_rgba(rt));
     SAR_TRY(do_colorize(cfg, rt, rt->d_rgba));
     HIP_TRY(hipMemcpyAsync(rgba_out_host, rt->d_rgba, static_cast<size_t>(rt->npix) * 8, hipMemcpyDeviceToHost, rt->stream));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    return SAR_OK;
+}
+
+int sar_image_convert_device(sar_runtime* rt, const void* rgba16_dev, int format, void* out_dev) {
+    if (!rt || !rgba16_dev || !out_dev) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    if (format == SAR_FMT_RGBA16) {
+        HIP_TRY(hipMemcpyAsync(out_dev, rgba16_dev, static_cast<size_t>(rt->npix) * 8, hipMemcpyDeviceToDevice, rt->stream));
+        return SAR_OK;
+    }
+    if (launch_convert(rgba16_dev, format, out_dev, rt->npix, rt->stream) != 0) {
+        set_error("unknown image format %d", format);
+        return SAR_ERR_INVALID;
+    }
+    HIP_TRY(hipGetLastError());
+    return SAR_OK;
+}
+
+int sar_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host) {
+    SAR_TRY(check_cfg_matches(cfg, rt));
+    const size_t bytes = sar_image_bytes(format, rt->W, rt->H);
+    if (!out_host || bytes == 0) { set_error("sar_colorize_format: bad format or NULL output"); return SAR_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(rt->device));
+    SAR_TRY(ensure_rgba(rt));
+    SAR_TRY(do_colorize(cfg, rt, rt->d_rgba));
+    const void* src = rt->d_rgba;
+    if (format != SAR_FMT_RGBA16) {
+        if (!rt->d_export) HIP_TRY(hipMalloc(&rt->d_export, static_cast<size_t>(rt->npix) * 6));  // largest converted format
+        SAR_TRY(sar_image_convert_device(rt, rt->d_rgba, format, rt->d_export));
+        src = rt->d_export;
+    }
+    HIP_TRY(hipMemcpyAsync(out_host, src, bytes, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
     return SAR_OK;
 }

@@ -95,54 +95,12 @@ def kat():
 
 
 def decode_png16(path):
-    """Minimal PNG decoder (non-interlaced, 8/16-bit, colour types 0/2/6): PIL flattens 16-bit RGB to 8."""
-    import struct
-    import zlib
-    data = open(path, "rb").read()
-    assert data[:8] == b"\x89PNG\r\n\x1a\n"
-    pos, idat, hdr = 8, [], None
-    while pos < len(data):
-        ln, typ = struct.unpack(">I4s", data[pos:pos + 8])
-        body = data[pos + 8:pos + 8 + ln]
-        if typ == b"IHDR":
-            hdr = struct.unpack(">IIBBBBB", body)
-        elif typ == b"IDAT":
-            idat.append(body)
-        pos += 12 + ln
-    w, h, depth, ctype, _, _, interlace = hdr
-    assert interlace == 0 and depth in (8, 16)
-    ch = {0: 1, 2: 3, 6: 4}[ctype]
-    bpp = ch * depth // 8
-    raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, 1 + w * bpp)
-    out = np.zeros((h, w * bpp), dtype=np.uint8)
-    prev = np.zeros(w * bpp, dtype=np.int32)
-    for y in range(h):
-        f, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
-        cur = np.zeros(w * bpp, dtype=np.int32)
-        if f == 0:
-            cur = line
-        elif f == 2:
-            cur = (line + prev) & 255
-        elif f == 1:
-            cur = line.copy()
-            for k in range(bpp, w * bpp):
-                cur[k] = (cur[k] + cur[k - bpp]) & 255
-        elif f in (3, 4):
-            for k in range(w * bpp):
-                a = cur[k - bpp] if k >= bpp else 0
-                b = prev[k]
-                c = prev[k - bpp] if k >= bpp else 0
-                if f == 3:
-                    pred = (a + b) >> 1
-                else:
-                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
-                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
-                cur[k] = (line[k] + pred) & 255
-        out[y] = cur
-        prev = cur
-    if depth == 16:
-        return out.reshape(h, w, ch, 2).astype(np.uint16)[..., 0] << 8 | out.reshape(h, w, ch, 2)[..., 1]
-    return out.reshape(h, w, ch)
+    """PIL flattens 16-bit RGB to 8: use the tests' own minimal decoder."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from image_decode import decode_png
+    return decode_png(path)
 
 
 def png_stats(path):

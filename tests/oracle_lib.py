@@ -78,6 +78,8 @@ def lib():
     L.sar_oracle_palette.restype = None
     L.sar_oracle_colorize.argtypes = [cfgp, rtp, C.POINTER(C.c_uint16)]
     L.sar_oracle_colorize.restype = None
+    L.sar_oracle_convert.argtypes = [C.c_int, C.c_uint64, C.POINTER(C.c_uint16), C.c_void_p]
+    L.sar_oracle_convert.restype = None
     L.sar_oracle_start_points.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, dp]
     L.sar_oracle_start_points.restype = None
     L.sar_oracle_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
@@ -240,6 +242,16 @@ def rotation_matrix(cfg: SarConfig) -> np.ndarray:
 def colorize(cfg: SarConfig, rt: Runtime) -> np.ndarray:
     out = np.empty((rt.height, rt.width, 4), dtype=np.uint16)
     lib().sar_oracle_colorize(C.byref(cfg), rt.ptr, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return out
+
+
+def convert(fmt: int, rgba16: np.ndarray) -> np.ndarray:
+    """write_image_matches' format conversion (src/bin/main.rs:52-57) of an (H, W, 4) uint16 image."""
+    h, w = rgba16.shape[:2]
+    ch, dt = {0: (4, np.uint16), 1: (3, np.uint16), 2: (4, np.uint8), 3: (3, np.uint8)}[fmt]
+    src = np.ascontiguousarray(rgba16, dtype=np.uint16)
+    out = np.zeros((h, w, ch), dtype=dt)
+    lib().sar_oracle_convert(fmt, h * w, src.ctypes.data_as(C.POINTER(C.c_uint16)), out.ctypes.data_as(C.c_void_p))
     return out
 
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(sar):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sar.h but not exported by libsar_hip.so"
     assert sorted(_abi.PROTOTYPES) == names, "ctypes prototypes and header declarations differ"
-    assert lib.sar_abi_version() == 1
+    assert lib.sar_abi_version() == 2
 
 
 def test_struct_layout_matches_c(sar):
