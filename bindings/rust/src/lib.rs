@@ -110,6 +110,8 @@ extern "C" {
     pub fn sar_colorize(cfg: *const SarConfig, rt: *mut SarRuntime, rgba_out_host: *mut u16) -> c_int; // colorize (:841)
     pub fn sar_colorize_device(cfg: *const SarConfig, rt: *mut SarRuntime, rgba_out_dev: *mut c_void) -> c_int;
 
+    pub fn sar_runtime_extent(cfg: *const SarConfig, rt: *mut SarRuntime, n_jobs: u32, iters_per_job: u64,
+                              starts_xyz_host: *const f64, out12: *mut f64) -> c_int;
     // image export (src/bin/main.rs:40-100)
     pub fn sar_image_format(transparent: c_int, eight_bit: c_int) -> c_int;
     pub fn sar_image_bytes(format: c_int, width: u32, height: u32) -> usize;

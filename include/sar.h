@@ -174,6 +174,15 @@ int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host
 /* Same, leaving the image in device memory (width*height*8 bytes); stream-ordered, no host sync. */
 int sar_colorize_device(const sar_config* cfg, sar_runtime* rt, void* rgba_out_dev);
 
+/* ---- attractor extent: the "first pass" the reference leaves as a TODO (src/lib.rs:326-333) ----------------- *
+ * n_jobs trajectories (start points from starts_xyz_host[n_jobs*3], or from the runtime's stream when NULL), each
+ * 1000 warm-up iterations (:750-752) then iters_per_job iterations. out12[0..6) = xmin,xmax,ymin,ymax,zmin,zmax of the
+ * screen-space points (cfg's rotation matrix applied, :773: the quantities the comment at :329-333 lists and from
+ * which View::center_camera is chosen), out12[6..12) the same for the raw points. Bounds move through `<` / `>` only
+ * (NaN never moves one), so the result is independent of the execution order. Does not touch the runtime's buffers. */
+int sar_runtime_extent(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters_per_job,
+                       const double* starts_xyz_host, double* out12);
+
 /* ---- image export (src/bin/main.rs:40-100, write_image_matches) ------------------------------------ *
  * The CLI converts FinalImage (RGBA16) by (--transparent, --8bit) before it encodes (:52-57):
  *   (true,false) RGBA16 as is | (false,false) to_rgb16 | (true,true) to_rgba8 | (false,true) to_rgb8

@@ -98,6 +98,35 @@ static inline double magnitude(const double v[3]) {
     return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
 }
 
+/* Extent of the attractor (the reference's TODO first pass, src/lib.rs:326-333). */
+void sar_oracle_extent(const sar_config* cfg, const double* starts_xyz, uint32_t jobs, uint64_t iters_per_job,
+                       double out[12]) {
+    double m[9];
+    sar_oracle_rotation_matrix(cfg, m);
+    for (int k = 0; k < 6; ++k) {
+        out[2 * k] = INFINITY;
+        out[2 * k + 1] = -INFINITY;
+    }
+    for (uint32_t job = 0; job < jobs; ++job) {
+        double p[3] = {starts_xyz[3 * job], starts_xyz[3 * job + 1], starts_xyz[3 * job + 2]}, q[3], ss[3];
+        for (int w = 0; w < 1000; ++w) {  /* :750-752 */
+            sar_oracle_next_point(cfg, p, q);
+            p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+        }
+        for (uint64_t t = 0; t < iters_per_job; ++t) {
+            sar_oracle_next_point(cfg, p, q);
+            p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+            mul_right(m, p, ss);  /* :773 */
+            for (int c = 0; c < 3; ++c) {
+                if (ss[c] < out[2 * c]) out[2 * c] = ss[c];
+                if (ss[c] > out[2 * c + 1]) out[2 * c + 1] = ss[c];
+                if (p[c] < out[6 + 2 * c]) out[6 + 2 * c] = p[c];
+                if (p[c] > out[6 + 2 * c + 1]) out[6 + 2 * c + 1] = p[c];
+            }
+        }
+    }
+}
+
 /* ---- a8 / a8': colour transforms, src/lib.rs:507-516, 520-558 ------------------------------- */
 double sar_oracle_color_transform(const sar_config* cfg, const double delta[3], const double ss[3]) {
     if (cfg->color_transform == SAR_CT_ADJUSTED_VELOCITY) {

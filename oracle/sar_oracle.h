@@ -57,6 +57,13 @@ void sar_oracle_render_jobs(const sar_config* cfg, sar_oracle_runtime* rt, const
 /* Iterates only (no accumulation): writes the point after `n` applications of next_point. */
 void sar_oracle_iterate(const sar_config* cfg, const double p0[3], uint64_t n, double out[3]);
 
+/* The "first pass" the reference leaves as a TODO (src/lib.rs:326-333): extent of the attractor. For every job:
+ * 1000 warm-up iterations (:750-752), then `iters_per_job` iterations; out[0..6) = xmin,xmax,ymin,ymax,zmin,zmax of
+ * the SCREEN-SPACE points (rotation matrix applied, :773 — the numbers the comment at :329-333 lists), out[6..12) the
+ * same for the raw points. A coordinate updates a bound through `<` / `>` only, so NaN never does. */
+void sar_oracle_extent(const sar_config* cfg, const double* starts_xyz, uint32_t jobs, uint64_t iters_per_job,
+                       double out[12]);
+
 /* Palette::interpolate, src/lib.rs:442-472 */
 void sar_oracle_palette(const sar_config* cfg, double value, double rgb[3]);
 /* colorize, src/lib.rs:841-904; rgba: width*height*4 uint16 */

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "sar_render_job_range": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _P(C.c_double)]),
     "sar_colorize": (C.c_int, [_cfg_p, _vp, _P(C.c_uint16)]),
     "sar_colorize_device": (C.c_int, [_cfg_p, _vp, _vp]),
+    "sar_runtime_extent": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _P(C.c_double), _P(C.c_double)]),
     "sar_image_format": (C.c_int, [C.c_int, C.c_int]),
     "sar_image_bytes": (C.c_size_t, [C.c_int, C.c_uint32, C.c_uint32]),
     "sar_image_convert_device": (C.c_int, [_vp, _vp, C.c_int, _vp]),

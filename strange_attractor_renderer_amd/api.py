@@ -303,6 +303,21 @@ def colorize_device(config: Config, runtime: Runtime, rgba_dev_ptr: int):
            "sar_colorize_device")
 
 
+def attractor_extent(config: Config, runtime: Runtime, n_jobs: int, iters_per_job: int, starts=None) -> np.ndarray:
+    """The first pass the reference leaves as a TODO (src/lib.rs:326-333): ``[xmin, xmax, ymin, ymax, zmin, zmax]`` of
+    the screen-space points followed by the same six numbers for the raw points."""
+    out = np.zeros(12)
+    sp = None
+    if starts is not None:
+        st = np.ascontiguousarray(starts, dtype=np.float64)
+        if st.shape != (n_jobs, 3):
+            raise ValueError("starts must be (n_jobs, 3)")
+        sp = st.ctypes.data_as(C.POINTER(C.c_double))
+    _check(_lib().sar_runtime_extent(C.byref(config.c), runtime.handle, n_jobs, iters_per_job, sp,
+                                     out.ctypes.data_as(C.POINTER(C.c_double))), "sar_runtime_extent")
+    return out
+
+
 # ---- image export (src/bin/main.rs:40-100) -------------------------------------------------------------------
 _FMT_SHAPE = {_abi.SAR_FMT_RGBA16: (4, np.uint16), _abi.SAR_FMT_RGB16: (3, np.uint16),
               _abi.SAR_FMT_RGBA8: (4, np.uint8), _abi.SAR_FMT_RGB8: (3, np.uint8)}

@@ -1051,6 +1051,65 @@ __global__ void __launch_bounds__(256) k_convert(const ushort4* __restrict__ in,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_extent — the "first pass" the reference leaves as a TODO (src/lib.rs:326-333): bounds of the attractor in screen
+// space (what the comment at :329-333 lists) and in raw coordinates. One trajectory per lane: 1000 warm-up
+// iterations, then `iters` iterations with 12 running bounds in registers; a bound moves through `<` / `>` only, so NaN
+// never moves one and the result does not depend on the order of the reduction. Output: 12 doubles per block.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bound(double v, double& lo, double& hi) {
+    lo = v < lo ? v : lo;
+    hi = v > hi ? v : hi;
+}
+
+__global__ void __launch_bounds__(256) k_extent(const MapParams pin, const double* __restrict__ starts, uint32_t n_jobs,
+                                                uint64_t iters, double* __restrict__ out) {
+    __shared__ double part[4][12];
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    MapParams p = pin;
+    pin_map_params(p);
+    double b[12];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        b[2 * k] = __builtin_inf();
+        b[2 * k + 1] = -__builtin_inf();
+    }
+    if (job < n_jobs) {
+        double x = starts[job], y = starts[n_jobs + job], z = starts[2u * n_jobs + job];
+        for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);  // :750-752
+        for (uint64_t t = 0; t < iters; ++t) {
+            next_point(p, x, y, z);
+            double sx, sy, sz;
+            screen_space(p, x, y, z, sx, sy, sz);  // :773
+            bound(sx, b[0], b[1]);
+            bound(sy, b[2], b[3]);
+            bound(sz, b[4], b[5]);
+            bound(x, b[6], b[7]);
+            bound(y, b[8], b[9]);
+            bound(z, b[10], b[11]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        double v = b[k];
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_down(v, off);
+            v = (k & 1) ? (o > v ? o : v) : (o < v ? o : v);
+        }
+        if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const int k = threadIdx.x;
+        double v = part[0][k];
+        for (uint32_t w = 1; w < blockDim.x / 64u; ++w) {
+            const double o = part[w][k];
+            v = (k & 1) ? (o > v ? o : v) : (o < v ? o : v);
+        }
+        out[(size_t)blockIdx.x * 12u + k] = v;
+    }
+}
+
 void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode, hipStream_t s) {
     const uint32_t grid = (a.n_jobs + block - 1) / block;
     if (xcd_local) {
@@ -1153,6 +1212,12 @@ int launch_convert(const void* rgba16, int format, void* out, uint32_t npix, hip
         default: return 1;
     }
     return 0;
+}
+
+uint32_t launch_extent(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* out, hipStream_t s) {
+    const uint32_t blocks = (n_jobs + 255u) / 256u;
+    hipLaunchKernelGGL(k_extent, dim3(blocks), dim3(256), 0, s, p, starts, n_jobs, iters, out);
+    return blocks;
 }
 
 void launch_exch_export(const unsigned long long* key, uint32_t rank, void* out, uint32_t npix, hipStream_t s) {

@@ -733,6 +733,53 @@ int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host
     return SAR_OK;
 }
 
+int sar_runtime_extent(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters_per_job,
+                       const double* starts_xyz_host, double* out12) {
+    if (!cfg || !rt || !out12 || n_jobs == 0) return SAR_ERR_INVALID;
+    SAR_TRY(sar_config_validate(cfg));
+    HIP_TRY(hipSetDevice(rt->device));
+    std::vector<double> soa(static_cast<size_t>(n_jobs) * 3);
+    for (uint32_t k = 0; k < n_jobs; ++k) {
+        double p0[3];
+        if (starts_xyz_host) std::memcpy(p0, starts_xyz_host + 3 * static_cast<size_t>(k), sizeof(p0));
+        else rt->rng.start_point(p0);  // :748
+        soa[k] = p0[0];
+        soa[n_jobs + static_cast<size_t>(k)] = p0[1];
+        soa[2 * static_cast<size_t>(n_jobs) + k] = p0[2];
+    }
+    const uint32_t blocks = (n_jobs + 255u) / 256u;
+    double *d_starts = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_starts, soa.size() * sizeof(double)));
+    if (hipMalloc(&d_out, static_cast<size_t>(blocks) * 12 * sizeof(double)) != hipSuccess) {
+        hipFree(d_starts);
+        set_error("out of device memory");
+        return SAR_ERR_OOM;
+    }
+    MapParams mp;
+    std::memset(&mp, 0, sizeof(mp));
+    fill_map_params(*cfg, mp);
+    std::vector<double> part(static_cast<size_t>(blocks) * 12);
+    hipError_t e = hipMemcpyAsync(d_starts, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, rt->stream);
+    if (e == hipSuccess) {
+        launch_extent(mp, d_starts, n_jobs, iters_per_job, d_out, rt->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(part.data(), d_out, part.size() * sizeof(double), hipMemcpyDeviceToHost, rt->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(rt->stream);
+    hipFree(d_starts);
+    hipFree(d_out);
+    if (e != hipSuccess) { set_error("sar_runtime_extent: %s", hipGetErrorString(e)); return SAR_ERR_HIP; }
+    for (int k = 0; k < 12; ++k) {
+        double v = part[k];
+        for (uint32_t b = 1; b < blocks; ++b) {
+            const double o = part[static_cast<size_t>(b) * 12 + k];
+            v = (k & 1) ? (o > v ? o : v) : (o < v ? o : v);
+        }
+        out12[k] = v;
+    }
+    return SAR_OK;
+}
+
 int sar_image_convert_device(sar_runtime* rt, const void* rgba16_dev, int format, void* out_dev) {
     if (!rt || !rgba16_dev || !out_dev) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));

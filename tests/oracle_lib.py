@@ -78,6 +78,8 @@ def lib():
     L.sar_oracle_palette.restype = None
     L.sar_oracle_colorize.argtypes = [cfgp, rtp, C.POINTER(C.c_uint16)]
     L.sar_oracle_colorize.restype = None
+    L.sar_oracle_extent.argtypes = [cfgp, dp, C.c_uint32, C.c_uint64, dp]
+    L.sar_oracle_extent.restype = None
     L.sar_oracle_convert.argtypes = [C.c_int, C.c_uint64, C.POINTER(C.c_uint16), C.c_void_p]
     L.sar_oracle_convert.restype = None
     L.sar_oracle_start_points.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, dp]
@@ -242,6 +244,14 @@ def rotation_matrix(cfg: SarConfig) -> np.ndarray:
 def colorize(cfg: SarConfig, rt: Runtime) -> np.ndarray:
     out = np.empty((rt.height, rt.width, 4), dtype=np.uint16)
     lib().sar_oracle_colorize(C.byref(cfg), rt.ptr, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return out
+
+
+def extent(cfg: SarConfig, starts: np.ndarray, iters_per_job: int) -> np.ndarray:
+    """[xmin,xmax,ymin,ymax,zmin,zmax] of the screen-space points, then of the raw points (src/lib.rs:326-333)."""
+    st = np.ascontiguousarray(starts, dtype=np.float64)
+    out = np.zeros(12)
+    lib().sar_oracle_extent(C.byref(cfg), _dptr(st), st.shape[0], iters_per_job, _dptr(out))
     return out
 
 

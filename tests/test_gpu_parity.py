@@ -375,3 +375,20 @@ def test_exchange_kernels_reproduce_merge_in_rank_order(sar, oracle, gpu):
         assert oracle.merge(acc, other) == 0
     assert_state_equal(rts[0], acc, "exchange == merge folded in rank order")
     assert tie.sum() > 1000
+
+
+@pytest.mark.parametrize("preset", ["poisson_saturne", "solar_sail"])
+def test_attractor_extent_bit_exact(sar, oracle, gpu, preset):
+    """sar_runtime_extent (the reference's TODO first pass, src/lib.rs:326-333) against the oracle: min/max are exact
+    and order-free, so all 12 bounds must match bit for bit — with a ragged job count and NaN-ending jobs."""
+    jobs, n = 1000 + 13, 3000
+    cfg = _cfg(sar, preset, iterations=jobs * n, width=64, height=64, jobs_total=jobs)
+    st = sar.start_points(17, 0, jobs)
+    rt = sar.Runtime(cfg)
+    got = sar.attractor_extent(cfg, rt, jobs, n, st)
+    want = oracle.extent(cfg.c, st, n)
+    np.testing.assert_array_equal(_bits(got), _bits(want))
+    assert np.all(np.isfinite(got))
+    # drawing the start points from the runtime's stream gives the same bounds as passing that stream's points
+    rt.seed(17)
+    np.testing.assert_array_equal(_bits(sar.attractor_extent(cfg, rt, jobs, n)), _bits(want))

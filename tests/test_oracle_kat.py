@@ -105,3 +105,19 @@ def test_merge_semantics(oracle):
     assert a.max == 11                                                  # from merged counts only
     assert a.steps.tolist() == [[1.0, 2.0, 1.0, 1.0], [2.0, 1.0, 1.0, 2.0]]  # strict >, self wins ties
     assert oracle.merge(a, oracle.Runtime(3, 3)) != 0                   # dimension mismatch
+
+
+def test_attractor_extent_matches_the_numbers_in_the_reference_source(oracle):
+    """The only numbers the reference's source holds for this path: the comment at src/lib.rs:329-333 lists the extent
+    of poisson-saturne ("xmin = -0.327770, xmax = 0.335278, ymin = -0.012949, ymax = 0.492107, zmin = -0.628829,
+    zmax = 0.103010") — measured by the author in SCREEN space (raw coordinates are nowhere near). They pin the map
+    coefficients, the un-normalised rotation matrix and `screen_space` of the oracle: 6.4e7 iterations reproduce every
+    bound to better than 5e-5, from the inside (the author's run was longer; an extreme only ever grows)."""
+    ref = np.array([-0.327770, 0.335278, -0.012949, 0.492107, -0.628829, 0.103010])
+    cfg = oracle.poisson_saturne()
+    e = oracle.extent(cfg, oracle.start_points(1, 0, 64), 1_000_000)
+    sign = np.array([-1, 1, -1, 1, -1, 1])
+    assert np.all(np.abs(e[:6] - ref) < 5e-5), e[:6]
+    assert np.all((ref - e[:6]) * sign > -2e-6), "a bound lies outside the reference's"
+    # the raw extent is a different box: the comment's numbers are not raw coordinates
+    assert np.abs(e[6:] - ref).max() > 0.1
