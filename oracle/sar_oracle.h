@@ -10,10 +10,13 @@
  * PARITY STATUS: the reference is Rust and cannot be built here (no cargo/rustc, no lockfile, no
  * vendored crates), and its own test-suite holds no vectors for this path (the only `cargo test`
  * item is a doc-test that constructs a Config, src/lib.rs:9-15). Bit-level parity is therefore
- * UNPINNED; the oracle is pinned (a) statistically against the one artefact the reference ships,
- * media/poisson-saturne.png (tests/golden/ref_png_stats.json, tests/test_oracle_reference_png.py)
- * and (b) by known-answer vectors produced independently and frozen under
- * tests/golden/.
+ * UNPINNED; the oracle is pinned (a) by the only numbers the reference's source holds for this
+ * path, the screen-space extent of poisson-saturne in the comment at src/lib.rs:329-333, which
+ * sar_oracle_extent reproduces to < 5e-5 (tests/test_oracle_kat.py) — they cover the coefficients,
+ * the rotation matrix and screen_space; (b) statistically against the one artefact the reference
+ * ships, media/poisson-saturne.png (tests/golden/ref_png_stats.json,
+ * tests/test_oracle_reference_png.py); (c) by known-answer vectors produced independently
+ *  and frozen under tests/golden/.
  */
 #ifndef SAR_ORACLE_H
 #define SAR_ORACLE_H

@@ -17,6 +17,12 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
     for r in csv.DictReader(open(f)):
         print(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e6:.4f} | {r['Percentage']} |")
     print()
+for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if "k_iterate" in r["Kernel_Name"]]
+    if d:
+        print("`k_iterate_lean` per dispatch (ms): " + ", ".join(f"{x:.3f}" for x in d) +
+              f" — the first dispatch is bench.py's warm-up step (cold caches, first-touch of the arena); mean of the timed "
+              f"ones {sum(d[1:]) / max(len(d) - 1, 1):.3f} ms, which is what bench.py's HIP events average.\n")
 try:
     line = [l for l in open(os.path.join(root, "trace_bench.json")) if l.startswith("{")][-1]
     b = json.loads(line)
