@@ -392,3 +392,20 @@ def test_attractor_extent_bit_exact(sar, oracle, gpu, preset):
     # drawing the start points from the runtime's stream gives the same bounds as passing that stream's points
     rt.seed(17)
     np.testing.assert_array_equal(_bits(sar.attractor_extent(cfg, rt, jobs, n)), _bits(want))
+
+
+@pytest.mark.parametrize("records", [12, 20, 28])
+@pytest.mark.parametrize("splits,acc_threads", [(0, 0), (1, 256), (5, 512), (16, 1024)])
+def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, splits, acc_threads):
+    """Every chunk size of the binned path (32 / 48-on-64 / 64-byte chunks: different lane-group shapes in
+    k_bin_accumulate) with several accumulate grids, against the oracle; enough records per (bin, wave) list to chain
+    many chunks and to overflow staging buffers within one slot request (all trajectories start close together)."""
+    jobs, n = 2048 + 64, 1200
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=256, height=192, jobs_total=jobs)
+    st = sar.start_points(23, 0, jobs)
+    st[:512] = st[0] + np.arange(512)[:, None] * 1e-13  # near-identical trajectories: many lanes hit one bin at once
+    rt, ort = sar.Runtime(cfg), oracle.Runtime(256, 192)
+    rt.set_tuning(variant=3, chunk_records=records, splits=splits, acc_threads=acc_threads)
+    sar.render_jobs(cfg, rt, st)
+    oracle.render_jobs(cfg.c, ort, st, n)
+    assert_state_equal(rt, ort, f"records={records} splits={splits} acc_threads={acc_threads}")
