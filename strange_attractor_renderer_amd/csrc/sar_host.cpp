@@ -93,6 +93,9 @@ int validate(const sar_config* cfg) {
     if (static_cast<uint64_t>(cfg->width) * cfg->height > 0x7fffffffull) {
         set_error("width*height exceeds 2^31-1 pixels"); return SAR_ERR_RANGE;
     }
+    if (cfg->width >= (1u << 24) || cfg->height >= (1u << 24)) {  // pixel indices are formed with 24-bit multiplies
+        set_error("an image dimension exceeds 2^24-1"); return SAR_ERR_RANGE;
+    }
     if (cfg->render_kind != SAR_RENDER_GAS && cfg->render_kind != SAR_RENDER_DEPTH) {
         set_error("unknown render_kind %d", cfg->render_kind); return SAR_ERR_INVALID;
     }

@@ -268,9 +268,20 @@ constexpr uint32_t kChunkQuads(uint32_t R) { return (8u + 2u * R) / 16u; }  // 1
 // gather_runs.hip: 3.4 TB/s for 64-byte pieces) — a straddling chunk would cost two.
 constexpr uint32_t kChunkStride(uint32_t R) { return R == 12u ? 2u : 4u; }
 
+// a * b for operands below 2^24 as ONE full-rate instruction. (Through the __umul24 builtin the optimiser knows the
+// operand ranges, turns the product back into a 32-bit multiply and picks quarter-rate v_mul_lo_u32 / v_mad_u64_u32.)
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t wave_uniform_b) {
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(wave_uniform_b), "v"(a));  // src0 may be scalar, src1 is a VGPR
+    return r;
+}
+
+// Lane mask of a predicate. (HIP's __ballot goes through an integer: v_cndmask + v_cmp_ne per call.)
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // Everything a wave needs to turn a stream of visits into staged records + depth candidates. One visit
 // per lane per step(); all per-visit state lives in registers, the staging buffers in the wave's LDS slice.
-template <bool DEPTH, uint32_t R>
+template <bool DEPTH, uint32_t R, uint32_t U>
 struct Stager {
     static constexpr uint32_t Q = kChunkQuads(R);  // 16-byte quads per chunk
     unsigned short* rec;  // [B][R] staged records + 64 scratch slots
@@ -282,11 +293,14 @@ struct Stager {
     unsigned short* zhint;
     unsigned long long* key;
     uint32_t bin_shift, bin_mask, lo_base;
-    bool pv;              // depth candidate of the previous visit, waiting for its hint
-    uint32_t p_idx, p_zkey, p_lo, p_hint, p_q, n_sent;
-    bool gv;              // stage-2 candidate waiting for the chip-wide key
-    uint32_t g_idx, g_q;
-    unsigned long long g_mine, g_cur;
+    // The depth path is a software pipeline U visits deep: visit t uses slot t % U, whose previous occupant (visit
+    // t - U) is settled first. A hint or key load therefore has U whole iterations to arrive, and because the loop
+    // is unrolled U times every slot is a fixed set of registers: no copies that would have to wait for a load.
+    bool pv[U];           // stage-1 candidate, waiting for its hint
+    uint32_t p_idx[U], p_zkey[U], p_lo[U], p_hint[U], p_q[U], n_sent;
+    bool gv[U];           // stage-2 candidate, waiting for the chip-wide key
+    uint32_t g_idx[U], g_q[U];
+    unsigned long long g_mine[U], g_cur[U];
     bool b_have;          // previous visit, waiting for its LDS slot
     uint32_t b_bin, b_slot, b_local;
     bool f_on;            // a filled buffer whose 2R bytes sit in registers, waiting to be stored
@@ -311,10 +325,15 @@ struct Stager {
         bin_shift = shift;
         bin_mask = (1u << shift) - 1u;
         lo_base = lo_base_;
-        pv = gv = b_have = f_on = false;
-        p_idx = p_zkey = p_lo = p_hint = p_q = n_sent = 0;
-        g_idx = g_q = 0;
-        g_mine = g_cur = 0;
+        b_have = f_on = false;
+        n_sent = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < U; ++k) {
+            pv[k] = gv[k] = false;
+            p_idx[k] = p_zkey[k] = p_lo[k] = p_hint[k] = p_q[k] = 0;
+            g_idx[k] = g_q[k] = 0;
+            g_mine[k] = g_cur[k] = 0;
+        }
         b_bin = b_slot = b_local = 0;
         f_chunk = f_prev = 0;
 #pragma unroll
@@ -338,7 +357,7 @@ struct Stager {
     }
     // immediate copy-out (rare path)
     __device__ __forceinline__ void flush_full(uint32_t bin, uint32_t chunk) {
-        const uint2* r = (const uint2*)(rec + bin * R);  // 2R bytes, 8-byte aligned
+        const uint2* r = (const uint2*)(rec + mul24(bin, R));  // 2R bytes, 8-byte aligned
         uint2 f[R / 4u];
 #pragma unroll
         for (uint32_t k = 0; k < R / 4u; ++k) f[k] = r[k];
@@ -360,16 +379,20 @@ struct Stager {
     // write is unconditional (scratch slot for lanes without one); everything else only exists when some lane
     // filled a buffer in the same slot request.
     __device__ __forceinline__ void place_visit() {
-        const uint32_t gen = b_slot / R;
-        const uint32_t pos = b_slot - gen * R;
-        const uint32_t at = b_bin * R + pos;
+        // slot < R + 64 (a counter is below R whenever a slot request finds it), so slot / R is exact through a
+        // 24-bit multiply: full-rate v_mul_u32_u24 / v_mad_u32_u24 instead of the quarter-rate 32-bit multiplies
+        constexpr uint32_t kInvR = (65536u + R - 1u) / R;
+        const uint32_t gen = mul24(b_slot, kInvR) >> 16;
+        const uint32_t pos = b_slot - mul24(gen, R);
+        const uint32_t base = mul24(b_bin, R);
+        const uint32_t at = base + pos;
         const bool w0 = b_have && gen == 0u;
         rec[w0 ? at : trash] = (unsigned short)b_local;
         const bool fl = w0 && pos == R - 1u;
-        const unsigned long long fb = __ballot(fl);
+        const unsigned long long fb = wave_ballot(fl);
         if (fb) {
             if (fl) {
-                const uint2* r = (const uint2*)(rec + b_bin * R);
+                const uint2* r = (const uint2*)(rec + base);
 #pragma unroll
                 for (uint32_t k = 0; k < R / 4u; ++k) fpend[k] = r[k];
                 f_chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
@@ -384,11 +407,11 @@ struct Stager {
             const bool e1 = b_have && gen == 1u && pos < R - 1u;
             rec[e1 ? at : trash] = (unsigned short)b_local;
             bool pend = b_have && gen >= 1u && !e1;  // a later generation's last slot, or generation >= 2: rare
-            for (uint32_t g = 1; __ballot(pend); ++g) {
+            for (uint32_t g = 1; wave_ballot(pend); ++g) {
                 const bool mine = pend && gen == g;
                 if (mine) rec[at] = (unsigned short)b_local;
                 const bool fl2 = mine && pos == R - 1u;
-                const unsigned long long fb2 = __ballot(fl2);
+                const unsigned long long fb2 = wave_ballot(fl2);
                 if (fb2) {
                     if (fl2) flush_full(b_bin, cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb2 >> 32),
                                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)fb2, 0u)));
@@ -403,49 +426,50 @@ struct Stager {
 
     // Depth candidates go through two filters before they cost a global atomic (the chip retires only
     // ~2.1e10 of those per second):
-    //   stage 1  this XCD's private 16-bit hint (L2-resident, loaded one visit ahead);
-    //   stage 2  the chip-wide 64-bit key itself, read at device scope one visit after stage 1 passed
+    //   stage 1  this XCD's private 16-bit hint (L2-resident, loaded U visits ahead);
+    //   stage 2  the chip-wide 64-bit key itself, read at device scope U visits after stage 1 passed
     //            (~5 % of the visits): the atomic is sent only if this visit beats what ANY XCD has sent —
     //            and the private hint learns the chip-wide depth on the way.
-    __device__ __forceinline__ void settle_depth() {
-        if (gv) {
-            if (g_mine > g_cur) {
-                atomicMax(key + g_idx, g_mine);
+    // k is a compile-time constant after unrolling.
+    __device__ __forceinline__ void settle_depth(uint32_t k) {
+        if (gv[k]) {
+            if (g_mine[k] > g_cur[k]) {
+                atomicMax(key + g_idx[k], g_mine[k]);
                 ++n_sent;
             }
-            const uint32_t seen = (uint32_t)(g_cur >> 32);  // 0 while nobody has sent this pixel
+            const uint32_t seen = (uint32_t)(g_cur[k] >> 32);  // 0 while nobody has sent this pixel
             const uint32_t qs = seen ? depth_q16(sortable_f32(seen)) : 0u;
-            zhint[g_idx] = (unsigned short)(qs > g_q ? qs : g_q);
+            zhint[g_idx[k]] = (unsigned short)(qs > g_q[k] ? qs : g_q[k]);
         }
-        // p_hint is the raw dword holding this pixel's hint and its neighbour's: it is unpacked only HERE, one
-        // visit after the load was issued. (Unpacking next to the load makes the compiler wait for the load at
-        // the bottom of the loop — vmcnt(0) every iteration — instead of letting it fly across the map arithmetic.)
-        const uint32_t hint = (p_idx & 1u) ? (p_hint >> 16) : (p_hint & 0xFFFFu);
-        gv = pv && p_q >= hint;
-        if (gv) {
-            g_idx = p_idx;
-            g_q = p_q;
-            g_mine = ((unsigned long long)p_zkey << 32) | (unsigned long long)p_lo;
-            g_cur = __hip_atomic_load(key + p_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // p_hint is the raw dword holding this pixel's hint and its neighbour's: it is unpacked only HERE, U visits
+        // after the load was issued. (Unpacking next to the load makes the compiler wait for the load right there.)
+        const uint32_t hint = (p_idx[k] & 1u) ? (p_hint[k] >> 16) : (p_hint[k] & 0xFFFFu);
+        gv[k] = pv[k] && p_q[k] >= hint;
+        if (gv[k]) {
+            g_idx[k] = p_idx[k];
+            g_q[k] = p_q[k];
+            g_mine[k] = ((unsigned long long)p_zkey[k] << 32) | (unsigned long long)p_lo[k];
+            g_cur[k] = __hip_atomic_load(key + p_idx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 
     // One visit of this lane: inb = the iteration landed inside the image at pixel idx with depth zf
-    // (reference src/lib.rs:807-834); t = iteration number (for the visit ordinal).
-    __device__ __forceinline__ void step(bool inb, uint32_t idx, float zf, uint32_t t) {
-        // the previous visit's record first: pure LDS work that gives the hint load more time to arrive
+    // (reference src/lib.rs:807-834); t = iteration number (for the visit ordinal); k = t % U, a compile-time
+    // constant after unrolling.
+    __device__ __forceinline__ void step(uint32_t k, bool inb, uint32_t idx, float zf, uint32_t t) {
+        // the previous visit's record first: pure LDS work
         place_visit();
+        bool cand = false;
         if (DEPTH) {
-            settle_depth();  // the previous visit's candidate: its hint was requested a whole step ago
+            settle_depth(k);  // the candidate of visit t - U: its hint was requested U whole steps ago
             // this visit's candidate: strict `>` against the initial -1.0 (:693, :821); NaN fails
-            const bool cand = inb && zf > -1.0f;
+            cand = inb && zf > -1.0f;
             const float zc = zf + 0.0f;  // -0.0 -> +0.0: integer order == float order
-            p_zkey = f32_sortable(zc);
-            p_q = depth_q16(zc);
-            p_idx = idx;
-            p_lo = lo_base - t;
-            p_hint = *(const uint32_t*)(zhint + (cand ? (idx & ~1u) : 0u));
-            pv = cand;
+            p_zkey[k] = f32_sortable(zc);
+            p_q[k] = depth_q16(zc);
+            p_idx[k] = idx;
+            p_lo[k] = lo_base - t;
+            pv[k] = cand;
         }
         // chunk stores of a buffer that filled up (their LDS reads were issued by place_visit above), then this
         // visit's slot request
@@ -454,6 +478,10 @@ struct Stager {
         b_bin = idx >> bin_shift;
         b_local = idx & bin_mask;
         b_slot = atomicAdd(&cnt[inb ? b_bin : dummy], 1u);  // ds_add_rtn_u32
+        // the hint load is the LAST vector-memory operation of the step: the counter the hardware offers for "has
+        // my load returned" (vmcnt) counts operations in issue order, so anything issued after a load that is still
+        // wanted in flight would have to be waited for as well
+        if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (idx & ~1u) : 0u));
     }
 
     // After the last visit: settle what is in flight, flush the partly filled buffers, publish the list heads.
@@ -461,9 +489,13 @@ struct Stager {
         place_visit();
         flush_store_pending();
         if (DEPTH) {
-            settle_depth();  // moves the last stage-1 candidate to stage 2
-            pv = false;
-            settle_depth();  // settles it
+#pragma unroll
+            for (uint32_t k = 0; k < U; ++k) {
+                settle_depth(k);  // moves the slot's stage-1 candidate to stage 2
+                pv[k] = false;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < U; ++k) settle_depth(k);  // settles it
             uint32_t tot = n_sent;  // statistics: depth atomics issued by this wave
             for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
             if (lane == 0 && tot) atomicAdd(stats + 1, (unsigned long long)tot);
@@ -472,7 +504,7 @@ struct Stager {
             const uint32_t b = b0 + lane;
             const uint32_t have = (b < n_bins) ? cnt[b] : 0u;
             const bool flusher = have != 0u;
-            const unsigned long long fb = __ballot(flusher);
+            const unsigned long long fb = wave_ballot(flusher);
             uint32_t head[kChains];
 #pragma unroll
             for (uint32_t k = 0; k < kChains; ++k) head[k] = (b < n_bins) ? prv[b * kChains + k] : kNoChunk;
@@ -517,7 +549,7 @@ __device__ __forceinline__ void iterate_once(const MapParams& p, uint32_t width,
     inb = !((int)(fi >= p.width) | (int)(fj >= p.height) | (int)(fi < 0.) | (int)(fj < 0.));
     const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;  // Rust `as u32`: NaN -> 0 (non-finite coordinates pass :789)
     const uint32_t j = (fj == fj) ? (uint32_t)fj : 0u;
-    idx = j * width + i;
+    idx = __umul24(j, width) + i;  // v_mad_u32_u24 (full rate); exact for every in-bounds (i, j): width, height < 2^24
     zf = (float)z2;  // `z2 as f32`
 }
 
@@ -541,8 +573,8 @@ __device__ __forceinline__ void pin_map_params(MapParams& p) {
     p.scale_adjusted_mid = vgpr_pin(p.scale_adjusted_mid);
 }
 
-template <bool DEPTH, uint32_t R>
-__global__ void __launch_bounds__(256, R == 12u ? 4 : 2) k_iterate_lean(const BinIterArgs a) {
+template <bool DEPTH, uint32_t R, uint32_t U>
+__global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
@@ -550,7 +582,7 @@ __global__ void __launch_bounds__(256, R == 12u ? 4 : 2) k_iterate_lean(const Bi
     bool alive = job < a.it.n_jobs;
     const uint32_t n = (uint32_t)a.it.iters;
 
-    Stager<DEPTH, R> st;
+    Stager<DEPTH, R, U> st;
     // visit ordinal = job*n + t (job-major, iteration-minor == the sequential order of the reference); the key's
     // low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie
     st.init((char*)smem + (threadIdx.x >> 6) * kLeanWaveLds(a.n_bins, R), a.n_bins, lane,
@@ -566,34 +598,52 @@ __global__ void __launch_bounds__(256, R == 12u ? 4 : 2) k_iterate_lean(const Bi
         z = a.it.starts[2u * a.it.n_jobs + job];
         for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);  // warm-up (:750-752)
     }
-    const uint32_t C = a.it.ckpt_stride;
+    const uint32_t C = a.it.ckpt_stride;  // a multiple of U (the host rounds it)
     const size_t cs = a.it.n_jobs;
     uint32_t t = 0;
     double* ck = a.it.ckpt + job;
-    while (t < n) {
-        if (alive) {  // checkpoint: the state BEFORE iteration t (coalesced 512-B rows per wave)
+    auto checkpoint = [&]() {  // the state BEFORE iteration t (coalesced 512-B rows per wave)
+        if (alive) {
             __builtin_nontemporal_store(x, ck);
             __builtin_nontemporal_store(y, ck + cs);
             __builtin_nontemporal_store(z, ck + 2 * cs);
         }
         ck += 3 * cs;
-        const uint32_t tend = (n - t > C) ? t + C : n;
-        for (; t < tend; ++t) {
-            bool inb;
-            uint32_t idx;
-            float zf;
-            iterate_once(p, a.it.width, x, y, z, inb, idx, zf);  // every lane, finished or not: no divergence
-            const bool ended = alive && x != x;
-            if (__ballot(ended)) {
-                // absorbing NaN state: this and all remaining iterations pass the bounds test (:789), land on pixel
-                // (0,0) (:800-802) and never win the depth test — add them in one go
-                if (ended) atomicAdd(a.nan_count, (unsigned long long)(n - t));
-                alive = alive && !ended;
-            }
-            inb = inb && alive;
-            idx = inb ? idx : 0u;
-            st.step(inb, idx, zf, t);
+    };
+    // one iteration of the loop body; k = t % U is a compile-time constant where this is instantiated
+    auto iteration = [&](uint32_t k) {
+        bool inb;
+        uint32_t idx;
+        float zf;
+        iterate_once(p, a.it.width, x, y, z, inb, idx, zf);  // every lane, finished or not: no divergence
+        const bool ended = alive && x != x;
+        if (wave_ballot(ended)) {
+            // absorbing NaN state: this and all remaining iterations pass the bounds test (:789), land on pixel
+            // (0,0) (:800-802) and never win the depth test — add them in one go
+            if (ended) atomicAdd(a.nan_count, (unsigned long long)(n - t));
+            alive = alive && !ended;
         }
+        inb = inb && alive;
+        idx = inb ? idx : 0u;
+        st.step(k, inb, idx, zf, t);
+        ++t;
+    };
+    // Whole passes of U iterations first: the pass is the unit of the depth pipeline, and a loop that contains
+    // nothing else lets the compiler count exactly which loads may still be in flight at each use.
+    const uint32_t n_full = n - n % U;
+    while (t < n_full) {
+        checkpoint();
+        const uint32_t tend = (n_full - t > C) ? t + C : n_full;
+        while (t < tend) {
+#pragma unroll
+            for (uint32_t k = 0; k < U; ++k) iteration(k);
+        }
+    }
+    if (t < n) {  // the last n % U iterations of the job
+        if (t % C == 0u) checkpoint();
+#pragma unroll
+        for (uint32_t k = 0; k + 1 < U; ++k)
+            if (t < n) iteration(k);
     }
     st.finish(a.heads, a.n_waves, wave, a.nan_count);
 }
@@ -1126,20 +1176,24 @@ void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode,
 uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records) { return kLeanWaveLds(bins, records); }
 uint32_t chunk_bytes(uint32_t records) { return kChunkStride(records) * 16u; }
 
-int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, bool depth, hipStream_t s) {
+// the instantiations of the hot kernel: chunk size x depth-pipeline length (count-only kernels have no pipeline)
+#define SAR_FOR_EACH_LEAN(X) \
+    X(true, 12u, 1u) X(true, 12u, 2u) X(true, 20u, 1u) X(true, 20u, 2u) X(true, 28u, 1u) X(true, 28u, 2u) \
+    X(false, 12u, 1u) X(false, 20u, 1u) X(false, 28u, 1u)
+
+int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, bool depth, hipStream_t s) {
     const uint32_t grid = (a.it.n_jobs + block - 1) / block;
     const size_t lds = (size_t)(block / 64u) * kLeanWaveLds(a.n_bins, records);
-#define SAR_LAUNCH_LEAN(RR)                                                                                \
-    if (depth) hipLaunchKernelGGL((k_iterate_lean<true, RR>), dim3(grid), dim3(block), lds, s, a);         \
-    else hipLaunchKernelGGL((k_iterate_lean<false, RR>), dim3(grid), dim3(block), lds, s, a)
-    switch (records) {
-        case 12: SAR_LAUNCH_LEAN(12u); break;
-        case 20: SAR_LAUNCH_LEAN(20u); break;
-        case 28: SAR_LAUNCH_LEAN(28u); break;
-        default: return 1;
+    if (!depth) pipe = 1;
+    bool launched = false;
+#define SAR_LAUNCH_LEAN(DD, RR, UU)                                                                        \
+    if (!launched && depth == DD && records == RR && pipe == UU) {                                         \
+        hipLaunchKernelGGL((k_iterate_lean<DD, RR, UU>), dim3(grid), dim3(block), lds, s, a);              \
+        launched = true;                                                                                   \
     }
+    SAR_FOR_EACH_LEAN(SAR_LAUNCH_LEAN)
 #undef SAR_LAUNCH_LEAN
-    return 0;
+    return launched ? 0 : 1;
 }
 
 int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, hipStream_t s) {
@@ -1158,9 +1212,11 @@ int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t record
 int binned_kernel_attributes() {
     // both kernels need more dynamic LDS than the 64 KiB default window
     hipError_t e = hipSuccess;
-#define SAR_ATTR(RR)                                                                                                                                   \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<true, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<false, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+#define SAR_ATTR_LEAN(DD, RR, UU) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    SAR_FOR_EACH_LEAN(SAR_ATTR_LEAN)
+#undef SAR_ATTR_LEAN
+#define SAR_ATTR(RR) \
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)
     SAR_ATTR(12u);
     SAR_ATTR(20u);

@@ -101,6 +101,7 @@ struct sar_runtime {
     uint32_t bins_mode = 0;     // 0 default (binned when eligible), 1 one copy + agent-scope atomics,
                                 // 2 one copy per XCD + L2-local atomics, 3 LDS-binned records
     uint32_t measure_mode = 0;  // 0 full path, 1 count only, 2 arithmetic only
+    uint32_t depth_pipe = 0;         // visits of depth pipeline in the iterate kernel (0 = default)
     bool timing_accumulate = false;  // spans of successive render calls add up until sar_runtime_last_timing reads them
     uint32_t debug_chunk_jobs = 0;  // test hook: cap on jobs per launch chunk (0 = none)
     uint32_t bin_shift = 0;         // 0 = automatic
@@ -344,7 +345,9 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
     const bool xcd_local = (rt->bins_mode == 2);
     const uint32_t block = binned ? geo.block : rt->block_threads;
 
-    const uint32_t C = rt->ckpt_stride;
+    // checkpoint stride: a multiple of the depth pipeline's pass length (the iterate kernel runs whole passes)
+    const uint32_t pipe = rt->depth_pipe ? rt->depth_pipe : kDefaultDepthPipe;
+    const uint32_t C = ((rt->ckpt_stride + pipe - 1u) / pipe) * pipe;
     const uint64_t n_ckpt = (iters + C - 1) / C;
     const uint64_t chunks_per_wave = (iters * 64ull + R - 1) / R + geo.bins;
     uint64_t chunk_jobs = kMaxChunkOrdinals / iters;
@@ -489,7 +492,10 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             ba.zhint = rt->d_zhint;
             ba.nan_count = rt->d_nan_count;
             span_begin(rt, rt->iter_spans, rt->iter_used);
-            if (launch_iterate_lean(ba, block, R, mode == 2, rt->stream) != 0) { set_error("bad chunk_records"); return SAR_ERR_INVALID; }
+            if (launch_iterate_lean(ba, block, R, pipe, mode == 2, rt->stream) != 0) {
+                set_error("bad chunk_records / depth_pipe");
+                return SAR_ERR_INVALID;
+            }
             span_end(rt, rt->iter_spans, rt->iter_used);
             BinAccArgs ca;
             std::memset(&ca, 0, sizeof(ca));
@@ -1018,6 +1024,9 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "chunk_records")) {
         if (v && v != 12 && v != 20 && v != 28) { set_error("chunk_records must be 12, 20 or 28"); return SAR_ERR_INVALID; }
         rt->chunk_records = v;
+    } else if (!std::strcmp(name, "depth_pipe")) {
+        if (v > 2) { set_error("depth_pipe must be 1 or 2"); return SAR_ERR_INVALID; }
+        rt->depth_pipe = v;
     } else if (!std::strcmp(name, "acc_threads")) {
         if (v && v != 256 && v != 512 && v != 1024) { set_error("acc_threads must be 256, 512 or 1024"); return SAR_ERR_INVALID; }
         rt->acc_threads = v;

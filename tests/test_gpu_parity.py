@@ -395,17 +395,17 @@ def test_attractor_extent_bit_exact(sar, oracle, gpu, preset):
 
 
 @pytest.mark.parametrize("records", [12, 20, 28])
-@pytest.mark.parametrize("splits,acc_threads", [(0, 0), (1, 256), (5, 512), (16, 1024)])
-def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, splits, acc_threads):
+@pytest.mark.parametrize("splits,acc_threads,pipe", [(0, 0, 0), (1, 256, 1), (5, 512, 2), (16, 1024, 1)])
+def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, splits, acc_threads, pipe):
     """Every chunk size of the binned path (32 / 48-on-64 / 64-byte chunks: different lane-group shapes in
     k_bin_accumulate) with several accumulate grids, against the oracle; enough records per (bin, wave) list to chain
     many chunks and to overflow staging buffers within one slot request (all trajectories start close together)."""
-    jobs, n = 2048 + 64, 1200
+    jobs, n = 2048 + 64, 1201  # odd: the depth pipeline's pass of 2 leaves a last single iteration
     cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=256, height=192, jobs_total=jobs)
     st = sar.start_points(23, 0, jobs)
     st[:512] = st[0] + np.arange(512)[:, None] * 1e-13  # near-identical trajectories: many lanes hit one bin at once
     rt, ort = sar.Runtime(cfg), oracle.Runtime(256, 192)
-    rt.set_tuning(variant=3, chunk_records=records, splits=splits, acc_threads=acc_threads)
+    rt.set_tuning(variant=3, chunk_records=records, splits=splits, acc_threads=acc_threads, depth_pipe=pipe)
     sar.render_jobs(cfg, rt, st)
     oracle.render_jobs(cfg.c, ort, st, n)
-    assert_state_equal(rt, ort, f"records={records} splits={splits} acc_threads={acc_threads}")
+    assert_state_equal(rt, ort, f"records={records} splits={splits} acc_threads={acc_threads} depth_pipe={pipe}")
