@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 
 WIDTH = HEIGHT = 2048
 ITERS_PER_GPU = 1_000_000_000
-DEFAULT_JOBS = 196608            # trajectories per GPU (3 waves per SIMD on 256 CUs); n = floor(1e9 / jobs)
+DEFAULT_JOBS = 131072            # trajectories per GPU (2 waves per SIMD on 256 CUs); n = floor(1e9 / jobs)
 ALG_BYTES_PER_ITER = 12.0 + 12.0 * 0.0055   # count RMW 8 B + zbuf read 4 B + win-rate * 12 B
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_OPS_PER_ITER = 88           # unfused fp64 ops per counted iteration; FMA is not allowed
