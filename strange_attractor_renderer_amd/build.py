@@ -70,10 +70,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for s in SOURCES:
         obj = os.path.join(BUILD_DIR, s + ".o")
-        # SAR_EXTRA_FLAGS: extra flags for the kernel file in timing experiments (e.g. -DSAR_EXPERIMENT_...); never set by the product
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, s), "-o", obj]
+        # SAR_EXTRA_FLAGS: extra -D flags for timing experiments (e.g. -DSAR_EXPERIMENT_...); never set by the product
+        cmd = [hipcc, *FLAGS, *os.environ.get("SAR_EXTRA_FLAGS", "").split(), "-c", os.path.join(CSRC, s), "-o", obj]
         if s.endswith(".hip"):
-            cmd += ["-save-temps=obj", *os.environ.get("SAR_EXTRA_FLAGS", "").split()]
+            cmd += ["-save-temps=obj"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, cwd=BUILD_DIR)

@@ -67,7 +67,7 @@ struct BinIterArgs {
     uint32_t n_waves;            // launched waves (= heads stride)
     void* arena;                 // [n_waves][chunks_per_wave] chunks {prev, n, R x u16}, R = 12 / 20 / 28
     uint32_t* heads;             // [n_bins][n_waves][kListChains] last chunk of each chain of a (bin, wave) list, or kNoChunk
-    unsigned short* zhint;       // [8][npix] per-XCD depth hints (16-bit fixed point, see depth_q16)
+    void* zhint;                 // [8][npix(+1)] per-XCD depth hints: u16 fixed point (depth_q16) or u32 sortable f32
     unsigned long long* nan_count;  // iterations of diverged (NaN) trajectories: all land on pixel (0,0)
 };
 
@@ -125,6 +125,7 @@ constexpr uint64_t kMaxChunkOrdinals = 0xFFFFFFFEull;
 constexpr uint32_t kListChains = 1;  // interleaved chains per (bin, wave) record list; 2 was measured: no faster walk, and 4 B/bin more LDS per wave
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
 constexpr uint32_t kDefaultChunkRecords = 28;
+constexpr uint32_t kWideHintMaxPixels = 10u << 20;  // images up to 10 Mpx use 32-bit depth hints (measured crossover between 3072^2 and 4096^2)
 constexpr uint32_t kDefaultDepthPipe = 2;   // visits between a depth-hint load and its use in the iterate kernel  // u16 records per chunk (8-byte header): 12, 20 or 28 -> 32/48/64-byte chunks
 constexpr uint32_t kMaxBins = 1024;      // LDS staging is 64 B per bin per wave
 constexpr uint32_t kMaxBinPx = 32768;    // phase-2 LDS histogram: 4 B per pixel of the bin

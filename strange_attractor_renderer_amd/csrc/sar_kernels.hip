@@ -281,8 +281,12 @@ __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __bui
 
 // Everything a wave needs to turn a stream of visits into staged records + depth candidates. One visit
 // per lane per step(); all per-visit state lives in registers, the staging buffers in the wave's LDS slice.
-template <bool DEPTH, uint32_t R, uint32_t U>
+// H is the hint type: unsigned short = 16-bit fixed point (depth_q16; half the cache footprint, but every visit within
+// 2^-14 of the best depth passes stage 1), uint32_t = the sortable image of the f32 depth itself (only true improvements
+// and exact ties pass: 3x fewer waves have to wait for a stage-2 key load). The host picks by image size.
+template <bool DEPTH, uint32_t R, uint32_t U, typename H>
 struct Stager {
+    static constexpr bool kWide = sizeof(H) == 4;
     static constexpr uint32_t Q = kChunkQuads(R);  // 16-byte quads per chunk
     unsigned short* rec;  // [B][R] staged records + 64 scratch slots
     uint32_t* cnt;        // [B] fill counters + 64 dummy counters
@@ -290,7 +294,7 @@ struct Stager {
     uint32_t trash, dummy, lane, n_bins;
     uint4* arena;         // this wave's chunk arena
     uint32_t cursor;      // wave-uniform: next free chunk
-    unsigned short* zhint;
+    H* zhint;
     unsigned long long* key;
     uint32_t bin_shift, bin_mask, lo_base;
     // The depth path is a software pipeline U visits deep: visit t uses slot t % U, whose previous occupant (visit
@@ -307,7 +311,7 @@ struct Stager {
     uint32_t f_chunk, f_prev;
     uint2 fpend[R / 4u];
 
-    __device__ __forceinline__ void init(char* wbase, uint32_t bins, uint32_t lane_, uint4* arena_, unsigned short* zhint_,
+    __device__ __forceinline__ void init(char* wbase, uint32_t bins, uint32_t lane_, uint4* arena_, H* zhint_,
                                          unsigned long long* key_, uint32_t shift, uint32_t lo_base_) {
         n_bins = bins;
         lane = lane_;
@@ -438,12 +442,12 @@ struct Stager {
                 ++n_sent;
             }
             const uint32_t seen = (uint32_t)(g_cur[k] >> 32);  // 0 while nobody has sent this pixel
-            const uint32_t qs = seen ? depth_q16(sortable_f32(seen)) : 0u;
-            zhint[g_idx[k]] = (unsigned short)(qs > g_q[k] ? qs : g_q[k]);
+            const uint32_t qs = kWide ? seen : (seen ? depth_q16(sortable_f32(seen)) : 0u);
+            zhint[g_idx[k]] = (H)(qs > g_q[k] ? qs : g_q[k]);
         }
         // p_hint is the raw dword holding this pixel's hint and its neighbour's: it is unpacked only HERE, U visits
         // after the load was issued. (Unpacking next to the load makes the compiler wait for the load right there.)
-        const uint32_t hint = (p_idx[k] & 1u) ? (p_hint[k] >> 16) : (p_hint[k] & 0xFFFFu);
+        const uint32_t hint = kWide ? p_hint[k] : ((p_idx[k] & 1u) ? (p_hint[k] >> 16) : (p_hint[k] & 0xFFFFu));
         gv[k] = pv[k] && p_q[k] >= hint;
         if (gv[k]) {
             g_idx[k] = p_idx[k];
@@ -466,7 +470,7 @@ struct Stager {
             cand = inb && zf > -1.0f;
             const float zc = zf + 0.0f;  // -0.0 -> +0.0: integer order == float order
             p_zkey[k] = f32_sortable(zc);
-            p_q[k] = depth_q16(zc);
+            p_q[k] = kWide ? p_zkey[k] : depth_q16(zc);
             p_idx[k] = idx;
             p_lo[k] = lo_base - t;
             pv[k] = cand;
@@ -481,7 +485,7 @@ struct Stager {
         // the hint load is the LAST vector-memory operation of the step: the counter the hardware offers for "has
         // my load returned" (vmcnt) counts operations in issue order, so anything issued after a load that is still
         // wanted in flight would have to be waited for as well
-        if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (idx & ~1u) : 0u));
+        if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (idx & ~1u)) : 0u));
     }
 
     // After the last visit: settle what is in flight, flush the partly filled buffers, publish the list heads.
@@ -573,7 +577,7 @@ __device__ __forceinline__ void pin_map_params(MapParams& p) {
     p.scale_adjusted_mid = vgpr_pin(p.scale_adjusted_mid);
 }
 
-template <bool DEPTH, uint32_t R, uint32_t U>
+template <bool DEPTH, uint32_t R, uint32_t U, typename H>
 __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -582,12 +586,12 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     bool alive = job < a.it.n_jobs;
     const uint32_t n = (uint32_t)a.it.iters;
 
-    Stager<DEPTH, R, U> st;
+    Stager<DEPTH, R, U, H> st;
     // visit ordinal = job*n + t (job-major, iteration-minor == the sequential order of the reference); the key's
     // low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie
     st.init((char*)smem + (threadIdx.x >> 6) * kLeanWaveLds(a.n_bins, R), a.n_bins, lane,
             (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkStride(R),
-            a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.bin_shift, 0xFFFFFFFFu - job * n);
+            (H*)a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.bin_shift, 0xFFFFFFFFu - job * n);
 
     MapParams p = a.it.p;
     pin_map_params(p);
@@ -1176,19 +1180,26 @@ void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode,
 uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records) { return kLeanWaveLds(bins, records); }
 uint32_t chunk_bytes(uint32_t records) { return kChunkStride(records) * 16u; }
 
-// the instantiations of the hot kernel: chunk size x depth-pipeline length (count-only kernels have no pipeline)
-#define SAR_FOR_EACH_LEAN(X) \
-    X(true, 12u, 1u) X(true, 12u, 2u) X(true, 20u, 1u) X(true, 20u, 2u) X(true, 28u, 1u) X(true, 28u, 2u) \
-    X(false, 12u, 1u) X(false, 20u, 1u) X(false, 28u, 1u)
+// the instantiations of the hot kernel: chunk size x depth-pipeline length x hint type (count-only kernels have neither)
+#define SAR_FOR_EACH_LEAN(X)                                                                                          \
+    X(true, 12u, 1u, unsigned short) X(true, 12u, 2u, unsigned short) X(true, 20u, 1u, unsigned short)                \
+    X(true, 20u, 2u, unsigned short) X(true, 28u, 1u, unsigned short) X(true, 28u, 2u, unsigned short)                \
+    X(true, 12u, 1u, uint32_t) X(true, 12u, 2u, uint32_t) X(true, 20u, 1u, uint32_t) X(true, 20u, 2u, uint32_t)         \
+    X(true, 28u, 1u, uint32_t) X(true, 28u, 2u, uint32_t)                                                              \
+    X(false, 12u, 1u, unsigned short) X(false, 20u, 1u, unsigned short) X(false, 28u, 1u, unsigned short)
 
-int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, bool depth, hipStream_t s) {
+int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
+                        hipStream_t s) {
     const uint32_t grid = (a.it.n_jobs + block - 1) / block;
     const size_t lds = (size_t)(block / 64u) * kLeanWaveLds(a.n_bins, records);
-    if (!depth) pipe = 1;
+    if (!depth) {
+        pipe = 1;
+        hint_bytes = 2;
+    }
     bool launched = false;
-#define SAR_LAUNCH_LEAN(DD, RR, UU)                                                                        \
-    if (!launched && depth == DD && records == RR && pipe == UU) {                                         \
-        hipLaunchKernelGGL((k_iterate_lean<DD, RR, UU>), dim3(grid), dim3(block), lds, s, a);              \
+#define SAR_LAUNCH_LEAN(DD, RR, UU, HH)                                                                    \
+    if (!launched && depth == DD && records == RR && pipe == UU && hint_bytes == sizeof(HH)) {             \
+        hipLaunchKernelGGL((k_iterate_lean<DD, RR, UU, HH>), dim3(grid), dim3(block), lds, s, a);          \
         launched = true;                                                                                   \
     }
     SAR_FOR_EACH_LEAN(SAR_LAUNCH_LEAN)
@@ -1212,8 +1223,8 @@ int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t record
 int binned_kernel_attributes() {
     // both kernels need more dynamic LDS than the 64 KiB default window
     hipError_t e = hipSuccess;
-#define SAR_ATTR_LEAN(DD, RR, UU) \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define SAR_ATTR_LEAN(DD, RR, UU, HH) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SAR_FOR_EACH_LEAN(SAR_ATTR_LEAN)
 #undef SAR_ATTR_LEAN
 #define SAR_ATTR(RR) \

@@ -12,7 +12,9 @@ void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode,
 uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records);
 uint32_t chunk_bytes(uint32_t records);
 // records: 12 / 20 / 28 per chunk; pipe: 1 / 2 visits of depth pipeline
-int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, bool depth, hipStream_t s);
+// hint_bytes: 2 (16-bit fixed-point hints) or 4 (sortable f32 hints)
+int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
+                        hipStream_t s);
 int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, hipStream_t s);
 int binned_kernel_attributes();
 void launch_fold_resolve(const FoldArgs& a, hipStream_t s);

@@ -23,6 +23,9 @@ CONFIGS = {
     "C3": dict(preset="solar_sail", iters=1e9, w=1800, h=2000, kind=1, scale=1.0),
     "C4/8": dict(preset="poisson_saturne", iters=1.25e9, w=4096, h=4096, kind=0),
     "C5-frame": dict(preset="solar_sail", iters=1e8, w=1800, h=2000, kind=0, scale=1.0),
+    # not BASELINE configs: intermediate sizes for choosing size-dependent defaults (select with --only)
+    "X2560": dict(preset="poisson_saturne", iters=1e9, w=2560, h=2560, kind=0),
+    "X3072": dict(preset="poisson_saturne", iters=1e9, w=3072, h=3072, kind=0),
 }
 
 if __name__ == "__main__":
@@ -37,7 +40,7 @@ if __name__ == "__main__":
     opts = dict((kv.split("=")[0], int(kv.split("=")[1], 0)) for kv in a.option)
     with open(a.out, "a") as fh:
         for name, c in CONFIGS.items():
-            if a.only and name not in a.only:
+            if (a.only and name not in a.only) or (not a.only and name.startswith("X")):
                 continue
             for jobs in a.jobs:
                 n = int(c["iters"]) // jobs
