@@ -461,6 +461,9 @@ struct Stager {
     // (reference src/lib.rs:807-834); t = iteration number (for the visit ordinal); k = t % U, a compile-time
     // constant after unrolling.
     __device__ __forceinline__ void step(uint32_t k, bool inb, uint32_t idx, float zf, uint32_t t) {
+        // the staging phase is a chain of short dependent steps with memory round trips at its end: let it win the
+        // SIMD's issue arbitration against the other waves' long arithmetic phase, so that its loads start early
+        __builtin_amdgcn_s_setprio(3);
         // the previous visit's record first: pure LDS work
         place_visit();
         bool cand = false;
@@ -486,6 +489,7 @@ struct Stager {
         // my load returned" (vmcnt) counts operations in issue order, so anything issued after a load that is still
         // wanted in flight would have to be waited for as well
         if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (idx & ~1u)) : 0u));
+        __builtin_amdgcn_s_setprio(0);
     }
 
     // After the last visit: settle what is in flight, flush the partly filled buffers, publish the list heads.
