@@ -66,7 +66,7 @@ struct BinIterArgs {
     uint32_t chunks_per_wave;    // arena capacity of one wave, in 64-byte chunks
     uint32_t n_waves;            // launched waves (= heads stride)
     void* arena;                 // [n_waves][chunks_per_wave] chunks {prev, n, R x u16}, R = 12 / 20 / 28
-    uint32_t* heads;             // [n_bins][n_waves][kListChains] last chunk of each chain of a (bin, wave) list, or kNoChunk
+    uint32_t* heads;             // [n_bins][n_waves] last chunk of each (bin, wave) list, or kNoChunk
     void* zhint;                 // [8][npix(+1)] per-XCD depth hints: u16 fixed point (depth_q16) or u32 sortable f32
     unsigned long long* nan_count;  // iterations of diverged (NaN) trajectories: all land on pixel (0,0)
 };
@@ -122,7 +122,6 @@ static inline uint32_t f32_sortable_host(float f) {
 
 constexpr uint32_t kLnLutEntries = 1u << 20;  // ln(k+1), k < 2^20, host libm (exact parity with the oracle)
 constexpr uint64_t kMaxChunkOrdinals = 0xFFFFFFFEull;
-constexpr uint32_t kListChains = 1;  // interleaved chains per (bin, wave) record list; 2 was measured: no faster walk, and 4 B/bin more LDS per wave
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
 constexpr uint32_t kDefaultChunkRecords = 28;
 constexpr uint32_t kWideHintMaxPixels = 10u << 20;  // images up to 10 Mpx use 32-bit depth hints (measured crossover between 3072^2 and 4096^2)

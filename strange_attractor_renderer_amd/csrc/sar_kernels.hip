@@ -257,11 +257,7 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
 // LDS per wave: B buffers of R records + B counters + B links + 64 scratch records + 64 dummy counters
 // per-XCD hint arrays: an even number of 16-bit entries each, so that the dword holding a hint is aligned
 __host__ __device__ constexpr size_t kHintStride(uint32_t npix) { return ((size_t)npix + 1u) & ~(size_t)1u; }
-// Every (bin, wave) record list is kept as kChains interleaved chains (a chunk links to the previous chunk
-// with the same id parity): k_bin_accumulate walks them concurrently, which doubles the loads it has in
-// flight — its list walk is a dependent-load chain, bound by memory latency x lists, not by bandwidth.
-constexpr uint32_t kChains = kListChains;
-constexpr uint32_t kLeanWaveLds(uint32_t bins, uint32_t R) { return bins * (2u * R + 4u + 4u * kChains) + 384u; }
+constexpr uint32_t kLeanWaveLds(uint32_t bins, uint32_t R) { return bins * (2u * R + 8u) + 384u; }
 constexpr uint32_t kChunkQuads(uint32_t R) { return (8u + 2u * R) / 16u; }  // 16-byte quads of data per chunk: R = 12, 20, 28
 // Chunks never straddle a 64-byte sector of the arena: the 48-byte chunk (R = 20) is laid out on a 64-byte stride.
 // The accumulate kernel's chunk reads are isolated, and an isolated read moves whole sectors (measured, tools/ubench/
@@ -290,7 +286,7 @@ struct Stager {
     static constexpr uint32_t Q = kChunkQuads(R);  // 16-byte quads per chunk
     unsigned short* rec;  // [B][R] staged records + 64 scratch slots
     uint32_t* cnt;        // [B] fill counters + 64 dummy counters
-    uint32_t* prv;        // [B][kChains] last chunk of each chain of this (wave, bin)
+    uint32_t* prv;        // [B] previous chunk of this (wave, bin) list
     uint32_t trash, dummy, lane, n_bins;
     uint4* arena;         // this wave's chunk arena
     uint32_t cursor;      // wave-uniform: next free chunk
@@ -319,7 +315,7 @@ struct Stager {
         cnt = (uint32_t*)(wbase + bins * 2u * R + 128u);
         prv = cnt + bins + 64u;
         for (uint32_t b = lane; b < bins + 64u; b += 64u) cnt[b] = 0u;
-        for (uint32_t b = lane; b < bins * kChains; b += 64u) prv[b] = kNoChunk;
+        for (uint32_t b = lane; b < bins; b += 64u) prv[b] = kNoChunk;
         trash = bins * R + lane;
         dummy = bins + lane;
         arena = arena_;
@@ -365,9 +361,8 @@ struct Stager {
         uint2 f[R / 4u];
 #pragma unroll
         for (uint32_t k = 0; k < R / 4u; ++k) f[k] = r[k];
-        uint32_t* link = prv + bin * kChains + (chunk % kChains);
-        store_chunk(chunk, *link, R, f);
-        *link = chunk;
+        store_chunk(chunk, prv[bin], R, f);
+        prv[bin] = chunk;
         __hip_atomic_fetch_sub(&cnt[bin], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // The common copy-out is split: the lane that filled a buffer ISSUES the LDS reads (and frees the buffer:
@@ -400,10 +395,9 @@ struct Stager {
 #pragma unroll
                 for (uint32_t k = 0; k < R / 4u; ++k) fpend[k] = r[k];
                 f_chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
-                uint32_t* link = prv + b_bin * kChains + (f_chunk % kChains);
-                f_prev = *link;
+                f_prev = prv[b_bin];
                 f_on = true;
-                *link = f_chunk;
+                prv[b_bin] = f_chunk;
                 __hip_atomic_fetch_sub(&cnt[b_bin], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             cursor += (uint32_t)__popcll(fb);
@@ -513,9 +507,7 @@ struct Stager {
             const uint32_t have = (b < n_bins) ? cnt[b] : 0u;
             const bool flusher = have != 0u;
             const unsigned long long fb = wave_ballot(flusher);
-            uint32_t head[kChains];
-#pragma unroll
-            for (uint32_t k = 0; k < kChains; ++k) head[k] = (b < n_bins) ? prv[b * kChains + k] : kNoChunk;
+            uint32_t head = (b < n_bins) ? prv[b] : kNoChunk;
             if (flusher) {
                 const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
@@ -523,18 +515,11 @@ struct Stager {
                 uint2 f[R / 4u];
 #pragma unroll
                 for (uint32_t k = 0; k < R / 4u; ++k) f[k] = r[k];
-#pragma unroll
-                for (uint32_t k = 0; k < kChains; ++k)
-                    if (chunk % kChains == k) {
-                        store_chunk(chunk, head[k], have, f);
-                        head[k] = chunk;
-                    }
+                store_chunk(chunk, head, have, f);
+                head = chunk;
             }
             cursor += (uint32_t)__popcll(fb);
-            if (b < n_bins) {
-#pragma unroll
-                for (uint32_t k = 0; k < kChains; ++k) heads[((size_t)b * n_waves + wave) * kChains + k] = head[k];
-            }
+            if (b < n_bins) heads[(size_t)b * n_waves + wave] = head;
         }
     }
 };
@@ -676,53 +661,37 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     // leaves its partial histogram untouched — the scratch copies are all-zero between launches because
     // k_fold_resolve clears what it reads.
     int any = 0;
-    for (uint32_t w = s + a.splits * threadIdx.x; w < a.n_waves; w += a.splits * blockDim.x) {
-#pragma unroll
-        for (uint32_t k = 0; k < kChains; ++k) any |= a.heads[((size_t)b * a.n_waves + w) * kChains + k] != kNoChunk;
-    }
+    for (uint32_t w = s + a.splits * threadIdx.x; w < a.n_waves; w += a.splits * blockDim.x)
+        any |= a.heads[(size_t)b * a.n_waves + w] != kNoChunk;
     if (!__syncthreads_or(any)) return;
     for (uint32_t k = threadIdx.x; k < bin_px; k += blockDim.x) hist[k] = 0u;
     __syncthreads();
     const uint4* arena = (const uint4*)a.arena;
     // One (bin, wave) list per group of G lanes: a chunk is ONE 16-byte load per lane and one cache line per
-    // group (a lane that walked a list alone needed Q loads over 64 different lines per wave instruction), and
-    // the list's kChains chains are walked side by side, so every lane keeps kChains loads in flight.
+    // group (a lane that walked a list alone needed Q loads over 64 different lines per wave instruction).
     for (uint32_t w = s + a.splits * group; w < a.n_waves; w += a.splits * groups) {
-        uint32_t chunk[kChains];
-#pragma unroll
-        for (uint32_t k = 0; k < kChains; ++k) chunk[k] = a.heads[((size_t)b * a.n_waves + w) * kChains + k];
+        uint32_t chunk = a.heads[(size_t)b * a.n_waves + w];
         const uint4* base = arena + (size_t)w * a.chunks_per_wave * kChunkStride(R);
-        for (;;) {
-            bool live = false;
-#pragma unroll
-            for (uint32_t k = 0; k < kChains; ++k) live |= chunk[k] != kNoChunk;
-            if (!live) break;
-            uint4 v[kChains];
-#pragma unroll
-            for (uint32_t k = 0; k < kChains; ++k) {
-                v[k] = make_uint4(kNoChunk, 0u, 0u, 0u);
-                if (chunk[k] != kNoChunk && q < Q) v[k] = base[(size_t)chunk[k] * kChunkStride(R) + q];
+        while (chunk != kNoChunk) {
+            uint4 v = make_uint4(kNoChunk, 0u, 0u, 0u);
+            if (q < Q) v = base[(size_t)chunk * kChunkStride(R) + q];
+            // the chunk header {previous chunk of the list, record count} sits in lane 0's quad
+            const uint32_t prev = __shfl(v.x, 0, G);
+            const uint32_t nrec = __shfl(v.y, 0, G);
+            // records held by this lane: lane 0 -> records 0..3 (its .z/.w), lane q -> 8q-4 .. 8q+3
+            const uint32_t first = q == 0u ? 0u : 8u * q - 4u;
+            const uint32_t w0 = q == 0u ? v.z : v.x, w1 = q == 0u ? v.w : v.y;
+            if (first < nrec) atomicAdd(&hist[w0 & 0xFFFFu], 1u);
+            if (first + 1u < nrec) atomicAdd(&hist[w0 >> 16], 1u);
+            if (first + 2u < nrec) atomicAdd(&hist[w1 & 0xFFFFu], 1u);
+            if (first + 3u < nrec) atomicAdd(&hist[w1 >> 16], 1u);
+            if (q != 0u) {
+                if (first + 4u < nrec) atomicAdd(&hist[v.z & 0xFFFFu], 1u);
+                if (first + 5u < nrec) atomicAdd(&hist[v.z >> 16], 1u);
+                if (first + 6u < nrec) atomicAdd(&hist[v.w & 0xFFFFu], 1u);
+                if (first + 7u < nrec) atomicAdd(&hist[v.w >> 16], 1u);
             }
-#pragma unroll
-            for (uint32_t k = 0; k < kChains; ++k) {
-                // the chunk header {previous chunk of the chain, record count} sits in lane 0's quad
-                const uint32_t prev = __shfl(v[k].x, 0, G);
-                const uint32_t nrec = __shfl(v[k].y, 0, G);
-                // records held by this lane: lane 0 -> records 0..3 (its .z/.w), lane q -> 8q-4 .. 8q+3
-                const uint32_t first = q == 0u ? 0u : 8u * q - 4u;
-                const uint32_t w0 = q == 0u ? v[k].z : v[k].x, w1 = q == 0u ? v[k].w : v[k].y;
-                if (first < nrec) atomicAdd(&hist[w0 & 0xFFFFu], 1u);
-                if (first + 1u < nrec) atomicAdd(&hist[w0 >> 16], 1u);
-                if (first + 2u < nrec) atomicAdd(&hist[w1 & 0xFFFFu], 1u);
-                if (first + 3u < nrec) atomicAdd(&hist[w1 >> 16], 1u);
-                if (q != 0u) {
-                    if (first + 4u < nrec) atomicAdd(&hist[v[k].z & 0xFFFFu], 1u);
-                    if (first + 5u < nrec) atomicAdd(&hist[v[k].z >> 16], 1u);
-                    if (first + 6u < nrec) atomicAdd(&hist[v[k].w & 0xFFFFu], 1u);
-                    if (first + 7u < nrec) atomicAdd(&hist[v[k].w >> 16], 1u);
-                }
-                chunk[k] = prev;  // kNoChunk for an exhausted chain: v[k].x was preset to it
-            }
+            chunk = prev;
         }
     }
     __syncthreads();

@@ -432,7 +432,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             HIP_TRY(hipMalloc(&rt->d_arena, arena_need));
             rt->arena_cap = arena_need;
         }
-        const size_t heads_need = static_cast<size_t>(max_waves) * geo.bins * kListChains;
+        const size_t heads_need = static_cast<size_t>(max_waves) * geo.bins;
         if (heads_need > rt->heads_cap) {
             if (rt->d_heads) hipFree(rt->d_heads);
             rt->d_heads = nullptr;
