@@ -72,8 +72,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(BUILD_DIR, s + ".o")
         # SAR_EXTRA_FLAGS: extra -D flags for timing experiments (e.g. -DSAR_EXPERIMENT_...); never set by the product
         cmd = [hipcc, *FLAGS, *os.environ.get("SAR_EXTRA_FLAGS", "").split(), "-c", os.path.join(CSRC, s), "-o", obj]
-        if s.endswith(".hip"):
-            cmd += ["-save-temps=obj"]
+        if s.endswith(".hip"):  # SAR_KERNEL_FLAGS: device-compiler flags for experiments (e.g. -mllvm options)
+            cmd += ["-save-temps=obj", *os.environ.get("SAR_KERNEL_FLAGS", "").split()]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, cwd=BUILD_DIR)
