@@ -98,3 +98,37 @@ def test_c4_shape_4096_one_gpu_share(sar, gpu):
     sar.render_job_range(cfg, r2, n, starts)
     assert np.array_equal(r2.count(), cnt)
     assert np.array_equal(_bits(r2.zbuf()), _bits(rt.zbuf())) and np.array_equal(_bits(r2.steps()), _bits(rt.steps()))
+
+
+def test_readme_image_through_export_matches_reference_png(sar, gpu, tmp_path):
+    """The reference's one shipped artefact, end to end through the product: `-i1000000000 -b -0.25` at 1920x1080
+    (README.md:72-73) rendered on the GPU, converted to RGB16 on the device, written as PNG by sar_write_png, decoded
+    again — and compared with the statistics of media/poisson-saturne.png (tests/golden/ref_png_stats.json; only
+    statistics can be compared: the reference seeds from OS entropy)."""
+    import json
+    import os
+    import image_decode as D
+    stats = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_png_stats.json")))
+    w, h, jobs = stats["width"], stats["height"], 131072
+    n = 1_000_000_000 // jobs
+    cfg = sar.Config.poisson_saturne(iterations=jobs * n, width=w, height=h, jobs_total=jobs, brightness_offset=-0.25,
+                                     transparent=0, seed=20240928)
+    rt = sar.Runtime(cfg)
+    sar.render_jobs(cfg, rt, sar.start_points(20240928, 0, jobs))
+    path = sar.write_image_matches(cfg, rt, str(tmp_path / "poisson-saturne"), transparent=False, eight_bit=False)
+    img = D.decode_png(path)
+    assert img.shape == (h, w, 3) and img.dtype == np.uint16  # what the CLI writes without --transparent / --8bit
+    np.testing.assert_array_equal(img, sar.colorize(cfg, rt)[..., :3])
+    rgb = img.astype(np.float64)
+    nz = rgb.sum(axis=2) > 0
+    ys, xs = np.where(nz)
+    assert abs(int(xs.min()) - stats["bbox_x"][0]) <= 3 and abs(int(xs.max()) - stats["bbox_x"][1]) <= 3
+    assert abs(int(ys.min()) - stats["bbox_y"][0]) <= 3 and abs(int(ys.max()) - stats["bbox_y"][1]) <= 3
+    assert abs(float(nz.mean()) - stats["nonzero_fraction"]) < 2e-3
+    bh, bw = stats["thumb_block"]
+    thumb = rgb.reshape(h // bh, bh, w // bw, bw, 3).mean(axis=(1, 3))
+    ref = np.asarray(stats["thumb"], dtype=np.float64)
+    for ch in range(3):
+        assert np.corrcoef(thumb[..., ch].ravel(), ref[..., ch].ravel())[0, 1] > 0.998
+        assert np.corrcoef(thumb[:, ::-1, ch].ravel(), ref[..., ch].ravel())[0, 1] < 0.6
+        assert abs(rgb[..., ch].mean() / stats["channel_mean"][ch] - 1.0) < 0.01
