@@ -409,3 +409,26 @@ def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, 
     sar.render_jobs(cfg, rt, st)
     oracle.render_jobs(cfg.c, ort, st, n)
     assert_state_equal(rt, ort, f"records={records} splits={splits} acc_threads={acc_threads} depth_pipe={pipe} hint_bits={hint_bits}")
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_configurations_bit_exact(sar, oracle, gpu, seed):
+    """Seeded random shapes (tiny to ragged images, 1..3000 jobs, 1..900 iterations, both presets and render kinds,
+    view angle / scale / brightness / transparency) against the oracle, including the converted export formats."""
+    rng = np.random.default_rng(1000 + seed)
+    preset = ["poisson_saturne", "solar_sail"][int(rng.integers(2))]
+    w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+    jobs, n = int(rng.integers(1, 3000)), int(rng.integers(1, 900))
+    kw = dict(iterations=jobs * n, width=w, height=h, jobs_total=jobs, render_kind=int(rng.integers(2)),
+              transparent=int(rng.integers(2)), angle=float(rng.uniform(0, 6.3)), scale=float(rng.uniform(0.4, 2.5)),
+              brightness_offset=float(rng.uniform(-0.4, 0.1)))
+    cfg = _cfg(sar, preset, **kw)
+    st = sar.start_points(int(rng.integers(1 << 30)), 0, jobs)
+    rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
+    sar.render_jobs(cfg, rt, st)
+    oracle.render_jobs(cfg.c, ort, st, n)
+    assert_state_equal(rt, ort, f"seed {seed}: {preset} {w}x{h} jobs={jobs} n={n} {kw}")
+    want = oracle.colorize(cfg.c, ort)
+    np.testing.assert_array_equal(sar.colorize(cfg, rt), want)
+    fmt = int(rng.integers(4))
+    np.testing.assert_array_equal(sar.colorize_format(cfg, rt, fmt), oracle.convert(fmt, want))
