@@ -123,6 +123,7 @@ def test_device_conversion_matches_oracle(sar, oracle, gpu, size):
     for name, fmt in FMT.items():
         ch, dt = {0: (4, torch.int16), 1: (3, torch.int16), 2: (4, torch.uint8), 3: (3, torch.uint8)}[fmt]
         out = torch.zeros((h, w, ch), dtype=dt, device="cuda")
+        torch.cuda.synchronize()  # src / out were produced on torch's stream, the conversion runs on the runtime's
         sar.convert_device(rt, src.data_ptr(), fmt, out.data_ptr())
         rt.synchronize()
         got = out.cpu().numpy()
