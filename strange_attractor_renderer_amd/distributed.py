@@ -26,7 +26,9 @@ def shard_jobs(total_jobs: int, world: int, rank: int) -> tuple[int, int]:
 
 def exchange_merge(rt, rank: int, dist, key_buf, sum_buf, dst: int = 0):
     """Folds every rank's Runtime into rank `dst`'s (rank order == merge order). key_buf: int64[npix],
-    sum_buf: int32[3*npix] torch tensors on the runtime's device; work is enqueued on the current stream."""
+    sum_buf: int32[3*npix] torch tensors on the runtime's device. The pack/unpack kernels run on the RUNTIME's stream
+    (a non-blocking stream of its own unless set), the collectives on torch's current stream: give the runtime that
+    stream first — ``rt.set_stream(torch.cuda.current_stream().cuda_stream)`` — as bench.py does."""
     rt.exchange_export(rank, key_buf.data_ptr())
     dist.all_reduce(key_buf, op=dist.ReduceOp.MAX)
     rt.exchange_select(rank, key_buf.data_ptr(), sum_buf.data_ptr())
