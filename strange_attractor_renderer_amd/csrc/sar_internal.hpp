@@ -124,7 +124,7 @@ constexpr uint32_t kLnLutEntries = 1u << 20;  // ln(k+1), k < 2^20, host libm (e
 constexpr uint64_t kMaxChunkOrdinals = 0xFFFFFFFEull;
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
 constexpr uint32_t kDefaultChunkRecords = 28;
-constexpr uint32_t kWideHintMaxPixels = 10u << 20;  // images up to 10 Mpx use 32-bit depth hints (measured crossover between 3072^2 and 4096^2)
+constexpr double kWideHintMaxSpan2 = 11.0e6;  // (width * scale)^2 up to which 32-bit depth hints are used
 constexpr uint32_t kDefaultDepthPipe = 2;   // visits between a depth-hint load and its use in the iterate kernel  // u16 records per chunk (8-byte header): 12, 20 or 28 -> 32/48/64-byte chunks
 constexpr uint32_t kMaxBins = 1024;      // LDS staging is 64 B per bin per wave
 constexpr uint32_t kMaxBinPx = 32768;    // phase-2 LDS histogram: 4 B per pixel of the bin

@@ -349,9 +349,12 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
 
     // checkpoint stride: a multiple of the depth pipeline's pass length (the iterate kernel runs whole passes)
     const uint32_t pipe = rt->depth_pipe ? rt->depth_pipe : kDefaultDepthPipe;
-    // depth hints: the sortable f32 itself while one XCD's copy stays near its 4 MiB L2 (3x fewer stage-2 waits, -7 % at
-    // 2048^2), 16-bit fixed point beyond (4096^2: the 64 MiB copy of 32-bit hints is 13 % slower than the 32 MiB one)
-    const uint32_t hint_bytes = rt->hint_bits ? rt->hint_bits / 8u : (rt->npix <= kWideHintMaxPixels ? 4u : 2u);
+    // depth hints: the sortable f32 itself (3x fewer stage-2 waits, -7 % at 2048^2) while the hints of the pixels the
+    // attractor touches stay near an XCD's 4 MiB L2, 16-bit fixed point beyond. The view maps the attractor onto
+    // (width * scale)^2 pixels whatever the height, so that is the measure: 32-bit wins at 2048^2 / 2560^2 / 3072^2,
+    // 16-bit at 3840x2160 (-8 %) and 4096^2 (-13 %).
+    const double span = static_cast<double>(cfg->width) * cfg->scale;
+    const uint32_t hint_bytes = rt->hint_bits ? rt->hint_bits / 8u : ((span * span <= kWideHintMaxSpan2 && rt->npix <= (16u << 20)) ? 4u : 2u);
     const uint32_t C = ((rt->ckpt_stride + pipe - 1u) / pipe) * pipe;
     const uint64_t n_ckpt = (iters + C - 1) / C;
     const uint64_t chunks_per_wave = (iters * 64ull + R - 1) / R + geo.bins;

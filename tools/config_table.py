@@ -26,6 +26,8 @@ CONFIGS = {
     # not BASELINE configs: intermediate sizes for choosing size-dependent defaults (select with --only)
     "X2560": dict(preset="poisson_saturne", iters=1e9, w=2560, h=2560, kind=0),
     "X3072": dict(preset="poisson_saturne", iters=1e9, w=3072, h=3072, kind=0),
+    "XHD": dict(preset="poisson_saturne", iters=1e9, w=1920, h=1080, kind=0),
+    "X4K": dict(preset="poisson_saturne", iters=1e9, w=3840, h=2160, kind=0),
 }
 
 if __name__ == "__main__":
