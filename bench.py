@@ -87,8 +87,8 @@ def cpu_baseline(seconds_hint: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--jobs", type=int, default=DEFAULT_JOBS, help="trajectories per GPU")
     ap.add_argument("--iters", type=float, default=ITERS_PER_GPU, help="counted iterations per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
