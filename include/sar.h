@@ -168,6 +168,11 @@ int sar_render_jobs(const sar_config* cfg, sar_runtime* rt, const double* starts
 int sar_render_job_range(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
                          uint64_t iters_per_job, const double* starts_xyz_host);
 
+/* The same with the start points already in device memory (n_jobs*3 doubles, same [job][xyz] layout, on the
+ * runtime's device; read in stream order): nothing crosses PCIe, the call only enqueues. */
+int sar_render_job_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
+                                uint64_t iters_per_job, const double* starts_xyz_dev);
+
 /* ---- colorize (src/lib.rs:841-904) ---------------------------------------------------------------- */
 /* Writes width*height*4 uint16 (RGBA16, FinalImage layout :625) to host memory. */
 int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host);

@@ -289,6 +289,12 @@ def render_job_range(config: Config, runtime: Runtime, iters_per_job: int, start
                                        s.ctypes.data_as(C.POINTER(C.c_double))), "sar_render_job_range")
 
 
+def render_job_range_device(config: Config, runtime: Runtime, n_jobs: int, iters_per_job: int, starts_dev_ptr: int):
+    """The same shard with its start points already in device memory (n_jobs*3 float64, [job][xyz]); stream-ordered."""
+    _check(_lib().sar_render_job_range_device(C.byref(config.c), runtime.handle, n_jobs, iters_per_job,
+                                              C.c_void_p(starts_dev_ptr)), "sar_render_job_range_device")
+
+
 def colorize(config: Config, runtime: Runtime) -> np.ndarray:
     """``colorize(&config, &runtime) -> FinalImage`` as an (H, W, 4) uint16 array (src/lib.rs:841)."""
     out = np.empty((config.c.height, config.c.width, 4), dtype=np.uint16)

@@ -1137,6 +1137,16 @@ __global__ void __launch_bounds__(256) k_extent(const MapParams pin, const doubl
     }
 }
 
+// start points [m][3] (as the ABI takes them) -> the kernel's SoA block x[m] y[m] z[m]
+__global__ void __launch_bounds__(256) k_starts_soa(const double* __restrict__ aos, double* __restrict__ soa, uint32_t m) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < m) {
+        soa[k] = aos[3u * k];
+        soa[m + k] = aos[3u * k + 1u];
+        soa[2u * m + k] = aos[3u * k + 2u];
+    }
+}
+
 void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode, hipStream_t s) {
     const uint32_t grid = (a.n_jobs + block - 1) / block;
     if (xcd_local) {
@@ -1258,6 +1268,10 @@ uint32_t launch_extent(const MapParams& p, const double* starts, uint32_t n_jobs
     const uint32_t blocks = (n_jobs + 255u) / 256u;
     hipLaunchKernelGGL(k_extent, dim3(blocks), dim3(256), 0, s, p, starts, n_jobs, iters, out);
     return blocks;
+}
+
+void launch_starts_soa(const double* aos, double* soa, uint32_t m, hipStream_t s) {
+    hipLaunchKernelGGL(k_starts_soa, dim3((m + 255u) / 256u), dim3(256), 0, s, aos, soa, m);
 }
 
 void launch_exch_export(const unsigned long long* key, uint32_t rank, void* out, uint32_t npix, hipStream_t s) {

@@ -300,7 +300,7 @@ int check_cfg_matches(const sar_config* cfg, const sar_runtime* rt) {
 // and the checkpoint scratch inside kCkptBytesCap; chunk boundaries fall on whole jobs, and a later
 // chunk only replaces a depth winner with a strictly greater z, exactly like a later render call.
 int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters,
-                   const double* starts) {
+                   const double* starts, bool starts_on_device = false) {
     if (!rt->timing_accumulate) {
         rt->last_iterations = 0;
         rt->iter_used = 0;
@@ -399,18 +399,27 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
         HIP_TRY(hipMalloc(&rt->d_starts, need * sizeof(double)));
         rt->starts_cap = need;
     }
-    for (uint64_t off = 0; off < n_jobs; off += chunk_jobs) {
-        const uint64_t m = (n_jobs - off < chunk_jobs) ? n_jobs - off : chunk_jobs;
-        double* blk = rt->h_starts + off * 3;
-        for (uint64_t k = 0; k < m; ++k) {
-            blk[k] = starts[(off + k) * 3 + 0];
-            blk[m + k] = starts[(off + k) * 3 + 1];
-            blk[2 * m + k] = starts[(off + k) * 3 + 2];
+    if (starts_on_device) {
+        // the caller's [n_jobs][3] array is already in HBM: transpose it into the per-chunk SoA blocks on the device
+        for (uint64_t off = 0; off < n_jobs; off += chunk_jobs) {
+            const uint32_t m = static_cast<uint32_t>((n_jobs - off < chunk_jobs) ? n_jobs - off : chunk_jobs);
+            launch_starts_soa(starts + off * 3, rt->d_starts + off * 3, m, rt->stream);
         }
+        HIP_TRY(hipGetLastError());
+    } else {
+        for (uint64_t off = 0; off < n_jobs; off += chunk_jobs) {
+            const uint64_t m = (n_jobs - off < chunk_jobs) ? n_jobs - off : chunk_jobs;
+            double* blk = rt->h_starts + off * 3;
+            for (uint64_t k = 0; k < m; ++k) {
+                blk[k] = starts[(off + k) * 3 + 0];
+                blk[m + k] = starts[(off + k) * 3 + 1];
+                blk[2 * m + k] = starts[(off + k) * 3 + 2];
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(rt->d_starts, rt->h_starts, need * sizeof(double), hipMemcpyHostToDevice, rt->stream));
+        HIP_TRY(hipEventRecord(rt->starts_copied, rt->stream));
+        rt->starts_pending = true;
     }
-    HIP_TRY(hipMemcpyAsync(rt->d_starts, rt->h_starts, need * sizeof(double), hipMemcpyHostToDevice, rt->stream));
-    HIP_TRY(hipEventRecord(rt->starts_copied, rt->stream));
-    rt->starts_pending = true;
 
     const size_t ckpt_need = static_cast<size_t>(n_ckpt) * 3 * chunk_jobs;
     if (ckpt_need > rt->ckpt_cap) {
@@ -748,6 +757,13 @@ int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host
     HIP_TRY(hipMemcpyAsync(rgba_out_host, rt->d_rgba, static_cast<size_t>(rt->npix) * 8, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
     return SAR_OK;
+}
+
+int sar_render_job_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters_per_job,
+                                const double* starts_xyz_dev) {
+    SAR_TRY(check_cfg_matches(cfg, rt));
+    if (n_jobs && !starts_xyz_dev) { set_error("starts_xyz_dev is NULL"); return SAR_ERR_INVALID; }
+    return render_chunked(cfg, rt, n_jobs, iters_per_job, starts_xyz_dev, true);
 }
 
 int sar_runtime_extent(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters_per_job,

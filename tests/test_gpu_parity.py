@@ -435,3 +435,20 @@ def test_random_configurations_bit_exact(sar, oracle, gpu, seed):
     np.testing.assert_array_equal(sar.colorize(cfg, rt), want)
     fmt = int(rng.integers(4))
     np.testing.assert_array_equal(sar.colorize_format(cfg, rt, fmt), oracle.convert(fmt, want))
+
+
+def test_device_resident_start_points_give_the_same_bits(sar, oracle, gpu):
+    """sar_render_job_range_device: start points handed over in device memory (across several launch chunks)."""
+    import torch
+    jobs, n = 1500, 500
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=300, height=200, jobs_total=jobs)
+    st = sar.start_points(31, 0, jobs)
+    ort = oracle.Runtime(300, 200)
+    oracle.render_jobs(cfg.c, ort, st, n)
+    dev = torch.from_numpy(st).cuda()
+    torch.cuda.synchronize()
+    for cap in (0, 333):
+        rt = sar.Runtime(cfg)
+        rt.set_tuning(variant=cap << 8)
+        sar.render_job_range_device(cfg, rt, jobs, n, dev.data_ptr())
+        assert_state_equal(rt, ort, f"device starts, chunk cap {cap}")
