@@ -243,8 +243,9 @@ int sar_runtime_exchange_import(sar_runtime* rt, const void* key_i64_reduced_dev
 
 /* ---- ParallelRenderer / render_parallel (src/lib.rs:908-1082) -------------------------------------- */
 /* ParallelRenderer::new (:919-1004). `units` plays the role of num_threads (:920-922): the number of
- * execution units the job split divides by; 0 selects the device default (one lane per SIMD lane of
- * the chip: CUs*4*64). The renderer owns one runtime on `device`, seeded with `seed`. */
+ * execution units the job split divides by; 0 selects the device default, 64 per CU (16 384 on MI355X), so that the
+ * CLI's default of 12 jobs per thread (src/bin/main.rs:305) becomes 196 608 trajectories = three waves per SIMD.
+ * The renderer owns one runtime on `device`, seeded with `seed`. */
 int sar_renderer_new(int device, uint32_t units, uint64_t seed, sar_renderer** out);
 int sar_renderer_num_units(const sar_renderer* r, uint32_t* out_units);
 /* ParallelRenderer::shutdown (:1020-1025). */

@@ -942,11 +942,13 @@ int sar_renderer_new(int device, uint32_t units, uint64_t seed, sar_renderer** o
     r->device = device;
     r->seed = seed;
     if (units == 0) {
-        // the chip's lane count: one trajectory per SIMD lane (CUs x 4 SIMDs x 64 lanes), the role
-        // available_parallelism() plays at src/lib.rs:920-922
+        // the role available_parallelism() plays at src/lib.rs:920-922. 64 units per CU (16 384 on MI355X): with the
+        // CLI's default of 12 jobs per thread (src/bin/main.rs:305) the job split then gives 196 608 trajectories —
+        // three waves per SIMD — and 8 jobs per unit give 131 072; every job pays 1000 warm-up iterations, so a unit
+        // count that multiplied typical jobs_per_unit values into millions of jobs would only add warm-up work
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete r; return SAR_ERR_HIP; }
-        units = static_cast<uint32_t>(prop.multiProcessorCount) * 4u * 64u;
+        units = static_cast<uint32_t>(prop.multiProcessorCount) * 64u;
     }
     r->units = units;
     *out = r;

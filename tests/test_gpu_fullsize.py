@@ -132,3 +132,21 @@ def test_readme_image_through_export_matches_reference_png(sar, gpu, tmp_path):
         assert np.corrcoef(thumb[..., ch].ravel(), ref[..., ch].ravel())[0, 1] > 0.998
         assert np.corrcoef(thumb[:, ::-1, ch].ravel(), ref[..., ch].ravel())[0, 1] < 0.6
         assert abs(rgb[..., ch].mean() / stats["channel_mean"][ch] - 1.0) < 0.01
+
+
+def test_render_parallel_with_cli_defaults_is_fast_and_conserves(sar, gpu):
+    """The reference's headline call — render_parallel(renderer, config, 12), 1e9 iterations at 2048^2 — with the
+    default unit count: the N / T / J split lands on a job count the device runs at full speed."""
+    import time
+    r = sar.ParallelRenderer(seed=5)
+    units = r.num_threads()
+    cfg = sar.Config.poisson_saturne(iterations=1_000_000_000, width=2048, height=2048, transparent=0)
+    img = sar.render_parallel(r, cfg, 12)
+    t0 = time.perf_counter()
+    img = sar.render_parallel(r, cfg, 12)
+    dt = time.perf_counter() - t0
+    n = 1_000_000_000 // units // 12
+    count = r.runtime().count()
+    assert int(count.sum(dtype=np.uint64)) == n * units * 12   # poisson-saturne at scale 1 stays inside the frame
+    assert img.shape == (2048, 2048, 4) and img[..., 3].min() == 65535
+    assert dt < 0.1, f"render_parallel took {dt * 1e3:.1f} ms"  # ~8 ms of GPU work + the 32 MiB image read-back

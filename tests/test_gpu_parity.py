@@ -199,7 +199,7 @@ def test_render_parallel_job_split(sar, oracle, gpu):
     oracle.render_jobs(c2.c, ort, starts2, n)
     np.testing.assert_array_equal(img2, oracle.colorize(c2.c, ort))
     r.shutdown()
-    assert sar.ParallelRenderer().num_threads() % 256 == 0  # default: CUs*4*64 lanes
+    assert sar.ParallelRenderer().num_threads() % 64 == 0  # default: 64 units per CU
 
 
 def test_render_single_draws_from_seeded_stream(sar, oracle, gpu):
