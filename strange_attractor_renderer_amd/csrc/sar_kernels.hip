@@ -303,6 +303,21 @@ struct Stager {
     unsigned long long g_mine[U], g_cur[U];
     bool b_have;          // previous visit, waiting for its LDS slot
     uint32_t b_bin, b_slot, b_local;
+#ifdef SAR_EXPERIMENT_PROF
+    // timing experiment: wave-cycles per segment of the loop body (s_memtime; every mark drains lgkmcnt, so the LDS
+    // round trips that normally overlap the next segment are charged to the segment that issued them)
+    unsigned long long prof[4] = {0, 0, 0, 0}, prof_last = 0;
+    __device__ __forceinline__ void mark(int i) {
+        asm volatile("" ::: "memory");
+        const unsigned long long now = __builtin_readcyclecounter();
+        asm volatile("" ::: "memory");
+        prof[i] += now - prof_last;
+        prof_last = now;
+    }
+#define SAR_MARK(i) this->mark(i)
+#else
+#define SAR_MARK(i)
+#endif
     bool f_on;            // a filled buffer whose 2R bytes sit in registers, waiting to be stored
     uint32_t f_chunk, f_prev;
     uint2 fpend[R / 4u];
@@ -460,6 +475,7 @@ struct Stager {
         __builtin_amdgcn_s_setprio(3);
         // the previous visit's record first: pure LDS work
         place_visit();
+        SAR_MARK(1);
         bool cand = false;
         if (DEPTH) {
             settle_depth(k);  // the candidate of visit t - U: its hint was requested U whole steps ago
@@ -472,6 +488,7 @@ struct Stager {
             p_lo[k] = lo_base - t;
             pv[k] = cand;
         }
+        SAR_MARK(2);
         // chunk stores of a buffer that filled up (their LDS reads were issued by place_visit above), then this
         // visit's slot request
         flush_store_pending();
@@ -484,6 +501,7 @@ struct Stager {
         // wanted in flight would have to be waited for as well
         if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (idx & ~1u)) : 0u));
         __builtin_amdgcn_s_setprio(0);
+        SAR_MARK(3);
     }
 
     // After the last visit: settle what is in flight, flush the partly filled buffers, publish the list heads.
@@ -618,11 +636,20 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
         }
         inb = inb && alive;
         idx = inb ? idx : 0u;
+#ifdef SAR_EXPERIMENT_PROF
+        asm volatile("" : "+v"(idx), "+v"(zf));  // the map and the projection belong to segment 0
+#endif
+#ifdef SAR_EXPERIMENT_PROF
+        st.mark(0);
+#endif
         st.step(k, inb, idx, zf, t);
         ++t;
     };
     // Whole passes of U iterations first: the pass is the unit of the depth pipeline, and a loop that contains
     // nothing else lets the compiler count exactly which loads may still be in flight at each use.
+#ifdef SAR_EXPERIMENT_PROF
+    st.prof_last = __builtin_readcyclecounter();
+#endif
     const uint32_t n_full = n - n % U;
     while (t < n_full) {
         checkpoint();
@@ -638,6 +665,10 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
         for (uint32_t k = 0; k + 1 < U; ++k)
             if (t < n) iteration(k);
     }
+#ifdef SAR_EXPERIMENT_PROF
+    if (lane == 0)
+        for (int i = 0; i < 4; ++i) atomicAdd(a.nan_count + 2 + i, st.prof[i]);
+#endif
     st.finish(a.heads, a.n_waves, wave, a.nan_count);
 }
 

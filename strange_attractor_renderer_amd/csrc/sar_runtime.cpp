@@ -460,8 +460,9 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             SAR_TRY(clear_hints(rt));
         }
         if (!rt->d_nan_count) {
-            HIP_TRY(hipMalloc(&rt->d_nan_count, 2 * sizeof(unsigned long long)));  // [0] NaN iterations, [1] depth atomics (stat)
-            HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, 2 * sizeof(unsigned long long), rt->stream));
+            // [0] NaN iterations, [1] depth atomics (stat), [2..5] segment cycles of the SAR_EXPERIMENT_PROF build
+            HIP_TRY(hipMalloc(&rt->d_nan_count, 8 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, 8 * sizeof(unsigned long long), rt->stream));
         }
     }
     IterArgs ia;
@@ -1021,6 +1022,15 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
         unsigned long long sent = 0;
         HIP_TRY(hipMemcpy(&sent, rt->d_nan_count + 1, sizeof(sent), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(rt->d_nan_count + 1, 0, sizeof(sent)));
+#ifdef SAR_EXPERIMENT_PROF
+        unsigned long long seg[4];
+        HIP_TRY(hipMemcpy(seg, rt->d_nan_count + 2, sizeof(seg), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(rt->d_nan_count + 2, 0, sizeof(seg)));
+        const double tot = static_cast<double>(seg[0] + seg[1] + seg[2] + seg[3]);
+        if (tot > 0)
+            std::fprintf(stderr, "[prof] wave-cycles: map+projection %.1f%%  place_visit %.1f%%  depth %.1f%%  stores+requests %.1f%%  (total %.3g)\n",
+                         100. * seg[0] / tot, 100. * seg[1] / tot, 100. * seg[2] / tot, 100. * seg[3] / tot, tot);
+#endif
         out->depth_atomics = sent;
     }
     out->iterations_counted = rt->last_iterations;
