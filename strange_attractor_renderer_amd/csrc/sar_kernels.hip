@@ -6,18 +6,21 @@
 // deviation exponentially, so "close" does not exist here: either the op sequence is identical or
 // the images differ.
 //
-// Kernels
-//   k_iterate<XCD_LOCAL>  one trajectory ("job") per lane, fp64 state in registers; per counted
-//                         in-bounds iteration one no-return u32 atomic add (count) and one no-return
-//                         u64 atomic max (depth key = sortable(z as f32) << 32 | ~ordinal) into
-//                         scratch bins; trajectory checkpoints every `ckpt_stride` iterations.
-//                         No instruction in the loop waits on memory.
-//   k_fold_resolve        folds the scratch bins into the persistent Runtime buffers (count add,
-//                         running max, depth test with "earlier visit wins ties"), re-zeroes the
-//                         scratch, compacts the pixels whose depth winner changed (LDS) and recomputes
-//                         their colour-transform payload from the nearest checkpoint (the visit
-//                         ordinal in the key names job and iteration).
-//   k_merge, k_colorize_gas, k_zrange, k_colorize_depth, exchange pack/unpack, accessors.
+// Kernels (DESIGN.md section 3 has the measurements behind every choice)
+//   k_iterate_lean<DEPTH,R,U,H>  the hot loop: one trajectory ("job") per lane, fp64 state in registers; a visit
+//                         becomes a 2-byte record staged per (wave, bin) in LDS and copied out in chunks of R records
+//                         to the wave's arena; the depth test goes through per-XCD hints (type H) and a pipeline U
+//                         visits deep, so that only ~0.6 % of the visits send the 64-bit key atomic
+//                         (sortable(z as f32) << 32 | ~ordinal); trajectory checkpoints every `ckpt_stride` iterations.
+//   k_bin_accumulate<R>   walks the per-(bin, wave) chunk lists and counts the records in an LDS histogram per bin.
+//   k_iterate<XCD_LOCAL,MODE>  the first correct version — one no-return global atomic add and one atomic max per
+//                         visit — kept for images beyond the binned path's 32 Mpx and as an A/B reference.
+//   k_fold_resolve        folds the scratch bins into the persistent Runtime buffers (count add, running max, depth
+//                         test with "earlier visit wins ties"), re-zeroes the scratch, compacts the pixels whose depth
+//                         winner changed (LDS) and recomputes their colour-transform payload from the nearest
+//                         checkpoint (the visit ordinal in the key names job and iteration).
+//   k_merge, k_colorize_gas, k_zrange + k_colorize_depth, exchange pack/unpack, k_convert (export formats),
+//   k_extent (attractor bounds), k_reset, k_zbuf_in/out, k_starts_soa.
 #include <hip/hip_runtime.h>
 
 #include "sar_internal.hpp"
@@ -41,11 +44,10 @@ __device__ __forceinline__ float sortable_f32(uint32_t s) {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// Depth hints are 16-bit fixed point: q(z) = clamp(floor((z + 1) * 2^14), 0, 65535). Every step is monotone
-// non-decreasing in z, so q(a) < q(b) implies a < b: a visit whose q is below the stored q of an already-sent
-// visit cannot win the depth test. 6e-5 resolution over z in [-1, 3) passes ~as few visits as an exact hint,
-// at half the footprint — the hint arrays then stay L2-resident (scattered 4-byte loads run at 2.65e11/s out
-// of a 2 MiB region and at 0.8e11/s out of 16 MiB on this chip, tools/ubench).
+// The narrow depth hints are 16-bit fixed point: q(z) = clamp(floor((z + 1) * 2^14), 0, 65535). Every step is monotone
+// non-decreasing in z, so q(a) < q(b) implies a < b: a visit whose q is below the stored q of an already-sent visit
+// cannot win the depth test. Half the footprint of the 32-bit (sortable f32) hints, at the price of passing every
+// visit within 2^-14 of the best depth: the host picks the type by the view's footprint (sar_runtime.cpp).
 __device__ __forceinline__ uint32_t depth_q16(float zf) {
     const float s = (zf + 1.0f) * 16384.0f;
     const uint32_t q = (uint32_t)fminf(fmaxf(s, 0.0f), 65535.0f);
@@ -228,34 +230,32 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
 // k_iterate_lean — the hot loop without a global atomic per visit
 // ---------------------------------------------------------------------------------------------------
 // Measured on MI355X: the chip retires ~2.1e10 scattered global atomics per second whatever their
-// scope or width, while the fp64 arithmetic of this loop alone runs at ~3.6e11 iterations/s. So a
+// scope or width, while the fp64 arithmetic of this loop alone runs at ~3.3e11 iterations/s. So a
 // visit must not cost a global atomic. Here every visit becomes a 2-byte RECORD instead:
 //
 //   * the image is cut into B bins of 2^bin_shift consecutive pixels; a record is the pixel's offset
 //     inside its bin (u16);
-//   * each WAVE owns B staging buffers of 28 records in LDS (64 B per bin: counter, link, 28 x u16);
-//     a visit takes a slot with one LDS atomic (ds_add_rtn) and writes its u16 there;
-//   * the lane that takes the last slot copies the 28 records + {link to the previous chunk of this
-//     (wave, bin), count} as ONE 64-byte chunk to the wave's private arena in HBM — position from a
+//   * each WAVE owns B staging buffers of R records in LDS (2R + 8 bytes per bin: records, counter, link);
+//     a visit takes a slot with one LDS atomic (ds_add_rtn) and writes its u16 there one iteration later;
+//   * the lane that takes the last slot copies the R records + {link to the previous chunk of this
+//     (wave, bin), count} as ONE chunk to the wave's private arena in HBM — position from a
 //     wave-local cursor, so no global atomic and nothing to wait for — and resets the buffer;
 //   * k_bin_accumulate later walks the per-(bin, wave) chunk lists and histograms them in LDS.
 //
-// Depth: the 64-bit key atomic-max survives only for visits that can still win. Each XCD keeps a
-// private array of depth hints (a lower bound of the best sortable z this XCD has already sent for
-// the pixel, plain loads/stores served by the XCD's own L2); a visit is sent iff its z is >= the
-// hint. The hint read is issued one iteration ahead of its use, so its latency hides behind the next
-// iteration's arithmetic. A stale or lost hint only costs an extra atomic, never a wrong result.
+// Depth: see Stager::settle_depth — two filters (this XCD's hint, then the chip-wide key) in front of the
+// 64-bit atomic max, as a software pipeline U visits deep. A stale or lost hint only costs an extra atomic,
+// never a wrong result.
 //
 // Control flow: the per-visit operations are issued unconditionally with a select on the ADDRESS instead
 // of a branch (every `if` around an LDS or memory operation costs s_and_saveexec / s_cbranch_execz / s_or):
 //   * a lane without a visit requests its slot from a private dummy counter and writes its record to
-//     a private scratch slot (cnt[B + lane], rec[B*28 + lane]);
+//     a private scratch slot (cnt[B + lane], rec[B*R + lane]);
 //   * the hint of a lane without a depth candidate is loaded from element 0;
-//   * only the two rare-per-lane events keep a wave-level branch: "some lane filled a buffer" (copy-out,
-//     which also places the records that overflowed into the next buffer generation) and "some lane
-//     has a depth candidate that passes its hint" (the 64-bit atomic max).
+//   * only the rare-per-lane events keep a wave-level branch: "some lane filled a buffer" (copy-out,
+//     which also places the records that overflowed into the next buffer generation), "some lane passed
+//     a depth filter", "a trajectory ended in NaN".
 // LDS per wave: B buffers of R records + B counters + B links + 64 scratch records + 64 dummy counters
-// per-XCD hint arrays: an even number of 16-bit entries each, so that the dword holding a hint is aligned
+// per-XCD hint arrays: an even number of entries each, so that the dword holding a 16-bit hint is aligned
 __host__ __device__ constexpr size_t kHintStride(uint32_t npix) { return ((size_t)npix + 1u) & ~(size_t)1u; }
 constexpr uint32_t kLeanWaveLds(uint32_t bins, uint32_t R) { return bins * (2u * R + 8u) + 384u; }
 constexpr uint32_t kChunkQuads(uint32_t R) { return (8u + 2u * R) / 16u; }  // 16-byte quads of data per chunk: R = 12, 20, 28
