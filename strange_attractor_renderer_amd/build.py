@@ -54,7 +54,7 @@ def audit_no_fma(asm_path: str) -> dict:
     for m in re.finditer(r"^(_ZN3sar\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", text, flags=re.S | re.M):
         name, body = m.group(1), m.group(2)
         counts[name] = len(re.findall(r"\bv_(fma|fmac|mad)_f64\b", body))
-    bad = {k: v for k, v in counts.items() if any(t in k for t in ("k_iterate", "k_extent")) and v}
+    bad = {k: v for k, v in counts.items() if any(t in k for t in ("k_iterate", "k_extent", "k_warmup")) and v}
     if bad:
         raise RuntimeError(f"fused fp64 ops found in the iterate kernel: {bad}")
     if not any("k_iterate" in k for k in counts):

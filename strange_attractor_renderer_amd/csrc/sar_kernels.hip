@@ -584,13 +584,60 @@ __device__ __forceinline__ void pin_map_params(MapParams& p) {
     p.scale_adjusted_mid = vgpr_pin(p.scale_adjusted_mid);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_warmup — the 1000 uncounted iterations every job starts with (reference src/lib.rs:750-752), and the packing of
+// the survivors. NaN is absorbing: a job whose x is NaN after the warm-up spends all its counted iterations on pixel
+// (0,0) without ever winning a depth test, so its n iterations go straight to the NaN counter and the
+// job never occupies a lane of the hot kernel. The packed order depends on which wave's atomic lands first; results
+// do not (the visit ordinal is formed from the job index, which travels in `joblist`).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_warmup(const MapParams pin, const double* __restrict__ starts, uint32_t n_jobs,
+                                                uint64_t iters, double* __restrict__ warm, uint32_t* __restrict__ joblist,
+                                                uint32_t* active, unsigned long long* nan_count) {
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = job < n_jobs;
+    MapParams p = pin;
+    pin_map_params(p);
+    double x = 0., y = 0., z = 0.;
+    if (valid) {
+        x = starts[job];
+        y = starts[n_jobs + job];
+        z = starts[2u * n_jobs + job];
+        for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);
+    }
+    const bool live = valid && x == x;
+    const unsigned long long lm = wave_ballot(live), dm = wave_ballot(valid && !live);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+    uint32_t base = 0;
+    if ((threadIdx.x & 63u) == 0u) {
+        if (lm) base = atomicAdd(active, (uint32_t)__popcll(lm));
+        if (dm) atomicAdd(nan_count, iters * (unsigned long long)__popcll(dm));
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (live) {
+        const uint32_t slot = base + rank;
+        warm[slot] = x;
+        warm[n_jobs + slot] = y;
+        warm[2u * n_jobs + slot] = z;
+        joblist[slot] = job;
+    }
+}
+
 template <bool DEPTH, uint32_t R, uint32_t U, typename H>
 __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t wave = job >> 6;
-    bool alive = job < a.it.n_jobs;
+    // lanes take the packed trajectories k_warmup left (those that survived the warm-up), not raw job indices: a
+    // preset like solar-sail loses 38 % of its start points to NaN there, and they would sit in every wave as idle lanes
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t wave = slot >> 6;
+    const uint32_t active = *a.active;
+    if ((slot & ~63u) >= active) {  // nothing left for this wave: publish empty lists
+        for (uint32_t b = lane; b < a.n_bins; b += 64u) a.heads[(size_t)b * a.n_waves + wave] = kNoChunk;
+        return;
+    }
+    bool alive = slot < active;
+    const uint32_t job = alive ? a.joblist[slot] : 0u;
     const uint32_t n = (uint32_t)a.it.iters;
 
     Stager<DEPTH, R, U, H> st;
@@ -603,11 +650,10 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     MapParams p = a.it.p;
     pin_map_params(p);
     double x = 0., y = 0., z = 0.;
-    if (alive) {
-        x = a.it.starts[job];
-        y = a.it.starts[a.it.n_jobs + job];
-        z = a.it.starts[2u * a.it.n_jobs + job];
-        for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);  // warm-up (:750-752)
+    if (alive) {  // the point after the warm-up (:750-752), from k_warmup
+        x = a.warm[slot];
+        y = a.warm[a.it.n_jobs + slot];
+        z = a.warm[2u * a.it.n_jobs + slot];
     }
     const uint32_t C = a.it.ckpt_stride;  // a multiple of U (the host rounds it)
     const size_t cs = a.it.n_jobs;
@@ -1303,6 +1349,12 @@ uint32_t launch_extent(const MapParams& p, const double* starts, uint32_t n_jobs
 
 void launch_starts_soa(const double* aos, double* soa, uint32_t m, hipStream_t s) {
     hipLaunchKernelGGL(k_starts_soa, dim3((m + 255u) / 256u), dim3(256), 0, s, aos, soa, m);
+}
+
+void launch_warmup(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* warm, uint32_t* joblist,
+                   uint32_t* active, unsigned long long* nan_count, hipStream_t s) {
+    hipLaunchKernelGGL(k_warmup, dim3((n_jobs + 255u) / 256u), dim3(256), 0, s, p, starts, n_jobs, iters, warm, joblist, active,
+                       nan_count);
 }
 
 void launch_exch_export(const unsigned long long* key, uint32_t rank, void* out, uint32_t npix, hipStream_t s) {

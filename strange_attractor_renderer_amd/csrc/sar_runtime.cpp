@@ -87,6 +87,17 @@ struct sar_runtime {
     // staging
     double* h_starts = nullptr;  // pinned
     double* d_starts = nullptr;
+    double* d_warm = nullptr;        // binned path: packed post-warm-up points, job list, survivor count
+    uint32_t* d_joblist = nullptr;
+    uint32_t* d_active = nullptr;
+    size_t warm_cap = 0;             // jobs
+    // survivor statistics of the last launch, copied back lazily (never waited for): the next render call sizes its
+    // staging for the lanes that will really be busy (solar-sail loses 38 % of its jobs in the warm-up)
+    uint32_t* h_active = nullptr;    // pinned
+    hipEvent_t active_copied = nullptr;
+    bool active_pending = false;
+    uint32_t active_jobs_launched = 0;
+    double survivor_fraction = 1.0;
     size_t starts_cap = 0;       // doubles
     hipEvent_t starts_copied = nullptr;
     bool starts_pending = false;
@@ -323,7 +334,13 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
     if (!rt->chunk_records) {
         const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u);
         const uint64_t cus = rt->sm_count ? rt->sm_count : 256u;
-        uint64_t want = (n_jobs + 64u * cus - 1) / (64u * cus);  // waves per CU if all jobs were resident
+        if (rt->active_pending && hipEventQuery(rt->active_copied) == hipSuccess) {
+            rt->active_pending = false;
+            if (rt->active_jobs_launched) rt->survivor_fraction = static_cast<double>(*rt->h_active) / rt->active_jobs_launched;
+        }
+        const uint64_t busy = static_cast<uint64_t>(n_jobs * rt->survivor_fraction + 0.5);
+        uint64_t want = (busy + 64u * cus - 1) / (64u * cus);  // waves per CU if all surviving jobs were resident
+        want = ((want + 3) / 4) * 4;  // workgroups are four waves: residency comes in steps of four waves per CU
         want = want < 8 ? 8 : (want > 12 ? 12 : want);
         if (probe.ok) {
             bool found = false;
@@ -459,6 +476,22 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             rt->zhint_bytes = hint_bytes;
             SAR_TRY(clear_hints(rt));
         }
+        if (chunk_jobs > rt->warm_cap) {
+            if (rt->d_warm) hipFree(rt->d_warm);
+            if (rt->d_joblist) hipFree(rt->d_joblist);
+            rt->d_warm = nullptr;
+            rt->d_joblist = nullptr;
+            rt->warm_cap = 0;
+            HIP_TRY(hipMalloc(&rt->d_warm, static_cast<size_t>(chunk_jobs) * 3 * sizeof(double)));
+            HIP_TRY(hipMalloc(&rt->d_joblist, static_cast<size_t>(chunk_jobs) * sizeof(uint32_t)));
+            rt->warm_cap = chunk_jobs;
+        }
+        if (!rt->d_active) HIP_TRY(hipMalloc(&rt->d_active, sizeof(uint32_t)));
+        if (!rt->h_active) {
+            HIP_TRY(hipHostMalloc(&rt->h_active, sizeof(uint32_t), hipHostMallocDefault));
+            *rt->h_active = 0;
+            HIP_TRY(hipEventCreateWithFlags(&rt->active_copied, hipEventDisableTiming));
+        }
         if (!rt->d_nan_count) {
             // [0] NaN iterations, [1] depth atomics (stat), [2..5] segment cycles of the SAR_EXPERIMENT_PROF build
             HIP_TRY(hipMalloc(&rt->d_nan_count, 8 * sizeof(unsigned long long)));
@@ -511,8 +544,20 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             ba.arena = rt->d_arena;
             ba.heads = rt->d_heads;
             ba.zhint = rt->d_zhint;
+            ba.warm = rt->d_warm;
+            ba.joblist = rt->d_joblist;
+            ba.active = rt->d_active;
             ba.nan_count = rt->d_nan_count;
             span_begin(rt, rt->iter_spans, rt->iter_used);
+            HIP_TRY(hipMemsetAsync(rt->d_active, 0, sizeof(uint32_t), rt->stream));
+            launch_warmup(ia.p, ia.starts, m, iters, rt->d_warm, rt->d_joblist, rt->d_active, rt->d_nan_count, rt->stream);
+            if (!rt->active_pending && rt->h_active) {  // statistics for the next call; nobody waits for this copy
+                if (hipMemcpyAsync(rt->h_active, rt->d_active, sizeof(uint32_t), hipMemcpyDeviceToHost, rt->stream) == hipSuccess &&
+                    hipEventRecord(rt->active_copied, rt->stream) == hipSuccess) {
+                    rt->active_pending = true;
+                    rt->active_jobs_launched = m;
+                }
+            }
             if (launch_iterate_lean(ba, block, R, pipe, hint_bytes, mode == 2, rt->stream) != 0) {
                 set_error("bad chunk_records / depth_pipe");
                 return SAR_ERR_INVALID;
@@ -631,6 +676,11 @@ int sar_runtime_free(sar_runtime* rt) {
     free_device_buffers(rt);
     if (rt->d_scalars) hipFree(rt->d_scalars);
     if (rt->d_lnlut) hipFree(rt->d_lnlut);
+    if (rt->d_warm) hipFree(rt->d_warm);
+    if (rt->d_joblist) hipFree(rt->d_joblist);
+    if (rt->d_active) hipFree(rt->d_active);
+    if (rt->h_active) hipHostFree(rt->h_active);
+    if (rt->active_copied) hipEventDestroy(rt->active_copied);
     if (rt->d_starts) hipFree(rt->d_starts);
     if (rt->h_starts) hipHostFree(rt->h_starts);
     if (rt->d_ckpt) hipFree(rt->d_ckpt);
