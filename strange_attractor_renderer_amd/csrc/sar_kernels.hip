@@ -7,7 +7,8 @@
 // the images differ.
 //
 // Kernels (DESIGN.md section 3 has the measurements behind every choice)
-//   k_iterate_lean<DEPTH,R,U,H>  the hot loop: one trajectory ("job") per lane, fp64 state in registers; a visit
+//   k_warmup              the 1000 uncounted iterations of every job, and the packing of the jobs that survive them.
+//   k_iterate_lean<DEPTH,R,U,H>  the hot loop: one surviving trajectory per lane, fp64 state in registers; a visit
 //                         becomes a 2-byte record staged per (wave, bin) in LDS and copied out in chunks of R records
 //                         to the wave's arena; the depth test goes through per-XCD hints (type H) and a pipeline U
 //                         visits deep, so that only ~0.6 % of the visits send the 64-bit key atomic
