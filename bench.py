@@ -240,7 +240,8 @@ def main():
                                  "kernel's binding resource is fp64 VALU issue (88 unfused ops/iteration, no FMA "
                                  "allowed): valu_frac = 88*it/s / 39.3e12 op/s. traffic = PMC bytes/launch "
                                  "(profiles/), below the algorithmic bytes because the scatter state lives in LDS/L2"},
-            "kernel_ms_per_step": {"iterate": iter_ms / a.steps, "accumulate_fold_resolve": fold_ms / a.steps,
+            "kernel_ms_per_step": {"warmup_and_pack": tm.warmup_ms / a.steps, "iterate": iter_ms / a.steps,
+                                   "accumulate_fold_resolve": fold_ms / a.steps,
                                    "colorize_last": col_ms},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -66,7 +66,7 @@ pub struct SarTiming {
     pub colorize_ms: f32,
     pub merge_ms: f32,
     pub iterate_launches: u32,
-    pub _pad: u32,
+    pub warmup_ms: f32,
     pub iterations_counted: u64,
     pub depth_atomics: u64,
 }

@@ -96,12 +96,12 @@ typedef struct sar_renderer sar_renderer;   /* opaque; ParallelRenderer, src/lib
 
 /* Per-call device timings (HIP events on the runtime's stream), filled when timing is enabled. */
 typedef struct sar_timing {
-    float    iterate_ms;    /* sum over launch chunks of the iterate/accumulate kernel */
+    float    iterate_ms;    /* sum over launch chunks of the iterate kernel (k_iterate_lean) alone */
     float    resolve_ms;    /* depth-winner payload resolve + max reduction */
     float    colorize_ms;   /* last colorize */
     float    merge_ms;      /* last merge */
     uint32_t iterate_launches;
-    uint32_t _pad;
+    float    warmup_ms;     /* sum over launch chunks of the warm-up + packing kernel (was padding before ABI 2) */
     uint64_t iterations_counted; /* jobs * iterations-per-job executed by the last render call */
     uint64_t depth_atomics;      /* binned path: global depth atomics issued since the last query (statistic) */
 } sar_timing;

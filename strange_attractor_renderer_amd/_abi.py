@@ -70,7 +70,7 @@ class SarTiming(C.Structure):
         ("colorize_ms", C.c_float),
         ("merge_ms", C.c_float),
         ("iterate_launches", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("warmup_ms", C.c_float),
         ("iterations_counted", C.c_uint64),
         ("depth_atomics", C.c_uint64),
     ]

@@ -124,8 +124,8 @@ struct sar_runtime {
 
     // timing
     bool timing = false;
-    std::vector<Span> iter_spans, fold_spans;
-    size_t iter_used = 0, fold_used = 0;
+    std::vector<Span> iter_spans, fold_spans, warm_spans;
+    size_t iter_used = 0, fold_used = 0, warm_used = 0;
     Span colorize_span, merge_span;
     bool colorize_timed = false, merge_timed = false;
     uint64_t last_iterations = 0;
@@ -316,6 +316,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
         rt->last_iterations = 0;
         rt->iter_used = 0;
         rt->fold_used = 0;
+        rt->warm_used = 0;
     }
     if (n_jobs == 0 || iters == 0) return SAR_OK;
     if (iters > kMaxChunkOrdinals) {
@@ -548,7 +549,7 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
             ba.joblist = rt->d_joblist;
             ba.active = rt->d_active;
             ba.nan_count = rt->d_nan_count;
-            span_begin(rt, rt->iter_spans, rt->iter_used);
+            span_begin(rt, rt->warm_spans, rt->warm_used);
             HIP_TRY(hipMemsetAsync(rt->d_active, 0, sizeof(uint32_t), rt->stream));
             launch_warmup(ia.p, ia.starts, m, iters, rt->d_warm, rt->d_joblist, rt->d_active, rt->d_nan_count, rt->stream);
             if (!rt->active_pending && rt->h_active) {  // statistics for the next call; nobody waits for this copy
@@ -558,6 +559,8 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
                     rt->active_jobs_launched = m;
                 }
             }
+            span_end(rt, rt->warm_spans, rt->warm_used);
+            span_begin(rt, rt->iter_spans, rt->iter_used);
             if (launch_iterate_lean(ba, block, R, pipe, hint_bytes, mode == 2, rt->stream) != 0) {
                 set_error("bad chunk_records / depth_pipe");
                 return SAR_ERR_INVALID;
@@ -690,6 +693,7 @@ int sar_runtime_free(sar_runtime* rt) {
     if (rt->starts_copied) hipEventDestroy(rt->starts_copied);
     for (auto& s : rt->iter_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto& s : rt->fold_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    for (auto& s : rt->warm_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     if (rt->colorize_span.a) { hipEventDestroy(rt->colorize_span.a); hipEventDestroy(rt->colorize_span.b); }
     if (rt->merge_span.a) { hipEventDestroy(rt->merge_span.a); hipEventDestroy(rt->merge_span.b); }
     if (rt->own_stream && rt->stream) hipStreamDestroy(rt->stream);
@@ -1065,6 +1069,8 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
         if (hipEventElapsedTime(&ms, rt->iter_spans[k].a, rt->iter_spans[k].b) == hipSuccess) out->iterate_ms += ms;
     for (size_t k = 0; k < rt->fold_used; ++k)
         if (hipEventElapsedTime(&ms, rt->fold_spans[k].a, rt->fold_spans[k].b) == hipSuccess) out->resolve_ms += ms;
+    for (size_t k = 0; k < rt->warm_used; ++k)
+        if (hipEventElapsedTime(&ms, rt->warm_spans[k].a, rt->warm_spans[k].b) == hipSuccess) out->warmup_ms += ms;
     if (rt->colorize_timed && hipEventElapsedTime(&ms, rt->colorize_span.a, rt->colorize_span.b) == hipSuccess) out->colorize_ms = ms;
     if (rt->merge_timed && hipEventElapsedTime(&ms, rt->merge_span.a, rt->merge_span.b) == hipSuccess) out->merge_ms = ms;
     out->iterate_launches = static_cast<uint32_t>(rt->iter_used);
@@ -1088,6 +1094,7 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
         rt->last_iterations = 0;
         rt->iter_used = 0;
         rt->fold_used = 0;
+        rt->warm_used = 0;
     }
     return SAR_OK;
 }
@@ -1130,6 +1137,7 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
         rt->last_iterations = 0;
         rt->iter_used = 0;
         rt->fold_used = 0;
+        rt->warm_used = 0;
     } else if (!std::strcmp(name, "debug_chunk_jobs")) {
         rt->debug_chunk_jobs = v;
     } else {
