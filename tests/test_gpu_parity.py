@@ -452,3 +452,23 @@ def test_device_resident_start_points_give_the_same_bits(sar, oracle, gpu):
         rt.set_tuning(variant=cap << 8)
         sar.render_job_range_device(cfg, rt, jobs, n, dev.data_ptr())
         assert_state_equal(rt, ort, f"device starts, chunk cap {cap}")
+
+
+def test_every_job_diverging_in_the_warm_up(sar, oracle, gpu):
+    """No trajectory survives the warm-up (start points far outside the basin): the hot kernel has nothing to do, every
+    counted iteration lands on pixel (0,0) (reference src/lib.rs:789, 800-802) and the depth buffer stays empty."""
+    jobs, n = 300, 250
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=64, height=48, jobs_total=jobs)
+    st = np.full((jobs, 3), 50.0) + np.arange(jobs)[:, None]
+    rt, ort = sar.Runtime(cfg), oracle.Runtime(64, 48)
+    sar.render_jobs(cfg, rt, st)
+    oracle.render_jobs(cfg.c, ort, st, n)
+    assert_state_equal(rt, ort, "all jobs NaN")
+    assert rt.count()[0, 0] == jobs * n and rt.count().sum() == jobs * n
+    # a mix: the same diverging jobs interleaved with ordinary ones
+    st2 = sar.start_points(3, 0, jobs)
+    st2[::3] = st[::3]
+    rt2, ort2 = sar.Runtime(cfg), oracle.Runtime(64, 48)
+    sar.render_jobs(cfg, rt2, st2)
+    oracle.render_jobs(cfg.c, ort2, st2, n)
+    assert_state_equal(rt2, ort2, "every third job NaN")
