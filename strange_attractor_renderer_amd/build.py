@@ -83,7 +83,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print("fused-fp64 audit:", {k[:60]: v for k, v in counts.items()})
     tmp = OUT + ".tmp"
-    subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-lz", "-o", tmp], check=True)  # zlib: PNG export
+    subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-lz", "-lpthread", "-o", tmp], check=True)  # zlib: PNG export
     os.replace(tmp, OUT)
     return OUT
 

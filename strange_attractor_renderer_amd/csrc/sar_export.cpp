@@ -4,8 +4,10 @@
 // same samples"  and tests/test_export.py decodes every file it writes.
 #include <zlib.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "sar_internal.hpp"
@@ -119,64 +121,106 @@ int sar_write_png(const char* path, int format, uint32_t width, uint32_t height,
     }
     const size_t bpp = static_cast<size_t>(l.channels) * l.bytes_per_sample;
     const size_t row = static_cast<size_t>(width) * bpp;
-    // scanlines with PNG byte order (16-bit samples are big-endian in the file), each behind its filter byte
-    std::vector<unsigned char> prev(row), cur(row), best(row), trial(row);
-    z_stream zs;
-    std::memset(&zs, 0, sizeof(zs));
-    if (deflateInit(&zs, Z_DEFAULT_COMPRESSION) != Z_OK) {  // png::CompressionType::Default (:88)
-        set_error("deflateInit failed");
-        return SAR_ERR_OOM;
-    }
-    std::vector<unsigned char> idat;
-    std::vector<unsigned char> zbuf(1u << 16);
-    auto pump = [&](int flush) {
-        int rc;
-        do {
-            zs.next_out = zbuf.data();
-            zs.avail_out = static_cast<uInt>(zbuf.size());
-            rc = deflate(&zs, flush);
-            idat.insert(idat.end(), zbuf.data(), zbuf.data() + (zbuf.size() - zs.avail_out));
-        } while (zs.avail_out == 0 && rc != Z_STREAM_END);
-    };
     const unsigned char* src = static_cast<const unsigned char*>(pixels);
-    for (uint32_t y = 0; y < height; ++y) {
+
+    // The zlib stream is produced in bands of kBandRows scanlines that are filtered and deflated independently — raw
+    // deflate, every band but the last closed with a sync flush (byte aligned), adler32 combined afterwards — so that
+    // the bands can be encoded by several threads (a 1920x1080 RGB16 frame takes 0.3 s on one thread, 40x the time
+    // the GPU needs to render it). The band size is fixed: the file does not depend on the number of threads.
+    constexpr uint32_t kBandRows = 64;
+    const uint32_t bands = (height + kBandRows - 1) / kBandRows;
+    struct Band {
+        std::vector<unsigned char> z;
+        uLong adler = 1;
+        uLong raw_len = 0;
+        bool ok = false;
+    };
+    std::vector<Band> out(bands);
+    // scanline in PNG byte order (16-bit samples are big-endian in the file)
+    auto load_row = [&](uint32_t y, unsigned char* dst) {
         const unsigned char* in = src + static_cast<size_t>(y) * row;
         if (l.bytes_per_sample == 2) {
             const uint16_t* s16 = reinterpret_cast<const uint16_t*>(in);
             for (size_t k = 0; k < row / 2; ++k) {
-                cur[2 * k] = static_cast<unsigned char>(s16[k] >> 8);
-                cur[2 * k + 1] = static_cast<unsigned char>(s16[k]);
+                dst[2 * k] = static_cast<unsigned char>(s16[k] >> 8);
+                dst[2 * k + 1] = static_cast<unsigned char>(s16[k]);
             }
         } else {
-            std::memcpy(cur.data(), in, row);
+            std::memcpy(dst, in, row);
         }
-        // png::FilterType::Adaptive (:89): per row, the filter with the smallest sum of absolute differences
-        int best_type = 0;
-        uint64_t best_score = png_filter_row(0, cur.data(), y ? prev.data() : nullptr, row, bpp, best.data());
-        for (int t = 1; t <= 4; ++t) {
-            const uint64_t sc = png_filter_row(t, cur.data(), y ? prev.data() : nullptr, row, bpp, trial.data());
-            if (sc < best_score) {
-                best_score = sc;
-                best_type = t;
-                best.swap(trial);
+    };
+    auto encode_band = [&](uint32_t b) {
+        Band& o = out[b];
+        const uint32_t y0 = b * kBandRows, y1 = (y0 + kBandRows < height) ? y0 + kBandRows : height;
+        std::vector<unsigned char> prev(row), cur(row), best(row), trial(row), filtered;
+        filtered.reserve((row + 1) * (y1 - y0));
+        if (y0) load_row(y0 - 1, prev.data());
+        for (uint32_t y = y0; y < y1; ++y) {
+            load_row(y, cur.data());
+            // png::FilterType::Adaptive (:89): per row, the filter with the smallest sum of absolute differences
+            int best_type = 0;
+            uint64_t best_score = png_filter_row(0, cur.data(), y ? prev.data() : nullptr, row, bpp, best.data());
+            for (int t = 1; t <= 4; ++t) {
+                const uint64_t sc = png_filter_row(t, cur.data(), y ? prev.data() : nullptr, row, bpp, trial.data());
+                if (sc < best_score) {
+                    best_score = sc;
+                    best_type = t;
+                    best.swap(trial);
+                }
             }
+            filtered.push_back(static_cast<unsigned char>(best_type));
+            filtered.insert(filtered.end(), best.begin(), best.end());
+            prev.swap(cur);
         }
-        unsigned char ft = static_cast<unsigned char>(best_type);
-        zs.next_in = &ft;
-        zs.avail_in = 1;
-        pump(Z_NO_FLUSH);
-        zs.next_in = best.data();
-        zs.avail_in = static_cast<uInt>(row);
-        pump(Z_NO_FLUSH);
-        prev.swap(cur);
+        o.raw_len = static_cast<uLong>(filtered.size());
+        o.adler = adler32(adler32(0L, Z_NULL, 0), filtered.data(), static_cast<uInt>(filtered.size()));
+        z_stream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        // png::CompressionType::Default (:88) = zlib's default level; raw deflate (the zlib wrapper is written once)
+        if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return;
+        o.z.resize(deflateBound(&zs, o.raw_len) + 16);
+        zs.next_in = filtered.data();
+        zs.avail_in = static_cast<uInt>(filtered.size());
+        zs.next_out = o.z.data();
+        zs.avail_out = static_cast<uInt>(o.z.size());
+        const bool last = b + 1 == bands;
+        const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
+        o.ok = last ? rc == Z_STREAM_END : (rc == Z_OK && zs.avail_in == 0 && zs.avail_out != 0);
+        o.z.resize(o.z.size() - zs.avail_out);
+        deflateEnd(&zs);
+    };
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        unsigned nthreads = hw ? hw : 1;
+        if (nthreads > 16) nthreads = 16;
+        if (nthreads > bands) nthreads = bands;
+        std::atomic<uint32_t> next{0};
+        auto worker = [&]() {
+            for (uint32_t b = next.fetch_add(1); b < bands; b = next.fetch_add(1)) encode_band(b);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& t : pool) t.join();
     }
-    zs.next_in = nullptr;
-    zs.avail_in = 0;
-    pump(Z_FINISH);
-    deflateEnd(&zs);
+    std::vector<unsigned char> idat;
+    idat.push_back(0x78);  // zlib header: deflate, 32 KiB window; FLEVEL = default; FCHECK makes it a multiple of 31
+    idat.push_back(0x9C);
+    uLong adler = adler32(0L, Z_NULL, 0);
+    for (uint32_t b = 0; b < bands; ++b) {
+        if (!out[b].ok) {
+            set_error("deflate failed in band %u", b);
+            return SAR_ERR_OOM;
+        }
+        idat.insert(idat.end(), out[b].z.begin(), out[b].z.end());
+        adler = adler32_combine(adler, out[b].adler, static_cast<z_off_t>(out[b].raw_len));
+    }
+    unsigned char ad[4];
+    be32(ad, static_cast<uint32_t>(adler));
+    idat.insert(idat.end(), ad, ad + 4);
 
-    File out(path);
-    if (!out.f) return io_error(path);
+    File fout(path);
+    if (!fout.f) return io_error(path);
     static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     unsigned char ihdr[13];
     be32(ihdr, width);
@@ -184,13 +228,13 @@ int sar_write_png(const char* path, int format, uint32_t width, uint32_t height,
     ihdr[8] = static_cast<unsigned char>(8 * l.bytes_per_sample);  // bit depth
     ihdr[9] = l.channels == 4 ? 6 : 2;                              // colour type: RGBA / RGB
     ihdr[10] = ihdr[11] = ihdr[12] = 0;                             // deflate, adaptive filtering, no interlace
-    bool ok = out.put(sig, 8) && png_chunk(out, "IHDR", ihdr, 13);
+    bool ok = fout.put(sig, 8) && png_chunk(fout, "IHDR", ihdr, 13);
     // one IDAT chunk per 1 GiB at most (a chunk length is 31 bits)
     for (size_t off = 0; ok && off < idat.size(); off += (1u << 30)) {
         const size_t n = idat.size() - off < (1u << 30) ? idat.size() - off : (1u << 30);
-        ok = png_chunk(out, "IDAT", idat.data() + off, n);
+        ok = png_chunk(fout, "IDAT", idat.data() + off, n);
     }
-    ok = ok && png_chunk(out, "IEND", nullptr, 0);
+    ok = ok && png_chunk(fout, "IEND", nullptr, 0);
     return ok ? SAR_OK : io_error(path);
 }
 

@@ -156,3 +156,20 @@ def test_write_image_matches_end_to_end(sar, oracle, gpu, tmp_path):
             else:
                 with pytest.raises(ValueError):
                     sar.write_image_matches(cfg, rt, path, transparent, False, bmp=True)
+
+
+REF_PNG = "/root/reference/media/poisson-saturne.png"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PNG), reason="the reference checkout is only present in the build container")
+def test_reencoding_the_reference_png_gives_the_same_samples_and_file_size(sar, tmp_path):
+    """The one PNG the reference ships, decoded and encoded again by sar_write_png: identical samples, and a file within
+    0.5 % of the original's size — i.e. the same encoder settings (default compression, per-row adaptive filter,
+    src/bin/main.rs:84-92); the bytes themselves differ because the crate deflates with miniz_oxide, not zlib."""
+    im = D.decode_png(REF_PNG)
+    assert im.shape == (1080, 1920, 3) and im.dtype == np.uint16
+    out = str(tmp_path / "again.png")
+    sar.write_image(im, out, "png")
+    np.testing.assert_array_equal(D.decode_png(out), im)
+    ref_size, size = os.path.getsize(REF_PNG), os.path.getsize(out)
+    assert abs(size / ref_size - 1.0) < 0.005, (size, ref_size)
