@@ -90,3 +90,37 @@ def render_sequence(config: "api.Config", start: float, end: float, step: float,
             rt.close()
         renderer.shutdown()
     return out
+
+
+def render_sequence_to_files(config: "api.Config", start: float, end: float, step: float, *, file_name: str = "attractor.png",
+                             eight_bit: bool = False, pam: bool = False, bmp: bool = False, encoders: int = 2,
+                             **kw) -> list[str]:
+    """The `sequence` subcommand end to end for this rank's frames: render, convert by (config.transparent, 8bit) and
+    encode, with the encoding of frame k overlapping the rendering of frame k+1 on `encoders` extra threads — what the
+    reference CLI does with its writer threads (src/bin/main.rs:493-517). Returns the paths written, in frame order."""
+    from concurrent.futures import ThreadPoolExecutor
+    if (pam or bmp) and not eight_bit:
+        raise ValueError("--pam / --bmp require --8bit (src/bin/main.rs:256-258)")
+    kind = "pam" if pam else ("bmp" if bmp else "png")
+    fmt = api.image_format(bool(config.c.transparent), eight_bit)
+    pending = []
+
+    def encode(image: np.ndarray, path: str) -> str:
+        api.write_image(image, path, kind)
+        return path
+
+    with ThreadPoolExecutor(max_workers=max(1, encoders)) as pool:
+        def sink(k: int, name: str, rgba16: np.ndarray):
+            # the same conversions as write_image_matches (:52-57), on the host copy the frame loop already made
+            if fmt == api._abi.SAR_FMT_RGBA16:
+                img = rgba16
+            elif fmt == api._abi.SAR_FMT_RGB16:
+                img = np.ascontiguousarray(rgba16[..., :3])
+            else:
+                img8 = ((rgba16.astype(np.uint32) + 128) // 257).astype(np.uint8)
+                img = img8 if fmt == api._abi.SAR_FMT_RGBA8 else np.ascontiguousarray(img8[..., :3])
+            path = os.path.splitext(name)[0] + "." + kind
+            pending.append(pool.submit(encode, img, path))
+
+        render_sequence(config, start, end, step, file_name=file_name, sink=sink, **kw)
+        return [f.result() for f in pending]

@@ -1,5 +1,6 @@
 """The `sequence` angle iterator (reference src/bin/main.rs:107-176) and the frame-per-GPU driver."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -58,3 +59,25 @@ def test_sequence_frames_match_oracle_and_do_not_depend_on_world_size(sar, oracl
         ort = oracle.Runtime(180, 200)
         oracle.render_jobs(c.c, ort, oracle.start_points(seed, k * units * jpt, units * jpt), n)
         np.testing.assert_array_equal(img, oracle.colorize(c.c, ort))
+
+
+@pytest.mark.gpu
+def test_sequence_to_files_overlapped_encoding(sar, oracle, gpu, tmp_path):
+    """render_sequence_to_files: frames rendered, converted and encoded on writer threads; every file decodes to the
+    oracle's frame (start points continue across frames, runtime reset per frame)."""
+    import image_decode as D
+    from strange_attractor_renderer_amd.sequence import frames, render_sequence_to_files
+    jobs_per_thread, units, n_total = 3, 64, 192 * 400
+    cfg = sar.Config.solar_sail(iterations=n_total, width=96, height=80, scale=1.0, transparent=0)
+    paths = render_sequence_to_files(cfg, 0.0, 40.0, 10.0, file_name=str(tmp_path / "f.png"), eight_bit=True, units=units,
+                                     jobs_per_thread=jobs_per_thread, seed=9)
+    fl = frames(0.0, 40.0, 10.0, str(tmp_path / "f.png"))
+    assert [os.path.basename(p) for p in paths] == [os.path.basename(f) for (_, _, f) in fl] and len(paths) == 4
+    total_jobs = units * jobs_per_thread
+    per_job = n_total // units // jobs_per_thread
+    for (k, angle, _), path in zip(fl, paths):
+        c = cfg.replace(angle=angle, jobs_total=total_jobs, iterations=per_job * total_jobs)
+        ort = oracle.Runtime(96, 80)
+        oracle.render_jobs(c.c, ort, oracle.start_points(9, k * total_jobs, total_jobs), per_job)
+        want = oracle.convert(3, oracle.colorize(c.c, ort))
+        np.testing.assert_array_equal(D.decode_png(path), want)
