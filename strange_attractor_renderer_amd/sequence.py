@@ -10,8 +10,10 @@ an angle sweep rendered one frame per GPU. SURVEY.md section 8(f)-1.
     that count is <= 1 (main.rs:118-123); the extension is whatever the file name had.
 
 `render_sequence` renders frame k on rank k % world with the semantics of one ParallelRenderer rendering the
-frames in order: the runtime is reset per frame (src/lib.rs:950-951) and the start-point stream continues across
-frames (the reference's per-thread RNGs persist), so a frame does not depend on the number of GPUs.
+frames in order: the runtime is reset per frame (src/lib.rs:950-951) and every frame draws fresh start points (the
+reference's per-thread RNGs simply run on across frames). Frame k's points are the first `jobs` of the stream seeded
+with `frame_seed(seed, k)`: a frame does not depend on the number of GPUs, and no rank has to skip through the
+points of the frames it does not own (a continued stream costs 4e6 draws per frame at 8 GPUs: more than rendering).
 """
 from __future__ import annotations
 
@@ -57,12 +59,18 @@ def frames(start: float, end: float, step: float, file_name: str = "attractor") 
     return [(k, a, f) for k, (a, f) in enumerate(angle_iter(start, end, step, file_name))]
 
 
+def frame_seed(seed: int, k: int) -> int:
+    """Seed of frame k's start-point stream (SplitMix64's increment keeps consecutive frames far apart)."""
+    return (seed + 0x9E3779B97F4A7C15 * (k + 1)) & 0xFFFFFFFFFFFFFFFF
+
+
 def render_sequence(config: "api.Config", start: float, end: float, step: float, *, units: int = 0,
                     jobs_per_thread: int = 12, seed: int = 0, rank: int = 0, world: int = 1, device: int = 0,
-                    file_name: str = "attractor",
+                    file_name: str = "attractor", image_format: int | None = None,
                     sink: Callable[[int, str, np.ndarray], None] | None = None) -> list[tuple[int, str, np.ndarray]]:
     """Renders this rank's frames of the sweep (frame k belongs to rank k % world; no collective is needed).
-    Returns [(frame index, file name, RGBA16 image)] unless `sink` consumes the frames."""
+    Returns [(frame index, file name, image)] unless `sink` consumes the frames. The image is RGBA16, or — with
+    `image_format` (SAR_FMT_*) — the CLI's converted format, converted on the device before the read-back."""
     todo = [(k, a, f) for (k, a, f) in frames(start, end, step, file_name) if k % world == rank]
     out = []
     if not todo:
@@ -78,9 +86,9 @@ def render_sequence(config: "api.Config", start: float, end: float, step: float,
             if rt is None:
                 rt = api.Runtime(cfg, device=device)
             rt.reset()                                            # :950-951
-            starts = api.start_points(seed, k * total_jobs, total_jobs)   # the renderer's stream, frame k
+            starts = api.start_points(frame_seed(seed, k), 0, total_jobs)
             api.render_jobs(cfg, rt, starts)
-            img = api.colorize(cfg, rt)                           # :1080
+            img = api.colorize(cfg, rt) if image_format is None else api.colorize_format(cfg, rt, image_format)  # :1080
             if sink is not None:
                 sink(k, name, img)
             else:
@@ -93,7 +101,7 @@ def render_sequence(config: "api.Config", start: float, end: float, step: float,
 
 
 def render_sequence_to_files(config: "api.Config", start: float, end: float, step: float, *, file_name: str = "attractor.png",
-                             eight_bit: bool = False, pam: bool = False, bmp: bool = False, encoders: int = 2,
+                             eight_bit: bool = False, pam: bool = False, bmp: bool = False, encoders: int = 4,
                              **kw) -> list[str]:
     """The `sequence` subcommand end to end for this rank's frames: render, convert by (config.transparent, 8bit) and
     encode, with the encoding of frame k overlapping the rendering of frame k+1 on `encoders` extra threads — what the
@@ -110,17 +118,8 @@ def render_sequence_to_files(config: "api.Config", start: float, end: float, ste
         return path
 
     with ThreadPoolExecutor(max_workers=max(1, encoders)) as pool:
-        def sink(k: int, name: str, rgba16: np.ndarray):
-            # the same conversions as write_image_matches (:52-57), on the host copy the frame loop already made
-            if fmt == api._abi.SAR_FMT_RGBA16:
-                img = rgba16
-            elif fmt == api._abi.SAR_FMT_RGB16:
-                img = np.ascontiguousarray(rgba16[..., :3])
-            else:
-                img8 = ((rgba16.astype(np.uint32) + 128) // 257).astype(np.uint8)
-                img = img8 if fmt == api._abi.SAR_FMT_RGBA8 else np.ascontiguousarray(img8[..., :3])
-            path = os.path.splitext(name)[0] + "." + kind
-            pending.append(pool.submit(encode, img, path))
+        def sink(k: int, name: str, img: np.ndarray):  # img is already in the file's format (converted on the device)
+            pending.append(pool.submit(encode, img, os.path.splitext(name)[0] + "." + kind))
 
-        render_sequence(config, start, end, step, file_name=file_name, sink=sink, **kw)
+        render_sequence(config, start, end, step, file_name=file_name, image_format=fmt, sink=sink, **kw)
         return [f.result() for f in pending]
