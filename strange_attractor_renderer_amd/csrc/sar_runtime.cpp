@@ -306,10 +306,241 @@ int check_cfg_matches(const sar_config* cfg, const sar_runtime* rt) {
     return SAR_OK;
 }
 
-// Runs n_jobs trajectories of `iters` counted iterations each; starts is AoS [n_jobs][3] on the host.
-// Sequential semantics (job-major, iteration-minor). Launch chunks keep job*iters + t inside 32 bits
-// and the checkpoint scratch inside kCkptBytesCap; chunk boundaries fall on whole jobs, and a later
-// chunk only replaces a depth winner with a strictly greater z, exactly like a later render call.
+// Grows a device buffer (contents are not preserved). cap and need in elements of T.
+template <typename T>
+int grow_device(T*& ptr, size_t& cap, size_t need) {
+    if (need <= cap) return SAR_OK;
+    if (ptr) hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ptr), need * sizeof(T)));
+    cap = need;
+    return SAR_OK;
+}
+
+// Everything one render call decides before it launches: which accumulate path, its geometry, and how the job list is
+// cut into launch chunks (chunk boundaries fall on whole jobs; a chunk keeps job*iters + t inside 32 bits and its
+// scratch inside kCkptBytesCap).
+struct LaunchPlan {
+    bool binned = false, xcd_local = false;
+    BinGeometry geo;
+    uint32_t R = kDefaultChunkRecords;  // records per chunk
+    uint32_t block = 0;                 // trajectories per workgroup of the iterate kernel
+    uint32_t pipe = kDefaultDepthPipe;  // depth pipeline length
+    uint32_t hint_bytes = 4;            // per-XCD depth hints: 2 (fixed point) or 4 (sortable f32)
+    uint32_t C = 0;                     // checkpoint stride
+    uint32_t splits = 0;                // accumulate workgroups per bin
+    uint64_t n_ckpt = 0, chunks_per_wave = 0, chunk_jobs = 0;
+    uint32_t max_waves = 0;             // waves of the largest launch chunk
+};
+
+// Records per chunk: the largest of 28/20/12 whose per-wave LDS staging still fits the waves this launch can use — up to
+// 3 per SIMD (more jobs than that run in rounds), at least 2. Measured at 2048^2, 1e9 iterations: 131072 jobs with 28
+// records and 196608 jobs with 20 end within 2 % of each other; at 4096^2 12 records (2 waves/SIMD) beat 28 (1 wave/
+// SIMD) by 1.4x. The job count is scaled by the share of jobs that survived the previous launch's warm-up.
+uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs) {
+    if (rt->chunk_records) return rt->chunk_records;
+    const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u);
+    if (!probe.ok) return kDefaultChunkRecords;
+    if (rt->active_pending && hipEventQuery(rt->active_copied) == hipSuccess) {
+        rt->active_pending = false;
+        if (rt->active_jobs_launched) rt->survivor_fraction = static_cast<double>(*rt->h_active) / rt->active_jobs_launched;
+    }
+    const uint64_t cus = rt->sm_count ? rt->sm_count : 256u;
+    const uint64_t busy = static_cast<uint64_t>(n_jobs * rt->survivor_fraction + 0.5);
+    uint64_t want = (busy + 64u * cus - 1) / (64u * cus);  // waves per CU if all surviving jobs were resident
+    want = ((want + 3) / 4) * 4;  // workgroups are four waves: residency comes in steps of four waves per CU
+    want = want < 8 ? 8 : (want > 12 ? 12 : want);
+    for (uint32_t need : {static_cast<uint32_t>(want), 8u})
+        for (uint32_t cand : {28u, 20u, 12u})
+            if (lean_wave_lds_bytes(probe.bins, cand) * need <= 160u * 1024u) return cand;
+    return 12u;
+}
+
+int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, LaunchPlan& pl) {
+    pl.R = choose_chunk_records(rt, n_jobs);
+    pl.geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, pl.R);
+    // which accumulate path: LDS-binned records (default) or one global atomic per visit
+    pl.binned = (rt->bins_mode == 0 || rt->bins_mode == 3) && rt->measure_mode != 2 && pl.geo.ok;
+    if (rt->bins_mode == 3 && !pl.geo.ok) {
+        set_error("the binned path needs width*height <= %u pixels", kMaxBins * kMaxBinPx);
+        return SAR_ERR_RANGE;
+    }
+    pl.xcd_local = (rt->bins_mode == 2);
+    pl.block = pl.binned ? pl.geo.block : rt->block_threads;
+    pl.pipe = rt->depth_pipe ? rt->depth_pipe : kDefaultDepthPipe;
+    // depth hints: the sortable f32 itself (3x fewer stage-2 waits, -7 % at 2048^2) while the hints of the pixels the
+    // attractor touches stay near an XCD's 4 MiB L2, 16-bit fixed point beyond. The view maps the attractor onto
+    // (width * scale)^2 pixels whatever the height, so that is the measure: 32-bit wins at 2048^2 / 2560^2 / 3072^2,
+    // 16-bit at 3840x2160 (-8 %) and 4096^2 (-13 %).
+    const double span = static_cast<double>(cfg->width) * cfg->scale;
+    pl.hint_bytes = rt->hint_bits ? rt->hint_bits / 8u : ((span * span <= kWideHintMaxSpan2 && rt->npix <= (16u << 20)) ? 4u : 2u);
+    // checkpoint stride: a multiple of the depth pipeline's pass length (the iterate kernel runs whole passes)
+    pl.C = ((rt->ckpt_stride + pl.pipe - 1u) / pl.pipe) * pl.pipe;
+    pl.n_ckpt = (iters + pl.C - 1) / pl.C;
+    pl.chunks_per_wave = (iters * 64ull + pl.R - 1) / pl.R + pl.geo.bins;
+    if (pl.binned && pl.chunks_per_wave > 0xFFFFFFF0ull) pl.binned = false;
+    pl.chunk_jobs = kMaxChunkOrdinals / iters;
+    // scratch per job: checkpoints (24 B each) + its share of the wave's record arena (binned path)
+    const uint64_t bytes_per_job = pl.n_ckpt * 24ull + (pl.binned ? pl.chunks_per_wave : 0ull);
+    const uint64_t by_mem = kCkptBytesCap / bytes_per_job;
+    if (by_mem < pl.chunk_jobs) pl.chunk_jobs = by_mem ? by_mem : 1;
+    if (rt->debug_chunk_jobs && rt->debug_chunk_jobs < pl.chunk_jobs) pl.chunk_jobs = rt->debug_chunk_jobs;
+    if (pl.chunk_jobs > n_jobs) pl.chunk_jobs = n_jobs;
+    if (pl.chunk_jobs > pl.block) pl.chunk_jobs -= pl.chunk_jobs % pl.block;
+    pl.max_waves = static_cast<uint32_t>(((pl.chunk_jobs + pl.block - 1) / pl.block) * (pl.block / 64u));
+    pl.splits = pl.geo.splits;
+    if (pl.binned && pl.splits == 0) {
+        // k_bin_accumulate walks one (bin, wave) list per group of lanes (4, or 2 with 32-byte chunks): aim at one
+        // list per group, and at enough blocks to cover the chip when only a band of bins is populated
+        const uint32_t threads = rt->acc_threads ? rt->acc_threads : 1024u;
+        const uint32_t groups = threads / (pl.R == 12u ? 2u : 4u);
+        pl.splits = (pl.max_waves + groups - 1u) / groups;
+        const uint32_t cover = 2048u / pl.geo.bins;
+        if (pl.splits < cover) pl.splits = cover;
+        if (pl.splits < 1) pl.splits = 1;
+        if (pl.splits > 16) pl.splits = 16;
+    }
+    return SAR_OK;
+}
+
+// Start points into rt->d_starts, laid out as consecutive per-chunk SoA blocks x[m] y[m] z[m]; `starts` is the caller's
+// [n_jobs][3] array in host memory (through one pinned staging buffer) or already in device memory.
+int stage_starts(sar_runtime* rt, const LaunchPlan& pl, uint32_t n_jobs, const double* starts, bool on_device) {
+    const size_t need = static_cast<size_t>(n_jobs) * 3;
+    if (rt->starts_pending) {  // the previous call's upload still reads the staging buffer
+        HIP_TRY(hipEventSynchronize(rt->starts_copied));
+        rt->starts_pending = false;
+    }
+    if (need > rt->starts_cap) {
+        if (rt->h_starts) hipHostFree(rt->h_starts);
+        if (rt->d_starts) hipFree(rt->d_starts);
+        rt->h_starts = nullptr;
+        rt->d_starts = nullptr;
+        rt->starts_cap = 0;
+        HIP_TRY(hipHostMalloc(&rt->h_starts, need * sizeof(double), hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&rt->d_starts, need * sizeof(double)));
+        rt->starts_cap = need;
+    }
+    if (on_device) {
+        for (uint64_t off = 0; off < n_jobs; off += pl.chunk_jobs) {
+            const uint32_t m = static_cast<uint32_t>((n_jobs - off < pl.chunk_jobs) ? n_jobs - off : pl.chunk_jobs);
+            launch_starts_soa(starts + off * 3, rt->d_starts + off * 3, m, rt->stream);
+        }
+        HIP_TRY(hipGetLastError());
+        return SAR_OK;
+    }
+    for (uint64_t off = 0; off < n_jobs; off += pl.chunk_jobs) {
+        const uint64_t m = (n_jobs - off < pl.chunk_jobs) ? n_jobs - off : pl.chunk_jobs;
+        double* blk = rt->h_starts + off * 3;
+        for (uint64_t k = 0; k < m; ++k) {
+            blk[k] = starts[(off + k) * 3 + 0];
+            blk[m + k] = starts[(off + k) * 3 + 1];
+            blk[2 * m + k] = starts[(off + k) * 3 + 2];
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(rt->d_starts, rt->h_starts, need * sizeof(double), hipMemcpyHostToDevice, rt->stream));
+    HIP_TRY(hipEventRecord(rt->starts_copied, rt->stream));
+    rt->starts_pending = true;
+    return SAR_OK;
+}
+
+// Device buffers of the binned path: record arena, list heads, depth hints, warm-up output, counters.
+int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
+    static std::once_flag attr_once;
+    static int attr_status = 0;
+    std::call_once(attr_once, [] { attr_status = binned_kernel_attributes(); });
+    if (attr_status != 0) { set_error("hipFuncSetAttribute(max dynamic LDS) failed: %d", attr_status); return SAR_ERR_HIP; }
+    {
+        char* arena = static_cast<char*>(rt->d_arena);
+        const int rc = grow_device(arena, rt->arena_cap, static_cast<size_t>(pl.max_waves) * pl.chunks_per_wave * chunk_bytes(pl.R));
+        rt->d_arena = arena;  // also when the allocation failed: the old buffer is gone
+        SAR_TRY(rc);
+    }
+    SAR_TRY(grow_device(rt->d_heads, rt->heads_cap, static_cast<size_t>(pl.max_waves) * pl.geo.bins));
+    if (!rt->d_zhint || rt->zhint_bytes != pl.hint_bytes) {
+        if (rt->d_zhint) hipFree(rt->d_zhint);
+        rt->d_zhint = nullptr;
+        HIP_TRY(hipMalloc(&rt->d_zhint, (static_cast<size_t>(rt->npix) + 2u) * 8u * pl.hint_bytes));
+        rt->zhint_bytes = pl.hint_bytes;
+        SAR_TRY(clear_hints(rt));
+    }
+    if (pl.chunk_jobs > rt->warm_cap) {
+        size_t cap3 = 0, cap1 = 0;  // both buffers are replaced together
+        rt->warm_cap = 0;
+        SAR_TRY(grow_device(rt->d_warm, cap3, static_cast<size_t>(pl.chunk_jobs) * 3));
+        SAR_TRY(grow_device(rt->d_joblist, cap1, static_cast<size_t>(pl.chunk_jobs)));
+        rt->warm_cap = pl.chunk_jobs;
+    }
+    if (!rt->d_active) HIP_TRY(hipMalloc(&rt->d_active, sizeof(uint32_t)));
+    if (!rt->h_active) {
+        HIP_TRY(hipHostMalloc(&rt->h_active, sizeof(uint32_t), hipHostMallocDefault));
+        *rt->h_active = 0;
+        HIP_TRY(hipEventCreateWithFlags(&rt->active_copied, hipEventDisableTiming));
+    }
+    if (!rt->d_nan_count) {
+        // [0] NaN iterations, [1] depth atomics (stat), [2..5] segment cycles of the SAR_EXPERIMENT_PROF build
+        HIP_TRY(hipMalloc(&rt->d_nan_count, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, 8 * sizeof(unsigned long long), rt->stream));
+    }
+    return SAR_OK;
+}
+
+// One launch chunk of the binned path: warm-up + packing, iterate, accumulate, fold.
+int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& ia, const FoldArgs& fa, int mode) {
+    const uint32_t m = ia.n_jobs;
+    BinIterArgs ba;
+    std::memset(&ba, 0, sizeof(ba));
+    ba.it = ia;
+    ba.bin_shift = pl.geo.shift;
+    ba.n_bins = pl.geo.bins;
+    ba.chunks_per_wave = static_cast<uint32_t>(pl.chunks_per_wave);
+    ba.n_waves = ((m + pl.block - 1) / pl.block) * (pl.block / 64u);
+    ba.arena = rt->d_arena;
+    ba.heads = rt->d_heads;
+    ba.zhint = rt->d_zhint;
+    ba.warm = rt->d_warm;
+    ba.joblist = rt->d_joblist;
+    ba.active = rt->d_active;
+    ba.nan_count = rt->d_nan_count;
+    span_begin(rt, rt->warm_spans, rt->warm_used);
+    HIP_TRY(hipMemsetAsync(rt->d_active, 0, sizeof(uint32_t), rt->stream));
+    launch_warmup(ia.p, ia.starts, m, ia.iters, rt->d_warm, rt->d_joblist, rt->d_active, rt->d_nan_count, rt->stream);
+    if (!rt->active_pending) {  // statistics for the next call; nobody waits for this copy
+        if (hipMemcpyAsync(rt->h_active, rt->d_active, sizeof(uint32_t), hipMemcpyDeviceToHost, rt->stream) == hipSuccess &&
+            hipEventRecord(rt->active_copied, rt->stream) == hipSuccess) {
+            rt->active_pending = true;
+            rt->active_jobs_launched = m;
+        }
+    }
+    span_end(rt, rt->warm_spans, rt->warm_used);
+    span_begin(rt, rt->iter_spans, rt->iter_used);
+    if (launch_iterate_lean(ba, pl.block, pl.R, pl.pipe, pl.hint_bytes, mode == 2, rt->stream) != 0) {
+        set_error("bad chunk_records / depth_pipe");
+        return SAR_ERR_INVALID;
+    }
+    span_end(rt, rt->iter_spans, rt->iter_used);
+    BinAccArgs ca;
+    std::memset(&ca, 0, sizeof(ca));
+    ca.bin_shift = pl.geo.shift;
+    ca.n_bins = pl.geo.bins;
+    ca.chunks_per_wave = ba.chunks_per_wave;
+    ca.n_waves = ba.n_waves;
+    ca.npix = rt->npix;
+    ca.splits = pl.splits;
+    ca.arena = rt->d_arena;
+    ca.heads = rt->d_heads;
+    ca.scratch_count = rt->d_scratch_count;
+    span_begin(rt, rt->fold_spans, rt->fold_used);
+    launch_bin_accumulate(ca, rt->acc_threads, pl.R, rt->stream);
+    launch_fold_resolve(fa, rt->stream);
+    span_end(rt, rt->fold_spans, rt->fold_used);
+    return SAR_OK;
+}
+
+// Runs n_jobs trajectories of `iters` counted iterations each; starts is AoS [n_jobs][3] on the host (or, with
+// starts_on_device, in device memory). Sequential semantics (job-major, iteration-minor): a later launch chunk only
+// replaces a depth winner with a strictly greater z, exactly like a later render call.
 int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters,
                    const double* starts, bool starts_on_device = false) {
     if (!rt->timing_accumulate) {
@@ -326,186 +557,20 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
     }
     HIP_TRY(hipSetDevice(rt->device));
 
-    // which accumulate path: LDS-binned records (default) or one global atomic per visit
-    // records per chunk: the largest of 28/20/12 whose per-wave LDS staging still fits the waves this launch can
-    // use — up to 3 per SIMD (more jobs than that run in rounds), at least 2. Measured at 2048^2, 1e9 iterations:
-    // 131072 jobs 28 records 9.65 ms, 196608 jobs 20 records 9.29 ms; at 4096^2 12 records (2 waves/SIMD) beat
-    // 28 (1 wave/SIMD) by 1.4x.
-    uint32_t R = rt->chunk_records ? rt->chunk_records : kDefaultChunkRecords;
-    if (!rt->chunk_records) {
-        const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u);
-        const uint64_t cus = rt->sm_count ? rt->sm_count : 256u;
-        if (rt->active_pending && hipEventQuery(rt->active_copied) == hipSuccess) {
-            rt->active_pending = false;
-            if (rt->active_jobs_launched) rt->survivor_fraction = static_cast<double>(*rt->h_active) / rt->active_jobs_launched;
-        }
-        const uint64_t busy = static_cast<uint64_t>(n_jobs * rt->survivor_fraction + 0.5);
-        uint64_t want = (busy + 64u * cus - 1) / (64u * cus);  // waves per CU if all surviving jobs were resident
-        want = ((want + 3) / 4) * 4;  // workgroups are four waves: residency comes in steps of four waves per CU
-        want = want < 8 ? 8 : (want > 12 ? 12 : want);
-        if (probe.ok) {
-            bool found = false;
-            for (uint32_t need : {static_cast<uint32_t>(want), 8u})
-                for (uint32_t cand : {28u, 20u, 12u}) {
-                    if (found) break;
-                    if (lean_wave_lds_bytes(probe.bins, cand) * need <= 160u * 1024u) {
-                        R = cand;
-                        found = true;
-                    }
-                }
-            if (!found) R = 12u;
-        }
-    }
-    BinGeometry geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, R);
-    bool binned = (rt->bins_mode == 0 || rt->bins_mode == 3) && rt->measure_mode != 2 && geo.ok;
-    if (rt->bins_mode == 3 && !geo.ok) {
-        set_error("the binned path needs width*height <= %u pixels", kMaxBins * kMaxBinPx);
-        return SAR_ERR_RANGE;
-    }
-    const bool xcd_local = (rt->bins_mode == 2);
-    const uint32_t block = binned ? geo.block : rt->block_threads;
+    LaunchPlan pl;
+    SAR_TRY(plan_launch(cfg, rt, n_jobs, iters, pl));
+    SAR_TRY(ensure_scratch(rt, pl.binned ? pl.splits : (pl.xcd_local ? 8u : 1u), (!pl.binned && pl.xcd_local) ? 8u : 1u));
+    SAR_TRY(stage_starts(rt, pl, n_jobs, starts, starts_on_device));
+    SAR_TRY(grow_device(rt->d_ckpt, rt->ckpt_cap, static_cast<size_t>(pl.n_ckpt) * 3 * pl.chunk_jobs));
+    if (pl.binned) SAR_TRY(ensure_binned_buffers(rt, pl));
 
-    // checkpoint stride: a multiple of the depth pipeline's pass length (the iterate kernel runs whole passes)
-    const uint32_t pipe = rt->depth_pipe ? rt->depth_pipe : kDefaultDepthPipe;
-    // depth hints: the sortable f32 itself (3x fewer stage-2 waits, -7 % at 2048^2) while the hints of the pixels the
-    // attractor touches stay near an XCD's 4 MiB L2, 16-bit fixed point beyond. The view maps the attractor onto
-    // (width * scale)^2 pixels whatever the height, so that is the measure: 32-bit wins at 2048^2 / 2560^2 / 3072^2,
-    // 16-bit at 3840x2160 (-8 %) and 4096^2 (-13 %).
-    const double span = static_cast<double>(cfg->width) * cfg->scale;
-    const uint32_t hint_bytes = rt->hint_bits ? rt->hint_bits / 8u : ((span * span <= kWideHintMaxSpan2 && rt->npix <= (16u << 20)) ? 4u : 2u);
-    const uint32_t C = ((rt->ckpt_stride + pipe - 1u) / pipe) * pipe;
-    const uint64_t n_ckpt = (iters + C - 1) / C;
-    const uint64_t chunks_per_wave = (iters * 64ull + R - 1) / R + geo.bins;
-    uint64_t chunk_jobs = kMaxChunkOrdinals / iters;
-    // scratch per job: checkpoints (24 B each) + its share of the wave's record arena (binned path)
-    const uint64_t bytes_per_job = n_ckpt * 24ull + (binned ? chunks_per_wave : 0ull);
-    const uint64_t by_mem = kCkptBytesCap / bytes_per_job;
-    if (by_mem < chunk_jobs) chunk_jobs = by_mem ? by_mem : 1;
-    if (rt->debug_chunk_jobs && rt->debug_chunk_jobs < chunk_jobs) chunk_jobs = rt->debug_chunk_jobs;
-    if (chunk_jobs > n_jobs) chunk_jobs = n_jobs;
-    if (chunk_jobs > block) chunk_jobs -= chunk_jobs % block;
-    if (binned && chunks_per_wave > 0xFFFFFFF0ull) binned = false;
-
-    const uint32_t max_waves_pre = static_cast<uint32_t>(((chunk_jobs + block - 1) / block) * (block / 64u));
-    uint32_t splits = geo.splits;
-    if (binned && splits == 0) {
-        // k_bin_accumulate walks one (bin, wave) list per group of lanes (4, or 2 with 32-byte chunks): aim at one
-        // list per group, and at enough blocks to cover the chip when only a band of bins is populated
-        const uint32_t threads = rt->acc_threads ? rt->acc_threads : 1024u;
-        const uint32_t groups = threads / (R == 12u ? 2u : 4u);
-        splits = (max_waves_pre + groups - 1u) / groups;
-        const uint32_t cover = 2048u / geo.bins;
-        if (splits < cover) splits = cover;
-        if (splits < 1) splits = 1;
-        if (splits > 16) splits = 16;
-    }
-    SAR_TRY(ensure_scratch(rt, binned ? splits : (xcd_local ? 8u : 1u), (!binned && xcd_local) ? 8u : 1u));
-
-    // start points: one pinned staging buffer, laid out as consecutive per-chunk SoA blocks
-    const size_t need = static_cast<size_t>(n_jobs) * 3;
-    if (rt->starts_pending) {
-        HIP_TRY(hipEventSynchronize(rt->starts_copied));
-        rt->starts_pending = false;
-    }
-    if (need > rt->starts_cap) {
-        if (rt->h_starts) hipHostFree(rt->h_starts);
-        if (rt->d_starts) hipFree(rt->d_starts);
-        rt->h_starts = nullptr;
-        rt->d_starts = nullptr;
-        rt->starts_cap = 0;
-        HIP_TRY(hipHostMalloc(&rt->h_starts, need * sizeof(double), hipHostMallocDefault));
-        HIP_TRY(hipMalloc(&rt->d_starts, need * sizeof(double)));
-        rt->starts_cap = need;
-    }
-    if (starts_on_device) {
-        // the caller's [n_jobs][3] array is already in HBM: transpose it into the per-chunk SoA blocks on the device
-        for (uint64_t off = 0; off < n_jobs; off += chunk_jobs) {
-            const uint32_t m = static_cast<uint32_t>((n_jobs - off < chunk_jobs) ? n_jobs - off : chunk_jobs);
-            launch_starts_soa(starts + off * 3, rt->d_starts + off * 3, m, rt->stream);
-        }
-        HIP_TRY(hipGetLastError());
-    } else {
-        for (uint64_t off = 0; off < n_jobs; off += chunk_jobs) {
-            const uint64_t m = (n_jobs - off < chunk_jobs) ? n_jobs - off : chunk_jobs;
-            double* blk = rt->h_starts + off * 3;
-            for (uint64_t k = 0; k < m; ++k) {
-                blk[k] = starts[(off + k) * 3 + 0];
-                blk[m + k] = starts[(off + k) * 3 + 1];
-                blk[2 * m + k] = starts[(off + k) * 3 + 2];
-            }
-        }
-        HIP_TRY(hipMemcpyAsync(rt->d_starts, rt->h_starts, need * sizeof(double), hipMemcpyHostToDevice, rt->stream));
-        HIP_TRY(hipEventRecord(rt->starts_copied, rt->stream));
-        rt->starts_pending = true;
-    }
-
-    const size_t ckpt_need = static_cast<size_t>(n_ckpt) * 3 * chunk_jobs;
-    if (ckpt_need > rt->ckpt_cap) {
-        if (rt->d_ckpt) hipFree(rt->d_ckpt);
-        rt->d_ckpt = nullptr;
-        rt->ckpt_cap = 0;
-        HIP_TRY(hipMalloc(&rt->d_ckpt, ckpt_need * sizeof(double)));
-        rt->ckpt_cap = ckpt_need;
-    }
-
-    const uint32_t max_waves = static_cast<uint32_t>(((chunk_jobs + block - 1) / block) * (block / 64u));
-    if (binned) {
-        static std::once_flag attr_once;
-        static int attr_status = 0;
-        std::call_once(attr_once, [] { attr_status = binned_kernel_attributes(); });
-        if (attr_status != 0) { set_error("hipFuncSetAttribute(max dynamic LDS) failed: %d", attr_status); return SAR_ERR_HIP; }
-        const size_t arena_need = static_cast<size_t>(max_waves) * chunks_per_wave * chunk_bytes(R);
-        if (arena_need > rt->arena_cap) {
-            if (rt->d_arena) hipFree(rt->d_arena);
-            rt->d_arena = nullptr;
-            rt->arena_cap = 0;
-            HIP_TRY(hipMalloc(&rt->d_arena, arena_need));
-            rt->arena_cap = arena_need;
-        }
-        const size_t heads_need = static_cast<size_t>(max_waves) * geo.bins;
-        if (heads_need > rt->heads_cap) {
-            if (rt->d_heads) hipFree(rt->d_heads);
-            rt->d_heads = nullptr;
-            rt->heads_cap = 0;
-            HIP_TRY(hipMalloc(&rt->d_heads, heads_need * sizeof(uint32_t)));
-            rt->heads_cap = heads_need;
-        }
-        if (!rt->d_zhint || rt->zhint_bytes != hint_bytes) {
-            if (rt->d_zhint) hipFree(rt->d_zhint);
-            rt->d_zhint = nullptr;
-            HIP_TRY(hipMalloc(&rt->d_zhint, (static_cast<size_t>(rt->npix) + 2u) * 8u * hint_bytes));
-            rt->zhint_bytes = hint_bytes;
-            SAR_TRY(clear_hints(rt));
-        }
-        if (chunk_jobs > rt->warm_cap) {
-            if (rt->d_warm) hipFree(rt->d_warm);
-            if (rt->d_joblist) hipFree(rt->d_joblist);
-            rt->d_warm = nullptr;
-            rt->d_joblist = nullptr;
-            rt->warm_cap = 0;
-            HIP_TRY(hipMalloc(&rt->d_warm, static_cast<size_t>(chunk_jobs) * 3 * sizeof(double)));
-            HIP_TRY(hipMalloc(&rt->d_joblist, static_cast<size_t>(chunk_jobs) * sizeof(uint32_t)));
-            rt->warm_cap = chunk_jobs;
-        }
-        if (!rt->d_active) HIP_TRY(hipMalloc(&rt->d_active, sizeof(uint32_t)));
-        if (!rt->h_active) {
-            HIP_TRY(hipHostMalloc(&rt->h_active, sizeof(uint32_t), hipHostMallocDefault));
-            *rt->h_active = 0;
-            HIP_TRY(hipEventCreateWithFlags(&rt->active_copied, hipEventDisableTiming));
-        }
-        if (!rt->d_nan_count) {
-            // [0] NaN iterations, [1] depth atomics (stat), [2..5] segment cycles of the SAR_EXPERIMENT_PROF build
-            HIP_TRY(hipMalloc(&rt->d_nan_count, 8 * sizeof(unsigned long long)));
-            HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, 8 * sizeof(unsigned long long), rt->stream));
-        }
-    }
     IterArgs ia;
     std::memset(&ia, 0, sizeof(ia));
     fill_map_params(*cfg, ia.p);
     ia.iters = iters;
     ia.width = rt->W;
     ia.npix = rt->npix;
-    ia.ckpt_stride = C;
+    ia.ckpt_stride = pl.C;
     ia.scratch_count = rt->d_scratch_count;
     ia.scratch_key = rt->d_scratch_key;
     ia.ckpt = rt->d_ckpt;
@@ -516,10 +581,10 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
     fill_ct_params(*cfg, fa.ct);
     fa.iters = iters;
     fa.npix = rt->npix;
-    fa.ckpt_stride = C;
+    fa.ckpt_stride = pl.C;
     fa.copies = rt->copies;
     fa.key_copies = rt->key_copies;
-    fa.nan_count = binned ? rt->d_nan_count : nullptr;
+    fa.nan_count = pl.binned ? rt->d_nan_count : nullptr;
     fa.count = rt->d_count;
     fa.key = rt->d_key;
     fa.steps = rt->d_steps;
@@ -529,61 +594,16 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
     fa.scalars = rt->d_scalars;
 
     const int mode = rt->measure_mode == 0 ? 2 : (rt->measure_mode == 1 ? 1 : 0);
-    for (uint64_t off = 0; off < n_jobs; off += chunk_jobs) {
-        const uint32_t m = static_cast<uint32_t>((n_jobs - off < chunk_jobs) ? n_jobs - off : chunk_jobs);
+    for (uint64_t off = 0; off < n_jobs; off += pl.chunk_jobs) {
+        const uint32_t m = static_cast<uint32_t>((n_jobs - off < pl.chunk_jobs) ? n_jobs - off : pl.chunk_jobs);
         ia.n_jobs = m;
         ia.starts = rt->d_starts + off * 3;
         fa.n_jobs = m;
-        if (binned) {
-            BinIterArgs ba;
-            std::memset(&ba, 0, sizeof(ba));
-            ba.it = ia;
-            ba.bin_shift = geo.shift;
-            ba.n_bins = geo.bins;
-            ba.chunks_per_wave = static_cast<uint32_t>(chunks_per_wave);
-            ba.n_waves = ((m + block - 1) / block) * (block / 64u);
-            ba.arena = rt->d_arena;
-            ba.heads = rt->d_heads;
-            ba.zhint = rt->d_zhint;
-            ba.warm = rt->d_warm;
-            ba.joblist = rt->d_joblist;
-            ba.active = rt->d_active;
-            ba.nan_count = rt->d_nan_count;
-            span_begin(rt, rt->warm_spans, rt->warm_used);
-            HIP_TRY(hipMemsetAsync(rt->d_active, 0, sizeof(uint32_t), rt->stream));
-            launch_warmup(ia.p, ia.starts, m, iters, rt->d_warm, rt->d_joblist, rt->d_active, rt->d_nan_count, rt->stream);
-            if (!rt->active_pending && rt->h_active) {  // statistics for the next call; nobody waits for this copy
-                if (hipMemcpyAsync(rt->h_active, rt->d_active, sizeof(uint32_t), hipMemcpyDeviceToHost, rt->stream) == hipSuccess &&
-                    hipEventRecord(rt->active_copied, rt->stream) == hipSuccess) {
-                    rt->active_pending = true;
-                    rt->active_jobs_launched = m;
-                }
-            }
-            span_end(rt, rt->warm_spans, rt->warm_used);
-            span_begin(rt, rt->iter_spans, rt->iter_used);
-            if (launch_iterate_lean(ba, block, R, pipe, hint_bytes, mode == 2, rt->stream) != 0) {
-                set_error("bad chunk_records / depth_pipe");
-                return SAR_ERR_INVALID;
-            }
-            span_end(rt, rt->iter_spans, rt->iter_used);
-            BinAccArgs ca;
-            std::memset(&ca, 0, sizeof(ca));
-            ca.bin_shift = geo.shift;
-            ca.n_bins = geo.bins;
-            ca.chunks_per_wave = ba.chunks_per_wave;
-            ca.n_waves = ba.n_waves;
-            ca.npix = rt->npix;
-            ca.splits = splits;
-            ca.arena = rt->d_arena;
-            ca.heads = rt->d_heads;
-            ca.scratch_count = rt->d_scratch_count;
-            span_begin(rt, rt->fold_spans, rt->fold_used);
-            launch_bin_accumulate(ca, rt->acc_threads, R, rt->stream);
-            launch_fold_resolve(fa, rt->stream);
-            span_end(rt, rt->fold_spans, rt->fold_used);
+        if (pl.binned) {
+            SAR_TRY(launch_binned_chunk(rt, pl, ia, fa, mode));
         } else {
             span_begin(rt, rt->iter_spans, rt->iter_used);
-            launch_iterate(ia, block, xcd_local, mode, rt->stream);
+            launch_iterate(ia, pl.block, pl.xcd_local, mode, rt->stream);
             span_end(rt, rt->iter_spans, rt->iter_used);
             span_begin(rt, rt->fold_spans, rt->fold_used);
             launch_fold_resolve(fa, rt->stream);
