@@ -18,8 +18,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libsar_hip.so")
 BUILD_DIR = os.path.join(os.path.dirname(PKG), "build", "sar_hip")
-SOURCES = ["sar_host.cpp", "sar_export.cpp", "sar_runtime.cpp", "sar_kernels.hip"]
-HEADERS = ["sar_internal.hpp", "sar_launch.hpp", os.path.join("..", "..", "include", "sar.h")]
+SOURCES = ["sar_host.cpp", "sar_export.cpp", "sar_runtime.cpp", "sar_iterate.hip", "sar_accumulate.hip", "sar_image.hip"]
+HEADERS = ["sar_internal.hpp", "sar_launch.hpp", "sar_device.hpp", os.path.join("..", "..", "include", "sar.h")]
 ARCH = "gfx950"
 
 FLAGS = [
@@ -45,9 +45,9 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def audit_no_fma(asm_path: str) -> dict:
-    """Counts fused fp64 ops per kernel in the device assembly; k_iterate must have none."""
-    text = open(asm_path).read()
+def audit_no_fma(asm_paths) -> dict:
+    """Counts fused fp64 ops per kernel in the device assembly; the kernels that run the map must have none."""
+    text = "\n".join(open(p).read() for p in asm_paths)
     counts = {}
     # kernels are delimited by "<name>:" labels ... ".end_amdhsa_kernel"/"s_endpgm"
     # each function body runs from its "<name>:" label to the matching ".Lfunc_end<N>:" label
@@ -78,7 +78,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, cwd=BUILD_DIR)
         objs.append(obj)
-    asm = os.path.join(BUILD_DIR, f"sar_kernels-hip-amdgcn-amd-amdhsa-{ARCH}.s")
+    asm = [os.path.join(BUILD_DIR, f"{s[:-4]}-hip-amdgcn-amd-amdhsa-{ARCH}.s") for s in SOURCES if s.endswith(".hip")]
     counts = audit_no_fma(asm)
     if verbose:
         print("fused-fp64 audit:", {k[:60]: v for k, v in counts.items()})

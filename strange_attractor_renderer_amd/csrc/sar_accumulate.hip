@@ -1,0 +1,189 @@
+// sar_accumulate.hip — gfx950 (MI355X) kernels that turn what the iterate kernel left into the persistent Runtime
+// buffers: k_bin_accumulate (record lists -> per-bin LDS histograms -> partial histograms) and k_fold_resolve (partial
+// histograms + depth keys -> count / key / steps, payload of the new depth winners from the trajectory checkpoints).
+#include "sar_device.hpp"
+#include "sar_launch.hpp"
+
+namespace sar {
+
+// ---------------------------------------------------------------------------------------------------
+// k_bin_accumulate — records -> per-pixel hit counts, in LDS
+// ---------------------------------------------------------------------------------------------------
+// grid (B, splits): block (b, s) owns bin b and the waves w with w % splits == s. Every thread walks
+// whole (bin, wave) chunk lists (64-byte loads, newest chunk first) and adds the records into the
+// bin's LDS histogram with LDS atomics; the histogram is then written — plainly, fully — as copy s of
+// the scratch count bins, which k_fold_resolve sums into Runtime::count.
+template <uint32_t R>
+__global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
+    constexpr uint32_t Q = kChunkQuads(R);       // 16-byte quads per chunk
+    constexpr uint32_t G = Q == 2u ? 2u : 4u;    // lanes that share one list: lane q of a group reads quad q
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    const uint32_t b = blockIdx.x, s = blockIdx.y;
+    const uint32_t bin_px = 1u << a.bin_shift;
+    const uint32_t q = threadIdx.x % G;
+    const uint32_t group = threadIdx.x / G, groups = blockDim.x / G;
+    // Most bins of a frame are empty (the attractor covers a band of the image): a block with no chunk at all
+    // leaves its partial histogram untouched — the scratch copies are all-zero between launches because
+    // k_fold_resolve clears what it reads.
+    int any = 0;
+    for (uint32_t w = s + a.splits * threadIdx.x; w < a.n_waves; w += a.splits * blockDim.x)
+        any |= a.heads[(size_t)b * a.n_waves + w] != kNoChunk;
+    if (!__syncthreads_or(any)) return;
+    for (uint32_t k = threadIdx.x; k < bin_px; k += blockDim.x) hist[k] = 0u;
+    __syncthreads();
+    const uint4* arena = (const uint4*)a.arena;
+    // One (bin, wave) list per group of G lanes: a chunk is ONE 16-byte load per lane and one cache line per
+    // group (a lane that walked a list alone needed Q loads over 64 different lines per wave instruction).
+    for (uint32_t w = s + a.splits * group; w < a.n_waves; w += a.splits * groups) {
+        uint32_t chunk = a.heads[(size_t)b * a.n_waves + w];
+        const uint4* base = arena + (size_t)w * a.chunks_per_wave * kChunkStride(R);
+        while (chunk != kNoChunk) {
+            uint4 v = make_uint4(kNoChunk, 0u, 0u, 0u);
+            if (q < Q) v = base[(size_t)chunk * kChunkStride(R) + q];
+            // the chunk header {previous chunk of the list, record count} sits in lane 0's quad
+            const uint32_t prev = __shfl(v.x, 0, G);
+            const uint32_t nrec = __shfl(v.y, 0, G);
+            // records held by this lane: lane 0 -> records 0..3 (its .z/.w), lane q -> 8q-4 .. 8q+3
+            const uint32_t first = q == 0u ? 0u : 8u * q - 4u;
+            const uint32_t w0 = q == 0u ? v.z : v.x, w1 = q == 0u ? v.w : v.y;
+            if (first < nrec) atomicAdd(&hist[w0 & 0xFFFFu], 1u);
+            if (first + 1u < nrec) atomicAdd(&hist[w0 >> 16], 1u);
+            if (first + 2u < nrec) atomicAdd(&hist[w1 & 0xFFFFu], 1u);
+            if (first + 3u < nrec) atomicAdd(&hist[w1 >> 16], 1u);
+            if (q != 0u) {
+                if (first + 4u < nrec) atomicAdd(&hist[v.z & 0xFFFFu], 1u);
+                if (first + 5u < nrec) atomicAdd(&hist[v.z >> 16], 1u);
+                if (first + 6u < nrec) atomicAdd(&hist[v.w & 0xFFFFu], 1u);
+                if (first + 7u < nrec) atomicAdd(&hist[v.w >> 16], 1u);
+            }
+            chunk = prev;
+        }
+    }
+    __syncthreads();
+    const uint32_t px0 = b << a.bin_shift;
+    uint32_t* out = a.scratch_count + (size_t)s * a.npix;
+    for (uint32_t k = threadIdx.x; k < bin_px; k += blockDim.x)
+        if (px0 + k < a.npix) out[px0 + k] = hist[k];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_fold_resolve — scratch bins -> persistent Runtime buffers, then the payload of new depth winners
+// ---------------------------------------------------------------------------------------------------
+// Each block owns FOLD_PIX contiguous pixels: it folds the scratch copies into count / key (count add
+// with the running max, depth test where the value already held wins ties), re-zeroes the scratch,
+// compacts the pixels whose depth winner changed into LDS and then recomputes their colour-transform
+// payload (the rare branch of render, :821-834) from the nearest trajectory checkpoint — the visit
+// ordinal in the key names the job and the iteration. No global atomics except one max per block.
+constexpr uint32_t FOLD_PIX = 2048;
+
+__global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) {
+    __shared__ unsigned long long s_key[FOLD_PIX];
+    __shared__ uint32_t s_pix[FOLD_PIX];
+    __shared__ uint32_t s_n, s_wrap;
+    __shared__ uint32_t s_tmp[4];
+    if (threadIdx.x == 0) { s_n = 0; s_wrap = 0; }
+    __syncthreads();
+
+    uint32_t local_max = 0;
+    const uint32_t base = blockIdx.x * FOLD_PIX;
+    for (uint32_t k = threadIdx.x; k < FOLD_PIX; k += blockDim.x) {
+        const uint32_t px = base + k;
+        if (px >= a.npix) break;
+        unsigned long long add = 0, kbest = 0;
+        for (uint32_t c = 0; c < a.copies; ++c) {
+            const size_t o = (size_t)c * a.npix + px;
+            const uint32_t sc = a.scratch_count[o];
+            if (sc) { add += sc; a.scratch_count[o] = 0; }
+        }
+        for (uint32_t c = 0; c < a.key_copies; ++c) {
+            const size_t o = (size_t)c * a.npix + px;
+            const unsigned long long sk = a.scratch_key[o];
+            if (sk) { kbest = sk > kbest ? sk : kbest; a.scratch_key[o] = 0; }
+        }
+        if (px == 0 && a.nan_count) {  // diverged trajectories: every iteration after the NaN hits (0,0)
+            add += *a.nan_count;
+            *a.nan_count = 0;
+        }
+        if (add) {
+            // count += hits, wrapping like the release build (:811); if the u32 wraps, the reference's
+            // running max (:813-815) has seen u32::MAX on the way.
+            const unsigned long long total = (unsigned long long)a.count[px] + add;
+            if (total >> 32) s_wrap = 1;
+            const uint32_t c32 = (uint32_t)total;
+            a.count[px] = c32;
+            local_max = c32 > local_max ? c32 : local_max;
+        }
+        // depth test (:821): strictly greater than what the runtime already holds (an earlier render
+        // call or launch chunk wins ties; within the chunk the lowest ordinal already won the atomic max)
+        if (kbest && (uint32_t)(kbest >> 32) > (uint32_t)(a.key[px] >> 32)) {
+            const uint32_t pos = atomicAdd(&s_n, 1u);
+            s_key[pos] = kbest;
+            s_pix[pos] = px;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t total = s_n;
+    const uint32_t n = (uint32_t)a.iters;
+    const size_t cs = a.n_jobs;
+    for (uint32_t w = threadIdx.x; w < total; w += blockDim.x) {
+        const unsigned long long wk = s_key[w];
+        const uint32_t ord = 0xFFFFFFFFu - (uint32_t)wk;
+        const uint32_t job = ord / n;
+        const uint32_t t = ord - job * n;
+        const uint32_t k = t / a.ckpt_stride;
+        const uint32_t r = t - k * a.ckpt_stride;
+        const double* ck = a.ckpt + (size_t)k * 3 * cs + job;
+        double x = ck[0], y = ck[cs], z = ck[2 * cs];
+        for (uint32_t s = 0; s < r; ++s) next_point(a.p, x, y, z);
+        const double px = x, py = y, pz = z;  // previous_point (:766 / :836)
+        next_point(a.p, x, y, z);             // current_point (:770)
+        double sx, sy, sz;
+        screen_space(a.p, x, y, z, sx, sy, sz);
+        a.steps[s_pix[w]] = color_transform(a.ct, x - px, y - py, z - pz, sx, sy, sz);  // :822-830
+        a.key[s_pix[w]] = wk | 0xFFFFFFFFull;                                            // :832
+    }
+
+    const uint32_t m = block_max_u32(local_max, s_tmp);
+    if (threadIdx.x == 0) {
+        if (m) raise_scalar(&a.scalars[SC_MAX], m);
+        if (s_wrap) atomicOr(&a.scalars[SC_WRAP], 1u);
+    }
+}
+
+int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, hipStream_t s) {
+    const size_t lds = (size_t)4u << a.bin_shift;
+    // a list takes a group of 2 or 4 lanes: 1024 threads walk 256..512 lists per block
+    if (threads == 0) threads = 1024u;
+    switch (records) {
+        case 12: hipLaunchKernelGGL(k_bin_accumulate<12u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
+        case 20: hipLaunchKernelGGL(k_bin_accumulate<20u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
+        case 28: hipLaunchKernelGGL(k_bin_accumulate<28u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
+        default: return 1;
+    }
+    return 0;
+}
+
+int accumulate_kernel_attributes() {
+    // a bin's histogram needs more dynamic LDS than the 64 KiB default window when the bin has 32768 pixels
+    hipError_t e = hipSuccess;
+#define SAR_ATTR(RR) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)
+    SAR_ATTR(12u);
+    SAR_ATTR(20u);
+    SAR_ATTR(28u);
+#undef SAR_ATTR
+    return (int)e;
+}
+
+int binned_kernel_attributes() {
+    const int e = iterate_kernel_attributes();
+    return e ? e : accumulate_kernel_attributes();
+}
+
+void launch_fold_resolve(const FoldArgs& a, hipStream_t s) {
+    const uint32_t grid = (a.npix + FOLD_PIX - 1) / FOLD_PIX;
+    hipLaunchKernelGGL(k_fold_resolve, dim3(grid), dim3(256), 0, s, a);
+}
+
+}  // namespace sar

@@ -1,0 +1,320 @@
+// sar_image.hip — gfx950 (MI355X) streaming kernels around the Runtime buffers: reset, zbuf in/out, merge, colorize
+// (gas and depth), the export format conversion and the pack / select / import kernels of the multi-GPU exchange.
+#include "sar_device.hpp"
+#include "sar_launch.hpp"
+
+namespace sar {
+
+// ---------------------------------------------------------------------------------------------------
+// state management
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_reset(uint32_t* count, unsigned long long* key, double* steps, uint32_t npix,
+                        uint32_t* scalars) {
+    const unsigned long long init = ((unsigned long long)f32_sortable(-1.0f) << 32) | 0xFFFFFFFFull;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        count[p] = 0u;   // :687
+        steps[p] = 0.;   // :690
+        key[p] = init;   // zbuf = -1.0, :693
+    }
+    if (blockIdx.x == 0 && threadIdx.x < SC_COUNT) scalars[threadIdx.x] = 0u;  // max = 0, :694
+}
+
+__global__ void k_zbuf_out(const unsigned long long* key, float* out, uint32_t npix) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x)
+        out[p] = sortable_f32((uint32_t)(key[p] >> 32));
+}
+
+__global__ void k_zbuf_in(const float* z, unsigned long long* key, uint32_t npix) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x)
+        key[p] = ((unsigned long long)f32_sortable(z[p] + 0.0f) << 32) | 0xFFFFFFFFull;
+}
+
+// Runtime::merge (:708-738)
+__global__ void __launch_bounds__(256) k_merge(uint32_t* count, unsigned long long* key, double* steps,
+                                               const uint32_t* ocount, const unsigned long long* okey,
+                                               const double* osteps, uint32_t npix, uint32_t* scalars) {
+    uint32_t local_max = 0;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const uint32_t merged = count[p] + ocount[p];  // wrapping, :719
+        count[p] = merged;
+        local_max = merged > local_max ? merged : local_max;  // :721-723
+        const unsigned long long ok = okey[p];
+        if ((uint32_t)(ok >> 32) > (uint32_t)(key[p] >> 32)) {  // strict: self wins ties, :728
+            steps[p] = osteps[p];
+            key[p] = ok;
+        }
+    }
+    __shared__ uint32_t s_tmp[4];
+    const uint32_t m = block_max_u32(local_max, s_tmp);
+    if (threadIdx.x == 0 && m) raise_scalar(&scalars[SC_MAX], m);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// colorize (:841-904)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t as_u16(double v) {  // Rust `as u16`: saturating, NaN -> 0
+    if (!(v == v)) return 0;
+    if (v <= 0.) return 0;
+    if (v >= 65535.) return 65535;
+    return (uint16_t)(uint32_t)v;
+}
+__device__ __forceinline__ uint16_t as_u16_f32(float v) {
+    if (!(v == v)) return 0;
+    if (v <= 0.f) return 0;
+    if (v >= 65535.f) return 65535;
+    return (uint16_t)(uint32_t)v;
+}
+
+// ln(c) for an integer-valued u32 c: table of host-libm values where it exists (bit-identical to the
+// oracle/reference on the same host), device log beyond it (<= 1 ulp).
+__device__ __forceinline__ double ln_u32(uint32_t c, const double* lut, uint32_t lut_len) {
+    const uint32_t k = c - 1u;  // c == 0 (u32 wrap of count+1) -> huge index -> log(0) = -inf
+    return (k < lut_len) ? lut[k] : log((double)c);
+}
+
+__global__ void __launch_bounds__(256) k_colorize_gas(const uint32_t* count, const double* steps,
+                                                      const uint32_t* scalars, const double* lut,
+                                                      uint32_t lut_len, const PaletteParams pal,
+                                                      double b_offset, double b_factor, int transparent,
+                                                      uint32_t npix, ushort4* out) {
+    __shared__ double s_pal[(SAR_PALETTE_MAX + 1) * 3];
+    for (uint32_t k = threadIdx.x; k < (pal.len + 1) * 3; k += blockDim.x) s_pal[k] = pal.rgb[k / 3][k % 3];
+    __syncthreads();
+    const uint32_t rmax = scalars[SC_WRAP] ? 0xFFFFFFFFu : scalars[SC_MAX];
+    const double ln_base = ln_u32(rmax + 1u, lut, lut_len);  // ln(max + 1), :860
+    const double count_f64 = (double)pal.len;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        // Palette::interpolate (:442-472)
+        double v = steps[p];
+        if (v < 0.) v = 0.;
+        else if (v >= 1.) v = 0.999999;
+        v = v * count_f64;
+        const double fl = floor(v);
+        uint32_t n = (fl == fl) ? (uint32_t)fl : 0u;
+        if (n >= pal.len) n = pal.len - 1;  // unreachable for non-NaN
+        const double t = v - fl;            // == v % 1. for v >= 0 (exact)
+        const double t1 = 1.0 - t;
+        const double* c1 = &s_pal[n * 3];
+        const double* c2 = &s_pal[(n + 1) * 3];
+        const double r = sqrt(c2[0] * t + c1[0] * t1);
+        const double g = sqrt(c2[1] * t + c1[1] * t1);
+        const double b = sqrt(c2[2] * t + c1[2] * t1);
+        // factor = ln(count+1) / ln(max+1)  (f64::log(self, base), :860)
+        const double factor = ln_u32(count[p] + 1u, lut, lut_len) / ln_base;
+        ushort4 o;
+        o.x = as_u16((r * factor + b_offset) * b_factor * 65535.);
+        o.y = as_u16((g * factor + b_offset) * b_factor * 65535.);
+        o.z = as_u16((b * factor + b_offset) * b_factor * 65535.);
+        o.w = transparent ? as_u16(factor * 65535.) : (uint16_t)65535;
+        out[p] = o;
+    }
+}
+
+// fold (max, min) over zbuf != -1.0 with seeds (0.0, f32::MAX) (:877-882); the sortable image turns
+// f32 max/min into u32 atomics.
+__global__ void k_zrange_init(uint32_t* scalars) {
+    scalars[SC_ZMAX] = f32_sortable(0.0f);
+    scalars[SC_ZMIN] = f32_sortable(3.40282346638528859811704183484516925e+38f);
+}
+__global__ void __launch_bounds__(256) k_zrange(const unsigned long long* key, uint32_t npix, uint32_t* scalars) {
+    const uint32_t unset = f32_sortable(-1.0f);
+    uint32_t mx = f32_sortable(0.0f);
+    uint32_t mn = f32_sortable(3.40282346638528859811704183484516925e+38f);
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const uint32_t s = (uint32_t)(key[p] >> 32);
+        if (s != unset) {
+            mx = s > mx ? s : mx;
+            mn = s < mn ? s : mn;
+        }
+    }
+    __shared__ uint32_t s_tmp[4];
+    mx = block_max_u32(mx, s_tmp);
+    mn = block_min_u32(mn, s_tmp);
+    if (threadIdx.x == 0) {
+        atomicMax(&scalars[SC_ZMAX], mx);
+        atomicMin(&scalars[SC_ZMIN], mn);
+    }
+}
+__global__ void __launch_bounds__(256) k_colorize_depth(const unsigned long long* key, const uint32_t* scalars,
+                                                        uint32_t npix, ushort4* out) {
+    const float zmax = sortable_f32(scalars[SC_ZMAX]);
+    const float zmin = sortable_f32(scalars[SC_ZMIN]);
+    const float diff = zmax - zmin;  // :883
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        float z = sortable_f32((uint32_t)(key[p] >> 32));
+        if (z == -1.0f) z = 0.0f;
+        else z = __fdiv_rn(z - zmin, diff);  // f32 reverse lerp, :893
+        const uint16_t v = as_u16_f32(z * 65535.0f);
+        ushort4 o;
+        o.x = v; o.y = v; o.z = v; o.w = 65535;
+        out[p] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// multi-GPU exchange (merge folded in rank order, expressed as MAX / SUM reductions)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long exch_key(unsigned long long key, uint32_t rank) {
+    const unsigned long long k = (key & 0xFFFFFFFF00000000ull) | (unsigned long long)(0xFFFFFFFFu - rank);
+    return (long long)(k ^ 0x8000000000000000ull);  // unsigned order -> signed order
+}
+__global__ void k_exch_export(const unsigned long long* key, uint32_t rank, long long* out, uint32_t npix) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x)
+        out[p] = exch_key(key[p], rank);
+}
+__global__ void k_exch_select(const uint32_t* count, const unsigned long long* key, const double* steps,
+                              uint32_t rank, const long long* reduced, int* out, uint32_t npix) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        out[p] = (int)count[p];
+        const bool mine = exch_key(key[p], rank) == reduced[p];
+        const unsigned long long bits = mine ? (unsigned long long)__double_as_longlong(steps[p]) : 0ull;
+        out[(size_t)npix + 2 * (size_t)p] = (int)(uint32_t)bits;
+        out[(size_t)npix + 2 * (size_t)p + 1] = (int)(uint32_t)(bits >> 32);
+    }
+}
+__global__ void __launch_bounds__(256) k_exch_import(uint32_t* count, unsigned long long* key, double* steps,
+                                                     const long long* reduced, const int* sum, uint32_t npix,
+                                                     uint32_t* scalars) {
+    uint32_t local_max = 0;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)sum[p];
+        count[p] = c;
+        local_max = c > local_max ? c : local_max;
+        const unsigned long long k = (unsigned long long)reduced[p] ^ 0x8000000000000000ull;
+        key[p] = k | 0xFFFFFFFFull;
+        const unsigned long long bits = (unsigned long long)(uint32_t)sum[(size_t)npix + 2 * (size_t)p] |
+                                        ((unsigned long long)(uint32_t)sum[(size_t)npix + 2 * (size_t)p + 1] << 32);
+        steps[p] = __longlong_as_double((long long)bits);
+    }
+    __shared__ uint32_t s_tmp[4];
+    const uint32_t m = block_max_u32(local_max, s_tmp);
+    if (threadIdx.x == 0 && m) raise_scalar(&scalars[SC_MAX], m);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_convert — RGBA16 -> RGB16 / RGBA8 / RGB8 (src/bin/main.rs:52-57: DynamicImage::to_rgb16 / to_rgba8 / to_rgb8).
+// image 0.25's channel conversion u16 -> u8 is ((c + 128) / 257) (rounding, exact inverse of c * 257); alpha is
+// dropped, not pre-multiplied. Streaming: 8 B/px in, 3-6 B/px out; four pixels per thread keep stores 4-byte aligned.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t to8(uint32_t c16) { return (c16 + 128u) / 257u; }
+
+template <int FORMAT>
+__global__ void __launch_bounds__(256) k_convert(const ushort4* __restrict__ in, void* __restrict__ out, uint32_t npix) {
+    const uint32_t quads = (npix + 3u) / 4u;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < quads; g += gridDim.x * blockDim.x) {
+        const uint32_t p0 = 4u * g;
+        ushort4 px[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) px[k] = (p0 + k < npix) ? in[p0 + k] : make_ushort4(0, 0, 0, 0);
+        const bool full = p0 + 4u <= npix;
+        if (FORMAT == SAR_FMT_RGB16) {
+            unsigned short* o = (unsigned short*)out + (size_t)p0 * 3u;
+            if (full) {  // 12 u16 = three 8-byte stores
+                uint2* o2 = (uint2*)o;
+                o2[0] = make_uint2(px[0].x | ((uint32_t)px[0].y << 16), px[0].z | ((uint32_t)px[1].x << 16));
+                o2[1] = make_uint2(px[1].y | ((uint32_t)px[1].z << 16), px[2].x | ((uint32_t)px[2].y << 16));
+                o2[2] = make_uint2(px[2].z | ((uint32_t)px[3].x << 16), px[3].y | ((uint32_t)px[3].z << 16));
+            } else {
+                for (uint32_t k = 0; p0 + k < npix; ++k) {
+                    o[3u * k] = px[k].x;
+                    o[3u * k + 1u] = px[k].y;
+                    o[3u * k + 2u] = px[k].z;
+                }
+            }
+        } else if (FORMAT == SAR_FMT_RGBA8) {
+            uint32_t w[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) w[k] = to8(px[k].x) | (to8(px[k].y) << 8) | (to8(px[k].z) << 16) | (to8(px[k].w) << 24);
+            uint32_t* o = (uint32_t*)out + p0;
+            if (full) *(uint4*)o = make_uint4(w[0], w[1], w[2], w[3]);
+            else
+                for (uint32_t k = 0; p0 + k < npix; ++k) o[k] = w[k];
+        } else {  // RGB8: 12 bytes per four pixels
+            unsigned char* o = (unsigned char*)out + (size_t)p0 * 3u;
+            if (full) {
+                uint32_t b[12];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    b[3u * k] = to8(px[k].x);
+                    b[3u * k + 1u] = to8(px[k].y);
+                    b[3u * k + 2u] = to8(px[k].z);
+                }
+                uint32_t* o4 = (uint32_t*)o;
+                o4[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                o4[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+                o4[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+            } else {
+                for (uint32_t k = 0; p0 + k < npix; ++k) {
+                    o[3u * k] = (unsigned char)to8(px[k].x);
+                    o[3u * k + 1u] = (unsigned char)to8(px[k].y);
+                    o[3u * k + 2u] = (unsigned char)to8(px[k].z);
+                }
+            }
+        }
+    }
+}
+
+void launch_reset(uint32_t* count, unsigned long long* key, double* steps, uint32_t npix, uint32_t* scalars,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(k_reset, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, count, key, steps, npix, scalars);
+}
+
+void launch_zbuf_out(const unsigned long long* key, float* out, uint32_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_zbuf_out, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, key, out, npix);
+}
+
+void launch_zbuf_in(const float* z, unsigned long long* key, uint32_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_zbuf_in, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, z, key, npix);
+}
+
+void launch_merge(uint32_t* count, unsigned long long* key, double* steps, const uint32_t* ocount,
+                  const unsigned long long* okey, const double* osteps, uint32_t npix, uint32_t* scalars,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(k_merge, dim3(grid_for(npix, 256, 2048)), dim3(256), 0, s, count, key, steps, ocount, okey,
+                       osteps, npix, scalars);
+}
+
+void launch_colorize_gas(const uint32_t* count, const double* steps, const uint32_t* scalars, const double* lut,
+                         uint32_t lut_len, const PaletteParams& pal, double b_offset, double b_factor,
+                         int transparent, uint32_t npix, void* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_colorize_gas, dim3(grid_for(npix, 256, 8192)), dim3(256), 0, s, count, steps, scalars, lut,
+                       lut_len, pal, b_offset, b_factor, transparent, npix, (ushort4*)out);
+}
+
+void launch_colorize_depth(const unsigned long long* key, uint32_t* scalars, uint32_t npix, void* out,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(k_zrange_init, dim3(1), dim3(1), 0, s, scalars);
+    hipLaunchKernelGGL(k_zrange, dim3(grid_for(npix, 256, 1024)), dim3(256), 0, s, key, npix, scalars);
+    hipLaunchKernelGGL(k_colorize_depth, dim3(grid_for(npix, 256, 8192)), dim3(256), 0, s, key, scalars, npix,
+                       (ushort4*)out);
+}
+
+int launch_convert(const void* rgba16, int format, void* out, uint32_t npix, hipStream_t s) {
+    const dim3 grid(grid_for((npix + 3u) / 4u, 256, 8192)), block(256);
+    switch (format) {
+        case SAR_FMT_RGB16: hipLaunchKernelGGL(k_convert<SAR_FMT_RGB16>, grid, block, 0, s, (const ushort4*)rgba16, out, npix); break;
+        case SAR_FMT_RGBA8: hipLaunchKernelGGL(k_convert<SAR_FMT_RGBA8>, grid, block, 0, s, (const ushort4*)rgba16, out, npix); break;
+        case SAR_FMT_RGB8: hipLaunchKernelGGL(k_convert<SAR_FMT_RGB8>, grid, block, 0, s, (const ushort4*)rgba16, out, npix); break;
+        default: return 1;
+    }
+    return 0;
+}
+
+void launch_exch_export(const unsigned long long* key, uint32_t rank, void* out, uint32_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_export, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, key, rank, (long long*)out,
+                       npix);
+}
+
+void launch_exch_select(const uint32_t* count, const unsigned long long* key, const double* steps, uint32_t rank,
+                        const void* reduced, void* out, uint32_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_select, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, count, key, steps, rank,
+                       (const long long*)reduced, (int*)out, npix);
+}
+
+void launch_exch_import(uint32_t* count, unsigned long long* key, double* steps, const void* reduced,
+                        const void* sum, uint32_t npix, uint32_t* scalars, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_import, dim3(grid_for(npix, 256, 2048)), dim3(256), 0, s, count, key, steps,
+                       (const long long*)reduced, (const int*)sum, npix, scalars);
+}
+
+}  // namespace sar

@@ -58,7 +58,7 @@ struct IterArgs {
     double* ckpt;              // [n_ckpt][3][n_jobs]
 };
 
-// LDS-binned iterate kernel (see sar_kernels.hip: k_iterate_lean).
+// LDS-binned iterate kernel (see sar_iterate.hip: k_iterate_lean).
 struct BinIterArgs {
     IterArgs it;                 // scratch_count unused here (counts travel as records)
     uint32_t bin_shift;          // log2(pixels per bin)

@@ -1,0 +1,689 @@
+// sar_iterate.hip — gfx950 (MI355X) kernels that run the map: k_warmup, k_iterate_lean (the hot loop), k_iterate (one
+// global atomic per visit: fallback and A/B reference), k_extent, k_starts_soa. DESIGN.md section 3 has the measurements
+// behind every choice; sar_device.hpp states the bit-exactness contract.
+#include "sar_device.hpp"
+#include "sar_launch.hpp"
+
+namespace sar {
+
+// ---------------------------------------------------------------------------------------------------
+// k_iterate — the hot loop (render, src/lib.rs:747-838)
+// ---------------------------------------------------------------------------------------------------
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void bin_count(uint32_t* addr, uint32_t v) {
+    if (XCD_LOCAL) {
+        // this scratch copy is only ever touched by CUs of ONE XCD (copy index = hardware XCC id),
+        // so the XCD's own L2 is a sufficient coherence point: workgroup scope keeps the atomic in L2.
+        __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void bin_key(unsigned long long* addr, unsigned long long v) {
+    if (XCD_LOCAL) {
+        __hip_atomic_fetch_max(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        __hip_atomic_fetch_max(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <bool XCD_LOCAL, int MODE>
+__global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= a.n_jobs) return;
+    // 30 coefficients + 9 matrix entries + 10 projection constants are 98 SGPRs as kernel arguments —
+    // more than the scalar file holds next to pointers and exec masks, and the compiler then spills
+    // SGPRs to VGPR lanes inside the loop (v_readlane per use). The coefficients stay scalar operands;
+    // the matrix and the projection constants are pinned into (plentiful) VGPRs instead.
+    MapParams p = a.p;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p.m[k] = vgpr_pin(p.m[k]);
+    p.sin_v = vgpr_pin(p.sin_v);
+    p.cos_v = vgpr_pin(p.cos_v);
+    p.ccx = vgpr_pin(p.ccx);
+    p.ccy = vgpr_pin(p.ccy);
+    p.ccz = vgpr_pin(p.ccz);
+    p.width = vgpr_pin(p.width);
+    p.height = vgpr_pin(p.height);
+    p.half_height = vgpr_pin(p.half_height);
+    p.width_scaled = vgpr_pin(p.width_scaled);
+    p.scale_adjusted_mid = vgpr_pin(p.scale_adjusted_mid);
+
+    double x = a.starts[job];
+    double y = a.starts[a.n_jobs + job];
+    double z = a.starts[2u * a.n_jobs + job];
+
+    // "skip first 1000 to get good values in the attractor" (:750-752)
+    for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);
+
+    uint32_t* const count = a.scratch_count + (XCD_LOCAL ? (size_t)xcc_id() * a.npix : 0);
+    unsigned long long* const key = a.scratch_key + (XCD_LOCAL ? (size_t)xcc_id() * a.npix : 0);
+
+    const uint32_t n = (uint32_t)a.iters;
+    // visit ordinal = job*n + t (job-major, iteration-minor == the sequential order of the reference);
+    // the key's low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie.
+    const uint32_t lo_base = 0xFFFFFFFFu - job * n;
+    const uint32_t C = a.ckpt_stride;
+    const size_t cs = a.n_jobs;  // checkpoint component stride
+
+    uint32_t t = 0;
+    double* ck = a.ckpt + job;
+    while (t < n) {
+        // checkpoint: the state BEFORE iteration t (coalesced 512-B rows per wave)
+        ck[0] = x;
+        ck[cs] = y;
+        ck[2 * cs] = z;
+        ck += 3 * cs;
+        const uint32_t tend = (n - t > C) ? t + C : n;
+        for (; t < tend; ++t) {
+            next_point(p, x, y, z);  // :770
+            if (x != x) {
+                // Absorbing state: a NaN x makes every coordinate NaN from the next iteration on, and
+                // already makes all of screen space NaN now, so this and every remaining iteration
+                // passes the bounds test (:789, all comparisons false), casts to pixel (0,0)
+                // (:800-802) and never wins the depth test. Add them in one go instead of hammering
+                // one address n-t times.
+                if (MODE != 0) bin_count<XCD_LOCAL>(count, n - t);
+                return;
+            }
+            double sx, sy, sz;
+            screen_space(p, x, y, z, sx, sy, sz);  // :773
+            const double ax = sx + p.ccx;          // center_camera.x with screen_space.x
+            const double az = sz + p.ccy;          // center_camera.y with screen_space.z (:776-779)
+            const double x2 = ax * p.cos_v + az * p.sin_v;
+            const double z2 = ax * p.sin_v - az * p.cos_v;
+            const double fi = (p.scale_adjusted_mid - x2) * p.width_scaled;  // :783
+            const double fj = p.half_height - (sy + p.ccz) * p.width_scaled; // :786
+            if (fi >= p.width || fj >= p.height || fi < 0. || fj < 0.) continue;  // :789-795
+            const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;  // Rust `as u32`: NaN -> 0
+            const uint32_t j = (fj == fj) ? (uint32_t)fj : 0u;
+            const uint32_t idx = j * a.width + i;
+            if (MODE != 0) bin_count<XCD_LOCAL>(count + idx, 1u);  // :807-812
+            if (MODE == 2) {
+                float zf = (float)z2;  // `z2 as f32`
+                // strict `>` against an initial -1.0 (:693, :821): z <= -1 and NaN can never win
+                if (zf > -1.0f) {
+                    zf = zf + 0.0f;  // -0.0 -> +0.0 so the integer order agrees with the float order
+                    const unsigned long long k =
+                        ((unsigned long long)f32_sortable(zf) << 32) | (unsigned long long)(lo_base - t);
+                    bin_key<XCD_LOCAL>(key + idx, k);
+                }
+            }
+        }
+    }
+    if (MODE == 0) {  // measurement-only variant: keep the arithmetic alive
+        if (x + y + z == 12345.678) a.scratch_count[0] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_iterate_lean — the hot loop without a global atomic per visit
+// ---------------------------------------------------------------------------------------------------
+// Measured on MI355X: the chip retires ~2.1e10 scattered global atomics per second whatever their
+// scope or width, while the fp64 arithmetic of this loop alone runs at ~3.3e11 iterations/s. So a
+// visit must not cost a global atomic. Here every visit becomes a 2-byte RECORD instead:
+//
+//   * the image is cut into B bins of 2^bin_shift consecutive pixels; a record is the pixel's offset
+//     inside its bin (u16);
+//   * each WAVE owns B staging buffers of R records in LDS (2R + 8 bytes per bin: records, counter, link);
+//     a visit takes a slot with one LDS atomic (ds_add_rtn) and writes its u16 there one iteration later;
+//   * the lane that takes the last slot copies the R records + {link to the previous chunk of this
+//     (wave, bin), count} as ONE chunk to the wave's private arena in HBM — position from a
+//     wave-local cursor, so no global atomic and nothing to wait for — and resets the buffer;
+//   * k_bin_accumulate later walks the per-(bin, wave) chunk lists and histograms them in LDS.
+//
+// Depth: see Stager::settle_depth — two filters (this XCD's hint, then the chip-wide key) in front of the
+// 64-bit atomic max, as a software pipeline U visits deep. A stale or lost hint only costs an extra atomic,
+// never a wrong result.
+//
+// Control flow: the per-visit operations are issued unconditionally with a select on the ADDRESS instead
+// of a branch (every `if` around an LDS or memory operation costs s_and_saveexec / s_cbranch_execz / s_or):
+//   * a lane without a visit requests its slot from a private dummy counter and writes its record to
+//     a private scratch slot (cnt[B + lane], rec[B*R + lane]);
+//   * the hint of a lane without a depth candidate is loaded from element 0;
+//   * only the rare-per-lane events keep a wave-level branch: "some lane filled a buffer" (copy-out,
+//     which also places the records that overflowed into the next buffer generation), "some lane passed
+//     a depth filter", "a trajectory ended in NaN".
+// LDS per wave: B buffers of R records + B counters + B links + 64 scratch records + 64 dummy counters
+// Everything a wave needs to turn a stream of visits into staged records + depth candidates. One visit
+// per lane per step(); all per-visit state lives in registers, the staging buffers in the wave's LDS slice.
+// H is the hint type: unsigned short = 16-bit fixed point (depth_q16; half the cache footprint, but every visit within
+// 2^-14 of the best depth passes stage 1), uint32_t = the sortable image of the f32 depth itself (only true improvements
+// and exact ties pass: 3x fewer waves have to wait for a stage-2 key load). The host picks by image size.
+template <bool DEPTH, uint32_t R, uint32_t U, typename H>
+struct Stager {
+    static constexpr bool kWide = sizeof(H) == 4;
+    static constexpr uint32_t Q = kChunkQuads(R);  // 16-byte quads per chunk
+    unsigned short* rec;  // [B][R] staged records + 64 scratch slots
+    uint32_t* cnt;        // [B] fill counters + 64 dummy counters
+    uint32_t* prv;        // [B] previous chunk of this (wave, bin) list
+    uint32_t trash, dummy, lane, n_bins;
+    uint4* arena;         // this wave's chunk arena
+    uint32_t cursor;      // wave-uniform: next free chunk
+    H* zhint;
+    unsigned long long* key;
+    uint32_t bin_shift, bin_mask, lo_base;
+    // The depth path is a software pipeline U visits deep: visit t uses slot t % U, whose previous occupant (visit
+    // t - U) is settled first. A hint or key load therefore has U whole iterations to arrive, and because the loop
+    // is unrolled U times every slot is a fixed set of registers: no copies that would have to wait for a load.
+    bool pv[U];           // stage-1 candidate, waiting for its hint
+    uint32_t p_idx[U], p_zkey[U], p_lo[U], p_hint[U], p_q[U], n_sent;
+    bool gv[U];           // stage-2 candidate, waiting for the chip-wide key
+    uint32_t g_idx[U], g_q[U];
+    unsigned long long g_mine[U], g_cur[U];
+    bool b_have;          // previous visit, waiting for its LDS slot
+    uint32_t b_bin, b_slot, b_local;
+#ifdef SAR_EXPERIMENT_PROF
+    // timing experiment: wave-cycles per segment of the loop body (s_memtime; every mark drains lgkmcnt, so the LDS
+    // round trips that normally overlap the next segment are charged to the segment that issued them)
+    unsigned long long prof[4] = {0, 0, 0, 0}, prof_last = 0;
+    __device__ __forceinline__ void mark(int i) {
+        asm volatile("" ::: "memory");
+        const unsigned long long now = __builtin_readcyclecounter();
+        asm volatile("" ::: "memory");
+        prof[i] += now - prof_last;
+        prof_last = now;
+    }
+#define SAR_MARK(i) this->mark(i)
+#else
+#define SAR_MARK(i)
+#endif
+    bool f_on;            // a filled buffer whose 2R bytes sit in registers, waiting to be stored
+    uint32_t f_chunk, f_prev;
+    uint2 fpend[R / 4u];
+
+    __device__ __forceinline__ void init(char* wbase, uint32_t bins, uint32_t lane_, uint4* arena_, H* zhint_,
+                                         unsigned long long* key_, uint32_t shift, uint32_t lo_base_) {
+        n_bins = bins;
+        lane = lane_;
+        rec = (unsigned short*)wbase;
+        cnt = (uint32_t*)(wbase + bins * 2u * R + 128u);
+        prv = cnt + bins + 64u;
+        for (uint32_t b = lane; b < bins + 64u; b += 64u) cnt[b] = 0u;
+        for (uint32_t b = lane; b < bins; b += 64u) prv[b] = kNoChunk;
+        trash = bins * R + lane;
+        dummy = bins + lane;
+        arena = arena_;
+        cursor = 0;
+        zhint = zhint_;
+        key = key_;
+        bin_shift = shift;
+        bin_mask = (1u << shift) - 1u;
+        lo_base = lo_base_;
+        b_have = f_on = false;
+        n_sent = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < U; ++k) {
+            pv[k] = gv[k] = false;
+            p_idx[k] = p_zkey[k] = p_lo[k] = p_hint[k] = p_q[k] = 0;
+            g_idx[k] = g_q[k] = 0;
+            g_mine[k] = g_cur[k] = 0;
+        }
+        b_bin = b_slot = b_local = 0;
+        f_chunk = f_prev = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < R / 4u; ++k) fpend[k] = make_uint2(0u, 0u);
+    }
+
+    // one chunk: {previous chunk of this (wave, bin), record count, records}
+    __device__ __forceinline__ void store_chunk(uint32_t chunk, uint32_t prev, uint32_t count, const uint2 (&f)[R / 4u]) {
+        uint32_t w[4u * Q];
+        w[0] = prev;
+        w[1] = count;
+#pragma unroll
+        for (uint32_t k = 0; k < R / 4u; ++k) {
+            w[2u + 2u * k] = f[k].x;
+            w[3u + 2u * k] = f[k].y;
+        }
+        u32x4* dst = (u32x4*)(arena + (size_t)chunk * kChunkStride(R));
+#pragma unroll
+        for (uint32_t q = 0; q < Q; ++q)  // streamed once, read once: keep them out of the L2 the hints live in
+            __builtin_nontemporal_store((u32x4){w[4u * q], w[4u * q + 1u], w[4u * q + 2u], w[4u * q + 3u]}, dst + q);
+    }
+    // immediate copy-out (rare path)
+    __device__ __forceinline__ void flush_full(uint32_t bin, uint32_t chunk) {
+        const uint2* r = (const uint2*)(rec + mul24(bin, R));  // 2R bytes, 8-byte aligned
+        uint2 f[R / 4u];
+#pragma unroll
+        for (uint32_t k = 0; k < R / 4u; ++k) f[k] = r[k];
+        store_chunk(chunk, prv[bin], R, f);
+        prv[bin] = chunk;
+        __hip_atomic_fetch_sub(&cnt[bin], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // The common copy-out is split: the lane that filled a buffer ISSUES the LDS reads (and frees the buffer:
+    // LDS executes a wave's operations in order, so later writes cannot overtake them); the global stores go
+    // out later in the step, when the reads have long returned.
+    __device__ __forceinline__ void flush_store_pending() {
+        if (f_on) store_chunk(f_chunk, f_prev, R, fpend);
+        f_on = false;
+    }
+
+    // Places the pending record. slot = R*gen + pos: slots are handed out consecutively per bin, so the
+    // quotient says which refill generation of the R-record buffer a record belongs to. The generation-0
+    // write is unconditional (scratch slot for lanes without one); everything else only exists when some lane
+    // filled a buffer in the same slot request.
+    __device__ __forceinline__ void place_visit() {
+        // slot < R + 64 (a counter is below R whenever a slot request finds it), so slot / R is exact through a
+        // 24-bit multiply: full-rate v_mul_u32_u24 / v_mad_u32_u24 instead of the quarter-rate 32-bit multiplies
+        constexpr uint32_t kInvR = (65536u + R - 1u) / R;
+        const uint32_t gen = mul24(b_slot, kInvR) >> 16;
+        const uint32_t pos = b_slot - mul24(gen, R);
+        const uint32_t base = mul24(b_bin, R);
+        const uint32_t at = base + pos;
+        const bool w0 = b_have && gen == 0u;
+        rec[w0 ? at : trash] = (unsigned short)b_local;
+        const bool fl = w0 && pos == R - 1u;
+        const unsigned long long fb = wave_ballot(fl);
+        if (fb) {
+            if (fl) {
+                const uint2* r = (const uint2*)(rec + base);
+#pragma unroll
+                for (uint32_t k = 0; k < R / 4u; ++k) fpend[k] = r[k];
+                f_chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
+                f_prev = prv[b_bin];
+                f_on = true;
+                prv[b_bin] = f_chunk;
+                __hip_atomic_fetch_sub(&cnt[b_bin], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            cursor += (uint32_t)__popcll(fb);
+            // records that overflowed into the next generation of a buffer that was just emptied
+            const bool e1 = b_have && gen == 1u && pos < R - 1u;
+            rec[e1 ? at : trash] = (unsigned short)b_local;
+            bool pend = b_have && gen >= 1u && !e1;  // a later generation's last slot, or generation >= 2: rare
+            for (uint32_t g = 1; wave_ballot(pend); ++g) {
+                const bool mine = pend && gen == g;
+                if (mine) rec[at] = (unsigned short)b_local;
+                const bool fl2 = mine && pos == R - 1u;
+                const unsigned long long fb2 = wave_ballot(fl2);
+                if (fb2) {
+                    if (fl2) flush_full(b_bin, cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb2 >> 32),
+                                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)fb2, 0u)));
+                    cursor += (uint32_t)__popcll(fb2);
+                }
+                const bool early = pend && gen == g + 1u && pos < R - 1u;
+                if (early) rec[at] = (unsigned short)b_local;
+                pend = pend && !(mine || early);
+            }
+        }
+    }
+
+    // Depth candidates go through two filters before they cost a global atomic (the chip retires only
+    // ~2.1e10 of those per second):
+    //   stage 1  this XCD's private 16-bit hint (L2-resident, loaded U visits ahead);
+    //   stage 2  the chip-wide 64-bit key itself, read at device scope U visits after stage 1 passed
+    //            (~5 % of the visits): the atomic is sent only if this visit beats what ANY XCD has sent —
+    //            and the private hint learns the chip-wide depth on the way.
+    // k is a compile-time constant after unrolling.
+    __device__ __forceinline__ void settle_depth(uint32_t k) {
+        if (gv[k]) {
+            if (g_mine[k] > g_cur[k]) {
+                atomicMax(key + g_idx[k], g_mine[k]);
+                ++n_sent;
+            }
+            const uint32_t seen = (uint32_t)(g_cur[k] >> 32);  // 0 while nobody has sent this pixel
+            const uint32_t qs = kWide ? seen : (seen ? depth_q16(sortable_f32(seen)) : 0u);
+            zhint[g_idx[k]] = (H)(qs > g_q[k] ? qs : g_q[k]);
+        }
+        // p_hint is the raw dword holding this pixel's hint and its neighbour's: it is unpacked only HERE, U visits
+        // after the load was issued. (Unpacking next to the load makes the compiler wait for the load right there.)
+        const uint32_t hint = kWide ? p_hint[k] : ((p_idx[k] & 1u) ? (p_hint[k] >> 16) : (p_hint[k] & 0xFFFFu));
+        gv[k] = pv[k] && p_q[k] >= hint;
+        if (gv[k]) {
+            g_idx[k] = p_idx[k];
+            g_q[k] = p_q[k];
+            g_mine[k] = ((unsigned long long)p_zkey[k] << 32) | (unsigned long long)p_lo[k];
+            g_cur[k] = __hip_atomic_load(key + p_idx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // One visit of this lane: inb = the iteration landed inside the image at pixel idx with depth zf
+    // (reference src/lib.rs:807-834); t = iteration number (for the visit ordinal); k = t % U, a compile-time
+    // constant after unrolling.
+    __device__ __forceinline__ void step(uint32_t k, bool inb, uint32_t idx, float zf, uint32_t t) {
+        // the staging phase is a chain of short dependent steps with memory round trips at its end: let it win the
+        // SIMD's issue arbitration against the other waves' long arithmetic phase, so that its loads start early
+        __builtin_amdgcn_s_setprio(3);
+        // the previous visit's record first: pure LDS work
+        place_visit();
+        SAR_MARK(1);
+        bool cand = false;
+        if (DEPTH) {
+            settle_depth(k);  // the candidate of visit t - U: its hint was requested U whole steps ago
+            // this visit's candidate: strict `>` against the initial -1.0 (:693, :821); NaN fails
+            cand = inb && zf > -1.0f;
+            const float zc = zf + 0.0f;  // -0.0 -> +0.0: integer order == float order
+            p_zkey[k] = f32_sortable(zc);
+            p_q[k] = kWide ? p_zkey[k] : depth_q16(zc);
+            p_idx[k] = idx;
+            p_lo[k] = lo_base - t;
+            pv[k] = cand;
+        }
+        SAR_MARK(2);
+        // chunk stores of a buffer that filled up (their LDS reads were issued by place_visit above), then this
+        // visit's slot request
+        flush_store_pending();
+        b_have = inb;
+        b_bin = idx >> bin_shift;
+        b_local = idx & bin_mask;
+        b_slot = atomicAdd(&cnt[inb ? b_bin : dummy], 1u);  // ds_add_rtn_u32
+        // the hint load is the LAST vector-memory operation of the step: the counter the hardware offers for "has
+        // my load returned" (vmcnt) counts operations in issue order, so anything issued after a load that is still
+        // wanted in flight would have to be waited for as well
+        if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (idx & ~1u)) : 0u));
+        __builtin_amdgcn_s_setprio(0);
+        SAR_MARK(3);
+    }
+
+    // After the last visit: settle what is in flight, flush the partly filled buffers, publish the list heads.
+    __device__ __forceinline__ void finish(uint32_t* heads, uint32_t n_waves, uint32_t wave, unsigned long long* stats) {
+        place_visit();
+        flush_store_pending();
+        if (DEPTH) {
+#pragma unroll
+            for (uint32_t k = 0; k < U; ++k) {
+                settle_depth(k);  // moves the slot's stage-1 candidate to stage 2
+                pv[k] = false;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < U; ++k) settle_depth(k);  // settles it
+            uint32_t tot = n_sent;  // statistics: depth atomics issued by this wave
+            for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
+            if (lane == 0 && tot) atomicAdd(stats + 1, (unsigned long long)tot);
+        }
+        for (uint32_t b0 = 0; b0 < n_bins; b0 += 64u) {
+            const uint32_t b = b0 + lane;
+            const uint32_t have = (b < n_bins) ? cnt[b] : 0u;
+            const bool flusher = have != 0u;
+            const unsigned long long fb = wave_ballot(flusher);
+            uint32_t head = (b < n_bins) ? prv[b] : kNoChunk;
+            if (flusher) {
+                const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
+                                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
+                const uint2* r = (const uint2*)(rec + b * R);
+                uint2 f[R / 4u];
+#pragma unroll
+                for (uint32_t k = 0; k < R / 4u; ++k) f[k] = r[k];
+                store_chunk(chunk, head, have, f);
+                head = chunk;
+            }
+            cursor += (uint32_t)__popcll(fb);
+            if (b < n_bins) heads[(size_t)b * n_waves + wave] = head;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// k_warmup — the 1000 uncounted iterations every job starts with (reference src/lib.rs:750-752), and the packing of
+// the survivors. NaN is absorbing: a job whose x is NaN after the warm-up spends all its counted iterations on pixel
+// (0,0) without ever winning a depth test, so its n iterations go straight to the NaN counter and the
+// job never occupies a lane of the hot kernel. The packed order depends on which wave's atomic lands first; results
+// do not (the visit ordinal is formed from the job index, which travels in `joblist`).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_warmup(const MapParams pin, const double* __restrict__ starts, uint32_t n_jobs,
+                                                uint64_t iters, double* __restrict__ warm, uint32_t* __restrict__ joblist,
+                                                uint32_t* active, unsigned long long* nan_count) {
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = job < n_jobs;
+    MapParams p = pin;
+    pin_map_params(p);
+    double x = 0., y = 0., z = 0.;
+    if (valid) {
+        x = starts[job];
+        y = starts[n_jobs + job];
+        z = starts[2u * n_jobs + job];
+        for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);
+    }
+    const bool live = valid && x == x;
+    const unsigned long long lm = wave_ballot(live), dm = wave_ballot(valid && !live);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+    uint32_t base = 0;
+    if ((threadIdx.x & 63u) == 0u) {
+        if (lm) base = atomicAdd(active, (uint32_t)__popcll(lm));
+        if (dm) atomicAdd(nan_count, iters * (unsigned long long)__popcll(dm));
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (live) {
+        const uint32_t slot = base + rank;
+        warm[slot] = x;
+        warm[n_jobs + slot] = y;
+        warm[2u * n_jobs + slot] = z;
+        joblist[slot] = job;
+    }
+}
+
+template <bool DEPTH, uint32_t R, uint32_t U, typename H>
+__global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    // lanes take the packed trajectories k_warmup left (those that survived the warm-up), not raw job indices: a
+    // preset like solar-sail loses 38 % of its start points to NaN there, and they would sit in every wave as idle lanes
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t wave = slot >> 6;
+    const uint32_t active = *a.active;
+    if ((slot & ~63u) >= active) {  // nothing left for this wave: publish empty lists
+        for (uint32_t b = lane; b < a.n_bins; b += 64u) a.heads[(size_t)b * a.n_waves + wave] = kNoChunk;
+        return;
+    }
+    bool alive = slot < active;
+    const uint32_t job = alive ? a.joblist[slot] : 0u;
+    const uint32_t n = (uint32_t)a.it.iters;
+
+    Stager<DEPTH, R, U, H> st;
+    // visit ordinal = job*n + t (job-major, iteration-minor == the sequential order of the reference); the key's
+    // low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie
+    st.init((char*)smem + (threadIdx.x >> 6) * kLeanWaveLds(a.n_bins, R), a.n_bins, lane,
+            (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkStride(R),
+            (H*)a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.bin_shift, 0xFFFFFFFFu - job * n);
+
+    MapParams p = a.it.p;
+    pin_map_params(p);
+    double x = 0., y = 0., z = 0.;
+    if (alive) {  // the point after the warm-up (:750-752), from k_warmup
+        x = a.warm[slot];
+        y = a.warm[a.it.n_jobs + slot];
+        z = a.warm[2u * a.it.n_jobs + slot];
+    }
+    const uint32_t C = a.it.ckpt_stride;  // a multiple of U (the host rounds it)
+    const size_t cs = a.it.n_jobs;
+    uint32_t t = 0;
+    double* ck = a.it.ckpt + job;
+    auto checkpoint = [&]() {  // the state BEFORE iteration t (coalesced 512-B rows per wave)
+        if (alive) {
+            __builtin_nontemporal_store(x, ck);
+            __builtin_nontemporal_store(y, ck + cs);
+            __builtin_nontemporal_store(z, ck + 2 * cs);
+        }
+        ck += 3 * cs;
+    };
+    // one iteration of the loop body; k = t % U is a compile-time constant where this is instantiated
+    auto iteration = [&](uint32_t k) {
+        bool inb;
+        uint32_t idx;
+        float zf;
+        iterate_once(p, a.it.width, x, y, z, inb, idx, zf);  // every lane, finished or not: no divergence
+        const bool ended = alive && x != x;
+        if (wave_ballot(ended)) {
+            // absorbing NaN state: this and all remaining iterations pass the bounds test (:789), land on pixel
+            // (0,0) (:800-802) and never win the depth test — add them in one go
+            if (ended) atomicAdd(a.nan_count, (unsigned long long)(n - t));
+            alive = alive && !ended;
+        }
+        inb = inb && alive;
+        idx = inb ? idx : 0u;
+#ifdef SAR_EXPERIMENT_PROF
+        asm volatile("" : "+v"(idx), "+v"(zf));  // the map and the projection belong to segment 0
+#endif
+#ifdef SAR_EXPERIMENT_PROF
+        st.mark(0);
+#endif
+        st.step(k, inb, idx, zf, t);
+        ++t;
+    };
+    // Whole passes of U iterations first: the pass is the unit of the depth pipeline, and a loop that contains
+    // nothing else lets the compiler count exactly which loads may still be in flight at each use.
+#ifdef SAR_EXPERIMENT_PROF
+    st.prof_last = __builtin_readcyclecounter();
+#endif
+    const uint32_t n_full = n - n % U;
+    while (t < n_full) {
+        checkpoint();
+        const uint32_t tend = (n_full - t > C) ? t + C : n_full;
+        while (t < tend) {
+#pragma unroll
+            for (uint32_t k = 0; k < U; ++k) iteration(k);
+        }
+    }
+    if (t < n) {  // the last n % U iterations of the job
+        if (t % C == 0u) checkpoint();
+#pragma unroll
+        for (uint32_t k = 0; k + 1 < U; ++k)
+            if (t < n) iteration(k);
+    }
+#ifdef SAR_EXPERIMENT_PROF
+    if (lane == 0)
+        for (int i = 0; i < 4; ++i) atomicAdd(a.nan_count + 2 + i, st.prof[i]);
+#endif
+    st.finish(a.heads, a.n_waves, wave, a.nan_count);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_extent — the "first pass" the reference leaves as a TODO (src/lib.rs:326-333): bounds of the attractor in screen
+// space (what the comment at :329-333 lists) and in raw coordinates. One trajectory per lane: 1000 warm-up
+// iterations, then `iters` iterations with 12 running bounds in registers; a bound moves through `<` / `>` only, so NaN
+// never moves one and the result does not depend on the order of the reduction. Output: 12 doubles per block.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bound(double v, double& lo, double& hi) {
+    lo = v < lo ? v : lo;
+    hi = v > hi ? v : hi;
+}
+
+__global__ void __launch_bounds__(256) k_extent(const MapParams pin, const double* __restrict__ starts, uint32_t n_jobs,
+                                                uint64_t iters, double* __restrict__ out) {
+    __shared__ double part[4][12];
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    MapParams p = pin;
+    pin_map_params(p);
+    double b[12];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        b[2 * k] = __builtin_inf();
+        b[2 * k + 1] = -__builtin_inf();
+    }
+    if (job < n_jobs) {
+        double x = starts[job], y = starts[n_jobs + job], z = starts[2u * n_jobs + job];
+        for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);  // :750-752
+        for (uint64_t t = 0; t < iters; ++t) {
+            next_point(p, x, y, z);
+            double sx, sy, sz;
+            screen_space(p, x, y, z, sx, sy, sz);  // :773
+            bound(sx, b[0], b[1]);
+            bound(sy, b[2], b[3]);
+            bound(sz, b[4], b[5]);
+            bound(x, b[6], b[7]);
+            bound(y, b[8], b[9]);
+            bound(z, b[10], b[11]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        double v = b[k];
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_down(v, off);
+            v = (k & 1) ? (o > v ? o : v) : (o < v ? o : v);
+        }
+        if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const int k = threadIdx.x;
+        double v = part[0][k];
+        for (uint32_t w = 1; w < blockDim.x / 64u; ++w) {
+            const double o = part[w][k];
+            v = (k & 1) ? (o > v ? o : v) : (o < v ? o : v);
+        }
+        out[(size_t)blockIdx.x * 12u + k] = v;
+    }
+}
+
+// start points [m][3] (as the ABI takes them) -> the kernel's SoA block x[m] y[m] z[m]
+__global__ void __launch_bounds__(256) k_starts_soa(const double* __restrict__ aos, double* __restrict__ soa, uint32_t m) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < m) {
+        soa[k] = aos[3u * k];
+        soa[m + k] = aos[3u * k + 1u];
+        soa[2u * m + k] = aos[3u * k + 2u];
+    }
+}
+
+void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode, hipStream_t s) {
+    const uint32_t grid = (a.n_jobs + block - 1) / block;
+    if (xcd_local) {
+        if (mode == 2) hipLaunchKernelGGL((k_iterate<true, 2>), dim3(grid), dim3(block), 0, s, a);
+        else if (mode == 1) hipLaunchKernelGGL((k_iterate<true, 1>), dim3(grid), dim3(block), 0, s, a);
+        else hipLaunchKernelGGL((k_iterate<true, 0>), dim3(grid), dim3(block), 0, s, a);
+    } else {
+        if (mode == 2) hipLaunchKernelGGL((k_iterate<false, 2>), dim3(grid), dim3(block), 0, s, a);
+        else if (mode == 1) hipLaunchKernelGGL((k_iterate<false, 1>), dim3(grid), dim3(block), 0, s, a);
+        else hipLaunchKernelGGL((k_iterate<false, 0>), dim3(grid), dim3(block), 0, s, a);
+    }
+}
+
+uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records) { return kLeanWaveLds(bins, records); }
+uint32_t chunk_bytes(uint32_t records) { return kChunkStride(records) * 16u; }
+
+
+// the instantiations of the hot kernel: chunk size x depth-pipeline length x hint type (count-only kernels have neither)
+#define SAR_FOR_EACH_LEAN(X)                                                                                          \
+    X(true, 12u, 1u, unsigned short) X(true, 12u, 2u, unsigned short) X(true, 20u, 1u, unsigned short)                \
+    X(true, 20u, 2u, unsigned short) X(true, 28u, 1u, unsigned short) X(true, 28u, 2u, unsigned short)                \
+    X(true, 12u, 1u, uint32_t) X(true, 12u, 2u, uint32_t) X(true, 20u, 1u, uint32_t) X(true, 20u, 2u, uint32_t)         \
+    X(true, 28u, 1u, uint32_t) X(true, 28u, 2u, uint32_t)                                                              \
+    X(false, 12u, 1u, unsigned short) X(false, 20u, 1u, unsigned short) X(false, 28u, 1u, unsigned short)
+
+int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
+                        hipStream_t s) {
+    const uint32_t grid = (a.it.n_jobs + block - 1) / block;
+    const size_t lds = (size_t)(block / 64u) * kLeanWaveLds(a.n_bins, records);
+    if (!depth) {
+        pipe = 1;
+        hint_bytes = 2;
+    }
+    bool launched = false;
+#define SAR_LAUNCH_LEAN(DD, RR, UU, HH)                                                                    \
+    if (!launched && depth == DD && records == RR && pipe == UU && hint_bytes == sizeof(HH)) {             \
+        hipLaunchKernelGGL((k_iterate_lean<DD, RR, UU, HH>), dim3(grid), dim3(block), lds, s, a);          \
+        launched = true;                                                                                   \
+    }
+    SAR_FOR_EACH_LEAN(SAR_LAUNCH_LEAN)
+#undef SAR_LAUNCH_LEAN
+    return launched ? 0 : 1;
+}
+
+int iterate_kernel_attributes() {
+    // the staging buffers need more dynamic LDS than the 64 KiB default window
+    hipError_t e = hipSuccess;
+#define SAR_ATTR_LEAN(DD, RR, UU, HH) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    SAR_FOR_EACH_LEAN(SAR_ATTR_LEAN)
+#undef SAR_ATTR_LEAN
+    return (int)e;
+}
+
+uint32_t launch_extent(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* out, hipStream_t s) {
+    const uint32_t blocks = (n_jobs + 255u) / 256u;
+    hipLaunchKernelGGL(k_extent, dim3(blocks), dim3(256), 0, s, p, starts, n_jobs, iters, out);
+    return blocks;
+}
+
+void launch_starts_soa(const double* aos, double* soa, uint32_t m, hipStream_t s) {
+    hipLaunchKernelGGL(k_starts_soa, dim3((m + 255u) / 256u), dim3(256), 0, s, aos, soa, m);
+}
+
+void launch_warmup(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* warm, uint32_t* joblist,
+                   uint32_t* active, unsigned long long* nan_count, hipStream_t s) {
+    hipLaunchKernelGGL(k_warmup, dim3((n_jobs + 255u) / 256u), dim3(256), 0, s, p, starts, n_jobs, iters, warm, joblist, active,
+                       nan_count);
+}
+
+}  // namespace sar

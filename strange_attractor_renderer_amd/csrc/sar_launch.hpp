@@ -1,4 +1,4 @@
-// sar_launch.hpp — host-callable launch wrappers implemented in sar_kernels.hip.
+// sar_launch.hpp — host-callable launch wrappers implemented in sar_iterate.hip, sar_accumulate.hip and sar_image.hip.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -16,7 +16,9 @@ uint32_t chunk_bytes(uint32_t records);
 int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
                         hipStream_t s);
 int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, hipStream_t s);
-int binned_kernel_attributes();
+int iterate_kernel_attributes();     // sar_iterate.hip
+int accumulate_kernel_attributes();  // sar_accumulate.hip
+int binned_kernel_attributes();      // both
 void launch_fold_resolve(const FoldArgs& a, hipStream_t s);
 void launch_reset(uint32_t* count, unsigned long long* key, double* steps, uint32_t npix, uint32_t* scalars,
                   hipStream_t s);

@@ -2,7 +2,7 @@
 // ParallelRenderer mirror and the multi-GPU exchange helpers (include/sar.h).
 //
 // Host logic only (allocation, chunking, argument blocks, stream ordering); all arithmetic on image
-// data happens in sar_kernels.hip. There is no CPU fallback: without a HIP device every entry point
+// data happens in the kernel files (sar_iterate.hip, sar_accumulate.hip, sar_image.hip). There is no CPU fallback: without a HIP device every entry point
 // that touches a runtime returns SAR_ERR_NO_DEVICE.
 #include <cmath>
 #include <cstdio>

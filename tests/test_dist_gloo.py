@@ -2,7 +2,7 @@
 counts/steps halves) reproduces Runtime::merge folded in rank order, and job sharding covers every job once.
 
 The pack/select/import arithmetic below is a numpy mirror of the three exchange kernels in
-csrc/sar_kernels.hip (k_exch_export / k_exch_select / k_exch_import); the GPU versions are checked against
+csrc/sar_image.hip (k_exch_export / k_exch_select / k_exch_import); the GPU versions are checked against
 the same oracle merge in the -m gpu suite."""
 import os
 import socket

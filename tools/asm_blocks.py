@@ -1,7 +1,8 @@
 """Per-basic-block instruction mix of a kernel in the saved gfx950 assembly (build/sar_hip/*.s).
 usage: python tools/asm_blocks.py <mangled-name-prefix> [min_block_size]"""
 import re, sys
-s = open('build/sar_hip/sar_kernels-hip-amdgcn-amd-amdhsa-gfx950.s').read()
+import glob
+s = ''.join(open(f).read() for f in sorted(glob.glob('build/sar_hip/sar_*-hip-amdgcn-amd-amdhsa-gfx950.s')))
 pref = sys.argv[1]; mn = int(sys.argv[2]) if len(sys.argv) > 2 else 15
 m = re.search(r'^(%s[A-Za-z0-9_]*):' % re.escape(pref), s, re.M)
 a = m.end(); b = s.index('.Lfunc_end', a)
