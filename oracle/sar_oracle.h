@@ -93,6 +93,12 @@ double sar_oracle_render_parallel(const sar_config* cfg, uint32_t threads, uint3
                                   uint64_t seed, uint16_t* rgba, uint64_t* iters_done,
                                   sar_oracle_runtime* out_merged /* nullable, pre-allocated */);
 
+/* sar_oracle_render_jobs on `threads` host threads with the SAME result bit for bit: contiguous job slices into
+ * private runtimes, folded with Runtime::merge in slice order (earlier job wins depth ties, like the sequential
+ * strict `>`). Lets the full-size BASELINE frames (1e9 iterations) meet the oracle in seconds. 0 on success. */
+int sar_oracle_render_jobs_mt(const sar_config* cfg, sar_oracle_runtime* rt, const double* starts_xyz, uint32_t jobs,
+                              uint64_t iters_per_job, uint32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

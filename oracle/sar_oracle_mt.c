@@ -12,6 +12,7 @@
  * The reference binary itself cannot be built here (no Rust toolchain); this is the "port" CPU
  * baseline bench.py reports, never a product path.
  */
+#define _POSIX_C_SOURCE 200809L /* pthread_barrier_t, clock_gettime under -std=c11 */
 #include "sar_oracle.h"
 
 #include <pthread.h>
@@ -131,4 +132,83 @@ double sar_oracle_render_parallel(const sar_config* cfg, uint32_t threads, uint3
     pthread_mutex_destroy(&sh.mu);
     pthread_cond_destroy(&sh.cv);
     return t1 - t0;
+}
+
+/* ---- deterministic multi-threaded form of sar_oracle_render_jobs (full-size parity tests) -------------------------
+ * The result of `jobs` sequential render calls on one runtime (src/lib.rs:956-988) equals: cut the job list into
+ * `threads` CONTIGUOUS slices, render slice t into its own runtime (one reference worker's loop), then fold
+ * Runtime::merge (:708-738) over the slices in slice order — count is a sum, zbuf a max, and `self wins ties` (:728)
+ * keeps the payload of the EARLIER job exactly like the strict `>` of the sequential depth test (:821). The fold is
+ * done per pixel range on all threads (the per-pixel rule is :716-735 verbatim; the walk order does not enter). */
+typedef struct det_worker {
+    const sar_config* cfg;
+    sar_oracle_runtime* rt;     /* this slice's runtime (slice 0 renders straight into the output) */
+    sar_oracle_runtime** all;   /* every slice's runtime, in slice order */
+    const double* starts;
+    uint32_t first, count, threads, index;
+    uint64_t iters;
+    pthread_barrier_t* bar;
+    uint32_t max_seen;
+} det_worker;
+
+static void* det_main(void* arg) {
+    det_worker* w = (det_worker*)arg;
+    sar_oracle_render_jobs(w->cfg, w->rt, w->starts + 3 * (size_t)w->first, w->count, w->iters);
+    pthread_barrier_wait(w->bar);
+    sar_oracle_runtime* dst = w->all[0];
+    const size_t npix = (size_t)dst->width * dst->height;
+    const size_t lo = npix * w->index / w->threads, hi = npix * (w->index + 1) / w->threads;
+    uint32_t mx = 0;
+    for (uint32_t t = 1; t < w->threads; ++t) {
+        const sar_oracle_runtime* src = w->all[t];
+        for (size_t k = lo; k < hi; ++k) {
+            dst->count[k] += src->count[k];                    /* :719, wrapping */
+            if (dst->count[k] > mx) mx = dst->count[k];        /* :721-723 */
+            if (src->zbuf[k] > dst->zbuf[k]) {                 /* :728, strict: dst (earlier slice) wins ties */
+                dst->steps[k] = src->steps[k];
+                dst->zbuf[k] = src->zbuf[k];
+            }
+        }
+    }
+    w->max_seen = mx;
+    return NULL;
+}
+
+int sar_oracle_render_jobs_mt(const sar_config* cfg, sar_oracle_runtime* rt, const double* starts_xyz, uint32_t jobs,
+                              uint64_t iters_per_job, uint32_t threads) {
+    if (threads == 0) threads = 1;
+    if (threads > jobs) threads = jobs ? jobs : 1;
+    if (threads == 1) {
+        sar_oracle_render_jobs(cfg, rt, starts_xyz, jobs, iters_per_job);
+        return 0;
+    }
+    det_worker* ws = (det_worker*)calloc(threads, sizeof(det_worker));
+    pthread_t* tids = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+    sar_oracle_runtime** all = (sar_oracle_runtime**)calloc(threads, sizeof(*all));
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, threads);
+    int ok = 1;
+    all[0] = rt;
+    for (uint32_t t = 1; t < threads && ok; ++t) {
+        all[t] = sar_oracle_runtime_new(rt->width, rt->height);
+        if (!all[t]) ok = 0;
+        else sar_oracle_runtime_reset(all[t]);
+    }
+    if (ok) {
+        const uint32_t base = jobs / threads, rem = jobs % threads;
+        uint32_t first = 0;
+        for (uint32_t t = 0; t < threads; ++t) {
+            ws[t].cfg = cfg; ws[t].rt = all[t]; ws[t].all = all; ws[t].starts = starts_xyz;
+            ws[t].first = first; ws[t].count = base + (t < rem ? 1u : 0u); ws[t].threads = threads; ws[t].index = t;
+            ws[t].iters = iters_per_job; ws[t].bar = &bar;
+            first += ws[t].count;
+        }
+        for (uint32_t t = 0; t < threads; ++t) pthread_create(&tids[t], NULL, det_main, &ws[t]);
+        for (uint32_t t = 0; t < threads; ++t) pthread_join(tids[t], NULL);
+        for (uint32_t t = 0; t < threads; ++t) if (ws[t].max_seen > rt->max) rt->max = ws[t].max_seen;
+    }
+    for (uint32_t t = 1; t < threads; ++t) if (all[t]) sar_oracle_runtime_free(all[t]);
+    pthread_barrier_destroy(&bar);
+    free(all); free(tids); free(ws);
+    return ok ? 0 : -1;
 }

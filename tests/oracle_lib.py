@@ -72,6 +72,8 @@ def lib():
     L.sar_oracle_render.restype = None
     L.sar_oracle_render_jobs.argtypes = [cfgp, rtp, dp, C.c_uint32, C.c_uint64]
     L.sar_oracle_render_jobs.restype = None
+    L.sar_oracle_render_jobs_mt.argtypes = [cfgp, rtp, dp, C.c_uint32, C.c_uint64, C.c_uint32]
+    L.sar_oracle_render_jobs_mt.restype = C.c_int
     L.sar_oracle_iterate.argtypes = [cfgp, dp, C.c_uint64, dp]
     L.sar_oracle_iterate.restype = None
     L.sar_oracle_palette.argtypes = [cfgp, C.c_double, dp]
@@ -228,6 +230,20 @@ def render_jobs(cfg: SarConfig, rt: Runtime, starts: np.ndarray, iters_per_job: 
     lib().sar_oracle_render_jobs(C.byref(cfg), rt.ptr, _dptr(s), s.shape[0], iters_per_job)
 
 
+def host_threads(cap: int = 64) -> int:
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(cap, n))
+
+
+def render_jobs_mt(cfg: SarConfig, rt: Runtime, starts: np.ndarray, iters_per_job: int, threads: int = 0):
+    """render_jobs on `threads` host threads, identical bits (contiguous job slices merged in slice order)."""
+    s = np.ascontiguousarray(starts, dtype=np.float64)
+    rc = lib().sar_oracle_render_jobs_mt(C.byref(cfg), rt.ptr, _dptr(s), s.shape[0], iters_per_job,
+                                         threads or host_threads())
+    if rc != 0:
+        raise MemoryError("sar_oracle_render_jobs_mt")
+
+
 def iterate(cfg: SarConfig, p0, n: int) -> np.ndarray:
     p = np.ascontiguousarray(p0, dtype=np.float64)
     out = np.empty(3, dtype=np.float64)
@@ -288,6 +304,6 @@ def render_parallel(cfg: SarConfig, threads: int, jobs_per_thread: int, seed: in
 
 __all__ = [
     "lib", "build_oracle", "poisson_saturne", "solar_sail", "copy_config", "Runtime", "start_points",
-    "render", "render_jobs", "iterate", "rotation_matrix", "colorize", "merge", "fnv1a64",
+    "render", "render_jobs", "render_jobs_mt", "host_threads", "iterate", "rotation_matrix", "colorize", "merge", "fnv1a64",
     "render_parallel", "SAR_RENDER_GAS", "SAR_RENDER_DEPTH",
 ]

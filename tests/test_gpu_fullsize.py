@@ -1,4 +1,11 @@
-"""GPU, BASELINE.json's full sizes: size-independent properties (the oracle would need minutes per case).
+"""GPU, BASELINE.json's full sizes.
+
+Every full-size frame of BASELINE.json's configs meets the CPU oracle BIT FOR BIT (count, max, zbuf, steps, RGBA16):
+tests/oracle_lib.render_jobs_mt runs the oracle's sequential job loop on the GPU box's host threads with identical
+bits (contiguous job slices folded with Runtime::merge in slice order), so a 1e9-iteration frame takes a few seconds;
+the same buffers are also held to the FNV-1a checksums frozen in tests/golden/fullsize_checksums.json (generated in
+the build container by tests/golden/make_fullsize_checksums.py) — a checksum of checksums that pins the full-size
+result between builds and machines. On top of that, size-independent properties:
 
   * conservation: every counted iteration of a trajectory that stays finite and in bounds lands in exactly one
     pixel: sum(count) == jobs * iterations-per-job when nothing leaves the image (poisson-saturne at scale 1:
@@ -8,7 +15,6 @@
   * linearity: render(A) then render(B) on one runtime == merge(render(A), render(B)) for count / zbuf, and the
     count buffer does not depend on how the job list is cut into launches;
   * determinism across paths: the LDS-binned path and the one-atomic-per-visit path give the same bits;
-  * a checksum of checksums pins the full-size result between runs of the suite on the same build.
 """
 import numpy as np
 import pytest
@@ -19,6 +25,46 @@ pytestmark = pytest.mark.gpu
 def _bits(a):
     a = np.ascontiguousarray(a)
     return a.view({4: np.uint32, 8: np.uint64}[a.dtype.itemsize])
+
+
+def _golden():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fullsize_checksums.json")))
+
+
+def _meets_oracle(sar, oracle, name, **options):
+    """Renders the full-size case `name` on the GPU and on the host oracle; everything must agree bit for bit, and
+    with the committed checksums."""
+    import fullsize_cases as F
+    ocfg, starts, n = F.build_case(name, oracle)
+    cfg = sar.Config(oracle.copy_config(ocfg))
+    rt = sar.Runtime(cfg)
+    for k, v in options.items():
+        rt.set_option(k, v)
+    sar.render_job_range(cfg, rt, n, starts)
+    cnt, z, st, mx, img = rt.count(), rt.zbuf(), rt.steps(), rt.max(), sar.colorize(cfg, rt)
+    rt.close()
+    ort = oracle.Runtime(ocfg.width, ocfg.height)
+    oracle.render_jobs_mt(ocfg, ort, starts, n)
+    assert np.array_equal(cnt, ort.count), f"{name}: count differs from the oracle"
+    assert mx == ort.max
+    assert np.array_equal(_bits(z), _bits(ort.zbuf)), f"{name}: zbuf differs from the oracle"
+    assert np.array_equal(_bits(st), _bits(ort.steps)), f"{name}: steps differs from the oracle"
+    assert np.array_equal(img, oracle.colorize(ocfg, ort)), f"{name}: RGBA16 differs from the oracle"
+    g = _golden()[name]
+    assert g["jobs"] == starts.shape[0] and g["iters_per_job"] == n
+    got = {"max": mx, "count_sum": int(cnt.sum(dtype=np.uint64)), "touched": int((cnt > 0).sum()),
+           "count_fnv": f"{oracle.fnv1a64(cnt):016x}", "zbuf_fnv": f"{oracle.fnv1a64(z):016x}",
+           "steps_fnv": f"{oracle.fnv1a64(st):016x}", "rgba_fnv": f"{oracle.fnv1a64(img):016x}"}
+    assert got == {k: g[k] for k in got}, f"{name}: checksums differ from tests/golden/fullsize_checksums.json"
+
+
+@pytest.mark.parametrize("name", ["c2_131072", "c2_65536", "c3_solar_depth", "c4_rank5_share", "c5_frame37"])
+def test_fullsize_frame_equals_oracle_bit_for_bit(sar, oracle, gpu, name):
+    """BASELINE configs[1] (both the bench's 131 072 jobs and SURVEY's 65 536), configs[2], one rank's share of
+    configs[3] and one frame of configs[4], all at full size."""
+    _meets_oracle(sar, oracle, name)
 
 
 def test_c2_poisson_1e9_2048(sar, gpu):

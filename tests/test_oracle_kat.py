@@ -121,3 +121,27 @@ def test_attractor_extent_matches_the_numbers_in_the_reference_source(oracle):
     assert np.all((ref - e[:6]) * sign > -2e-6), "a bound lies outside the reference's"
     # the raw extent is a different box: the comment's numbers are not raw coordinates
     assert np.abs(e[6:] - ref).max() > 0.1
+
+
+def test_threaded_oracle_is_the_sequential_oracle_bit_for_bit(oracle):
+    """tests/oracle_lib.render_jobs_mt (what lets the full-size GPU frames meet the oracle in seconds): contiguous job
+    slices on private runtimes folded with Runtime::merge in slice order == `jobs` sequential render calls."""
+    for preset in (oracle.poisson_saturne, oracle.solar_sail):
+        c = preset()
+        c.width, c.height, c.scale = 160, 120, 1.0
+        st = oracle.start_points(21, 0, 37)
+        a, b = oracle.Runtime(160, 120), oracle.Runtime(160, 120)
+        oracle.render_jobs(c, a, st, 3000)
+        oracle.render_jobs_mt(c, b, st, 3000, 5)
+        assert np.array_equal(a.count, b.count) and a.max == b.max
+        assert np.array_equal(a.zbuf.view(np.uint32), b.zbuf.view(np.uint32))
+        assert np.array_equal(a.steps.view(np.uint64), b.steps.view(np.uint64))
+
+
+def test_fullsize_checksum_fixture_lists_every_case():
+    import json
+    import os
+    import fullsize_cases as F
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fullsize_checksums.json")))
+    assert set(g) == set(F.CASES)
+    assert g["c2_131072"]["count_sum"] == 131072 * 7629 and g["c4_rank5_share"]["count_sum"] == 65536 * 19073
