@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — attractor iterations/second of the MI355X iterate/accumulate path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(`python bench.py --gpus N` alone spawns the N ranks itself through torch.distributed.run.)
 
-A "step" is one whole frame of BASELINE.json configs[1] on every GPU: reset the runtime (as every
-render_parallel frame does, reference src/lib.rs:950-951), iterate/accumulate 1e9 counted attractor
-iterations of poisson-saturne into a 2048x2048 runtime (start points uploaded inside the step), then —
-for N>1 — the depth/count exchange over RCCL, and colorize to an RGBA16 image in device memory.
-Scaling is WEAK: every GPU renders its own 1e9 iterations of a (N x 1e9)-iteration frame.
+A "step" is one whole frame on every GPU: reset the runtime (as every render_parallel frame does, reference
+src/lib.rs:950-951), iterate/accumulate this rank's trajectories (start points resident in HBM), then — for N>1 —
+the one exchange step (all-to-all of the image slices, merge in rank order, 4-scalar all-reduce) and the colorize
+(sharded for N>1, RGBA16 gathered on rank 0) to an RGBA16 image in device memory.
+
+  --config c2 (default)  BASELINE.json configs[1]: poisson-saturne, 1e9 iterations PER GPU, 2048x2048. WEAK scaling:
+                         every GPU renders its own 1e9 iterations of an (N x 1e9)-iteration frame.
+  --config c4            BASELINE.json configs[3]: poisson-saturne, 1e10 iterations, 4096x4096, jobs_total = 524 288
+                         sharded over the ranks (shard_jobs). STRONG scaling: the frame is the same at every N; at
+                         N=1 the one GPU runs all 524 288 jobs in launch chunks.
 
 One JSON line on rank 0; see DESIGN.md "Measurement" for how each field is derived.
 """
@@ -24,6 +30,7 @@ sys.path.insert(0, ROOT)
 WIDTH = HEIGHT = 2048
 ITERS_PER_GPU = 1_000_000_000
 DEFAULT_JOBS = 131072            # trajectories per GPU (2 waves per SIMD on 256 CUs); n = floor(1e9 / jobs)
+C4_SIZE, C4_ITERS, C4_JOBS = 4096, 10_000_000_000, 524288   # BASELINE configs[3] (65 536 jobs per GPU at 8)
 ALG_BYTES_PER_ITER = 12.0 + 12.0 * 0.0055   # count RMW 8 B + zbuf read 4 B + win-rate * 12 B
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_OPS_PER_ITER = 88           # unfused fp64 ops per counted iteration; FMA is not allowed
@@ -106,26 +113,43 @@ def main():
                     "the per-rank buffers (debug; not timed)")
     ap.add_argument("--host-starts", action="store_true", help="hand the start points over from host memory every step "
                     "(PCIe-inclusive rate; the default keeps them resident in HBM)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4"], help="c2: BASELINE configs[1], weak scaling (default); "
+                    "c4: BASELINE configs[3] (1e10 iterations, 4096^2, 524288 jobs sharded over the ranks), strong scaling")
+    ap.add_argument("--exchange", default="sliced", choices=["sliced", "rooted"], help="N>1: all-to-all of image slices + "
+                    "sharded colorize (default) or all-reduce MAX + reduce SUM onto rank 0")
     ap.add_argument("--variant", type=lambda s: int(s, 0), default=0)
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--stride", type=int, default=0)
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU) and relay their output
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     import numpy as np
     import torch
     import strange_attractor_renderer_amd as S
-    from strange_attractor_renderer_amd.distributed import exchange_merge
+    from strange_attractor_renderer_amd.distributed import SlicedExchange, exchange_merge, shard_jobs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-        a.gpus = world
+    a.gpus = world
     if not torch.cuda.is_available() or S.device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
-    local_rank %= max(torch.cuda.device_count(), 1)
+    ndev = max(torch.cuda.device_count(), 1)
+    if world > ndev and a.backend == "nccl":
+        # more ranks than GPUs (a 1-GPU box exercising the N-rank path): RCCL refuses two ranks on one device
+        a.backend = "gloo"
+    local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -136,13 +160,24 @@ def main():
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
 
-    jobs = a.jobs
-    iters_gpu = int(a.iters)
-    n = iters_gpu // jobs
-    # global frame: world*jobs trajectories of n iterations; this rank owns jobs [rank*jobs, (rank+1)*jobs)
-    cfg = S.Config.poisson_saturne(iterations=n * jobs * world, width=WIDTH, height=HEIGHT,
-                                   jobs_total=jobs * world, transparent=0, seed=1)
-    starts = S.start_points(1, rank * jobs, jobs)
+    if a.config == "c4":
+        # STRONG scaling: the frame (1e10 iterations, 524 288 jobs, 4096^2) is the same at every N; rank r renders the
+        # contiguous job slice shard_jobs gives it (src/lib.rs:1056-1062 split)
+        width = height = C4_SIZE
+        total_jobs = C4_JOBS if a.jobs == DEFAULT_JOBS else a.jobs
+        n = int(a.iters if a.iters != ITERS_PER_GPU else C4_ITERS) // total_jobs
+        first_job, jobs = shard_jobs(total_jobs, world, rank)
+    else:
+        # WEAK scaling: world*jobs trajectories of n iterations; this rank owns jobs [rank*jobs, (rank+1)*jobs)
+        width = height = WIDTH
+        jobs = a.jobs
+        n = int(a.iters) // jobs
+        total_jobs = jobs * world
+        first_job = rank * jobs
+    iters_gpu = n * jobs
+    cfg = S.Config.poisson_saturne(iterations=n * total_jobs, width=width, height=height,
+                                   jobs_total=total_jobs, transparent=0, seed=1)
+    starts = S.start_points(1, first_job, jobs)
 
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
@@ -150,11 +185,18 @@ def main():
         rt.set_stream(stream.cuda_stream)
         rt.enable_timing(True)
         rt.set_tuning(block_threads=a.block, checkpoint_stride=a.stride, variant=a.variant)
-        npix = WIDTH * HEIGHT
+        npix = width * height
         rgba = torch.empty(npix * 4, dtype=torch.int16, device="cuda")
-        if world > 1:
+        ex = None
+        if world > 1 and a.exchange == "sliced":
+            ex = SlicedExchange(S, cfg, rt, rank, world, "cuda")
+        elif world > 1:
             key = torch.empty(npix, dtype=torch.int64, device="cuda")
             sums = torch.empty(3 * npix, dtype=torch.int32, device="cuda")
+        # per timed step: render end / exchange end / colorize end (read after the closing fence, never inside the region)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(max(a.steps, a.warmup, 1))] if world > 1 else []
+        exch_ms = [0.0, 0.0]
+        step_no = [0]
 
         # the inputs of the path — the start points of this rank's trajectories — are resident in HBM before the
         # timed region starts (with host start points each frame uploads 3 MiB: +0.1 ms)
@@ -167,10 +209,23 @@ def main():
             else:
                 S.render_job_range_device(cfg, rt, jobs, n, starts_dev.data_ptr())
             if world > 1:
-                # Runtime::merge folded in rank order as two collectives over xGMI:
-                # depth keys (z, lowest rank wins ties) -> all-reduce MAX; counts + winner's steps -> reduce SUM
-                exchange_merge(rt, rank, dist, key, sums, dst=0)
-            if rank == 0:
+                ev = evs[step_no[0] % len(evs)]
+                step_no[0] += 1
+                ev[0].record()
+                if ex is not None:
+                    # Runtime::merge folded in rank order, sliced: all-to-all of the image slices (16 B/px), the owner
+                    # folds its slice, 4 scalars all-reduced, every rank colorizes its slice, RGBA16 gathered on rank 0
+                    ex.merge(dist)
+                    ev[1].record()
+                    ex.colorize(dist, dst=0)
+                else:
+                    # rooted: depth keys -> all-reduce MAX; counts + winner's steps -> reduce SUM; rank 0 colorizes
+                    exchange_merge(rt, rank, dist, key, sums, dst=0)
+                    ev[1].record()
+                    if rank == 0:
+                        S.colorize_device(cfg, rt, rgba.data_ptr())
+                ev[2].record()
+            else:
                 S.colorize_device(cfg, rt, rgba.data_ptr())
 
         def fence():
@@ -183,25 +238,42 @@ def main():
         fence()
         if world > 1 and a.check:
             # each rank's own (un-merged) count summed over ranks must equal the merged count on rank 0
+            def reduce_sum(a_np):  # int64 SUM onto rank 0, through whatever the backend can move
+                t = torch.from_numpy(np.ascontiguousarray(a_np))
+                t = t.cuda() if a.backend == "nccl" else t
+                dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+                return t.cpu().numpy()
+
             rt.reset()
             S.render_job_range(cfg, rt, n, starts)
-            own = torch.from_numpy(rt.count().astype(np.int64)).cuda()
-            exchange_merge(rt, rank, dist, key, sums, dst=0)
-            dist.reduce(own, dst=0, op=dist.ReduceOp.SUM)
+            own = reduce_sum(rt.count().ravel().astype(np.int64))
+            if ex is not None:
+                ex.merge(dist)
+                torch.cuda.synchronize()
+                mine = np.zeros(npix, np.int64)  # every rank holds the merged frame inside its own slice: assemble them
+                mine[ex.first:ex.first + ex.count] = rt.count().ravel()[ex.first:ex.first + ex.count]
+                merged = reduce_sum(mine)
+            else:
+                exchange_merge(rt, rank, dist, key, sums, dst=0)
+                torch.cuda.synchronize()
+                merged = rt.count().ravel().astype(np.int64)
             if rank == 0:
-                merged = rt.count().astype(np.int64)
-                assert np.array_equal(merged, own.cpu().numpy() % (1 << 32)), "merged count != sum of rank counts"
-                assert int(merged.sum()) == n * jobs * world
-                print(f"[check] merged count over {world} ranks == sum of per-rank counts == {n * jobs * world}", file=sys.stderr)
+                assert np.array_equal(merged, own % (1 << 32)), "merged count != sum of rank counts"
+                assert int(merged.sum()) == n * total_jobs
+                print(f"[check] merged count over {world} ranks == sum of per-rank counts == {n * total_jobs}", file=sys.stderr)
             fence()
         # HIP events around every launch of the timed region, recorded on the launch stream by the library and
         # summed until they are read after the closing fence (reading them synchronises, so not inside the region)
         rt.set_option("timing_accumulate", 1)
         t0 = time.perf_counter()
+        step_no[0] = 0
         for _ in range(a.steps):
             step()
         fence()
         elapsed = time.perf_counter() - t0
+        for ev in evs[:a.steps]:
+            exch_ms[0] += ev[0].elapsed_time(ev[1])
+            exch_ms[1] += ev[1].elapsed_time(ev[2])
         tm = rt.last_timing()
         iter_ms, fold_ms, launches = tm.iterate_ms, tm.resolve_ms, tm.iterate_launches
         col_ms = tm.colorize_ms
@@ -210,28 +282,36 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
-    counted = n * jobs * world * a.steps
+    counted = n * total_jobs * a.steps
     value = counted / elapsed
     if rank == 0:
         kern_s = iter_ms * 1e-3 / max(launches, 1)             # average duration of one k_iterate_lean launch
         per_launch = n * jobs * a.steps / max(launches, 1)      # counted iterations one launch processes
         ach = ALG_BYTES_PER_ITER * per_launch / kern_s / 1e9
         out = {
-            "metric": "attractor iterations/sec at 1e9 iters, 2048x2048 buffer (poisson-saturne), per-GPU frame",
+            "metric": ("attractor iterations/sec at 1e9 iters, 2048x2048 buffer (poisson-saturne), per-GPU frame" if a.config == "c2"
+                       else "attractor iterations/sec at 1e10 iters, 4096x4096 buffer (poisson-saturne), whole frame"),
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if a.config == "c2" else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: poisson-saturne, 1e9 iterations per GPU, 2048x2048, "
-                                   "Gas colorize to RGBA16 in HBM", "jobs_per_gpu": jobs,
-                       "iterations_per_job": n, "counted_iterations_per_step": n * jobs * world,
+            "config": {"workload": ("BASELINE configs[1]: poisson-saturne, 1e9 iterations per GPU, 2048x2048, "
+                                    "Gas colorize to RGBA16 in HBM") if a.config == "c2" else
+                                   ("BASELINE configs[3]: poisson-saturne, 1e10 iterations, 4096x4096, 524288 jobs "
+                                    "sharded over the GPUs, Gas colorize to RGBA16 in HBM"),
+                       "jobs_per_gpu": jobs, "jobs_total": total_jobs,
+                       "iterations_per_job": n, "counted_iterations_per_step": n * total_jobs,
                        "warmup_iterations_per_job_uncounted": 1000,
                        "start_points": "uploaded from host memory every step" if a.host_starts else "resident in HBM",
                        "parallelism": f"trajectories sharded over {world} GPU(s)"
-                                      + (f"; all-reduce MAX (depth keys) + reduce SUM (count, steps) over "
-                                         f"{'RCCL/xGMI' if a.backend == 'nccl' else a.backend}" if world > 1 else "")},
+                                      + ((f"; all-to-all of image slices (16 B/px) + merge in rank order + sharded "
+                                          f"colorize + RGBA16 gather (8 B/px)" if a.exchange == "sliced" else
+                                          f"; all-reduce MAX (depth keys) + reduce SUM (count, steps)")
+                                         + f" over {'RCCL/xGMI' if a.backend == 'nccl' else a.backend + ' (ranks share GPUs: staged through host)'}"
+                                         if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes() if (iters_gpu == ITERS_PER_GPU and jobs == DEFAULT_JOBS) else None,
+                         "traffic": pmc_traffic_bytes() if (a.config == "c2" and int(a.iters) == ITERS_PER_GPU and jobs == DEFAULT_JOBS) else None,
                          "kernel": "k_iterate_lean", "kernel_ms": kern_s * 1e3,
                          "alg_bytes_per_iteration": ALG_BYTES_PER_ITER,
                          "launches_timed": launches,
@@ -244,7 +324,12 @@ def main():
                                    "accumulate_fold_resolve": fold_ms / a.steps,
                                    "colorize_last": col_ms},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world > 1:
+            out["exchange_ms_per_step"] = {"merge": exch_ms[0] / a.steps, "colorize_and_gather": exch_ms[1] / a.steps,
+                                           "form": a.exchange, "backend": a.backend}
+            if ex is not None:
+                out["exchange_ms_per_step"]["bytes_on_the_wire_per_rank"] = ex.bytes_on_the_wire()
+        if world == 1 and not a.no_cpu_baseline and a.config == "c2":
             out["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)

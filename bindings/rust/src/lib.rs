@@ -72,6 +72,18 @@ pub struct SarTiming {
 }
 
 #[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct SarParallelTiming {
+    pub total_ms: f32,
+    pub render_ms: f32,
+    pub exchange_ms: f32,
+    pub colorize_ms: f32,
+    pub n_devices: u32,
+    pub _pad: u32,
+    pub exchange_bytes_per_device: u64,
+}
+
+#[repr(C)]
 pub struct SarRuntime {
     _private: [u8; 0],
 }
@@ -135,6 +147,19 @@ extern "C" {
     pub fn sar_runtime_exchange_import(rt: *mut SarRuntime, key_i64_reduced_dev: *const c_void,
                                        sum_i32_reduced_dev: *const c_void) -> c_int;
 
+    // sliced exchange: every rank owns one slice of the image (all-to-all 16 B/px, merge in rank order, sharded colorize)
+    pub fn sar_exchange_slice_pixels(npix: u32, world: u32, out_slice_pixels: *mut u32) -> c_int;
+    pub fn sar_runtime_exchange_pack(rt: *mut SarRuntime, world: u32, blocks_out_dev: *mut c_void) -> c_int;
+    pub fn sar_runtime_exchange_merge_slices(rt: *mut SarRuntime, world: u32, rank: u32, blocks_in_dev: *const c_void) -> c_int;
+    pub fn sar_runtime_exchange_scalars_export(rt: *mut SarRuntime, i64x4_out_dev: *mut c_void) -> c_int;
+    pub fn sar_runtime_exchange_scalars_import(rt: *mut SarRuntime, i64x4_dev: *const c_void) -> c_int;
+    pub fn sar_colorize_range_device(cfg: *const SarConfig, rt: *mut SarRuntime, first_px: u32, n_px: u32,
+                                     rgba_out_dev: *mut c_void) -> c_int;
+
+    pub fn sar_renderer_new_multi(devices: *const c_int, n_devices: u32, units: u32, seed: u64,
+                                  out: *mut *mut SarRenderer) -> c_int; // ParallelRenderer::new over several GPUs (:919)
+    pub fn sar_renderer_num_devices(r: *const SarRenderer, out_devices: *mut u32) -> c_int;
+    pub fn sar_renderer_last_timing(r: *const SarRenderer, out: *mut SarParallelTiming) -> c_int;
     pub fn sar_renderer_new(device: c_int, units: u32, seed: u64, out: *mut *mut SarRenderer) -> c_int; // ParallelRenderer::new (:919)
     pub fn sar_renderer_num_units(r: *const SarRenderer, out_units: *mut u32) -> c_int;
     pub fn sar_renderer_shutdown(r: *mut SarRenderer) -> c_int; // ParallelRenderer::shutdown (:1020)

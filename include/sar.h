@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SAR_ABI_VERSION 2
+#define SAR_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -241,12 +241,42 @@ int sar_runtime_exchange_select(sar_runtime* rt, uint32_t rank, const void* key_
 int sar_runtime_exchange_import(sar_runtime* rt, const void* key_i64_reduced_dev,
                                 const void* sum_i32_reduced_dev);
 
+/* ---- multi-GPU exchange, sliced form (preferred) ------------------------------------------------------
+ * Every rank OWNS the slice [rank*S, min(npix, (rank+1)*S)) of the image, S = sar_exchange_slice_pixels(npix, world).
+ *   1. pack:          out = `world` blocks of S*16 bytes, block d = this rank's partial buffers of rank d's slice as
+ *                     [count u32 x S | sortable(zbuf) u32 x S | steps f64 x S]                  -> all-to-all (16 B/px)
+ *   2. merge_slices:  in = `world` blocks of S*16 bytes, block s = rank s's partial buffers of MY slice; folded with
+ *                     Runtime::merge (:708-738) in rank order (rank 0 = the accumulator of :1070, the earlier rank
+ *                     wins depth ties, `max` follows every intermediate sum) into rt's own buffers at my slice
+ *   3. scalars:       {max, wrap flag, depth range} as 4 x int64                                 -> all-reduce MAX
+ *   4. sar_colorize_range_device on my slice                                                      -> gather (8 B/px)
+ * After step 2 a runtime holds the merged frame only inside its own slice. */
+int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice_pixels);
+int sar_runtime_exchange_pack(sar_runtime* rt, uint32_t world, void* blocks_out_dev /* world*S*16 bytes */);
+int sar_runtime_exchange_merge_slices(sar_runtime* rt, uint32_t world, uint32_t rank,
+                                      const void* blocks_in_dev /* world*S*16 bytes */);
+int sar_runtime_exchange_scalars_export(sar_runtime* rt, void* i64x4_out_dev);
+int sar_runtime_exchange_scalars_import(sar_runtime* rt, const void* i64x4_dev);
+/* colorize (:841-904) of the pixel range [first_px, first_px + n_px) into out_dev (n_px*8 bytes, RGBA16), using the
+ * max / depth range the runtime's scalars hold (made global by step 3); stream-ordered. */
+int sar_colorize_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t first_px, uint32_t n_px, void* rgba_out_dev);
+
 /* ---- ParallelRenderer / render_parallel (src/lib.rs:908-1082) -------------------------------------- */
 /* ParallelRenderer::new (:919-1004). `units` plays the role of num_threads (:920-922): the number of
  * execution units the job split divides by; 0 selects the device default, 64 per CU (16 384 on MI355X), so that the
  * CLI's default of 12 jobs per thread (src/bin/main.rs:305) becomes 196 608 trajectories = three waves per SIMD.
  * The renderer owns one runtime on `device`, seeded with `seed`. */
 int sar_renderer_new(int device, uint32_t units, uint64_t seed, sar_renderer** out);
+/* The same over SEVERAL GPUs of one node, behind this ABI alone (no Python, no RCCL): ParallelRenderer::new owns every
+ * execution unit of the machine (:919-1004). devices[n_devices] are HIP device ordinals in FOLD ORDER (device 0 is the
+ * accumulator of :1070; a device may be listed more than once — each entry is its own shard). units == 0: 64 per CU
+ * summed over the devices. render_parallel then cuts the units*jobs_per_unit jobs into contiguous slices, one per
+ * device, renders them concurrently (one host thread + one stream per device), lets every device own one slice of
+ * the image, moves the partial buffers point-to-point (hipMemcpyPeerAsync: every pair of GPUs over its own xGMI link,
+ * 16 B/px), folds them with Runtime::merge in device order, colorizes each slice where it lives and copies it
+ * straight into rgba_out_host. The result is bit-identical to the single-device renderer's for the same units. */
+int sar_renderer_new_multi(const int* devices, uint32_t n_devices, uint32_t units, uint64_t seed, sar_renderer** out);
+int sar_renderer_num_devices(const sar_renderer* r, uint32_t* out_devices);
 int sar_renderer_num_units(const sar_renderer* r, uint32_t* out_units);
 /* ParallelRenderer::shutdown (:1020-1025). */
 int sar_renderer_shutdown(sar_renderer* r);
@@ -254,8 +284,20 @@ int sar_renderer_shutdown(sar_renderer* r);
  * jobs (:1062), reset, render, colorize. rgba_out_host: width*height*4 uint16. */
 int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_per_unit,
                         uint16_t* rgba_out_host);
-/* The renderer's runtime (borrowed), e.g. to read the count buffer after render_parallel. */
+/* The renderer's runtime (borrowed; device 0's), e.g. to read the count buffer after render_parallel. With several
+ * devices the merged slices are first gathered into it (20 B/px over xGMI, once per frame, only when asked). */
 int sar_renderer_runtime(sar_renderer* r, sar_runtime** out_borrowed);
+/* Phases of the last sar_render_parallel on a multi-device renderer: the slowest device's stream time per phase. */
+typedef struct sar_parallel_timing {
+    float    total_ms;      /* host wall time of the call */
+    float    render_ms;     /* reset + warm-up + iterate + accumulate + fold + pack */
+    float    exchange_ms;   /* peer copies + merge of the owned slice (includes waiting for the slowest peer) */
+    float    colorize_ms;   /* scalars + colorize of the slice + its copy to the host image */
+    uint32_t n_devices;
+    uint32_t _pad;
+    uint64_t exchange_bytes_per_device;  /* bytes every device pulls over xGMI per frame */
+} sar_parallel_timing;
+int sar_renderer_last_timing(const sar_renderer* r, sar_parallel_timing* out);
 
 /* ---- measurement ----------------------------------------------------------------------------------- */
 int sar_runtime_enable_timing(sar_runtime* rt, int enabled);

@@ -63,6 +63,18 @@ class SarConfig(C.Structure):
     ]
 
 
+class SarParallelTiming(C.Structure):
+    _fields_ = [
+        ("total_ms", C.c_float),
+        ("render_ms", C.c_float),
+        ("exchange_ms", C.c_float),
+        ("colorize_ms", C.c_float),
+        ("n_devices", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("exchange_bytes_per_device", C.c_uint64),
+    ]
+
+
 class SarTiming(C.Structure):
     _fields_ = [
         ("iterate_ms", C.c_float),
@@ -123,7 +135,16 @@ PROTOTYPES = {
     "sar_runtime_exchange_export": (C.c_int, [_vp, C.c_uint32, _vp]),
     "sar_runtime_exchange_select": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
     "sar_runtime_exchange_import": (C.c_int, [_vp, _vp, _vp]),
+    "sar_exchange_slice_pixels": (C.c_int, [C.c_uint32, C.c_uint32, _P(C.c_uint32)]),
+    "sar_runtime_exchange_pack": (C.c_int, [_vp, C.c_uint32, _vp]),
+    "sar_runtime_exchange_merge_slices": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
+    "sar_runtime_exchange_scalars_export": (C.c_int, [_vp, _vp]),
+    "sar_runtime_exchange_scalars_import": (C.c_int, [_vp, _vp]),
+    "sar_colorize_range_device": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint32, _vp]),
     "sar_renderer_new": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, _P(_vp)]),
+    "sar_renderer_new_multi": (C.c_int, [_P(C.c_int), C.c_uint32, C.c_uint32, C.c_uint64, _P(_vp)]),
+    "sar_renderer_num_devices": (C.c_int, [_vp, _P(C.c_uint32)]),
+    "sar_renderer_last_timing": (C.c_int, [_vp, _P(SarParallelTiming)]),
     "sar_renderer_num_units": (C.c_int, [_vp, _P(C.c_uint32)]),
     "sar_renderer_shutdown": (C.c_int, [_vp]),
     "sar_render_parallel": (C.c_int, [_vp, _cfg_p, C.c_uint32, _P(C.c_uint16)]),

@@ -23,7 +23,7 @@ import numpy as np
 
 from . import _abi
 from ._abi import (SAR_CT_ADJUSTED_VELOCITY, SAR_CT_POISSON_SATURNE, SAR_RENDER_DEPTH,  # noqa: F401
-                   SAR_RENDER_GAS, SarConfig, SarTiming)
+                   SAR_RENDER_GAS, SarConfig, SarParallelTiming, SarTiming)
 
 
 class SarError(RuntimeError):
@@ -261,6 +261,36 @@ class Runtime:
                                                   C.c_void_p(sum_reduced_dev_ptr)), "sar_runtime_exchange_import")
 
 
+    # sliced form: every rank owns one slice of the image (include/sar.h)
+    def exchange_pack(self, world: int, blocks_dev_ptr: int):
+        _check(_lib().sar_runtime_exchange_pack(self._h, world, C.c_void_p(blocks_dev_ptr)), "sar_runtime_exchange_pack")
+
+    def exchange_merge_slices(self, world: int, rank: int, blocks_dev_ptr: int):
+        _check(_lib().sar_runtime_exchange_merge_slices(self._h, world, rank, C.c_void_p(blocks_dev_ptr)),
+               "sar_runtime_exchange_merge_slices")
+
+    def exchange_scalars_export(self, i64x4_dev_ptr: int):
+        _check(_lib().sar_runtime_exchange_scalars_export(self._h, C.c_void_p(i64x4_dev_ptr)),
+               "sar_runtime_exchange_scalars_export")
+
+    def exchange_scalars_import(self, i64x4_dev_ptr: int):
+        _check(_lib().sar_runtime_exchange_scalars_import(self._h, C.c_void_p(i64x4_dev_ptr)),
+               "sar_runtime_exchange_scalars_import")
+
+
+def exchange_slice_pixels(npix: int, world: int) -> int:
+    """Pixels per owned slice of the sliced multi-GPU exchange (the last slice may be shorter)."""
+    s = C.c_uint32()
+    _check(_lib().sar_exchange_slice_pixels(npix, world, C.byref(s)), "sar_exchange_slice_pixels")
+    return int(s.value)
+
+
+def colorize_range_device(config: Config, runtime: Runtime, first_px: int, n_px: int, rgba_dev_ptr: int):
+    """colorize of a pixel range with the max / depth range the runtime's scalars hold (n_px*8 bytes out); stream-ordered."""
+    _check(_lib().sar_colorize_range_device(C.byref(config.c), runtime.handle, first_px, n_px, C.c_void_p(rgba_dev_ptr)),
+           "sar_colorize_range_device")
+
+
 def _starts_ptr(starts, n_jobs: int):
     if starts is None:
         return None, None
@@ -383,11 +413,28 @@ class ParallelRenderer:
     """``ParallelRenderer`` (src/lib.rs:908): `units` stands in for the thread count the job split
     divides by (0 = one trajectory per SIMD lane of the device)."""
 
-    def __init__(self, device: int = 0, units: int = 0, seed: int = 0):
+    def __init__(self, device: int = 0, units: int = 0, seed: int = 0, devices=None):
+        """devices: a list of HIP device ordinals -> one renderer over several GPUs (sar_renderer_new_multi): the jobs
+        are sharded over them, the partial buffers merged point-to-point over xGMI, all behind the C ABI."""
         h = C.c_void_p()
-        _check(_lib().sar_renderer_new(device, units, seed, C.byref(h)), "sar_renderer_new")
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            _check(_lib().sar_renderer_new_multi(devs, len(devices), units, seed, C.byref(h)), "sar_renderer_new_multi")
+            device = int(devices[0])
+        else:
+            _check(_lib().sar_renderer_new(device, units, seed, C.byref(h)), "sar_renderer_new")
         self._h = h
         self.device = device
+
+    def num_devices(self) -> int:
+        n = C.c_uint32()
+        _check(_lib().sar_renderer_num_devices(self._h, C.byref(n)), "sar_renderer_num_devices")
+        return int(n.value)
+
+    def last_timing(self) -> dict:
+        t = SarParallelTiming()
+        _check(_lib().sar_renderer_last_timing(self._h, C.byref(t)), "sar_renderer_last_timing")
+        return {k: getattr(t, k) for k, _ in SarParallelTiming._fields_ if k != "_pad"}
 
     def num_threads(self) -> int:
         n = C.c_uint32()

@@ -192,6 +192,93 @@ __global__ void __launch_bounds__(256) k_exch_import(uint32_t* count, unsigned l
 }
 
 // ---------------------------------------------------------------------------------------------------
+// multi-GPU exchange, sliced form: every rank OWNS one slice of S consecutive pixels. All-to-all of the slices
+// (16 B/px on the wire, each pair of GPUs over its own xGMI link), then the owner folds the G partial slices with
+// Runtime::merge (:708-738) in rank order, colorizes its slice, and only RGBA16 (8 B/px) travels to the root.
+// Block layout (pack output and merge input alike): [G blocks][count u32 x S | sortable(z) u32 x S | steps f64 x S].
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_exch_pack(const uint32_t* __restrict__ count, const unsigned long long* __restrict__ key,
+                                                   const double* __restrict__ steps, uint32_t npix, uint32_t S, uint32_t G,
+                                                   unsigned char* __restrict__ out) {
+    const uint32_t total = S * G;  // host guarantees S * G < 2^32
+    const uint32_t unset = f32_sortable(-1.0f);
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+        const uint32_t d = p / S, o = p - d * S;
+        unsigned char* blk = out + (size_t)d * S * 16u;
+        const bool in = p < npix;  // slices are consecutive pixel ranges: pixel index == p
+        ((uint32_t*)blk)[o] = in ? count[p] : 0u;
+        ((uint32_t*)(blk + (size_t)S * 4u))[o] = in ? (uint32_t)(key[p] >> 32) : unset;
+        ((double*)(blk + (size_t)S * 8u))[o] = in ? steps[p] : 0.;
+    }
+}
+
+// seeds of the depth range (:877-882) and, on every rank but the accumulator of the fold (rank 0), max <- 0: the
+// reference's merge never looks at other.max (:716-724), only at the merged counts it walks over
+__global__ void k_exch_scalars_init(uint32_t* scalars, int keep_max) {
+    scalars[SC_ZMAX] = f32_sortable(0.0f);
+    scalars[SC_ZMIN] = f32_sortable(3.40282346638528859811704183484516925e+38f);
+    if (!keep_max) {
+        scalars[SC_MAX] = 0u;
+        scalars[SC_WRAP] = 0u;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_exch_merge_slices(uint32_t* __restrict__ count, unsigned long long* __restrict__ key,
+                                                           double* __restrict__ steps, uint32_t first, uint32_t n, uint32_t S,
+                                                           uint32_t G, const unsigned char* __restrict__ in, uint32_t* scalars) {
+    const uint32_t unset = f32_sortable(-1.0f);
+    uint32_t local_max = 0;
+    uint32_t zmx = f32_sortable(0.0f), zmn = f32_sortable(3.40282346638528859811704183484516925e+38f);
+    for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) {
+        // the accumulator is rank 0's partial (`current`, :1070); ranks 1.. are merged into it in order (:1072-1076)
+        uint32_t c = ((const uint32_t*)in)[o];
+        uint32_t z = ((const uint32_t*)(in + (size_t)S * 4u))[o];
+        double st = ((const double*)(in + (size_t)S * 8u))[o];
+        for (uint32_t r = 1; r < G; ++r) {
+            const unsigned char* blk = in + (size_t)r * S * 16u;
+            c += ((const uint32_t*)blk)[o];                      // wrapping, :719
+            local_max = c > local_max ? c : local_max;           // the running max sees every intermediate sum, :721-723
+            const uint32_t oz = ((const uint32_t*)(blk + (size_t)S * 4u))[o];
+            if (oz > z) {                                        // strict: the earlier rank wins ties, :728
+                z = oz;
+                st = ((const double*)(blk + (size_t)S * 8u))[o];
+            }
+        }
+        const uint32_t px = first + o;
+        count[px] = c;
+        key[px] = ((unsigned long long)z << 32) | 0xFFFFFFFFull;
+        steps[px] = st;
+        if (z != unset) {
+            zmx = z > zmx ? z : zmx;
+            zmn = z < zmn ? z : zmn;
+        }
+    }
+    __shared__ uint32_t s_tmp[4];
+    const uint32_t m = block_max_u32(local_max, s_tmp);
+    zmx = block_max_u32(zmx, s_tmp);
+    zmn = block_min_u32(zmn, s_tmp);
+    if (threadIdx.x == 0) {
+        if (m) raise_scalar(&scalars[SC_MAX], m);
+        atomicMax(&scalars[SC_ZMAX], zmx);
+        atomicMin(&scalars[SC_ZMIN], zmn);
+    }
+}
+
+// {max, wrap flag, sortable(zmax), ~sortable(zmin)} as int64: one all-reduce MAX makes them global
+__global__ void k_exch_scalars_export(const uint32_t* scalars, long long* out4) {
+    out4[0] = scalars[SC_MAX];
+    out4[1] = scalars[SC_WRAP];
+    out4[2] = scalars[SC_ZMAX];
+    out4[3] = (long long)(~scalars[SC_ZMIN]);
+}
+__global__ void k_exch_scalars_import(uint32_t* scalars, const long long* in4) {
+    scalars[SC_MAX] = (uint32_t)in4[0];
+    scalars[SC_WRAP] = (uint32_t)in4[1];
+    scalars[SC_ZMAX] = (uint32_t)in4[2];
+    scalars[SC_ZMIN] = ~(uint32_t)in4[3];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k_convert — RGBA16 -> RGB16 / RGBA8 / RGB8 (src/bin/main.rs:52-57: DynamicImage::to_rgb16 / to_rgba8 / to_rgb8).
 // image 0.25's channel conversion u16 -> u8 is ((c + 128) / 257) (rounding, exact inverse of c * 257); alpha is
 // dropped, not pre-multiplied. Streaming: 8 B/px in, 3-6 B/px out; four pixels per thread keep stores 4-byte aligned.
@@ -287,6 +374,32 @@ void launch_colorize_depth(const unsigned long long* key, uint32_t* scalars, uin
     hipLaunchKernelGGL(k_zrange, dim3(grid_for(npix, 256, 1024)), dim3(256), 0, s, key, npix, scalars);
     hipLaunchKernelGGL(k_colorize_depth, dim3(grid_for(npix, 256, 8192)), dim3(256), 0, s, key, scalars, npix,
                        (ushort4*)out);
+}
+
+// a pixel range with the depth range the scalars already hold (sliced multi-GPU colorize: the range is global)
+void launch_colorize_depth_range(const unsigned long long* key, const uint32_t* scalars, uint32_t n, void* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_colorize_depth, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, key, scalars, n, (ushort4*)out);
+}
+
+void launch_exch_pack(const uint32_t* count, const unsigned long long* key, const double* steps, uint32_t npix, uint32_t S,
+                      uint32_t G, void* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_pack, dim3(grid_for(S * G, 256, 8192)), dim3(256), 0, s, count, key, steps, npix, S, G,
+                       (unsigned char*)out);
+}
+
+void launch_exch_merge_slices(uint32_t* count, unsigned long long* key, double* steps, uint32_t first, uint32_t n, uint32_t S,
+                              uint32_t G, const void* in, uint32_t* scalars, bool keep_max, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_scalars_init, dim3(1), dim3(1), 0, s, scalars, keep_max ? 1 : 0);
+    if (n)
+        hipLaunchKernelGGL(k_exch_merge_slices, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, count, key, steps, first, n, S, G,
+                           (const unsigned char*)in, scalars);
+}
+
+void launch_exch_scalars_export(const uint32_t* scalars, void* out4, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_scalars_export, dim3(1), dim3(1), 0, s, scalars, (long long*)out4);
+}
+void launch_exch_scalars_import(uint32_t* scalars, const void* in4, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_scalars_import, dim3(1), dim3(1), 0, s, scalars, (const long long*)in4);
 }
 
 int launch_convert(const void* rgba16, int format, void* out, uint32_t npix, hipStream_t s) {

@@ -32,6 +32,14 @@ void launch_colorize_gas(const uint32_t* count, const double* steps, const uint3
                          int transparent, uint32_t npix, void* out, hipStream_t s);
 void launch_colorize_depth(const unsigned long long* key, uint32_t* scalars, uint32_t npix, void* out,
                            hipStream_t s);
+void launch_colorize_depth_range(const unsigned long long* key, const uint32_t* scalars, uint32_t n, void* out, hipStream_t s);
+// sliced exchange (sar_image.hip): S = pixels per slice, G = ranks; blocks of S*16 bytes [count | sortable z | steps]
+void launch_exch_pack(const uint32_t* count, const unsigned long long* key, const double* steps, uint32_t npix, uint32_t S,
+                      uint32_t G, void* out, hipStream_t s);
+void launch_exch_merge_slices(uint32_t* count, unsigned long long* key, double* steps, uint32_t first, uint32_t n, uint32_t S,
+                              uint32_t G, const void* in, uint32_t* scalars, bool keep_max, hipStream_t s);
+void launch_exch_scalars_export(const uint32_t* scalars, void* out4, hipStream_t s);
+void launch_exch_scalars_import(uint32_t* scalars, const void* in4, hipStream_t s);
 int launch_convert(const void* rgba16, int format, void* out, uint32_t npix, hipStream_t s);
 // returns the number of blocks = 12-double partial results written to `out`
 uint32_t launch_extent(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* out, hipStream_t s);

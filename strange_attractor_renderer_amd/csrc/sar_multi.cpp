@@ -1,0 +1,370 @@
+// sar_multi.cpp — ParallelRenderer / render_parallel (reference src/lib.rs:908-1082) over one OR SEVERAL GPUs, behind
+// the C ABI alone (no Python, no torch.distributed, no RCCL: the exchange is point-to-point, which is exactly what
+// xGMI is).
+//
+// The reference owns `available_parallelism()` worker threads, each with a private Runtime (:919-1004), hands them
+// T*J jobs through a shared counter (:1062), folds the runtimes with Runtime::merge (:1068-1076) and colorizes (:1080).
+// Here a "worker" is a whole GPU:
+//   1. the T*J jobs are cut into contiguous slices, one per device; one host thread per device draws the slice's start
+//      points and enqueues the render on that device's stream (no data-path traffic between devices);
+//   2. every device OWNS one slice of S consecutive pixels of the image: it packs its partial buffers into one block per
+//      owner (16 B/px), the owners PULL their blocks with hipMemcpyPeerAsync — G*(G-1) copies, every pair over its own
+//      xGMI link — and fold them with Runtime::merge in device order (k_exch_merge_slices: device 0 is the accumulator,
+//      the earlier device wins depth ties, the running max sees every intermediate sum);
+//   3. four scalars (max, wrap flag, depth range) are combined on the host, every device colorizes ITS slice and copies
+//      it straight into the caller's host image over its own PCIe link.
+// With one device steps 2-3 collapse to a plain colorize.
+#include <chrono>
+#include <cstring>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "sar_runtime_impl.hpp"
+
+using namespace sar;
+
+#define HIP_TRY(expr)                                                                 \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorOutOfMemory) ? SAR_ERR_OOM : SAR_ERR_HIP;           \
+        }                                                                             \
+    } while (0)
+
+#define SAR_TRY(expr)                    \
+    do {                                 \
+        int s_ = (expr);                 \
+        if (s_ != SAR_OK) return s_;     \
+    } while (0)
+
+namespace {
+
+struct Shard {
+    int device = 0;
+    sar_runtime* rt = nullptr;
+    // sliced exchange
+    void* d_pack = nullptr;   // [G][S*16] this device's partial buffers, one block per owner
+    void* d_recv = nullptr;   // [G][S*16] every device's block of the slice this device owns
+    void* d_rgba = nullptr;   // [S*8] colorized slice
+    void* d_sc = nullptr;     // int64[4] scalars in / out
+    long long* h_sc = nullptr;  // pinned int64[4]
+    size_t slice_cap = 0;     // S the buffers were sized for
+    hipEvent_t packed = nullptr, merged = nullptr, begin = nullptr, end = nullptr;
+    // job slice of the current frame
+    uint32_t first_job = 0, n_jobs = 0;
+    int status = SAR_OK;
+    char error[512] = {0};
+};
+
+}  // namespace
+
+struct sar_renderer {
+    uint32_t units = 0;
+    uint64_t seed = 0;
+    Rng rng;                      // the renderer's start-point stream: job k of a frame takes the next three draws
+    std::vector<Shard> shards;    // one per device, in fold order
+    uint32_t W = 0, H = 0;
+    bool scattered = false;       // shard runtimes hold only their own merged slice (gather before handing one out)
+    sar_parallel_timing timing{};
+};
+
+namespace {
+
+uint32_t slice_pixels(uint32_t npix, uint32_t world) {
+    const uint64_t s = (static_cast<uint64_t>(npix) + world - 1) / world;
+    return static_cast<uint32_t>((s + 3u) & ~3ull);
+}
+
+int free_shard_buffers(Shard& sh) {
+    hipSetDevice(sh.device);
+    if (sh.d_pack) hipFree(sh.d_pack);
+    if (sh.d_recv) hipFree(sh.d_recv);
+    if (sh.d_rgba) hipFree(sh.d_rgba);
+    sh.d_pack = sh.d_recv = sh.d_rgba = nullptr;
+    sh.slice_cap = 0;
+    return SAR_OK;
+}
+
+int ensure_shard(sar_renderer* r, Shard& sh, const sar_config* cfg, uint32_t S) {
+    const uint32_t G = static_cast<uint32_t>(r->shards.size());
+    if (!sh.rt) {
+        sar_config c0 = *cfg;
+        c0.seed = r->seed;
+        SAR_TRY(sar_runtime_new(&c0, sh.device, &sh.rt));
+    }
+    SAR_TRY(sar_runtime_set_width_height(sh.rt, cfg->width, cfg->height));  // :950
+    if (G == 1) return SAR_OK;
+    HIP_TRY(hipSetDevice(sh.device));
+    if (!sh.packed) {
+        HIP_TRY(hipEventCreate(&sh.packed));
+        HIP_TRY(hipEventCreate(&sh.merged));
+        HIP_TRY(hipEventCreate(&sh.begin));
+        HIP_TRY(hipEventCreate(&sh.end));
+        HIP_TRY(hipMalloc(&sh.d_sc, 4 * sizeof(long long)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sh.h_sc), 4 * sizeof(long long), hipHostMallocDefault));
+    }
+    if (sh.slice_cap != S) {
+        HIP_TRY(hipStreamSynchronize(sh.rt->stream));
+        free_shard_buffers(sh);
+        HIP_TRY(hipMalloc(&sh.d_pack, static_cast<size_t>(G) * S * 16u));
+        HIP_TRY(hipMalloc(&sh.d_recv, static_cast<size_t>(G) * S * 16u));
+        HIP_TRY(hipMalloc(&sh.d_rgba, static_cast<size_t>(S) * 8u));
+        sh.slice_cap = S;
+    }
+    return SAR_OK;
+}
+
+// what one reference worker thread does with its share of the jobs (:950-988), for a whole GPU
+void render_shard(sar_renderer* r, Shard* sh, const sar_config* cfg, uint64_t per_job, const double* starts, uint32_t S) {
+    const uint32_t G = static_cast<uint32_t>(r->shards.size());
+    auto run = [&]() -> int {
+        HIP_TRY(hipSetDevice(sh->device));
+        sar_runtime* rt = sh->rt;
+        if (G > 1) HIP_TRY(hipEventRecord(sh->begin, rt->stream));
+        SAR_TRY(sar_runtime_reset(rt));  // :951
+        SAR_TRY(render_chunked(cfg, rt, sh->n_jobs, per_job, starts + 3 * static_cast<size_t>(sh->first_job)));
+        if (G > 1) {
+            launch_exch_pack(rt->d_count, rt->d_key, rt->d_steps, rt->npix, S, G, sh->d_pack, rt->stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(sh->packed, rt->stream));
+        }
+        return SAR_OK;
+    };
+    sh->status = run();
+    if (sh->status != SAR_OK) std::snprintf(sh->error, sizeof(sh->error), "%s", sar_last_error());
+}
+
+// Makes shard 0's runtime hold the whole merged frame (every owner's slice copied over): what a caller that asks for
+// "the renderer's runtime" expects to read.
+int gather_into_first(sar_renderer* r) {
+    if (!r->scattered) return SAR_OK;
+    const uint32_t G = static_cast<uint32_t>(r->shards.size());
+    Shard& s0 = r->shards[0];
+    const uint32_t npix = s0.rt->npix;
+    const uint32_t S = static_cast<uint32_t>(s0.slice_cap);
+    HIP_TRY(hipSetDevice(s0.device));
+    for (uint32_t d = 1; d < G; ++d) {
+        const Shard& sd = r->shards[d];
+        const uint64_t first = static_cast<uint64_t>(d) * S;
+        if (first >= npix) break;
+        const size_t n = (npix - first < S) ? npix - first : S;
+        HIP_TRY(hipMemcpyPeerAsync(s0.rt->d_count + first, s0.device, sd.rt->d_count + first, sd.device, n * 4u, s0.rt->stream));
+        HIP_TRY(hipMemcpyPeerAsync(s0.rt->d_key + first, s0.device, sd.rt->d_key + first, sd.device, n * 8u, s0.rt->stream));
+        HIP_TRY(hipMemcpyPeerAsync(s0.rt->d_steps + first, s0.device, sd.rt->d_steps + first, sd.device, n * 8u, s0.rt->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s0.rt->stream));
+    r->scattered = false;
+    return SAR_OK;
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" {
+
+int sar_renderer_new_multi(const int* devices, uint32_t n_devices, uint32_t units, uint64_t seed, sar_renderer** out) {
+    if (!out) return SAR_ERR_INVALID;
+    *out = nullptr;
+    if (!devices || n_devices == 0 || n_devices > 64) { set_error("sar_renderer_new_multi: 1..64 devices"); return SAR_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (this library has no CPU fallback)");
+        return SAR_ERR_NO_DEVICE;
+    }
+    for (uint32_t k = 0; k < n_devices; ++k)
+        if (devices[k] < 0 || devices[k] >= ndev) { set_error("device %d out of range (%d devices)", devices[k], ndev); return SAR_ERR_INVALID; }
+    sar_renderer* r = new (std::nothrow) sar_renderer();
+    if (!r) return SAR_ERR_OOM;
+    r->seed = seed;
+    r->rng.seed(seed);
+    r->shards.resize(n_devices);
+    uint64_t lanes = 0;
+    for (uint32_t k = 0; k < n_devices; ++k) {
+        r->shards[k].device = devices[k];
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, devices[k]) != hipSuccess) { delete r; return SAR_ERR_HIP; }
+        lanes += static_cast<uint64_t>(prop.multiProcessorCount) * 64u;
+    }
+    // the role available_parallelism() plays at src/lib.rs:920-922. 64 units per CU and device (16 384 per MI355X): with
+    // the CLI's default of 12 jobs per thread (src/bin/main.rs:305) the job split then gives 196 608 trajectories per
+    // GPU — three waves per SIMD — and 8 jobs per unit give 131 072; every job pays 1000 warm-up iterations, so a unit
+    // count that multiplied typical jobs_per_unit values into millions of jobs would only add warm-up work
+    r->units = units ? units : static_cast<uint32_t>(lanes > 0xFFFFFFFFull ? 0xFFFFFFFFull : lanes);
+    *out = r;
+    return SAR_OK;
+}
+
+int sar_renderer_new(int device, uint32_t units, uint64_t seed, sar_renderer** out) {
+    return sar_renderer_new_multi(&device, 1, units, seed, out);
+}
+
+int sar_renderer_num_units(const sar_renderer* r, uint32_t* out_units) {
+    if (!r || !out_units) return SAR_ERR_INVALID;
+    *out_units = r->units;
+    return SAR_OK;
+}
+
+int sar_renderer_num_devices(const sar_renderer* r, uint32_t* out_devices) {
+    if (!r || !out_devices) return SAR_ERR_INVALID;
+    *out_devices = static_cast<uint32_t>(r->shards.size());
+    return SAR_OK;
+}
+
+int sar_renderer_shutdown(sar_renderer* r) {
+    if (!r) return SAR_OK;
+    for (Shard& sh : r->shards) {
+        hipSetDevice(sh.device);
+        if (sh.rt) hipStreamSynchronize(sh.rt->stream);
+    }
+    for (Shard& sh : r->shards) {
+        free_shard_buffers(sh);
+        if (sh.d_sc) hipFree(sh.d_sc);
+        if (sh.h_sc) hipHostFree(sh.h_sc);
+        if (sh.packed) hipEventDestroy(sh.packed);
+        if (sh.merged) hipEventDestroy(sh.merged);
+        if (sh.begin) hipEventDestroy(sh.begin);
+        if (sh.end) hipEventDestroy(sh.end);
+        if (sh.rt) sar_runtime_free(sh.rt);
+    }
+    delete r;
+    return SAR_OK;
+}
+
+int sar_renderer_runtime(sar_renderer* r, sar_runtime** out_borrowed) {
+    if (!r || !out_borrowed) return SAR_ERR_INVALID;
+    *out_borrowed = nullptr;
+    if (r->shards.empty() || !r->shards[0].rt) { set_error("the renderer has not rendered yet"); return SAR_ERR_INVALID; }
+    SAR_TRY(gather_into_first(r));
+    *out_borrowed = r->shards[0].rt;
+    return SAR_OK;
+}
+
+int sar_renderer_last_timing(const sar_renderer* r, sar_parallel_timing* out) {
+    if (!r || !out) return SAR_ERR_INVALID;
+    *out = r->timing;
+    return SAR_OK;
+}
+
+int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_per_unit, uint16_t* rgba_out_host) {
+    if (!r) return SAR_ERR_INVALID;
+    SAR_TRY(validate(cfg));
+    if (jobs_per_unit == 0) { set_error("jobs_per_unit is 0"); return SAR_ERR_INVALID; }
+    const uint64_t total_jobs = static_cast<uint64_t>(r->units) * jobs_per_unit;  // :1062
+    if (total_jobs > 0xFFFFFFFFull) { set_error("units*jobs_per_unit exceeds 2^32-1"); return SAR_ERR_RANGE; }
+    const uint64_t per_job = cfg->iterations / r->units / jobs_per_unit;  // :1058
+    const uint32_t G = static_cast<uint32_t>(r->shards.size());
+    const uint64_t npix64 = static_cast<uint64_t>(cfg->width) * cfg->height;
+    if (npix64 > 0x7fffffffull) { set_error("width*height exceeds 2^31-1"); return SAR_ERR_RANGE; }
+    const uint32_t npix = static_cast<uint32_t>(npix64);
+    const uint32_t S = slice_pixels(npix, G);
+    const double t0 = now_ms();
+    std::memset(&r->timing, 0, sizeof(r->timing));
+    r->timing.n_devices = G;
+    r->scattered = false;
+
+    for (Shard& sh : r->shards) SAR_TRY(ensure_shard(r, sh, cfg, S));
+
+    // fresh start points for every job, in job order, from the renderer's stream (the reference's workers draw from
+    // per-thread RNGs as they pick jobs up, :748; here the stream is one and the job -> point map is deterministic)
+    std::vector<double> starts(static_cast<size_t>(total_jobs) * 3);
+    for (uint64_t k = 0; k < total_jobs; ++k) r->rng.start_point(&starts[3 * static_cast<size_t>(k)]);
+
+    // contiguous job slices, sizes differ by at most one (the same partition as distributed.shard_jobs)
+    {
+        const uint64_t base = total_jobs / G, rem = total_jobs % G;
+        uint64_t first = 0;
+        for (uint32_t d = 0; d < G; ++d) {
+            r->shards[d].first_job = static_cast<uint32_t>(first);
+            r->shards[d].n_jobs = static_cast<uint32_t>(base + (d < rem ? 1u : 0u));
+            first += r->shards[d].n_jobs;
+        }
+    }
+
+    if (G == 1) {
+        Shard& sh = r->shards[0];
+        render_shard(r, &sh, cfg, per_job, starts.data(), S);
+        if (sh.status != SAR_OK) { set_error("%s", sh.error); return sh.status; }
+        int st = SAR_OK;
+        if (rgba_out_host) st = sar_colorize(cfg, sh.rt, rgba_out_host);  // :1080
+        r->timing.total_ms = static_cast<float>(now_ms() - t0);
+        return st;
+    }
+
+    // 1. one host thread per device (as the reference has one per core): stage, render, pack
+    {
+        std::vector<std::thread> workers;
+        workers.reserve(G);
+        for (uint32_t d = 0; d < G; ++d) workers.emplace_back(render_shard, r, &r->shards[d], cfg, per_job, starts.data(), S);
+        for (auto& w : workers) w.join();
+    }
+    for (Shard& sh : r->shards)
+        if (sh.status != SAR_OK) { set_error("device %d: %s", sh.device, sh.error); return sh.status; }
+
+    // 2. the owners pull their blocks (every pair of devices over its own link) and fold them in device order
+    const size_t blk = static_cast<size_t>(S) * 16u;
+    for (uint32_t d = 0; d < G; ++d) {
+        Shard& dst = r->shards[d];
+        HIP_TRY(hipSetDevice(dst.device));
+        hipStream_t st = dst.rt->stream;
+        for (uint32_t k = 0; k < G; ++k) {
+            const uint32_t s = (d + k) % G;  // start with the local block; stagger the sources over the links
+            Shard& src = r->shards[s];
+            if (s != d) HIP_TRY(hipStreamWaitEvent(st, src.packed, 0));
+            HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(dst.d_recv) + s * blk, dst.device,
+                                       static_cast<const char*>(src.d_pack) + d * blk, src.device, blk, st));
+        }
+        const uint64_t first = static_cast<uint64_t>(d) * S;
+        const uint32_t n = first >= npix ? 0u : static_cast<uint32_t>((npix - first < S) ? npix - first : S);
+        launch_exch_merge_slices(dst.rt->d_count, dst.rt->d_key, dst.rt->d_steps, static_cast<uint32_t>(first >= npix ? 0 : first), n, S, G,
+                                 dst.d_recv, dst.rt->d_scalars, d == 0, st);
+        launch_exch_scalars_export(dst.rt->d_scalars, dst.d_sc, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(dst.h_sc, dst.d_sc, 4 * sizeof(long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(dst.merged, st));
+    }
+    r->scattered = true;
+
+    // 3. the four scalars become global on the host; every device colorizes its slice into the caller's image
+    long long red[4] = {0, 0, 0, 0};
+    for (uint32_t d = 0; d < G; ++d) {
+        Shard& sh = r->shards[d];
+        HIP_TRY(hipSetDevice(sh.device));
+        HIP_TRY(hipEventSynchronize(sh.merged));
+        for (int k = 0; k < 4; ++k) red[k] = sh.h_sc[k] > red[k] ? sh.h_sc[k] : red[k];
+    }
+    const double t_merged = now_ms();
+    for (uint32_t d = 0; d < G; ++d) {
+        Shard& sh = r->shards[d];
+        HIP_TRY(hipSetDevice(sh.device));
+        hipStream_t st = sh.rt->stream;
+        for (int k = 0; k < 4; ++k) sh.h_sc[k] = red[k];
+        HIP_TRY(hipMemcpyAsync(sh.d_sc, sh.h_sc, 4 * sizeof(long long), hipMemcpyHostToDevice, st));
+        launch_exch_scalars_import(sh.rt->d_scalars, sh.d_sc, st);
+        const uint64_t first = static_cast<uint64_t>(d) * S;
+        const uint32_t n = first >= npix ? 0u : static_cast<uint32_t>((npix - first < S) ? npix - first : S);
+        if (rgba_out_host && n) {
+            SAR_TRY(colorize_range(cfg, sh.rt, static_cast<uint32_t>(first), n, sh.d_rgba, true));  // :1080, sharded
+            HIP_TRY(hipMemcpyAsync(rgba_out_host + first * 4u, sh.d_rgba, static_cast<size_t>(n) * 8u, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipEventRecord(sh.end, st));
+    }
+    (void)t_merged;
+    for (Shard& sh : r->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        HIP_TRY(hipStreamSynchronize(sh.rt->stream));
+        float ms = 0.f;  // per-device stream time of the three phases; the frame is as slow as the slowest device
+        if (hipEventElapsedTime(&ms, sh.begin, sh.packed) == hipSuccess && ms > r->timing.render_ms) r->timing.render_ms = ms;
+        if (hipEventElapsedTime(&ms, sh.packed, sh.merged) == hipSuccess && ms > r->timing.exchange_ms) r->timing.exchange_ms = ms;
+        if (hipEventElapsedTime(&ms, sh.merged, sh.end) == hipSuccess && ms > r->timing.colorize_ms) r->timing.colorize_ms = ms;
+    }
+    r->timing.total_ms = static_cast<float>(now_ms() - t0);
+    r->timing.exchange_bytes_per_device = static_cast<uint64_t>(G - 1) * blk;
+    return SAR_OK;
+}
+
+}  // extern "C"

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "sar_launch.hpp"
+#include "sar_runtime_impl.hpp"
 
 using namespace sar;
 
@@ -32,14 +33,6 @@ using namespace sar;
 
 namespace {
 
-struct Span {
-    hipEvent_t a = nullptr, b = nullptr;
-};
-
-constexpr uint32_t kDefaultBlock = 256;
-constexpr uint32_t kDefaultCkptStride = 64;
-constexpr uint64_t kCkptBytesCap = 24ull << 30;  // checkpoint scratch per launch chunk (HBM is 288 GB)
-
 // ln(k+1) for k < kLnLutEntries, computed once per process with the host libm — the same function
 // the oracle (and the reference, through Rust's f64::ln) calls on this machine.
 const double* host_ln_lut() {
@@ -53,90 +46,6 @@ const double* host_ln_lut() {
 }
 
 }  // namespace
-
-struct sar_runtime {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    uint32_t W = 0, H = 0, npix = 0;
-    uint32_t sm_count = 0;
-
-    // persistent state (Runtime, reference src/lib.rs:631-646)
-    uint32_t* d_count = nullptr;            // count
-    unsigned long long* d_key = nullptr;    // hi: sortable(zbuf), lo: 0xFFFFFFFF between launches
-    double* d_steps = nullptr;              // steps
-    uint32_t* d_scalars = nullptr;          // max + flags + depth range
-    Rng rng;
-
-    // scratch bins the iterate kernel accumulates into (zero between launches)
-    uint32_t copies = 0;      // scratch_count copies
-    uint32_t key_copies = 0;  // scratch_key copies
-    uint32_t* d_scratch_count = nullptr;
-    unsigned long long* d_scratch_key = nullptr;
-
-    // binned path: per-wave record arenas, list heads, per-XCD depth hints, NaN iteration counter
-    void* d_arena = nullptr;
-    size_t arena_cap = 0;  // bytes
-    uint32_t* d_heads = nullptr;
-    size_t heads_cap = 0;  // entries
-    void* d_zhint = nullptr;
-    uint32_t zhint_bytes = 0;        // bytes per hint of the current allocation (2 or 4)
-    uint32_t hint_bits = 0;          // option: 0 = by image size, 16, 32
-    unsigned long long* d_nan_count = nullptr;
-
-    // staging
-    double* h_starts = nullptr;  // pinned
-    double* d_starts = nullptr;
-    double* d_warm = nullptr;        // binned path: packed post-warm-up points, job list, survivor count
-    uint32_t* d_joblist = nullptr;
-    uint32_t* d_active = nullptr;
-    size_t warm_cap = 0;             // jobs
-    // survivor statistics of the last launch, copied back lazily (never waited for): the next render call sizes its
-    // staging for the lanes that will really be busy (solar-sail loses 38 % of its jobs in the warm-up)
-    uint32_t* h_active = nullptr;    // pinned
-    hipEvent_t active_copied = nullptr;
-    bool active_pending = false;
-    uint32_t active_jobs_launched = 0;
-    double survivor_fraction = 1.0;
-    size_t starts_cap = 0;       // doubles
-    hipEvent_t starts_copied = nullptr;
-    bool starts_pending = false;
-    double* d_ckpt = nullptr;
-    size_t ckpt_cap = 0;         // doubles
-    double* d_lnlut = nullptr;
-    void* d_rgba = nullptr;
-    void* d_export = nullptr;  // converted image of sar_colorize_format (<= 6 bytes per pixel)
-    float* d_ztmp = nullptr;
-
-    // tuning
-    uint32_t block_threads = kDefaultBlock;
-    uint32_t ckpt_stride = kDefaultCkptStride;
-    uint32_t bins_mode = 0;     // 0 default (binned when eligible), 1 one copy + agent-scope atomics,
-                                // 2 one copy per XCD + L2-local atomics, 3 LDS-binned records
-    uint32_t measure_mode = 0;  // 0 full path, 1 count only, 2 arithmetic only
-    uint32_t depth_pipe = 0;         // visits of depth pipeline in the iterate kernel (0 = default)
-    bool timing_accumulate = false;  // spans of successive render calls add up until sar_runtime_last_timing reads them
-    uint32_t debug_chunk_jobs = 0;  // test hook: cap on jobs per launch chunk (0 = none)
-    uint32_t bin_shift = 0;         // 0 = automatic
-    uint32_t splits = 0;            // 0 = automatic
-    uint32_t acc_threads = 0;       // threads per k_bin_accumulate block (0 = automatic)
-    uint32_t chunk_records = 0;     // records per chunk (0 = default 28; 12 / 20 shrink the LDS staging per wave)
-
-    // timing
-    bool timing = false;
-    std::vector<Span> iter_spans, fold_spans, warm_spans;
-    size_t iter_used = 0, fold_used = 0, warm_used = 0;
-    Span colorize_span, merge_span;
-    bool colorize_timed = false, merge_timed = false;
-    uint64_t last_iterations = 0;
-};
-
-struct sar_renderer {
-    int device = 0;
-    uint32_t units = 0;
-    uint64_t seed = 0;
-    sar_runtime* rt = nullptr;
-};
 
 namespace {
 
@@ -168,13 +77,27 @@ int alloc_image_buffers(sar_runtime* rt, uint32_t w, uint32_t h) {
     const uint64_t npix64 = static_cast<uint64_t>(w) * h;
     if (w == 0 || h == 0) { set_error("zero image dimension"); return SAR_ERR_INVALID; }
     if (npix64 > 0x7fffffffull) { set_error("width*height exceeds 2^31-1"); return SAR_ERR_RANGE; }
+    // allocate first, commit on full success: a failed grow leaves the runtime as it was (old size, old buffers)
+    uint32_t* count = nullptr;
+    unsigned long long* key = nullptr;
+    double* steps = nullptr;
+    hipError_t e = hipMalloc(&count, npix64 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&key, npix64 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&steps, npix64 * sizeof(double));
+    if (e != hipSuccess) {
+        if (count) hipFree(count);
+        if (key) hipFree(key);
+        if (steps) hipFree(steps);
+        set_error("image buffers for %ux%u: %s", w, h, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? SAR_ERR_OOM : SAR_ERR_HIP;
+    }
     free_device_buffers(rt);
     rt->W = w;
     rt->H = h;
     rt->npix = static_cast<uint32_t>(npix64);
-    HIP_TRY(hipMalloc(&rt->d_count, npix64 * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&rt->d_key, npix64 * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(&rt->d_steps, npix64 * sizeof(double)));
+    rt->d_count = count;
+    rt->d_key = key;
+    rt->d_steps = steps;
     return SAR_OK;
 }
 
@@ -296,7 +219,9 @@ void fill_ct_params(const sar_config& cfg, ColorTransformParams& ct) {
     ct.ccy = cfg.center_camera[1];
 }
 
-int check_cfg_matches(const sar_config* cfg, const sar_runtime* rt) {
+}  // namespace
+
+int sar::check_cfg_matches(const sar_config* cfg, const sar_runtime* rt) {
     SAR_TRY(validate(cfg));
     if (!rt) { set_error("runtime is NULL"); return SAR_ERR_INVALID; }
     if (cfg->width != rt->W || cfg->height != rt->H) {
@@ -305,6 +230,8 @@ int check_cfg_matches(const sar_config* cfg, const sar_runtime* rt) {
     }
     return SAR_OK;
 }
+
+namespace {
 
 // Grows a device buffer (contents are not preserved). cap and need in elements of T.
 template <typename T>
@@ -332,6 +259,7 @@ struct LaunchPlan {
     uint32_t splits = 0;                // accumulate workgroups per bin
     uint64_t n_ckpt = 0, chunks_per_wave = 0, chunk_jobs = 0;
     uint32_t max_waves = 0;             // waves of the largest launch chunk
+    uint32_t arena_waves = 0;           // ... of which hold at least one job: only they own a slice of the record arena
 };
 
 // Records per chunk: the largest of 28/20/12 whose per-wave LDS staging still fits the waves this launch can use — up to
@@ -378,17 +306,33 @@ int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_
     // checkpoint stride: a multiple of the depth pipeline's pass length (the iterate kernel runs whole passes)
     pl.C = ((rt->ckpt_stride + pl.pipe - 1u) / pl.pipe) * pl.pipe;
     pl.n_ckpt = (iters + pl.C - 1) / pl.C;
-    pl.chunks_per_wave = (iters * 64ull + pl.R - 1) / pl.R + pl.geo.bins;
-    if (pl.binned && pl.chunks_per_wave > 0xFFFFFFF0ull) pl.binned = false;
+    // Record arena: a wave emits at most one record per lane and iteration, in chunks of R, plus one partly filled chunk
+    // per bin at the end. Sized for the lanes that really hold a job — a single-trajectory sar_render (n_jobs = 1) is one
+    // lane of one wave, not a full 256-thread block of busy lanes.
+    auto lanes_of = [](uint64_t jobs) { return jobs < 64 ? jobs : 64ull; };
+    auto chunks_per_wave_of = [&](uint64_t jobs) { return (iters * lanes_of(jobs) + pl.R - 1) / pl.R + pl.geo.bins; };
     pl.chunk_jobs = kMaxChunkOrdinals / iters;
-    // scratch per job: checkpoints (24 B each) + its share of the wave's record arena (binned path)
-    const uint64_t bytes_per_job = pl.n_ckpt * 24ull + (pl.binned ? pl.chunks_per_wave : 0ull);
-    const uint64_t by_mem = kCkptBytesCap / bytes_per_job;
-    if (by_mem < pl.chunk_jobs) pl.chunk_jobs = by_mem ? by_mem : 1;
-    if (rt->debug_chunk_jobs && rt->debug_chunk_jobs < pl.chunk_jobs) pl.chunk_jobs = rt->debug_chunk_jobs;
     if (pl.chunk_jobs > n_jobs) pl.chunk_jobs = n_jobs;
+    if (pl.binned && chunks_per_wave_of(pl.chunk_jobs) > 0xFFFFFFF0ull) pl.binned = false;
+    // scratch per job: checkpoints (24 B each) + its share of its wave's arena (binned path)
+    const uint64_t cb = chunk_bytes(pl.R);
+    auto scratch_bytes = [&](uint64_t jobs) {
+        const uint64_t waves = (jobs + 63) / 64;
+        return jobs * pl.n_ckpt * 24ull + (pl.binned ? waves * chunks_per_wave_of(jobs) * cb : 0ull);
+    };
+    while (pl.chunk_jobs > 1 && scratch_bytes(pl.chunk_jobs) > kCkptBytesCap) {
+        // linear in the job count above one wave: one division gets close, the loop finishes the rounding
+        const uint64_t per_job = scratch_bytes(pl.chunk_jobs) / pl.chunk_jobs + 1;
+        uint64_t fit = kCkptBytesCap / per_job;
+        if (fit >= pl.chunk_jobs) fit = pl.chunk_jobs - 1;
+        pl.chunk_jobs = fit ? fit : 1;
+    }
+    if (pl.binned && scratch_bytes(1) > kCkptBytesCap) pl.binned = false;  // one job alone overflows the arena cap: atomics path
+    if (rt->debug_chunk_jobs && rt->debug_chunk_jobs < pl.chunk_jobs) pl.chunk_jobs = rt->debug_chunk_jobs;
     if (pl.chunk_jobs > pl.block) pl.chunk_jobs -= pl.chunk_jobs % pl.block;
+    pl.chunks_per_wave = chunks_per_wave_of(pl.chunk_jobs);
     pl.max_waves = static_cast<uint32_t>(((pl.chunk_jobs + pl.block - 1) / pl.block) * (pl.block / 64u));
+    pl.arena_waves = static_cast<uint32_t>((pl.chunk_jobs + 63) / 64);  // waves that hold a job (the others exit at once)
     pl.splits = pl.geo.splits;
     if (pl.binned && pl.splits == 0) {
         // k_bin_accumulate walks one (bin, wave) list per group of lanes (4, or 2 with 32-byte chunks): aim at one
@@ -447,13 +391,20 @@ int stage_starts(sar_runtime* rt, const LaunchPlan& pl, uint32_t n_jobs, const d
 
 // Device buffers of the binned path: record arena, list heads, depth hints, warm-up output, counters.
 int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
-    static std::once_flag attr_once;
-    static int attr_status = 0;
-    std::call_once(attr_once, [] { attr_status = binned_kernel_attributes(); });
-    if (attr_status != 0) { set_error("hipFuncSetAttribute(max dynamic LDS) failed: %d", attr_status); return SAR_ERR_HIP; }
+    {   // hipFuncSetAttribute is per device and function: once for every device a runtime lives on
+        static std::mutex attr_mu;
+        static bool attr_done[64] = {false};
+        std::lock_guard<std::mutex> lock(attr_mu);
+        const int dev = rt->device;
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+            const int attr_status = binned_kernel_attributes();  // on the current device (render_chunked set it)
+            if (attr_status != 0) { set_error("hipFuncSetAttribute(max dynamic LDS) failed: %d", attr_status); return SAR_ERR_HIP; }
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
+    }
     {
         char* arena = static_cast<char*>(rt->d_arena);
-        const int rc = grow_device(arena, rt->arena_cap, static_cast<size_t>(pl.max_waves) * pl.chunks_per_wave * chunk_bytes(pl.R));
+        const int rc = grow_device(arena, rt->arena_cap, static_cast<size_t>(pl.arena_waves) * pl.chunks_per_wave * chunk_bytes(pl.R));
         rt->d_arena = arena;  // also when the allocation failed: the old buffer is gone
         SAR_TRY(rc);
     }
@@ -519,6 +470,7 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
         set_error("bad chunk_records / depth_pipe");
         return SAR_ERR_INVALID;
     }
+    HIP_TRY(hipGetLastError());
     span_end(rt, rt->iter_spans, rt->iter_used);
     BinAccArgs ca;
     std::memset(&ca, 0, sizeof(ca));
@@ -533,6 +485,7 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     ca.scratch_count = rt->d_scratch_count;
     span_begin(rt, rt->fold_spans, rt->fold_used);
     launch_bin_accumulate(ca, rt->acc_threads, pl.R, rt->stream);
+    HIP_TRY(hipGetLastError());
     launch_fold_resolve(fa, rt->stream);
     span_end(rt, rt->fold_spans, rt->fold_used);
     return SAR_OK;
@@ -541,8 +494,10 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
 // Runs n_jobs trajectories of `iters` counted iterations each; starts is AoS [n_jobs][3] on the host (or, with
 // starts_on_device, in device memory). Sequential semantics (job-major, iteration-minor): a later launch chunk only
 // replaces a depth winner with a strictly greater z, exactly like a later render call.
-int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters,
-                   const double* starts, bool starts_on_device = false) {
+}  // namespace
+
+int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, const double* starts,
+                        bool starts_on_device) {
     if (!rt->timing_accumulate) {
         rt->last_iterations = 0;
         rt->iter_used = 0;
@@ -615,8 +570,13 @@ int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint
     return SAR_OK;
 }
 
-int do_colorize(const sar_config* cfg, sar_runtime* rt, void* out_dev) {
+namespace {
+
+}  // namespace
+
+int sar::colorize_range(const sar_config* cfg, sar_runtime* rt, uint32_t first, uint32_t n, void* out_dev, bool global_scalars) {
     HIP_TRY(hipSetDevice(rt->device));
+    if (first > rt->npix || n > rt->npix - first) { set_error("colorize: pixel range out of bounds"); return SAR_ERR_RANGE; }
     single_begin(rt, rt->colorize_span);
     if (cfg->render_kind == SAR_RENDER_GAS) {
         PaletteParams pal;
@@ -626,16 +586,22 @@ int do_colorize(const sar_config* cfg, sar_runtime* rt, void* out_dev) {
             for (int ch = 0; ch < 3; ++ch) pal.rgb[k][ch] = cfg->palette_rgb[k][ch];
         for (int ch = 0; ch < 3; ++ch)  // Palette::new duplicates the last entry (:416-418)
             pal.rgb[cfg->palette_len][ch] = cfg->palette_rgb[cfg->palette_len - 1][ch];
-        launch_colorize_gas(rt->d_count, rt->d_steps, rt->d_scalars, rt->d_lnlut, kLnLutEntries, pal,
-                            cfg->brightness_offset, cfg->brightness_factor, cfg->transparent ? 1 : 0, rt->npix,
-                            out_dev, rt->stream);
+        if (n)
+            launch_colorize_gas(rt->d_count + first, rt->d_steps + first, rt->d_scalars, rt->d_lnlut, kLnLutEntries, pal,
+                                cfg->brightness_offset, cfg->brightness_factor, cfg->transparent ? 1 : 0, n, out_dev, rt->stream);
+    } else if (global_scalars) {
+        if (n) launch_colorize_depth_range(rt->d_key + first, rt->d_scalars, n, out_dev, rt->stream);
     } else {
-        launch_colorize_depth(rt->d_key, rt->d_scalars, rt->npix, out_dev, rt->stream);
+        launch_colorize_depth(rt->d_key + first, rt->d_scalars, n, out_dev, rt->stream);
     }
     single_end(rt, rt->colorize_span, rt->colorize_timed);
     HIP_TRY(hipGetLastError());
     return SAR_OK;
 }
+
+namespace {
+
+int do_colorize(const sar_config* cfg, sar_runtime* rt, void* out_dev) { return colorize_range(cfg, rt, 0, rt->npix, out_dev, false); }
 
 int ensure_rgba(sar_runtime* rt) {
     if (!rt->d_rgba) HIP_TRY(hipMalloc(&rt->d_rgba, static_cast<size_t>(rt->npix) * 8));
@@ -1001,74 +967,59 @@ int sar_runtime_exchange_import(sar_runtime* rt, const void* key_i64_reduced_dev
     return SAR_OK;
 }
 
-// ---- ParallelRenderer mirror ------------------------------------------------------------------------
+// ---- sliced exchange (all-to-all of pixel slices; see include/sar.h) ---------------------------------------
 
-int sar_renderer_new(int device, uint32_t units, uint64_t seed, sar_renderer** out) {
-    if (!out) return SAR_ERR_INVALID;
-    *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        set_error("no HIP device available (this library has no CPU fallback)");
-        return SAR_ERR_NO_DEVICE;
-    }
-    if (device < 0 || device >= ndev) { set_error("device %d out of range", device); return SAR_ERR_INVALID; }
-    sar_renderer* r = new (std::nothrow) sar_renderer();
-    if (!r) return SAR_ERR_OOM;
-    r->device = device;
-    r->seed = seed;
-    if (units == 0) {
-        // the role available_parallelism() plays at src/lib.rs:920-922. 64 units per CU (16 384 on MI355X): with the
-        // CLI's default of 12 jobs per thread (src/bin/main.rs:305) the job split then gives 196 608 trajectories —
-        // three waves per SIMD — and 8 jobs per unit give 131 072; every job pays 1000 warm-up iterations, so a unit
-        // count that multiplied typical jobs_per_unit values into millions of jobs would only add warm-up work
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete r; return SAR_ERR_HIP; }
-        units = static_cast<uint32_t>(prop.multiProcessorCount) * 64u;
-    }
-    r->units = units;
-    *out = r;
+int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice_pixels) {
+    if (!out_slice_pixels || world == 0) return SAR_ERR_INVALID;
+    const uint64_t s = ((static_cast<uint64_t>(npix) + world - 1) / world + 3u) & ~3ull;
+    if (s * world > 0xFFFFFFFFull) { set_error("slice geometry exceeds 2^32 pixels"); return SAR_ERR_RANGE; }
+    *out_slice_pixels = static_cast<uint32_t>(s);
     return SAR_OK;
 }
 
-int sar_renderer_num_units(const sar_renderer* r, uint32_t* out_units) {
-    if (!r || !out_units) return SAR_ERR_INVALID;
-    *out_units = r->units;
+int sar_runtime_exchange_pack(sar_runtime* rt, uint32_t world, void* blocks_out_dev) {
+    if (!rt || !blocks_out_dev) return SAR_ERR_INVALID;
+    uint32_t S = 0;
+    SAR_TRY(sar_exchange_slice_pixels(rt->npix, world, &S));
+    HIP_TRY(hipSetDevice(rt->device));
+    launch_exch_pack(rt->d_count, rt->d_key, rt->d_steps, rt->npix, S, world, blocks_out_dev, rt->stream);
+    HIP_TRY(hipGetLastError());
     return SAR_OK;
 }
 
-int sar_renderer_shutdown(sar_renderer* r) {
-    if (!r) return SAR_OK;
-    if (r->rt) sar_runtime_free(r->rt);
-    delete r;
+int sar_runtime_exchange_merge_slices(sar_runtime* rt, uint32_t world, uint32_t rank, const void* blocks_in_dev) {
+    if (!rt || !blocks_in_dev || rank >= world) return SAR_ERR_INVALID;
+    uint32_t S = 0;
+    SAR_TRY(sar_exchange_slice_pixels(rt->npix, world, &S));
+    HIP_TRY(hipSetDevice(rt->device));
+    const uint64_t first = static_cast<uint64_t>(rank) * S;
+    const uint32_t n = first >= rt->npix ? 0u : static_cast<uint32_t>((rt->npix - first < S) ? rt->npix - first : S);
+    launch_exch_merge_slices(rt->d_count, rt->d_key, rt->d_steps, n ? static_cast<uint32_t>(first) : 0u, n, S, world, blocks_in_dev,
+                             rt->d_scalars, rank == 0, rt->stream);
+    HIP_TRY(hipGetLastError());  // (the depth hints stay valid: a merge only raises zbuf)
     return SAR_OK;
 }
 
-int sar_renderer_runtime(sar_renderer* r, sar_runtime** out_borrowed) {
-    if (!r || !out_borrowed) return SAR_ERR_INVALID;
-    *out_borrowed = r->rt;
-    return r->rt ? SAR_OK : SAR_ERR_INVALID;
+int sar_runtime_exchange_scalars_export(sar_runtime* rt, void* i64x4_out_dev) {
+    if (!rt || !i64x4_out_dev) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    launch_exch_scalars_export(rt->d_scalars, i64x4_out_dev, rt->stream);
+    HIP_TRY(hipGetLastError());
+    return SAR_OK;
 }
 
-int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_per_unit, uint16_t* rgba_out_host) {
-    if (!r) return SAR_ERR_INVALID;
-    SAR_TRY(validate(cfg));
-    if (jobs_per_unit == 0) { set_error("jobs_per_unit is 0"); return SAR_ERR_INVALID; }
-    const uint64_t total_jobs = static_cast<uint64_t>(r->units) * jobs_per_unit;  // :1062
-    if (total_jobs > 0xFFFFFFFFull) { set_error("units*jobs_per_unit exceeds 2^32-1"); return SAR_ERR_RANGE; }
-    if (!r->rt) {
-        sar_config c0 = *cfg;
-        c0.seed = r->seed;
-        SAR_TRY(sar_runtime_new(&c0, r->device, &r->rt));
-    }
-    sar_runtime* rt = r->rt;
-    SAR_TRY(sar_runtime_set_width_height(rt, cfg->width, cfg->height));  // :950
-    SAR_TRY(sar_runtime_reset(rt));                                       // :951
-    const uint64_t per_job = cfg->iterations / r->units / jobs_per_unit;  // :1058
-    std::vector<double> starts(static_cast<size_t>(total_jobs) * 3);
-    for (uint64_t k = 0; k < total_jobs; ++k) rt->rng.start_point(&starts[3 * static_cast<size_t>(k)]);
-    SAR_TRY(render_chunked(cfg, rt, static_cast<uint32_t>(total_jobs), per_job, starts.data()));
-    if (rgba_out_host) return sar_colorize(cfg, rt, rgba_out_host);  // :1080
+int sar_runtime_exchange_scalars_import(sar_runtime* rt, const void* i64x4_dev) {
+    if (!rt || !i64x4_dev) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    launch_exch_scalars_import(rt->d_scalars, i64x4_dev, rt->stream);
+    HIP_TRY(hipGetLastError());
     return SAR_OK;
+}
+
+int sar_colorize_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t first_px, uint32_t n_px, void* rgba_out_dev) {
+    SAR_TRY(check_cfg_matches(cfg, rt));
+    if (!rgba_out_dev) return SAR_ERR_INVALID;
+    return colorize_range(cfg, rt, first_px, n_px, rgba_out_dev, true);
 }
 
 // ---- measurement --------------------------------------------------------------------------------------

@@ -1,0 +1,113 @@
+// sar_runtime_impl.hpp — the private layout of sar_runtime and the few internals of sar_runtime.cpp that the
+// multi-device ParallelRenderer (sar_multi.cpp) builds on. Not part of the ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "sar_launch.hpp"
+
+namespace sar {
+
+struct Span {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+constexpr uint32_t kDefaultBlock = 256;
+constexpr uint32_t kDefaultCkptStride = 64;
+constexpr uint64_t kCkptBytesCap = 24ull << 30;  // checkpoint + record-arena scratch per launch chunk (HBM is 288 GB)
+
+}  // namespace sar
+
+struct sar_runtime {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t W = 0, H = 0, npix = 0;
+    uint32_t sm_count = 0;
+
+    // persistent state (Runtime, reference src/lib.rs:631-646)
+    uint32_t* d_count = nullptr;            // count
+    unsigned long long* d_key = nullptr;    // hi: sortable(zbuf), lo: 0xFFFFFFFF between launches
+    double* d_steps = nullptr;              // steps
+    uint32_t* d_scalars = nullptr;          // max + flags + depth range
+    sar::Rng rng;
+
+    // scratch bins the iterate kernel accumulates into (zero between launches)
+    uint32_t copies = 0;      // scratch_count copies
+    uint32_t key_copies = 0;  // scratch_key copies
+    uint32_t* d_scratch_count = nullptr;
+    unsigned long long* d_scratch_key = nullptr;
+
+    // binned path: per-wave record arenas, list heads, per-XCD depth hints, NaN iteration counter
+    void* d_arena = nullptr;
+    size_t arena_cap = 0;  // bytes
+    uint32_t* d_heads = nullptr;
+    size_t heads_cap = 0;  // entries
+    void* d_zhint = nullptr;
+    uint32_t zhint_bytes = 0;        // bytes per hint of the current allocation (2 or 4)
+    uint32_t hint_bits = 0;          // option: 0 = by image size, 16, 32
+    unsigned long long* d_nan_count = nullptr;
+
+    // staging
+    double* h_starts = nullptr;  // pinned
+    double* d_starts = nullptr;
+    double* d_warm = nullptr;        // binned path: packed post-warm-up points, job list, survivor count
+    uint32_t* d_joblist = nullptr;
+    uint32_t* d_active = nullptr;
+    size_t warm_cap = 0;             // jobs
+    // survivor statistics of the last launch, copied back lazily (never waited for): the next render call sizes its
+    // staging for the lanes that will really be busy (solar-sail loses 38 % of its jobs in the warm-up)
+    uint32_t* h_active = nullptr;    // pinned
+    hipEvent_t active_copied = nullptr;
+    bool active_pending = false;
+    uint32_t active_jobs_launched = 0;
+    double survivor_fraction = 1.0;
+    size_t starts_cap = 0;       // doubles
+    hipEvent_t starts_copied = nullptr;
+    bool starts_pending = false;
+    double* d_ckpt = nullptr;
+    size_t ckpt_cap = 0;         // doubles
+    double* d_lnlut = nullptr;
+    void* d_rgba = nullptr;
+    void* d_export = nullptr;  // converted image of sar_colorize_format (<= 6 bytes per pixel)
+    float* d_ztmp = nullptr;
+
+    // tuning
+    uint32_t block_threads = sar::kDefaultBlock;
+    uint32_t ckpt_stride = sar::kDefaultCkptStride;
+    uint32_t bins_mode = 0;     // 0 default (binned when eligible), 1 one copy + agent-scope atomics,
+                                // 2 one copy per XCD + L2-local atomics, 3 LDS-binned records
+    uint32_t measure_mode = 0;  // 0 full path, 1 count only, 2 arithmetic only
+    uint32_t depth_pipe = 0;         // visits of depth pipeline in the iterate kernel (0 = default)
+    bool timing_accumulate = false;  // spans of successive render calls add up until sar_runtime_last_timing reads them
+    uint32_t debug_chunk_jobs = 0;  // test hook: cap on jobs per launch chunk (0 = none)
+    uint32_t bin_shift = 0;         // 0 = automatic
+    uint32_t splits = 0;            // 0 = automatic
+    uint32_t acc_threads = 0;       // threads per k_bin_accumulate block (0 = automatic)
+    uint32_t chunk_records = 0;     // records per chunk (0 = default 28; 12 / 20 shrink the LDS staging per wave)
+
+    // timing
+    bool timing = false;
+    std::vector<sar::Span> iter_spans, fold_spans, warm_spans;
+    size_t iter_used = 0, fold_used = 0, warm_used = 0;
+    sar::Span colorize_span, merge_span;
+    bool colorize_timed = false, merge_timed = false;
+    uint64_t last_iterations = 0;
+};
+
+
+namespace sar {
+
+// Runs n_jobs trajectories of `iters` counted iterations each into rt (sequential job-major semantics); `starts` is
+// [n_jobs][3] in host memory, or in device memory with starts_on_device. Enqueues only.
+int render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, const double* starts,
+                   bool starts_on_device = false);
+// colorize of the pixel range [first, first + n) into out_dev (n * 8 bytes). global_scalars: the scalars (max, depth
+// range) already hold the values of the WHOLE image (sliced multi-GPU colorize); otherwise the depth range is folded
+// over the range first, as colorize does (:877-882).
+int colorize_range(const sar_config* cfg, sar_runtime* rt, uint32_t first, uint32_t n, void* out_dev, bool global_scalars);
+int check_cfg_matches(const sar_config* cfg, const sar_runtime* rt);
+
+}  // namespace sar

@@ -1,15 +1,23 @@
 """Multi-GPU glue: one process per GPU, trajectories sharded by rank, Runtime::merge (reference
-src/lib.rs:708-738) folded in rank order expressed as two collectives over xGMI.
+src/lib.rs:708-738) folded in rank order (:1068-1076) over xGMI. PyTorch is plumbing here (device buffers, streams,
+torch.distributed == RCCL on ROCm); the arithmetic is in libsar_hip.so behind the C ABI (sar_runtime_exchange_*).
 
-The reference merges per-thread runtimes with a serial pairwise fold (src/lib.rs:1070-1076). Across GPUs the
-same fold is order-free once written as reductions:
-    count  : wrapping u32 add                      -> SUM over int32 (two's complement add wraps identically)
-    zbuf   : max, ties -> the EARLIER runtime wins  -> MAX over int64 keys (sortable(z) << 32 | ~rank)
-    steps  : payload of the zbuf winner            -> SUM over the two int32 halves of the f64 bits, every
-                                                      rank but the winner contributing zeros (exact)
-so the data path is ONE all-reduce(MAX, int64[npix]) + ONE reduce(SUM, int32[3*npix]) before colorize.
-The device-side packing/unpacking lives behind the C ABI (sar_runtime_exchange_*); the collective is
-torch.distributed's (backend "nccl" == RCCL on ROCm). PyTorch is plumbing here, nothing else.
+Two forms of the one exchange step before colorize:
+
+``exchange_colorize`` (sliced, the default of bench.py)
+    every rank OWNS one slice of S consecutive pixels. all-to-all of the partial slices (16 B/px: count u32, sortable
+    zbuf u32, steps f64 — each pair of GPUs over its own xGMI link), the owner folds the `world` partials of its slice
+    with Runtime::merge in rank order, a 4-scalar all-reduce MAX makes max / the depth range global, every rank
+    colorizes its slice and only RGBA16 (8 B/px) is gathered on the root. Per rank on the wire:
+    16 B * npix * (world-1)/world out, the same in, + 8 B * npix / world to the root.
+
+``exchange_merge`` (rooted, two collectives)
+    all-reduce(MAX, int64 keys: sortable(z) << 32 | ~rank) + reduce(SUM, int32[3*npix]: count and the two halves of the
+    winner's steps bits): rank `dst` ends up holding the complete merged Runtime (20 B/px through ring collectives) — for
+    callers that want the merged buffers themselves, not only the image.
+
+Backends: "nccl" (RCCL) moves device buffers directly. With "gloo" (several ranks sharing one GPU, or CPU-only CI) the
+same buffers are staged through host memory — the kernels and the protocol are the ones that run under RCCL.
 """
 from __future__ import annotations
 
@@ -24,14 +32,129 @@ def shard_jobs(total_jobs: int, world: int, rank: int) -> tuple[int, int]:
     return first, base + (1 if rank < rem else 0)
 
 
+def slice_of(npix: int, world: int, rank: int, slice_pixels: int) -> tuple[int, int]:
+    """The pixel range [first, first+count) rank `rank` owns in the sliced exchange."""
+    first = min(npix, rank * slice_pixels)
+    return first, min(npix, first + slice_pixels) - first
+
+
+def _device_native(dist) -> bool:
+    return dist.get_backend() == "nccl"
+
+
+def _sync_runtime_stream(rt):
+    rt.synchronize()
+
+
+def _all_reduce(dist, t, op, rt):
+    if _device_native(dist):
+        dist.all_reduce(t, op=op)
+    else:  # gloo: through host memory (ranks sharing a GPU, or no GPU at all)
+        _sync_runtime_stream(rt)
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+
+
+def _reduce(dist, t, dst, op, rt):
+    if _device_native(dist):
+        dist.reduce(t, dst=dst, op=op)
+    else:
+        _sync_runtime_stream(rt)
+        h = t.cpu()
+        dist.reduce(h, dst=dst, op=op)
+        if dist.get_rank() == dst:
+            t.copy_(h)
+
+
+def _all_to_all(dist, out, inp, rt):
+    import torch
+    if _device_native(dist):
+        dist.all_to_all_single(out, inp)
+        return
+    _sync_runtime_stream(rt)
+    world = dist.get_world_size()
+    hin = inp.cpu()
+    parts = [torch.empty_like(c) for c in hin.chunk(world)]
+    # gloo has no all_to_all: `world` scatters (rank r scatters its blocks) — same data movement, test-path only
+    for r in range(world):
+        dist.scatter(parts[r], list(hin.chunk(world)) if dist.get_rank() == r else None, src=r)
+    out.copy_(torch.cat(parts))
+
+
+def _gather(dist, gathered, t, dst, rt):
+    import torch
+    if _device_native(dist):
+        dist.gather(t, list(gathered.chunk(dist.get_world_size())) if dist.get_rank() == dst else None, dst=dst)
+        return
+    _sync_runtime_stream(rt)
+    h = t.cpu()
+    if dist.get_rank() == dst:
+        parts = [torch.empty_like(h) for _ in range(dist.get_world_size())]
+        dist.gather(h, parts, dst=dst)
+        gathered.copy_(torch.cat(parts))
+    else:
+        dist.gather(h, None, dst=dst)
+
+
 def exchange_merge(rt, rank: int, dist, key_buf, sum_buf, dst: int = 0):
-    """Folds every rank's Runtime into rank `dst`'s (rank order == merge order). key_buf: int64[npix],
+    """Rooted form: folds every rank's Runtime into rank `dst`'s (rank order == merge order). key_buf: int64[npix],
     sum_buf: int32[3*npix] torch tensors on the runtime's device. The pack/unpack kernels run on the RUNTIME's stream
     (a non-blocking stream of its own unless set), the collectives on torch's current stream: give the runtime that
     stream first — ``rt.set_stream(torch.cuda.current_stream().cuda_stream)`` — as bench.py does."""
     rt.exchange_export(rank, key_buf.data_ptr())
-    dist.all_reduce(key_buf, op=dist.ReduceOp.MAX)
+    _all_reduce(dist, key_buf, dist.ReduceOp.MAX, rt)
     rt.exchange_select(rank, key_buf.data_ptr(), sum_buf.data_ptr())
-    dist.reduce(sum_buf, dst=dst, op=dist.ReduceOp.SUM)
+    _reduce(dist, sum_buf, dst, dist.ReduceOp.SUM, rt)
     if rank == dst:
         rt.exchange_import(key_buf.data_ptr(), sum_buf.data_ptr())
+
+
+class SlicedExchange:
+    """Buffers of the sliced exchange for one runtime: allocate once, use every frame."""
+
+    def __init__(self, S_mod, cfg, rt, rank: int, world: int, device):
+        import torch
+        self.S, self.cfg, self.rt, self.rank, self.world = S_mod, cfg, rt, rank, world
+        w, h = rt.dims()
+        self.npix = w * h
+        self.slice_pixels = S_mod.exchange_slice_pixels(self.npix, world)
+        blk = self.slice_pixels * 16
+        self.pack = torch.empty(world * blk, dtype=torch.uint8, device=device)
+        self.recv = torch.empty(world * blk, dtype=torch.uint8, device=device)
+        self.scalars = torch.empty(4, dtype=torch.int64, device=device)
+        # RGBA16 travels as bytes (gloo moves no 16-bit integers; RCCL does not care)
+        self.rgba_slice = torch.empty(self.slice_pixels * 8, dtype=torch.uint8, device=device)
+        # the root's image: `world` slices back to back (a few pixels of padding after npix)
+        self.rgba = torch.empty(world * self.slice_pixels * 8, dtype=torch.uint8, device=device)
+        self.first, self.count = slice_of(self.npix, world, rank, self.slice_pixels)
+
+    def bytes_on_the_wire(self) -> dict:
+        blk = self.slice_pixels * 16
+        return {"all_to_all_out_per_rank": (self.world - 1) * blk, "gather_to_root_per_rank": self.slice_pixels * 8,
+                "scalars": 32}
+
+    def merge(self, dist):
+        """Steps 1-3: after this the runtime holds the merged frame inside its own slice and global scalars."""
+        rt = self.rt
+        rt.exchange_pack(self.world, self.pack.data_ptr())
+        _all_to_all(dist, self.recv, self.pack, rt)
+        rt.exchange_merge_slices(self.world, self.rank, self.recv.data_ptr())
+        rt.exchange_scalars_export(self.scalars.data_ptr())
+        _all_reduce(dist, self.scalars, dist.ReduceOp.MAX, rt)
+        rt.exchange_scalars_import(self.scalars.data_ptr())
+
+    def colorize(self, dist, dst: int = 0):
+        """Step 4: every rank colorizes its slice; the root gathers the image (the first npix*8 bytes of self.rgba there)."""
+        import torch
+        if self.count:
+            self.S.colorize_range_device(self.cfg, self.rt, self.first, self.count, self.rgba_slice.data_ptr())
+        _gather(dist, self.rgba, self.rgba_slice, dst, self.rt)
+        return self.rgba[: self.npix * 8].view(torch.int16) if self.rank == dst else None
+
+
+def exchange_colorize(ex: SlicedExchange, dist, dst: int = 0):
+    """Sliced form in one call: merge + sharded colorize + gather. Returns the RGBA16 image (flat int16 view of the
+    u16 samples, H*W*4) on rank `dst`, None elsewhere."""
+    ex.merge(dist)
+    return ex.colorize(dist, dst)

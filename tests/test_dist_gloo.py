@@ -1,9 +1,14 @@
-"""CPU, world_size 2 over gloo: the multi-GPU exchange protocol (all-reduce MAX of depth keys + reduce SUM of
-counts/steps halves) reproduces Runtime::merge folded in rank order, and job sharding covers every job once.
+"""CPU, world_size 2 and 3 over gloo: strange_attractor_renderer_amd.distributed ITSELF — exchange_merge (rooted: all-reduce
+MAX of depth keys + reduce SUM of counts / steps halves) and SlicedExchange / exchange_colorize (all-to-all of image
+slices, merge in rank order, scalar all-reduce, sharded colorize, gather) — reproduces Runtime::merge folded in rank order
+(reference src/lib.rs:708-738, 1068-1076), and job sharding covers every job once.
 
-The pack/select/import arithmetic below is a numpy mirror of the three exchange kernels in
-csrc/sar_image.hip (k_exch_export / k_exch_select / k_exch_import); the GPU versions are checked against
-the same oracle merge in the -m gpu suite."""
+There is no HIP device here, so the Runtime handed to distributed.py is a numpy stand-in for the six exchange kernels of
+csrc/sar_image.hip (k_exch_export / _select / _import, k_exch_pack / _merge_slices / scalars) working on the same raw
+buffers through the same pointers; the oracle stands in for the renderer. The process groups, the collectives, the
+buffer geometry and the call sequence are the real ones; the HIP kernels run through the very same distributed.py
+calls in tests/test_gpu_dist.py (-m gpu)."""
+import ctypes
 import os
 import socket
 import sys
@@ -15,6 +20,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+UNSET = np.uint32(0x407FFFFF)  # sortable(-1.0f)
 
 
 def sortable(z32: np.ndarray) -> np.ndarray:
@@ -27,48 +33,152 @@ def unsortable(s: np.ndarray) -> np.ndarray:
     return b.view(np.float32)
 
 
-def exch_key(z32, rank):
-    k = (sortable(z32).astype(np.uint64) << np.uint64(32)) | np.uint64(0xFFFFFFFF - rank)
-    return (k ^ np.uint64(1 << 63)).view(np.int64)
+def _at(ptr, dtype, n):
+    return np.ctypeslib.as_array((ctypes.c_uint8 * (n * np.dtype(dtype).itemsize)).from_address(ptr)).view(dtype)
 
 
-def _worker(rank, world, port, W, H, jobs, n, seed, q):
+class NumpyRuntime:
+    """The exchange half of api.Runtime with numpy in place of the HIP kernels (same buffers, same layouts)."""
+
+    def __init__(self, ort, slice_pixels_fn):
+        self.W, self.H = ort.width, ort.height
+        self.npix = self.W * self.H
+        self.count = ort.count.ravel().copy()
+        self.z = sortable(ort.zbuf.ravel())
+        self.steps = ort.steps.ravel().copy()
+        self.max, self.wrap = ort.max, 0
+        self.zmax = self.zmin = None
+        self._slice_pixels = slice_pixels_fn
+
+    def dims(self):
+        return self.W, self.H
+
+    def synchronize(self):
+        pass
+
+    # ---- rooted form (k_exch_export / k_exch_select / k_exch_import) ----
+    def _key(self, rank):
+        k = (self.z.astype(np.uint64) << np.uint64(32)) | np.uint64(0xFFFFFFFF - rank)
+        return (k ^ np.uint64(1 << 63)).view(np.int64)
+
+    def exchange_export(self, rank, key_ptr):
+        _at(key_ptr, np.int64, self.npix)[:] = self._key(rank)
+
+    def exchange_select(self, rank, key_ptr, sum_ptr):
+        red = _at(key_ptr, np.int64, self.npix)
+        out = _at(sum_ptr, np.int32, 3 * self.npix)
+        mine = self._key(rank) == red
+        bits = np.where(mine, self.steps.view(np.uint64), np.uint64(0))
+        out[:self.npix] = self.count.view(np.int32)
+        out[self.npix::2] = (bits & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)
+        out[self.npix + 1::2] = (bits >> np.uint64(32)).astype(np.uint32).view(np.int32)
+
+    def exchange_import(self, key_ptr, sum_ptr):
+        red = _at(key_ptr, np.int64, self.npix)
+        s = _at(sum_ptr, np.int32, 3 * self.npix)
+        self.count = s[:self.npix].view(np.uint32).copy()
+        self.z = ((red.view(np.uint64) ^ np.uint64(1 << 63)) >> np.uint64(32)).astype(np.uint32)
+        lo = s[self.npix::2].view(np.uint32).astype(np.uint64)
+        hi = s[self.npix + 1::2].view(np.uint32).astype(np.uint64)
+        self.steps = (lo | (hi << np.uint64(32))).view(np.float64).copy()
+        self.max = max(self.max, int(self.count.max()))
+
+    # ---- sliced form (k_exch_pack / k_exch_merge_slices / scalars) ----
+    def exchange_pack(self, world, out_ptr):
+        S = self._slice_pixels(self.npix, world)
+        out = _at(out_ptr, np.uint8, world * S * 16)
+        for d in range(world):
+            blk = out[d * S * 16:(d + 1) * S * 16]
+            lo, hi = min(self.npix, d * S), min(self.npix, (d + 1) * S)
+            c, z, st = np.zeros(S, np.uint32), np.full(S, UNSET, np.uint32), np.zeros(S, np.float64)
+            c[:hi - lo], z[:hi - lo], st[:hi - lo] = self.count[lo:hi], self.z[lo:hi], self.steps[lo:hi]
+            blk[:S * 4] = c.view(np.uint8)
+            blk[S * 4:S * 8] = z.view(np.uint8)
+            blk[S * 8:] = st.view(np.uint8)
+
+    def exchange_merge_slices(self, world, rank, in_ptr):
+        S = self._slice_pixels(self.npix, world)
+        buf = _at(in_ptr, np.uint8, world * S * 16)
+        lo, hi = min(self.npix, rank * S), min(self.npix, (rank + 1) * S)
+        n = hi - lo
+        parts = []
+        for r in range(world):
+            blk = buf[r * S * 16:(r + 1) * S * 16]
+            parts.append((blk[:S * 4].view(np.uint32)[:n].copy(), blk[S * 4:S * 8].view(np.uint32)[:n].copy(),
+                          blk[S * 8:].view(np.float64)[:n].copy()))
+        c, z, st = parts[0]
+        if rank != 0:
+            self.max, self.wrap = 0, 0
+        for oc, oz, ost in parts[1:]:
+            c = c + oc                                           # wrapping u32, :719
+            if n:
+                self.max = max(self.max, int(c.max()))           # running max over every intermediate sum, :721-723
+            take = oz > z                                        # strict: the earlier rank wins ties, :728
+            z = np.where(take, oz, z)
+            st = np.where(take, ost, st)
+        self.count[lo:hi], self.z[lo:hi], self.steps[lo:hi] = c, z, st
+        seen = z[z != UNSET]
+        self.zmax = max(int(sortable(np.float32([0.0]))[0]), int(seen.max()) if seen.size else 0)
+        self.zmin = min(int(sortable(np.float32([np.finfo(np.float32).max]))[0]), int(seen.min()) if seen.size else 2**32 - 1)
+
+    def exchange_scalars_export(self, ptr):
+        _at(ptr, np.int64, 4)[:] = [self.max, self.wrap, self.zmax, (~np.uint32(self.zmin)) & 0xFFFFFFFF]
+
+    def exchange_scalars_import(self, ptr):
+        v = _at(ptr, np.int64, 4)
+        self.max, self.wrap, self.zmax = int(v[0]), int(v[1]), int(v[2])
+        self.zmin = int(~np.uint32(v[3]) & 0xFFFFFFFF)
+
+
+class NumpyApi:
+    """The two api.* functions SlicedExchange calls, for a NumpyRuntime: slice geometry from the real library (a host
+    function), colorize through the oracle with the GLOBAL max."""
+
+    def __init__(self, O, S):
+        self.O, self.S = O, S
+
+    def exchange_slice_pixels(self, npix, world):
+        return self.S.exchange_slice_pixels(npix, world)
+
+    def colorize_range_device(self, cfg, rt, first, n, out_ptr):
+        O = self.O
+        ort = O.Runtime(rt.W, rt.H)
+        ort.count[:] = rt.count.reshape(rt.H, rt.W)
+        ort.steps[:] = rt.steps.reshape(rt.H, rt.W)
+        ort.zbuf[:] = unsortable(rt.z).reshape(rt.H, rt.W)
+        ort.set_max(0xFFFFFFFF if rt.wrap else rt.max)
+        img = O.colorize(cfg, ort).reshape(-1, 4)
+        _at(out_ptr, np.uint16, n * 4)[:] = img[first:first + n].ravel()
+
+
+def _worker(rank, world, port, W, H, jobs, n, seed, mode, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from strange_attractor_renderer_amd.distributed import shard_jobs
+    import strange_attractor_renderer_amd as S
+    from strange_attractor_renderer_amd import distributed as D
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = O.poisson_saturne()
-    cfg.width, cfg.height = W, H
-    first, cnt = shard_jobs(jobs, world, rank)
-    starts = O.start_points(seed, first, cnt)
-    rt = O.Runtime(W, H)
-    O.render_jobs(cfg, rt, starts, n)          # this rank's partial render (the oracle stands in for the GPU)
+    cfg.width, cfg.height, cfg.transparent = W, H, 0
+    first, cnt = D.shard_jobs(jobs, world, rank)
+    ort = O.Runtime(W, H)
+    O.render_jobs(cfg, ort, O.start_points(seed, first, cnt), n)   # this rank's partial render (the oracle stands in for the GPU)
+    rt = NumpyRuntime(ort, S.exchange_slice_pixels)
     npix = W * H
-    # 1. export + all-reduce MAX
-    key = torch.from_numpy(exch_key(rt.zbuf.ravel(), rank).copy())
-    dist.all_reduce(key, op=dist.ReduceOp.MAX)
-    red = key.numpy()
-    # 2. select + reduce SUM (int32: count, then the two halves of the winner's steps bits)
-    mine = exch_key(rt.zbuf.ravel(), rank) == red
-    bits = np.where(mine, rt.steps.ravel().view(np.uint64), np.uint64(0))
-    sums = np.empty(3 * npix, dtype=np.int32)
-    sums[:npix] = rt.count.ravel().view(np.int32)
-    sums[npix::2] = (bits & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)
-    sums[npix + 1::2] = (bits >> np.uint64(32)).astype(np.uint32).view(np.int32)
-    t = torch.from_numpy(sums)
-    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
-    if rank == 0:
-        # 3. import
-        s = t.numpy()
-        count = s[:npix].view(np.uint32).reshape(H, W)
-        k = (red.view(np.uint64) ^ np.uint64(1 << 63))
-        zbuf = unsortable((k >> np.uint64(32)).astype(np.uint32)).reshape(H, W)
-        sbits = s[npix::2].view(np.uint32).astype(np.uint64) | (s[npix + 1::2].view(np.uint32).astype(np.uint64) << np.uint64(32))
-        steps = sbits.view(np.float64).reshape(H, W)
-        q.put((count.copy(), zbuf.copy(), steps.copy(), max(rt.max, int(count.max()))))
+    if mode == "rooted":
+        key = torch.empty(npix, dtype=torch.int64)
+        sums = torch.empty(3 * npix, dtype=torch.int32)
+        D.exchange_merge(rt, rank, dist, key, sums, dst=0)          # the real function, real collectives
+        if rank == 0:
+            q.put((rt.count.reshape(H, W).copy(), unsortable(rt.z).reshape(H, W).copy(), rt.steps.reshape(H, W).copy(), rt.max, None))
+    else:
+        ex = D.SlicedExchange(NumpyApi(O, S), cfg, rt, rank, world, "cpu")
+        img = D.exchange_colorize(ex, dist, dst=0)                  # pack, all-to-all, merge, scalars, colorize, gather
+        f, c = ex.first, ex.count
+        q.put((rank, f, c, rt.count[f:f + c].copy(), unsortable(rt.z[f:f + c]).copy(), rt.steps[f:f + c].copy(), rt.max,
+               img.numpy().view(np.uint16).reshape(H, W, 4).copy() if rank == 0 else None))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,23 +191,24 @@ def _free_port():
     return p
 
 
-@pytest.mark.timeout(300)
-def test_exchange_protocol_equals_merge_in_rank_order(oracle):
-    from strange_attractor_renderer_amd.distributed import shard_jobs
-    W, H, jobs, n, seed, world = 96, 80, 37, 4000, 5, 2
+def _spawn(world, mode, W, H, jobs, n, seed, n_results):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, jobs, n, seed, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, jobs, n, seed, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
-    count, zbuf, steps, mx = q.get(timeout=240)
+    got = [q.get(timeout=240) for _ in range(n_results)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # expectation: per-rank partial renders merged with Runtime::merge, rank 0 first
+    return got
+
+
+def _fold_in_rank_order(oracle, W, H, jobs, n, seed, world):
+    from strange_attractor_renderer_amd.distributed import shard_jobs
     cfg = oracle.poisson_saturne()
-    cfg.width, cfg.height = W, H
+    cfg.width, cfg.height, cfg.transparent = W, H, 0
     parts = []
     for r in range(world):
         first, cnt = shard_jobs(jobs, world, r)
@@ -107,6 +218,14 @@ def test_exchange_protocol_equals_merge_in_rank_order(oracle):
     acc = parts[0]
     for other in parts[1:]:
         assert oracle.merge(acc, other) == 0
+    return cfg, acc
+
+
+@pytest.mark.timeout(300)
+def test_exchange_merge_equals_merge_in_rank_order(oracle):
+    W, H, jobs, n, seed, world = 96, 80, 37, 4000, 5, 2
+    (count, zbuf, steps, mx, _), = _spawn(world, "rooted", W, H, jobs, n, seed, 1)
+    cfg, acc = _fold_in_rank_order(oracle, W, H, jobs, n, seed, world)
     assert np.array_equal(count, acc.count)
     assert np.array_equal(zbuf.view(np.uint32), acc.zbuf.view(np.uint32))
     assert np.array_equal(steps.view(np.uint64), acc.steps.view(np.uint64))
@@ -117,8 +236,28 @@ def test_exchange_protocol_equals_merge_in_rank_order(oracle):
     assert np.array_equal(count, whole.count) and np.array_equal(zbuf.view(np.uint32), whole.zbuf.view(np.uint32))
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sliced_exchange_colorize_equals_merge_in_rank_order(oracle, world):
+    W, H, jobs, n, seed = 97, 83, 41, 3000, 6                      # npix % world != 0, jobs % world != 0
+    got = _spawn(world, "sliced", W, H, jobs, n, seed, world)
+    cfg, acc = _fold_in_rank_order(oracle, W, H, jobs, n, seed, world)
+    count, zbuf, steps = np.zeros(W * H, np.uint32), np.zeros(W * H, np.float32), np.zeros(W * H)
+    img, covered = None, 0
+    for rank, f, c, cs, zs, ss, mx, im in got:
+        count[f:f + c], zbuf[f:f + c], steps[f:f + c] = cs, zs, ss
+        covered += c
+        assert mx == acc.max
+        img = im if rank == 0 else img
+    assert covered == W * H
+    assert np.array_equal(count.reshape(H, W), acc.count)
+    assert np.array_equal(zbuf.view(np.uint32).reshape(H, W), acc.zbuf.view(np.uint32))
+    assert np.array_equal(steps.view(np.uint64).reshape(H, W), acc.steps.view(np.uint64))
+    assert np.array_equal(img, oracle.colorize(cfg, acc))
+
+
 def test_shard_jobs_partitions_exactly():
-    from strange_attractor_renderer_amd.distributed import shard_jobs
+    from strange_attractor_renderer_amd.distributed import shard_jobs, slice_of
     for total in (0, 1, 7, 64, 65536, 524288, 1000003):
         for world in (1, 2, 3, 4, 8):
             seen = 0
@@ -129,3 +268,9 @@ def test_shard_jobs_partitions_exactly():
             assert seen == total
     with pytest.raises(ValueError):
         shard_jobs(10, 2, 2)
+    import strange_attractor_renderer_amd as S
+    for npix in (1, 5, 4096, 2048 * 2048, 1800 * 2000, 4096 * 4096):
+        for world in (1, 2, 3, 8):
+            sp = S.exchange_slice_pixels(npix, world)
+            assert sp % 4 == 0 and sp * world >= npix
+            assert sum(slice_of(npix, world, r, sp)[1] for r in range(world)) == npix

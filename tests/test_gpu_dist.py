@@ -1,0 +1,184 @@
+"""GPU, several ranks on ONE device: the multi-GPU exchange itself — strange_attractor_renderer_amd.distributed
+(exchange_merge, the rooted form; SlicedExchange / exchange_colorize, the sliced form) with real processes, real
+torch.distributed collectives (gloo: the ranks share cuda:0, so buffers are staged through the host; the kernels and
+the protocol are the ones RCCL drives on an 8-GPU node) and the HIP exchange kernels — against Runtime::merge folded in
+rank order by the oracle (reference src/lib.rs:708-738, 1068-1076). Also the C-ABI multi-device ParallelRenderer with
+one device standing in for several shards."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view({4: np.uint32, 8: np.uint64}[a.dtype.itemsize])
+
+
+def _worker(rank, world, port, preset, W, H, kind, jobs, n, seed, mode, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import strange_attractor_renderer_amd as S
+    from strange_attractor_renderer_amd import distributed as D
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    cfg = getattr(S.Config, preset)(iterations=jobs * n, width=W, height=H, jobs_total=jobs, render_kind=kind, scale=1.0,
+                                    seed=seed, transparent=0)
+    first, cnt = D.shard_jobs(jobs, world, rank)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        rt = S.Runtime(cfg, device=0)
+        rt.set_stream(stream.cuda_stream)
+        S.render_job_range(cfg, rt, n, S.start_points(seed, first, cnt))
+        npix = W * H
+        if mode == "rooted":
+            key = torch.empty(npix, dtype=torch.int64, device="cuda")
+            sums = torch.empty(3 * npix, dtype=torch.int32, device="cuda")
+            D.exchange_merge(rt, rank, dist, key, sums, dst=0)
+            if rank == 0:
+                q.put(("rooted", rt.count(), rt.zbuf(), rt.steps(), rt.max(), S.colorize(cfg, rt)))
+        else:
+            ex = D.SlicedExchange(S, cfg, rt, rank, world, "cuda")
+            img = D.exchange_colorize(ex, dist, dst=0)
+            torch.cuda.synchronize()
+            # every rank's runtime holds the merged frame inside its own slice
+            f, c = ex.first, ex.count
+            q.put(("slice", rank, f, c, rt.count().ravel()[f:f + c].copy(), rt.zbuf().ravel()[f:f + c].copy(),
+                   rt.steps().ravel()[f:f + c].copy(), rt.max(),
+                   img.cpu().numpy().view(np.uint16).reshape(H, W, 4).copy() if rank == 0 else None,
+                   ex.bytes_on_the_wire()))
+        rt.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _expected(oracle, preset, W, H, kind, jobs, n, seed, world):
+    from strange_attractor_renderer_amd.distributed import shard_jobs
+    cfg = getattr(oracle, preset)()
+    cfg.width, cfg.height, cfg.scale, cfg.render_kind, cfg.transparent = W, H, 1.0, kind, 0
+    parts = []
+    for r in range(world):
+        first, cnt = shard_jobs(jobs, world, r)
+        rt = oracle.Runtime(W, H)
+        oracle.render_jobs(cfg, rt, oracle.start_points(seed, first, cnt), n)
+        parts.append(rt)
+    acc = parts[0]
+    for other in parts[1:]:
+        assert oracle.merge(acc, other) == 0           # Runtime::merge folded in rank order (:1070-1076)
+    return cfg, acc
+
+
+def _run(world, mode, preset, W, H, kind, jobs, n, seed):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, preset, W, H, kind, jobs, n, seed, mode, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(1 if mode == "rooted" else world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("preset,kind", [("poisson_saturne", 0), ("solar_sail", 1)])
+def test_rooted_exchange_merge_two_ranks_equals_oracle_merge(sar, oracle, gpu, preset, kind):
+    """distributed.exchange_merge itself, 2 ranks on cuda:0: rank 0's merged count / zbuf / steps / max / image equal
+    the oracle's per-rank renders folded with Runtime::merge in rank order."""
+    W, H, jobs, n, seed, world = 320, 200, 600, 1500, 11, 2
+    (_, count, zbuf, steps, mx, img), = _run(world, "rooted", preset, W, H, kind, jobs, n, seed)
+    cfg, acc = _expected(oracle, preset, W, H, kind, jobs, n, seed, world)
+    assert np.array_equal(count, acc.count) and mx == acc.max
+    assert np.array_equal(_bits(zbuf), _bits(acc.zbuf))
+    assert np.array_equal(_bits(steps), _bits(acc.steps))
+    assert np.array_equal(img, oracle.colorize(cfg, acc))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,preset,kind", [(2, "poisson_saturne", 0), (3, "solar_sail", 1), (3, "poisson_saturne", 0)])
+def test_sliced_exchange_colorize_equals_oracle_merge(sar, oracle, gpu, world, preset, kind):
+    """distributed.exchange_colorize, 2 and 3 ranks on cuda:0 (3: uneven last slice, uneven job shards): the merged
+    slices assembled from the ranks, `max`, and the root's gathered image equal the oracle's fold in rank order."""
+    W, H, jobs, n, seed = 321, 199, 601, 1200, 17        # odd sizes: npix % world != 0, jobs % world != 0
+    got = _run(world, "sliced", preset, W, H, kind, jobs, n, seed)
+    cfg, acc = _expected(oracle, preset, W, H, kind, jobs, n, seed, world)
+    count = np.zeros(W * H, np.uint32)
+    zbuf = np.zeros(W * H, np.float32)
+    steps = np.zeros(W * H, np.float64)
+    img = None
+    covered = 0
+    for _, rank, f, c, cs, zs, ss, mx, im, wire in got:
+        count[f:f + c], zbuf[f:f + c], steps[f:f + c] = cs, zs, ss
+        covered += c
+        assert mx == acc.max                                  # the scalars are global on every rank
+        assert wire["all_to_all_out_per_rank"] == (world - 1) * 16 * sar.exchange_slice_pixels(W * H, world)
+        if rank == 0:
+            img = im
+    assert covered == W * H
+    assert np.array_equal(count.reshape(H, W), acc.count)
+    assert np.array_equal(_bits(zbuf.reshape(H, W)), _bits(acc.zbuf))
+    assert np.array_equal(_bits(steps.reshape(H, W)), _bits(acc.steps))
+    assert np.array_equal(img, oracle.colorize(cfg, acc))
+
+
+@pytest.mark.parametrize("devices,preset,kind", [([0, 0], "poisson_saturne", 0), ([0, 0, 0], "solar_sail", 1)])
+def test_c_abi_multi_device_renderer_equals_single_device_and_oracle(sar, oracle, gpu, devices, preset, kind):
+    """sar_renderer_new_multi with ONE device listed as several shards (what an 8-GPU node does with 8 devices): job
+    slices rendered concurrently on their own streams and host threads, slices exchanged with hipMemcpyPeerAsync,
+    folded in device order, colorized per slice straight into the host image. Equal to the single-device renderer and
+    to the oracle's fold — for two consecutive frames (the start-point stream runs on, the buffers are reused)."""
+    from strange_attractor_renderer_amd.distributed import shard_jobs
+    W, H, units, jpu, seed = 333, 211, 96, 5, 23
+    cfg = getattr(sar.Config, preset)(iterations=units * jpu * 900 + 77, width=W, height=H, render_kind=kind, scale=1.0,
+                                      transparent=0)
+    multi = sar.ParallelRenderer(devices=devices, units=units, seed=seed)
+    single = sar.ParallelRenderer(device=0, units=units, seed=seed)
+    assert multi.num_devices() == len(devices) and multi.num_threads() == units
+    jobs, n = units * jpu, cfg.iterations // units // jpu
+    ocfg = getattr(oracle, preset)()
+    ocfg.width, ocfg.height, ocfg.scale, ocfg.render_kind, ocfg.transparent = W, H, 1.0, kind, 0
+    for frame in range(2):
+        img_m = sar.render_parallel(multi, cfg, jpu)
+        img_s = sar.render_parallel(single, cfg, jpu)
+        # oracle: the frame's jobs (start points continue across frames), sharded like the devices, folded in order
+        parts = []
+        for r in range(len(devices)):
+            first, cnt = shard_jobs(jobs, len(devices), r)
+            rt = oracle.Runtime(W, H)
+            oracle.render_jobs(ocfg, rt, oracle.start_points(seed, frame * jobs + first, cnt), n)
+            parts.append(rt)
+        acc = parts[0]
+        for other in parts[1:]:
+            oracle.merge(acc, other)
+        want = oracle.colorize(ocfg, acc)
+        assert np.array_equal(img_m, want)
+        assert np.array_equal(img_m, img_s)          # contiguous shards folded in order == the sequential result
+        rm = multi.runtime()                          # gathers the merged slices into device 0's runtime
+        assert np.array_equal(rm.count(), acc.count) and rm.max() == acc.max
+        assert np.array_equal(_bits(rm.zbuf()), _bits(acc.zbuf)) and np.array_equal(_bits(rm.steps()), _bits(acc.steps))
+        t = multi.last_timing()
+        assert t["n_devices"] == len(devices) and t["exchange_bytes_per_device"] == (len(devices) - 1) * 16 * \
+            sar.exchange_slice_pixels(W * H, len(devices))
+    multi.shutdown()
+    single.shutdown()
