@@ -21,6 +21,7 @@ BUILD_DIR = os.path.join(os.path.dirname(PKG), "build", "sar_hip")
 SOURCES = ["sar_host.cpp", "sar_export.cpp", "sar_runtime.cpp", "sar_multi.cpp", "sar_iterate.hip", "sar_accumulate.hip", "sar_image.hip"]
 HEADERS = ["sar_internal.hpp", "sar_launch.hpp", "sar_device.hpp", "sar_runtime_impl.hpp", os.path.join("..", "..", "include", "sar.h")]
 ARCH = "gfx950"
+FOLD_FUSED_OPS = 6   # v_fma_f64 in k_fold_resolve: the sqrt + div expansions of color_transform, nothing else
 
 FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17",
@@ -59,34 +60,50 @@ def audit_no_fma(asm_paths) -> dict:
         raise RuntimeError(f"fused fp64 ops found in the iterate kernel: {bad}")
     if not any("k_iterate" in k for k in counts):
         raise RuntimeError("audit could not find k_iterate in the device assembly")
+    # k_fold_resolve replays next_point / screen_space from the checkpoints for the bit-exact `steps` payload, next to a
+    # sqrt and a division whose correctly-rounded expansions legitimately use fused ops: exactly FOLD_FUSED_OPS of them
+    # (sqrt 4, div 2... as emitted by ROCm 7.2's device libs). One more means the replay was contracted.
+    fold = [v for k, v in counts.items() if "k_fold_resolve" in k]
+    if fold != [FOLD_FUSED_OPS]:
+        raise RuntimeError(f"k_fold_resolve holds {fold} fused fp64 ops, expected [{FOLD_FUSED_OPS}] (sqrt/div expansion only): "
+                           "either the payload replay was contracted or the device libs changed — inspect the assembly")
     return counts
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+def build_library(force: bool = False, verbose: bool = False, out: str | None = None, build_dir: str | None = None) -> str:
+    """out / build_dir: build a VARIANT of the library somewhere else (with SAR_EXTRA_FLAGS / SAR_KERNEL_FLAGS set) for
+    A/B timing or test builds; load it through the SAR_LIBRARY environment variable. The product is the default."""
+    if out is None and not force and not _stale():
         return OUT
-    os.makedirs(BUILD_DIR, exist_ok=True)
+    OUT_ = out or OUT
+    BUILD_DIR_ = build_dir or BUILD_DIR
+    os.makedirs(BUILD_DIR_, exist_ok=True)
     hipcc = _hipcc()
     objs = []
     for s in SOURCES:
-        obj = os.path.join(BUILD_DIR, s + ".o")
+        obj = os.path.join(BUILD_DIR_, s + ".o")
         # SAR_EXTRA_FLAGS: extra -D flags for timing experiments (e.g. -DSAR_EXPERIMENT_...); never set by the product
         cmd = [hipcc, *FLAGS, *os.environ.get("SAR_EXTRA_FLAGS", "").split(), "-c", os.path.join(CSRC, s), "-o", obj]
         if s.endswith(".hip"):  # SAR_KERNEL_FLAGS: device-compiler flags for experiments (e.g. -mllvm options)
             cmd += ["-save-temps=obj", *os.environ.get("SAR_KERNEL_FLAGS", "").split()]
         if verbose:
             print(" ".join(cmd))
-        subprocess.run(cmd, check=True, cwd=BUILD_DIR)
+        subprocess.run(cmd, check=True, cwd=BUILD_DIR_)
         objs.append(obj)
-    asm = [os.path.join(BUILD_DIR, f"{s[:-4]}-hip-amdgcn-amd-amdhsa-{ARCH}.s") for s in SOURCES if s.endswith(".hip")]
+    asm = [os.path.join(BUILD_DIR_, f"{s[:-4]}-hip-amdgcn-amd-amdhsa-{ARCH}.s") for s in SOURCES if s.endswith(".hip")]
     counts = audit_no_fma(asm)
     if verbose:
         print("fused-fp64 audit:", {k[:60]: v for k, v in counts.items()})
-    tmp = OUT + ".tmp"
+    tmp = OUT_ + ".tmp"
     subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-lz", "-lpthread", "-o", tmp], check=True)  # zlib: PNG export
-    os.replace(tmp, OUT)
-    return OUT
+    os.replace(tmp, OUT_)
+    return OUT_
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:  # python -m ...build --variant NAME  (flags from SAR_EXTRA_FLAGS / SAR_KERNEL_FLAGS)
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        print(build_library(force=True, verbose=True, out=os.path.join(PKG, f"libsar_hip_{name}.so"),
+                            build_dir=os.path.join(os.path.dirname(PKG), "build", f"sar_hip_{name}")))
+    else:
+        print(build_library(force="--force" in sys.argv, verbose=True))

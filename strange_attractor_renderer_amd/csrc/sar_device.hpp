@@ -105,6 +105,16 @@ __device__ __forceinline__ uint32_t xcc_id() {
 // per-XCD hint arrays: an even number of entries each, so that the dword holding a 16-bit hint is aligned
 __host__ __device__ constexpr size_t kHintStride(uint32_t npix) { return ((size_t)npix + 1u) & ~(size_t)1u; }
 constexpr uint32_t kLeanWaveLds(uint32_t bins, uint32_t R) { return bins * (2u * R + 8u) + 384u; }
+// PoolStager (sar_iterate.hip): a staged chunk has its final form {prev, n, R x u16}; kPoolSpare spare buffers per wave
+#ifndef SAR_POOL_SPARE
+#define SAR_POOL_SPARE 16u  // a test build shrinks it (SAR_EXTRA_FLAGS=-DSAR_POOL_SPARE=2u) to force the many-fillers rounds
+#endif
+constexpr uint32_t kPoolSpare = SAR_POOL_SPARE;
+constexpr uint32_t kPoolChunkBytes(uint32_t R) { return 8u + 2u * R; }
+constexpr uint32_t kPoolWaveLds(uint32_t bins, uint32_t R) {
+    // buffers | ctl words (+64 dummy) | list heads | ring | 64 scratch records; a multiple of 16 bytes
+    return (bins + kPoolSpare) * kPoolChunkBytes(R) + (bins + 64u) * 4u + bins * 4u + kPoolSpare * 4u + 128u;
+}
 constexpr uint32_t kChunkQuads(uint32_t R) { return (8u + 2u * R) / 16u; }  // 16-byte quads of data per chunk: R = 12, 20, 28
 // Chunks never straddle a 64-byte sector of the arena: the 48-byte chunk (R = 20) is laid out on a 64-byte stride.
 // The accumulate kernel's chunk reads are isolated, and an isolated read moves whole sectors (measured, tools/ubench/

@@ -4,6 +4,8 @@
 #include "sar_device.hpp"
 #include "sar_launch.hpp"
 
+#include <type_traits>
+
 namespace sar {
 
 // ---------------------------------------------------------------------------------------------------
@@ -414,6 +416,238 @@ struct Stager {
 };
 
 // ---------------------------------------------------------------------------------------------------
+// PoolStager — the same staging with the copy-out taken off the per-iteration path
+// ---------------------------------------------------------------------------------------------------
+// In Stager the lane that fills a buffer copies it out by itself: 2R bytes of LDS reads, four 16-byte stores, list
+// bookkeeping — ~30 instructions that 90 % of a wave's iterations execute with 2-3 of 64 lanes active (a wave fills
+// 64 / R buffers per iteration). Here a full buffer is only SWAPPED against a spare one:
+//   * the staged chunk already has its final form in LDS: {previous chunk of this (wave, bin), n, R x u16};
+//   * ctl[bin] = (LDS address of the bin's current buffer << 7) | fill: one ds_add_rtn hands out the slot AND names the
+//     buffer, so swapping a buffer is one more atomic add on that word;
+//   * a ring of P = 16 entries holds the spare buffers: the lane that fills a buffer takes the next chunk number c of
+//     the wave (ballot + mbcnt), exchanges ring[c % P] (a free buffer) against its full one — which thereby becomes
+//     "pending chunk c" — writes the chunk header and re-points ctl[bin]: four LDS operations, no copy;
+//   * when the ring is full (every ~7 iterations) the WHOLE wave copies the pending chunks out: lane l moves quad l % 4
+//     of pending chunk l / 4 — one 16-byte LDS read and one 16-byte store per lane for 16 chunks, to consecutive
+//     addresses of the wave's arena (1 KiB runs) — and the buffers are free again where they stand in the ring.
+// Records that overflow a buffer within one slot request (several lanes, same bin, across the R boundary) are placed
+// in the new buffer by a generation loop, as in Stager (rare).
+template <bool DEPTH, uint32_t R, uint32_t U, typename H>
+struct PoolStager {
+    static constexpr bool kWide = sizeof(H) == 4;
+    static constexpr uint32_t CB = kPoolChunkBytes(R);   // staged chunk == final chunk: 8-byte header + R records
+    static constexpr uint32_t Q = CB / 16u;              // 16-byte quads per chunk
+    static constexpr uint32_t P = kPoolSpare;            // spare buffers == most chunks that wait for the copy-out
+    static constexpr uint32_t kFillBits = 7u, kFillMask = 127u;  // fill < R + 64 <= 92
+    uint32_t* ctl;        // [B] (LDS address of the records of the bin's buffer << 7) | fill, + 64 dummy words
+    uint32_t* prv;        // [B] previous chunk of this (wave, bin) list
+    uint32_t* ring;       // [P] LDS addresses (records) of the spare / pending buffers
+    uint32_t pool0;       // LDS address of buffer 0's records
+    uint32_t trash, dummy, lane, n_bins;
+    uint4* arena;         // this wave's chunk arena
+    uint32_t cursor;      // wave-uniform: next chunk number
+    uint32_t drained;     // wave-uniform: chunks below this one are in the arena
+    H* zhint;
+    unsigned long long* key;
+    uint32_t bin_shift, bin_mask, lo_base;
+    bool pv[U];
+    uint32_t p_idx[U], p_zkey[U], p_lo[U], p_hint[U], p_q[U], n_sent;
+    bool gv[U];
+    uint32_t g_idx[U], g_q[U];
+    unsigned long long g_mine[U], g_cur[U];
+    bool b_have;          // previous visit, waiting for its LDS slot
+    uint32_t b_bin, b_old, b_local;
+
+    static __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+    static __device__ __forceinline__ char* lds_ptr(uint32_t a) { return (char*)(__attribute__((address_space(3))) char*)(uintptr_t)a; }
+
+    __device__ __forceinline__ void init(char* wbase, uint32_t bins, uint32_t lane_, uint4* arena_, H* zhint_,
+                                         unsigned long long* key_, uint32_t shift, uint32_t lo_base_) {
+        n_bins = bins;
+        lane = lane_;
+        // layout: buffers (bins + P) * CB | ctl (bins + 64) | prv bins | ring P | 64 scratch records
+        char* pool = wbase;
+        ctl = (uint32_t*)(wbase + (bins + P) * CB);
+        prv = ctl + bins + 64u;
+        ring = prv + bins;
+        unsigned short* scratch = (unsigned short*)(ring + P);
+        pool0 = lds_addr(pool) + 8u;
+        for (uint32_t b = lane; b < bins; b += 64u) {
+            ctl[b] = (pool0 + b * CB) << kFillBits;
+            prv[b] = kNoChunk;
+        }
+        ctl[bins + lane] = lds_addr(scratch + lane) << kFillBits;
+        if (lane < P) ring[lane] = pool0 + (bins + lane) * CB;
+        trash = lds_addr(scratch + lane);
+        dummy = bins + lane;
+        arena = arena_;
+        cursor = drained = 0;
+        zhint = zhint_;
+        key = key_;
+        bin_shift = shift;
+        bin_mask = (1u << shift) - 1u;
+        lo_base = lo_base_;
+        b_have = false;
+        n_sent = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < U; ++k) {
+            pv[k] = gv[k] = false;
+            p_idx[k] = p_zkey[k] = p_lo[k] = p_hint[k] = p_q[k] = 0;
+            g_idx[k] = g_q[k] = 0;
+            g_mine[k] = g_cur[k] = 0;
+        }
+        b_bin = b_old = b_local = 0;
+    }
+
+    // The whole wave copies the pending chunks [drained, cursor) out — at most P = 16 of them, so one pass: lane l moves
+    // quad l % G of pending chunk l / G (G = 4 lanes per chunk; 2 for the 32-byte chunk).
+    __device__ __forceinline__ void drain_all() {
+        constexpr uint32_t G = Q == 2u ? 2u : 4u;
+        static_assert(P <= 64u / G, "one pass must cover the ring");
+        const uint32_t q = lane % G;
+        const uint32_t e = drained + lane / G;
+        if ((int32_t)(cursor - e) > 0 && q < Q) {
+            const uint32_t rec = ring[e % P];
+            const u32x4 v = *(const u32x4*)lds_ptr(rec - 8u + q * 16u);
+            __builtin_nontemporal_store(v, (u32x4*)(arena + (size_t)e * kChunkStride(R)) + q);
+        }
+        drained = cursor;
+    }
+
+    // One round of swaps: the lanes with `mine` (at most P of them, ranked 0.. by `rank`) have just filled the buffer at
+    // LDS address `rec` of bin `bin`.
+    __device__ __forceinline__ void swap_round(bool mine, uint32_t rank, uint32_t count, uint32_t bin, uint32_t rec) {
+        if (cursor - drained + count > P) drain_all();
+        if (mine) {
+            const uint32_t chunk = cursor + rank;
+            const uint32_t prev = __hip_atomic_exchange(&prv[bin], chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t fresh = __hip_atomic_exchange(&ring[chunk % P], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            *(uint2*)lds_ptr(rec - 8u) = make_uint2(prev, R);
+            // buffer address and fill live in one word: re-point the bin and take R off the fill (records that
+            // overflowed in the same request keep their count)
+            __hip_atomic_fetch_add(&ctl[bin], ((fresh - rec) << kFillBits) - R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        cursor = __builtin_amdgcn_readfirstlane(cursor + count);
+    }
+    __device__ __forceinline__ void swap_full(bool fl, unsigned long long fb, uint32_t bin, uint32_t rec) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
+        const uint32_t nfill = (uint32_t)__popcll(fb);
+        if (nfill <= P) {
+            swap_round(fl, rank, nfill, bin, rec);
+        } else {  // more than P lanes fill a buffer in one request: P at a time
+            for (uint32_t base = 0; base < nfill; base += P)
+                swap_round(fl && rank - base < P, rank - base, nfill - base < P ? nfill - base : P, bin, rec);
+        }
+    }
+
+    // Places the pending record: b_old is the control word its slot request returned.
+    __device__ __forceinline__ void place_visit() {
+        uint32_t slot = b_old & kFillMask;
+        uint32_t rec = b_old >> kFillBits;
+        const bool w0 = b_have && slot < R;
+        *(unsigned short*)lds_ptr(w0 ? rec + 2u * slot : trash) = (unsigned short)b_local;
+        bool fl = w0 && slot == R - 1u;
+        unsigned long long fb = wave_ballot(fl);
+        if (fb) {
+            bool over = b_have && slot >= R;  // overflowed into a later generation of a buffer that filled within this request
+            for (;;) {
+                swap_full(fl, fb, b_bin, rec);
+                if (!wave_ballot(over)) break;  // the common case
+                slot -= over ? R : 0u;
+                if (over) rec = ctl[b_bin] >> kFillBits;  // the buffer the swap installed
+                const bool w = over && slot < R;
+                if (w) *(unsigned short*)lds_ptr(rec + 2u * slot) = (unsigned short)b_local;
+                fl = w && slot == R - 1u;
+                over = over && slot >= R;
+                fb = wave_ballot(fl);
+                if (!fb) break;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void settle_depth(uint32_t k) {
+        if (gv[k]) {
+            if (g_mine[k] > g_cur[k]) {
+                atomicMax(key + g_idx[k], g_mine[k]);
+                ++n_sent;
+            }
+            const uint32_t seen = (uint32_t)(g_cur[k] >> 32);  // 0 while nobody has sent this pixel
+            const uint32_t qs = kWide ? seen : (seen ? depth_q16(sortable_f32(seen)) : 0u);
+            zhint[g_idx[k]] = (H)(qs > g_q[k] ? qs : g_q[k]);
+        }
+        const uint32_t hint = kWide ? p_hint[k] : ((p_idx[k] & 1u) ? (p_hint[k] >> 16) : (p_hint[k] & 0xFFFFu));
+        gv[k] = pv[k] && p_q[k] >= hint;
+        if (gv[k]) {
+            g_idx[k] = p_idx[k];
+            g_q[k] = p_q[k];
+            g_mine[k] = ((unsigned long long)p_zkey[k] << 32) | (unsigned long long)p_lo[k];
+            g_cur[k] = __hip_atomic_load(key + p_idx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    __device__ __forceinline__ void step(uint32_t k, bool inb, uint32_t idx, float zf, uint32_t t) {
+        __builtin_amdgcn_s_setprio(3);
+        place_visit();
+        bool cand = false;
+        if (DEPTH) {
+            settle_depth(k);
+            cand = inb && zf > -1.0f;
+            const float zc = zf + 0.0f;
+            p_zkey[k] = f32_sortable(zc);
+            p_q[k] = kWide ? p_zkey[k] : depth_q16(zc);
+            p_idx[k] = idx;
+            p_lo[k] = lo_base - t;
+            pv[k] = cand;
+        }
+        b_have = inb;
+        b_bin = idx >> bin_shift;
+        b_local = idx & bin_mask;
+        b_old = atomicAdd(&ctl[inb ? b_bin : dummy], 1u);  // ds_add_rtn_u32: slot and buffer in one word
+        if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (idx & ~1u)) : 0u));
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    __device__ __forceinline__ void finish(uint32_t* heads, uint32_t n_waves, uint32_t wave, unsigned long long* stats) {
+        place_visit();
+        drain_all();
+        if (DEPTH) {
+#pragma unroll
+            for (uint32_t k = 0; k < U; ++k) {
+                settle_depth(k);
+                pv[k] = false;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < U; ++k) settle_depth(k);
+            uint32_t tot = n_sent;
+            for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
+            if (lane == 0 && tot) atomicAdd(stats + 1, (unsigned long long)tot);
+        }
+        // the partly filled buffers: one lane per bin writes {list head, fill, records} as the list's last chunk
+        for (uint32_t b0 = 0; b0 < n_bins; b0 += 64u) {
+            const uint32_t b = b0 + lane;
+            const uint32_t word = (b < n_bins) ? ctl[b] : 0u;
+            const uint32_t have = word & kFillMask;
+            const bool flusher = have != 0u;
+            const unsigned long long fb = wave_ballot(flusher);
+            uint32_t head = (b < n_bins) ? prv[b] : kNoChunk;
+            if (flusher) {
+                const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
+                                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
+                const uint32_t rec = word >> kFillBits;
+                *(uint2*)lds_ptr(rec - 8u) = make_uint2(head, have);
+                u32x4* dst = (u32x4*)(arena + (size_t)chunk * kChunkStride(R));
+#pragma unroll
+                for (uint32_t q = 0; q < Q; ++q)
+                    __builtin_nontemporal_store(*(const u32x4*)lds_ptr(rec - 8u + q * 16u), dst + q);
+                head = chunk;
+            }
+            cursor += (uint32_t)__popcll(fb);
+            if (b < n_bins) heads[(size_t)b * n_waves + wave] = head;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
 // k_warmup — the 1000 uncounted iterations every job starts with (reference src/lib.rs:750-752), and the packing of
 // the survivors. NaN is absorbing: a job whose x is NaN after the warm-up spends all its counted iterations on pixel
 // (0,0) without ever winning a depth test, so its n iterations go straight to the NaN counter and the
@@ -452,7 +686,7 @@ __global__ void __launch_bounds__(256) k_warmup(const MapParams pin, const doubl
     }
 }
 
-template <bool DEPTH, uint32_t R, uint32_t U, typename H>
+template <bool DEPTH, uint32_t R, uint32_t U, typename H, bool POOL>
 __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -469,15 +703,19 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     const uint32_t job = alive ? a.joblist[slot] : 0u;
     const uint32_t n = (uint32_t)a.it.iters;
 
-    Stager<DEPTH, R, U, H> st;
+    typename std::conditional<POOL, PoolStager<DEPTH, R, U, H>, Stager<DEPTH, R, U, H>>::type st;
     // visit ordinal = job*n + t (job-major, iteration-minor == the sequential order of the reference); the key's
     // low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie
-    st.init((char*)smem + (threadIdx.x >> 6) * kLeanWaveLds(a.n_bins, R), a.n_bins, lane,
+    st.init((char*)smem + (threadIdx.x >> 6) * (POOL ? kPoolWaveLds(a.n_bins, R) : kLeanWaveLds(a.n_bins, R)), a.n_bins, lane,
             (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkStride(R),
             (H*)a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.bin_shift, 0xFFFFFFFFu - job * n);
 
     MapParams p = a.it.p;
     pin_map_params(p);
+    if (POOL) {  // fewer VGPRs than Stager: room to keep the y coefficients out of the (spilling) scalar file as well
+#pragma unroll
+        for (int k = 0; k < 10; ++k) p.cy[k] = vgpr_pin(p.cy[k]);
+    }
     double x = 0., y = 0., z = 0.;
     if (alive) {  // the point after the warm-up (:750-752), from k_warmup
         x = a.warm[slot];
@@ -629,7 +867,7 @@ void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode,
     }
 }
 
-uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records) { return kLeanWaveLds(bins, records); }
+uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records, bool pool) { return pool ? kPoolWaveLds(bins, records) : kLeanWaveLds(bins, records); }
 uint32_t chunk_bytes(uint32_t records) { return kChunkStride(records) * 16u; }
 
 
@@ -642,9 +880,9 @@ uint32_t chunk_bytes(uint32_t records) { return kChunkStride(records) * 16u; }
     X(false, 12u, 1u, unsigned short) X(false, 20u, 1u, unsigned short) X(false, 28u, 1u, unsigned short)
 
 int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
-                        hipStream_t s) {
+                        bool pool, hipStream_t s) {
     const uint32_t grid = (a.it.n_jobs + block - 1) / block;
-    const size_t lds = (size_t)(block / 64u) * kLeanWaveLds(a.n_bins, records);
+    const size_t lds = (size_t)(block / 64u) * lean_wave_lds_bytes(a.n_bins, records, pool);
     if (!depth) {
         pipe = 1;
         hint_bytes = 2;
@@ -652,7 +890,8 @@ int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, 
     bool launched = false;
 #define SAR_LAUNCH_LEAN(DD, RR, UU, HH)                                                                    \
     if (!launched && depth == DD && records == RR && pipe == UU && hint_bytes == sizeof(HH)) {             \
-        hipLaunchKernelGGL((k_iterate_lean<DD, RR, UU, HH>), dim3(grid), dim3(block), lds, s, a);          \
+        if (pool) hipLaunchKernelGGL((k_iterate_lean<DD, RR, UU, HH, true>), dim3(grid), dim3(block), lds, s, a);   \
+        else hipLaunchKernelGGL((k_iterate_lean<DD, RR, UU, HH, false>), dim3(grid), dim3(block), lds, s, a);       \
         launched = true;                                                                                   \
     }
     SAR_FOR_EACH_LEAN(SAR_LAUNCH_LEAN)
@@ -664,7 +903,8 @@ int iterate_kernel_attributes() {
     // the staging buffers need more dynamic LDS than the 64 KiB default window
     hipError_t e = hipSuccess;
 #define SAR_ATTR_LEAN(DD, RR, UU, HH) \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU, HH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU, HH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SAR_FOR_EACH_LEAN(SAR_ATTR_LEAN)
 #undef SAR_ATTR_LEAN
     return (int)e;

@@ -9,12 +9,13 @@ namespace sar {
 
 // mode: 2 = full path (count + depth key); 1 = count only, 0 = arithmetic only (measurement variants)
 void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode, hipStream_t s);
-uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records);
+uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records, bool pool);
 uint32_t chunk_bytes(uint32_t records);
 // records: 12 / 20 / 28 per chunk; pipe: 1 / 2 visits of depth pipeline
 // hint_bytes: 2 (16-bit fixed-point hints) or 4 (sortable f32 hints)
+// pool: PoolStager (full buffers swapped against spares, cooperative copy-out) instead of Stager
 int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
-                        hipStream_t s);
+                        bool pool, hipStream_t s);
 int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, hipStream_t s);
 int iterate_kernel_attributes();     // sar_iterate.hip
 int accumulate_kernel_attributes();  // sar_accumulate.hip

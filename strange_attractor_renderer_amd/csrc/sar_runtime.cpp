@@ -6,6 +6,7 @@
 // that touches a runtime returns SAR_ERR_NO_DEVICE.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -128,7 +129,7 @@ struct BinGeometry {
     uint32_t shift = 0, bins = 0, block = 0, splits = 0;
     bool ok = false;
 };
-BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift, uint32_t want_splits, uint32_t records) {
+BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift, uint32_t want_splits, uint32_t records, bool pool) {
     BinGeometry g;
     uint32_t px = 4096;
     while (px < kMaxBinPx && static_cast<uint64_t>(px) * 256u < npix) px <<= 1;
@@ -136,7 +137,7 @@ BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift
     g.bins = (npix + px - 1) / px;
     if (g.bins > kMaxBins) return g;
     while ((1u << g.shift) < px) ++g.shift;
-    const uint32_t waves_fit = (160u * 1024u) / lean_wave_lds_bytes(g.bins, records);
+    const uint32_t waves_fit = (160u * 1024u) / lean_wave_lds_bytes(g.bins, records, pool);
     uint32_t block = want_block;
     if (block > waves_fit * 64u) block = waves_fit * 64u;
     if (block == 0) return g;
@@ -249,7 +250,7 @@ int grow_device(T*& ptr, size_t& cap, size_t need) {
 // cut into launch chunks (chunk boundaries fall on whole jobs; a chunk keeps job*iters + t inside 32 bits and its
 // scratch inside kCkptBytesCap).
 struct LaunchPlan {
-    bool binned = false, xcd_local = false;
+    bool binned = false, xcd_local = false, pool = false;
     BinGeometry geo;
     uint32_t R = kDefaultChunkRecords;  // records per chunk
     uint32_t block = 0;                 // trajectories per workgroup of the iterate kernel
@@ -268,7 +269,8 @@ struct LaunchPlan {
 // SIMD) by 1.4x. The job count is scaled by the share of jobs that survived the previous launch's warm-up.
 uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs) {
     if (rt->chunk_records) return rt->chunk_records;
-    const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u);
+    const bool pool = rt->stager == 1;
+    const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u, pool);
     if (!probe.ok) return kDefaultChunkRecords;
     if (rt->active_pending && hipEventQuery(rt->active_copied) == hipSuccess) {
         rt->active_pending = false;
@@ -281,13 +283,14 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs) {
     want = want < 8 ? 8 : (want > 12 ? 12 : want);
     for (uint32_t need : {static_cast<uint32_t>(want), 8u})
         for (uint32_t cand : {28u, 20u, 12u})
-            if (lean_wave_lds_bytes(probe.bins, cand) * need <= 160u * 1024u) return cand;
+            if (lean_wave_lds_bytes(probe.bins, cand, pool) * need <= 160u * 1024u) return cand;
     return 12u;
 }
 
 int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, LaunchPlan& pl) {
     pl.R = choose_chunk_records(rt, n_jobs);
-    pl.geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, pl.R);
+    pl.pool = rt->stager == 1;
+    pl.geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, pl.R, pl.pool);
     // which accumulate path: LDS-binned records (default) or one global atomic per visit
     pl.binned = (rt->bins_mode == 0 || rt->bins_mode == 3) && rt->measure_mode != 2 && pl.geo.ok;
     if (rt->bins_mode == 3 && !pl.geo.ok) {
@@ -466,7 +469,7 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     }
     span_end(rt, rt->warm_spans, rt->warm_used);
     span_begin(rt, rt->iter_spans, rt->iter_used);
-    if (launch_iterate_lean(ba, pl.block, pl.R, pl.pipe, pl.hint_bytes, mode == 2, rt->stream) != 0) {
+    if (launch_iterate_lean(ba, pl.block, pl.R, pl.pipe, pl.hint_bytes, mode == 2, pl.pool, rt->stream) != 0) {
         set_error("bad chunk_records / depth_pipe");
         return SAR_ERR_INVALID;
     }
@@ -639,6 +642,7 @@ int sar_runtime_new(const sar_config* cfg, int device, sar_runtime** out) {
     sar_runtime* rt = new (std::nothrow) sar_runtime();
     if (!rt) return SAR_ERR_OOM;
     rt->device = device;
+    if (const char* e = std::getenv("SAR_STAGER")) rt->stager = (e[0] == '1') ? 1u : 0u;  // test / A-B hook: default stager
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) rt->sm_count = static_cast<uint32_t>(prop.multiProcessorCount);
     int st = SAR_OK;
@@ -1091,6 +1095,9 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "chunk_records")) {
         if (v && v != 12 && v != 20 && v != 28) { set_error("chunk_records must be 12, 20 or 28"); return SAR_ERR_INVALID; }
         rt->chunk_records = v;
+    } else if (!std::strcmp(name, "stager")) {
+        if (v > 1) { set_error("stager must be 0 (copy-out by the filling lane) or 1 (buffer pool, cooperative copy-out)"); return SAR_ERR_INVALID; }
+        rt->stager = v;
     } else if (!std::strcmp(name, "hint_bits")) {
         if (v && v != 16 && v != 32) { set_error("hint_bits must be 16 or 32"); return SAR_ERR_INVALID; }
         rt->hint_bits = v;

@@ -86,6 +86,7 @@ struct sar_runtime {
     uint32_t bin_shift = 0;         // 0 = automatic
     uint32_t splits = 0;            // 0 = automatic
     uint32_t acc_threads = 0;       // threads per k_bin_accumulate block (0 = automatic)
+    uint32_t stager = 0;            // 0 Stager (the filling lane copies its buffer out), 1 PoolStager (sar_iterate.hip)
     uint32_t chunk_records = 0;     // records per chunk (0 = default 28; 12 / 20 shrink the LDS staging per wave)
 
     // timing

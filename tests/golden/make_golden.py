@@ -2,9 +2,11 @@
 
   kat.json            known-answer vectors of the CPU oracle. Nothing in the reference's own test-suite
                       pins this path (its only test is a doc-test that constructs a Config), so these are
-                      oracle-emitted; the values listed in SURVEY.md §8c were produced independently by a
-                      separate throw-away restatement (gcc AND AMD-clang) and agree bit for bit — the
-                      script asserts that agreement before writing.
+                      oracle-emitted — after the oracle has been cross-checked, bit for bit, against the
+                      committed independent restatement in pure-Python floats (second_restatement.py: >= 1e5
+                      iterations of next_point per preset, the rotation matrices, both colour transforms,
+                      Palette::interpolate and whole small renders). The values listed in SURVEY.md §8c (from
+                      the survey session's throw-away restatement, gcc AND AMD-clang) are asserted as well.
   ref_png_stats.json  statistics of the one artefact the reference ships, media/poisson-saturne.png
                       (README.md:72-73: `-i1000000000 -b -0.25`, 1920x1080, OS-random seed): bounding box,
                       non-zero fraction and a 96x54 block-mean thumbnail per channel. Data derived from a
@@ -22,6 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
 import oracle_lib as O  # noqa: E402
 
 
@@ -29,7 +32,41 @@ def hexes(v):
     return [float.hex(float(x)) for x in v]
 
 
+def cross_check_against_second_restatement(iterations=120_000):
+    """The KATs below are oracle-emitted; before they are frozen the oracle must agree, bit for bit, with the independent
+    pure-Python restatement (tests/golden/second_restatement.py: no compiler, no contraction) over >= 1e5 iterations of
+    next_point per preset, the projection (through a render), both colour transforms and Palette::interpolate."""
+    import second_restatement as R
+    rng = np.random.default_rng(11)
+    for cfg, pre, p0 in ((O.poisson_saturne(), R.POISSON, (0.05, 0.031, 0.077)), (O.solar_sail(), R.SOLAR, (0.025, 0.0155, 0.0385))):
+        q = p0
+        for k in range(iterations):
+            q = R.next_point(pre, q)
+            if k + 1 in (1, 1000, 10_000, iterations):
+                got = O.iterate(cfg, np.array(p0), k + 1)
+                assert got.view(np.uint64).tolist() == np.array(q).view(np.uint64).tolist(), (k, got, q)
+        assert np.array_equal(O.rotation_matrix(cfg).ravel().view(np.uint64), np.array(R.rotation_matrix(pre)).ravel().view(np.uint64))
+        for _ in range(5000):
+            d, s = rng.uniform(-0.6, 0.6, 3), rng.uniform(-0.8, 0.8, 3)
+            got = O.lib().sar_oracle_color_transform(O.C.byref(cfg), O._dptr(d), O._dptr(s))
+            assert np.float64(got).view(np.uint64) == np.float64(R.color_transform(pre, tuple(d), tuple(s))).view(np.uint64)
+        # projection + bounds + depth test + payload: a whole (small) render
+        cfg.width, cfg.height, cfg.scale = 64, 48, 1.0
+        a, b = O.Runtime(64, 48), R.Runtime(64, 48)
+        O.render(cfg, a, np.array(p0), 20_000)
+        R.render(pre, b, p0, 20_000, angle=0.0, scale=1.0)
+        assert np.array_equal(a.count.ravel(), np.array(b.count, dtype=np.uint32)) and a.max == b.max
+        assert np.array_equal(a.zbuf.ravel().view(np.uint32), np.array(b.zbuf, dtype=np.float32).view(np.uint32))
+        assert np.array_equal(a.steps.ravel().view(np.uint64), np.array(b.steps).view(np.uint64))
+    cfg = O.poisson_saturne()
+    for v in rng.uniform(-0.3, 1.3, 5000):
+        rgb = np.empty(3)
+        O.lib().sar_oracle_palette(O.C.byref(cfg), float(v), O._dptr(rgb))
+        assert rgb.view(np.uint64).tolist() == np.array(R.palette_interpolate(R.DEFAULT_PALETTE, float(v))).view(np.uint64).tolist()
+
+
 def kat():
+    cross_check_against_second_restatement()
     out = {}
     ps, ss = O.poisson_saturne(), O.solar_sail()
     p0 = np.array([0.05, 0.031, 0.077])

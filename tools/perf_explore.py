@@ -46,6 +46,8 @@ if __name__ == "__main__":
     ap.add_argument("--splits", type=int, nargs="+", default=[0])
     ap.add_argument("--acc-threads", type=int, nargs="+", default=[0])
     ap.add_argument("--records", type=int, nargs="+", default=[0])
+    ap.add_argument("--opt", action="append", default=[], help="extra runtime option name=value (repeatable), e.g. stager=1")
+    ap.add_argument("--tag", default="")
     ap.add_argument("--out", default="gpurun_out/perf_explore.jsonl")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
@@ -57,7 +59,9 @@ if __name__ == "__main__":
             for block in a.blocks:
                 for variant in a.variants:
                     for stride, bs, sp, at, rc in [(x, y, z, w, v) for x in a.stride for y in a.bin_shift for z in a.splits for w in a.acc_threads for v in a.records]:
-                        r = run(cfg, starts, block, stride, variant, bin_shift=bs, splits=sp, acc_threads=at, chunk_records=rc)
+                        extra = {k: int(v) for k, v in (o.split("=") for o in a.opt)}
+                        r = run(cfg, starts, block, stride, variant, bin_shift=bs, splits=sp, acc_threads=at, chunk_records=rc, **extra)
+                        r.update(extra, tag=a.tag, lib=os.environ.get("SAR_LIBRARY", ""))
                         r.update(jobs=jobs, block=block, variant=hex(variant), stride=stride, size=a.size,
                                  bin_shift=bs, splits=sp, acc_threads=at, records=rc,
                                  preset=a.preset,
