@@ -310,6 +310,9 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *   "bin_shift"          log2(pixels per bin) of the binned path (12..15)
  *   "splits"             workgroups per bin in the record-accumulate kernel (1..16)
  *   "chunk_records"      u16 records per chunk: 12, 20 or 28 (32/48/64-byte chunks; fewer = less LDS per wave)
+ *   "stager"             how the iterate kernel copies full staging buffers out: 1 the lane that filled one copies it,
+ *                        2 full buffers are swapped against spares and the whole wave copies them out in batches
+ *                        (needs slightly more LDS); 0 = 2 where it keeps the waves per CU, else 1
  *   "hint_bits"          per-XCD depth hints of the iterate kernel: 16 (fixed point) or 32 (sortable f32); 0 = by image size
  *   "depth_pipe"         visits between a depth-hint (or depth-key) load and its use in the iterate kernel: 1 or 2 (default 2)
  *   "acc_threads"        threads per block of the record-accumulate kernel (256, 512, 1024)

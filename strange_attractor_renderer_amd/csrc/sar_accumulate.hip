@@ -29,6 +29,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     for (uint32_t w = s + a.splits * threadIdx.x; w < a.n_waves; w += a.splits * blockDim.x)
         any |= a.heads[(size_t)b * a.n_waves + w] != kNoChunk;
     if (!__syncthreads_or(any)) return;
+    if (threadIdx.x == 0) a.bin_any[b] = 1u;  // k_fold_resolve skips the pixels of bins nobody flagged
     for (uint32_t k = threadIdx.x; k < bin_px; k += blockDim.x) hist[k] = 0u;
     __syncthreads();
     const uint4* arena = (const uint4*)a.arena;
@@ -82,10 +83,14 @@ __global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) {
     __shared__ uint32_t s_n, s_wrap;
     __shared__ uint32_t s_tmp[4];
     if (threadIdx.x == 0) { s_n = 0; s_wrap = 0; }
+    const uint32_t base = blockIdx.x * FOLD_PIX;
+    // Binned path: most bins of a frame are empty (the attractor covers a band of the image). A block of FOLD_PIX pixels
+    // lies inside ONE bin (bins are >= 4096 pixels, a power of two); no visit in the bin means no partial count and no
+    // depth key to fold — only block 0 must always run (the NaN iterations land on pixel 0).
+    if (a.bin_any && blockIdx.x != 0 && a.bin_any[base >> a.bin_shift] == 0u) return;
     __syncthreads();
 
     uint32_t local_max = 0;
-    const uint32_t base = blockIdx.x * FOLD_PIX;
     for (uint32_t k = threadIdx.x; k < FOLD_PIX; k += blockDim.x) {
         const uint32_t px = base + k;
         if (px >= a.npix) break;

@@ -150,8 +150,11 @@ __device__ __forceinline__ void iterate_once(const MapParams& p, uint32_t width,
     const double fj = p.half_height - (sy + p.ccz) * p.width_scaled;  // :786
     // :789 — `|` instead of `||`: four compares and three mask ORs, not four nested branches
     inb = !((int)(fi >= p.width) | (int)(fj >= p.height) | (int)(fi < 0.) | (int)(fj < 0.));
-    const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;  // Rust `as u32`: NaN -> 0 (non-finite coordinates pass :789)
-    const uint32_t j = (fj == fj) ? (uint32_t)fj : 0u;
+    // Rust `as u32` is the hardware conversion: v_cvt_u32_f64 truncates, saturates and turns NaN into 0 (a C cast would
+    // be undefined for NaN / out-of-range values, so the compiler is not asked)
+    uint32_t i, j;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(i) : "v"(fi));
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(j) : "v"(fj));
     idx = __umul24(j, width) + i;  // v_mad_u32_u24 (full rate); exact for every in-bounds (i, j): width, height < 2^24
     zf = (float)z2;  // `z2 as f32`
 }

@@ -81,6 +81,7 @@ struct BinAccArgs {
     const void* arena;
     const uint32_t* heads;
     uint32_t* scratch_count;     // [splits][npix], fully overwritten
+    uint32_t* bin_any;           // [n_bins] set to 1 by every block that found a chunk (zero before the launch)
 };
 
 struct FoldArgs {
@@ -92,7 +93,8 @@ struct FoldArgs {
     uint32_t ckpt_stride;
     uint32_t copies;             // scratch_count copies
     uint32_t key_copies;         // scratch_key copies
-    uint32_t _pad;
+    uint32_t bin_shift;          // binned path: log2(pixels per bin), for bin_any
+    const uint32_t* bin_any;     // binned path: [n_bins] "some visit landed in this bin" (nullptr: fold everything)
     unsigned long long* nan_count;  // nullable; added to pixel 0 and cleared
     uint32_t* count;                 // persistent [npix]
     unsigned long long* key;         // persistent [npix]: hi = sortable(zbuf), lo = 0xFFFFFFFF

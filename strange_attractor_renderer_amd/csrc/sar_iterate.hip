@@ -372,7 +372,11 @@ struct Stager {
         // the hint load is the LAST vector-memory operation of the step: the counter the hardware offers for "has
         // my load returned" (vmcnt) counts operations in issue order, so anything issued after a load that is still
         // wanted in flight would have to be waited for as well
+#ifdef SAR_X_NO_HINT_LOAD  // timing experiment only: no visit passes stage 1
+        if (DEPTH) p_hint[k] = 0xFFFFFFFFu;
+#else
         if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (idx & ~1u)) : 0u));
+#endif
         __builtin_amdgcn_s_setprio(0);
         SAR_MARK(3);
     }
@@ -603,7 +607,11 @@ struct PoolStager {
         b_bin = idx >> bin_shift;
         b_local = idx & bin_mask;
         b_old = atomicAdd(&ctl[inb ? b_bin : dummy], 1u);  // ds_add_rtn_u32: slot and buffer in one word
+#ifdef SAR_X_NO_HINT_LOAD  // timing experiment only: no visit passes stage 1
+        if (DEPTH) p_hint[k] = 0xFFFFFFFFu;
+#else
         if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (idx & ~1u)) : 0u));
+#endif
         __builtin_amdgcn_s_setprio(0);
     }
 
@@ -727,6 +735,17 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     uint32_t t = 0;
     double* ck = a.it.ckpt + job;
     auto checkpoint = [&]() {  // the state BEFORE iteration t (coalesced 512-B rows per wave)
+        // Diverged trajectories are looked for HERE, once per checkpoint, not in every iteration: NaN is absorbing, and
+        // an iteration whose point is NaN passes the bounds test (:789) and lands on pixel (0,0) (:800-802) through the
+        // ordinary record path (count is a sum: it does not matter which way an iteration is counted). From the first
+        // checkpoint that sees the NaN on, the remaining iterations are added in one go.
+        {
+            const bool ended = alive && x != x;
+            if (wave_ballot(ended)) {
+                if (ended) atomicAdd(a.nan_count, (unsigned long long)(n - t));
+                alive = alive && !ended;
+            }
+        }
         if (alive) {
             __builtin_nontemporal_store(x, ck);
             __builtin_nontemporal_store(y, ck + cs);
@@ -740,15 +759,7 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
         uint32_t idx;
         float zf;
         iterate_once(p, a.it.width, x, y, z, inb, idx, zf);  // every lane, finished or not: no divergence
-        const bool ended = alive && x != x;
-        if (wave_ballot(ended)) {
-            // absorbing NaN state: this and all remaining iterations pass the bounds test (:789), land on pixel
-            // (0,0) (:800-802) and never win the depth test — add them in one go
-            if (ended) atomicAdd(a.nan_count, (unsigned long long)(n - t));
-            alive = alive && !ended;
-        }
-        inb = inb && alive;
-        idx = inb ? idx : 0u;
+        inb = inb && alive;  // idx is only ever used under inb (slot request, hint address, depth candidate)
 #ifdef SAR_EXPERIMENT_PROF
         asm volatile("" : "+v"(idx), "+v"(zf));  // the map and the projection belong to segment 0
 #endif
@@ -872,12 +883,16 @@ uint32_t chunk_bytes(uint32_t records) { return kChunkStride(records) * 16u; }
 
 
 // the instantiations of the hot kernel: chunk size x depth-pipeline length x hint type (count-only kernels have neither)
+#ifdef SAR_FEW_KERNELS  // variant builds for timing experiments: only the shapes the sweeps use
+#define SAR_FOR_EACH_LEAN(X) X(true, 20u, 2u, uint32_t) X(true, 28u, 2u, uint32_t) X(true, 12u, 2u, unsigned short) X(false, 28u, 1u, unsigned short)
+#else
 #define SAR_FOR_EACH_LEAN(X)                                                                                          \
     X(true, 12u, 1u, unsigned short) X(true, 12u, 2u, unsigned short) X(true, 20u, 1u, unsigned short)                \
     X(true, 20u, 2u, unsigned short) X(true, 28u, 1u, unsigned short) X(true, 28u, 2u, unsigned short)                \
     X(true, 12u, 1u, uint32_t) X(true, 12u, 2u, uint32_t) X(true, 20u, 1u, uint32_t) X(true, 20u, 2u, uint32_t)         \
     X(true, 28u, 1u, uint32_t) X(true, 28u, 2u, uint32_t)                                                              \
     X(false, 12u, 1u, unsigned short) X(false, 20u, 1u, unsigned short) X(false, 28u, 1u, unsigned short)
+#endif
 
 int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
                         bool pool, hipStream_t s) {

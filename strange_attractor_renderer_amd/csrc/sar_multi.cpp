@@ -64,6 +64,12 @@ struct sar_renderer {
     uint32_t units = 0;
     uint64_t seed = 0;
     Rng rng;                      // the renderer's start-point stream: job k of a frame takes the next three draws
+    // start points of the NEXT frame, drawn while the GPUs work on the current one (a frame's job list costs ~1 ms of
+    // host time at 2e5 jobs — as much as a whole configs[4] frame renders in): valid for `ahead_jobs` jobs; `rng_mark` is
+    // the stream's state before they were drawn, restored if the next frame asks for another job count
+    std::vector<double> ahead;
+    uint64_t ahead_jobs = 0;
+    Rng rng_mark;
     std::vector<Shard> shards;    // one per device, in fold order
     uint32_t W = 0, H = 0;
     bool scattered = false;       // shard runtimes hold only their own merged slice (gather before handing one out)
@@ -271,8 +277,21 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
 
     // fresh start points for every job, in job order, from the renderer's stream (the reference's workers draw from
     // per-thread RNGs as they pick jobs up, :748; here the stream is one and the job -> point map is deterministic)
-    std::vector<double> starts(static_cast<size_t>(total_jobs) * 3);
-    for (uint64_t k = 0; k < total_jobs; ++k) r->rng.start_point(&starts[3 * static_cast<size_t>(k)]);
+    std::vector<double> starts;
+    if (r->ahead_jobs == total_jobs && !r->ahead.empty()) {
+        starts.swap(r->ahead);              // drawn during the previous frame
+    } else {
+        if (r->ahead_jobs) r->rng = r->rng_mark;  // a different job count: un-draw what was drawn ahead
+        starts.resize(static_cast<size_t>(total_jobs) * 3);
+        for (uint64_t k = 0; k < total_jobs; ++k) r->rng.start_point(&starts[3 * static_cast<size_t>(k)]);
+    }
+    r->ahead_jobs = 0;
+    auto draw_ahead = [&]() {               // called once the GPUs have their work: the host has nothing else to do
+        r->rng_mark = r->rng;
+        r->ahead.resize(static_cast<size_t>(total_jobs) * 3);
+        for (uint64_t k = 0; k < total_jobs; ++k) r->rng.start_point(&r->ahead[3 * static_cast<size_t>(k)]);
+        r->ahead_jobs = total_jobs;
+    };
 
     // contiguous job slices, sizes differ by at most one (the same partition as distributed.shard_jobs)
     {
@@ -290,6 +309,7 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
         render_shard(r, &sh, cfg, per_job, starts.data(), S);
         if (sh.status != SAR_OK) { set_error("%s", sh.error); return sh.status; }
         int st = SAR_OK;
+        draw_ahead();
         if (rgba_out_host) st = sar_colorize(cfg, sh.rt, rgba_out_host);  // :1080
         r->timing.total_ms = static_cast<float>(now_ms() - t0);
         return st;
@@ -304,6 +324,7 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
     }
     for (Shard& sh : r->shards)
         if (sh.status != SAR_OK) { set_error("device %d: %s", sh.device, sh.error); return sh.status; }
+    draw_ahead();
 
     // 2. the owners pull their blocks (every pair of devices over its own link) and fold them in device order
     const size_t blk = static_cast<size_t>(S) * 16u;

@@ -267,11 +267,11 @@ struct LaunchPlan {
 // 3 per SIMD (more jobs than that run in rounds), at least 2. Measured at 2048^2, 1e9 iterations: 131072 jobs with 28
 // records and 196608 jobs with 20 end within 2 % of each other; at 4096^2 12 records (2 waves/SIMD) beat 28 (1 wave/
 // SIMD) by 1.4x. The job count is scaled by the share of jobs that survived the previous launch's warm-up.
-uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs) {
-    if (rt->chunk_records) return rt->chunk_records;
-    const bool pool = rt->stager == 1;
-    const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u, pool);
-    if (!probe.ok) return kDefaultChunkRecords;
+// Also picks the stager: the pool stager (sar_iterate.hip: full buffers swapped against spares, cooperative copy-out;
+// 3-4 % faster where it fits) needs a little more LDS per wave — it is used when it keeps the waves per CU the classic
+// stager reaches with the same chunk size.
+uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool) {
+    const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u, false);
     if (rt->active_pending && hipEventQuery(rt->active_copied) == hipSuccess) {
         rt->active_pending = false;
         if (rt->active_jobs_launched) rt->survivor_fraction = static_cast<double>(*rt->h_active) / rt->active_jobs_launched;
@@ -281,15 +281,26 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs) {
     uint64_t want = (busy + 64u * cus - 1) / (64u * cus);  // waves per CU if all surviving jobs were resident
     want = ((want + 3) / 4) * 4;  // workgroups are four waves: residency comes in steps of four waves per CU
     want = want < 8 ? 8 : (want > 12 ? 12 : want);
-    for (uint32_t need : {static_cast<uint32_t>(want), 8u})
-        for (uint32_t cand : {28u, 20u, 12u})
-            if (lean_wave_lds_bytes(probe.bins, cand, pool) * need <= 160u * 1024u) return cand;
-    return 12u;
+    uint32_t R = rt->chunk_records, need_waves = 8;
+    if (R == 0 && !probe.ok) R = kDefaultChunkRecords;
+    if (R == 0) {
+        R = 12u;
+        bool found = false;
+        for (uint32_t need : {static_cast<uint32_t>(want), 8u}) {
+            for (uint32_t cand : {28u, 20u, 12u})
+                if (lean_wave_lds_bytes(probe.bins, cand, false) * need <= 160u * 1024u) { R = cand; need_waves = need; found = true; break; }
+            if (found) break;
+        }
+    } else if (probe.ok) {
+        need_waves = (lean_wave_lds_bytes(probe.bins, R, false) * want <= 160u * 1024u) ? static_cast<uint32_t>(want) : 8u;
+    }
+    pool = rt->stager == 2 || (rt->stager == 0 && probe.ok && lean_wave_lds_bytes(probe.bins, R, true) * need_waves <= 160u * 1024u &&
+                               lean_wave_lds_bytes(probe.bins, R, false) * need_waves <= 160u * 1024u);
+    return R;
 }
 
 int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, LaunchPlan& pl) {
-    pl.R = choose_chunk_records(rt, n_jobs);
-    pl.pool = rt->stager == 1;
+    pl.R = choose_chunk_records(rt, n_jobs, pl.pool);
     pl.geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, pl.R, pl.pool);
     // which accumulate path: LDS-binned records (default) or one global atomic per visit
     pl.binned = (rt->bins_mode == 0 || rt->bins_mode == 3) && rt->measure_mode != 2 && pl.geo.ok;
@@ -427,6 +438,7 @@ int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
         rt->warm_cap = pl.chunk_jobs;
     }
     if (!rt->d_active) HIP_TRY(hipMalloc(&rt->d_active, sizeof(uint32_t)));
+    if (!rt->d_bin_any) HIP_TRY(hipMalloc(&rt->d_bin_any, kMaxBins * sizeof(uint32_t)));
     if (!rt->h_active) {
         HIP_TRY(hipHostMalloc(&rt->h_active, sizeof(uint32_t), hipHostMallocDefault));
         *rt->h_active = 0;
@@ -441,7 +453,10 @@ int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
 }
 
 // One launch chunk of the binned path: warm-up + packing, iterate, accumulate, fold.
-int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& ia, const FoldArgs& fa, int mode) {
+int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& ia, const FoldArgs& fa_in, int mode) {
+    FoldArgs fa = fa_in;
+    fa.bin_shift = pl.geo.shift;
+    fa.bin_any = rt->d_bin_any;
     const uint32_t m = ia.n_jobs;
     BinIterArgs ba;
     std::memset(&ba, 0, sizeof(ba));
@@ -486,7 +501,9 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     ca.arena = rt->d_arena;
     ca.heads = rt->d_heads;
     ca.scratch_count = rt->d_scratch_count;
+    ca.bin_any = rt->d_bin_any;
     span_begin(rt, rt->fold_spans, rt->fold_used);
+    HIP_TRY(hipMemsetAsync(rt->d_bin_any, 0, kMaxBins * sizeof(uint32_t), rt->stream));
     launch_bin_accumulate(ca, rt->acc_threads, pl.R, rt->stream);
     HIP_TRY(hipGetLastError());
     launch_fold_resolve(fa, rt->stream);
@@ -642,7 +659,7 @@ int sar_runtime_new(const sar_config* cfg, int device, sar_runtime** out) {
     sar_runtime* rt = new (std::nothrow) sar_runtime();
     if (!rt) return SAR_ERR_OOM;
     rt->device = device;
-    if (const char* e = std::getenv("SAR_STAGER")) rt->stager = (e[0] == '1') ? 1u : 0u;  // test / A-B hook: default stager
+    if (const char* e = std::getenv("SAR_STAGER")) rt->stager = (e[0] == '1') ? 1u : (e[0] == '2' ? 2u : 0u);  // test / A-B hook
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) rt->sm_count = static_cast<uint32_t>(prop.multiProcessorCount);
     int st = SAR_OK;
@@ -672,6 +689,7 @@ int sar_runtime_free(sar_runtime* rt) {
     if (rt->d_warm) hipFree(rt->d_warm);
     if (rt->d_joblist) hipFree(rt->d_joblist);
     if (rt->d_active) hipFree(rt->d_active);
+    if (rt->d_bin_any) hipFree(rt->d_bin_any);
     if (rt->h_active) hipHostFree(rt->h_active);
     if (rt->active_copied) hipEventDestroy(rt->active_copied);
     if (rt->d_starts) hipFree(rt->d_starts);
@@ -1096,7 +1114,7 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
         if (v && v != 12 && v != 20 && v != 28) { set_error("chunk_records must be 12, 20 or 28"); return SAR_ERR_INVALID; }
         rt->chunk_records = v;
     } else if (!std::strcmp(name, "stager")) {
-        if (v > 1) { set_error("stager must be 0 (copy-out by the filling lane) or 1 (buffer pool, cooperative copy-out)"); return SAR_ERR_INVALID; }
+        if (v > 2) { set_error("stager must be 0 (automatic), 1 (copy-out by the filling lane) or 2 (buffer pool, cooperative copy-out)"); return SAR_ERR_INVALID; }
         rt->stager = v;
     } else if (!std::strcmp(name, "hint_bits")) {
         if (v && v != 16 && v != 32) { set_error("hint_bits must be 16 or 32"); return SAR_ERR_INVALID; }

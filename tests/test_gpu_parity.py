@@ -397,9 +397,10 @@ def test_attractor_extent_bit_exact(sar, oracle, gpu, preset):
     np.testing.assert_array_equal(_bits(sar.attractor_extent(cfg, rt, jobs, n)), _bits(want))
 
 
+@pytest.mark.parametrize("stager", [1, 2])
 @pytest.mark.parametrize("records", [12, 20, 28])
 @pytest.mark.parametrize("splits,acc_threads,pipe,hint_bits", [(0, 0, 0, 0), (1, 256, 1, 16), (5, 512, 2, 16), (16, 1024, 1, 32)])
-def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, splits, acc_threads, pipe, hint_bits):
+def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, splits, acc_threads, pipe, hint_bits, stager):
     """Every chunk size of the binned path (32 / 48-on-64 / 64-byte chunks: different lane-group shapes in
     k_bin_accumulate) with several accumulate grids, against the oracle; enough records per (bin, wave) list to chain
     many chunks and to overflow staging buffers within one slot request (all trajectories start close together)."""
@@ -408,10 +409,11 @@ def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, 
     st = sar.start_points(23, 0, jobs)
     st[:512] = st[0] + np.arange(512)[:, None] * 1e-13  # near-identical trajectories: many lanes hit one bin at once
     rt, ort = sar.Runtime(cfg), oracle.Runtime(256, 192)
-    rt.set_tuning(variant=3, chunk_records=records, splits=splits, acc_threads=acc_threads, depth_pipe=pipe, hint_bits=hint_bits)
+    rt.set_tuning(variant=3, chunk_records=records, splits=splits, acc_threads=acc_threads, depth_pipe=pipe, hint_bits=hint_bits,
+                  stager=stager)
     sar.render_jobs(cfg, rt, st)
     oracle.render_jobs(cfg.c, ort, st, n)
-    assert_state_equal(rt, ort, f"records={records} splits={splits} acc_threads={acc_threads} depth_pipe={pipe} hint_bits={hint_bits}")
+    assert_state_equal(rt, ort, f"records={records} splits={splits} acc_threads={acc_threads} depth_pipe={pipe} hint_bits={hint_bits} stager={stager}")
 
 
 @pytest.mark.parametrize("seed", range(32))
