@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
 //     wave-local cursor, so no global atomic and nothing to wait for — and resets the buffer;
 //   * k_bin_accumulate later walks the per-(bin, wave) chunk lists and histograms them in LDS.
 //
-// Depth: see Stager::settle_depth — two filters (this XCD's hint, then the chip-wide key) in front of the
+// Depth: see DepthPipe::settle_depth — two filters (this XCD's hint, then the chip-wide key) in front of the
 // 64-bit atomic max, as a software pipeline U visits deep. A stale or lost hint only costs an extra atomic,
 // never a wrong result.
 //
@@ -146,16 +146,119 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
 //   * the hint of a lane without a depth candidate is loaded from element 0;
 //   * only the rare-per-lane events keep a wave-level branch: "some lane filled a buffer" (copy-out,
 //     which also places the records that overflowed into the next buffer generation), "some lane passed
-//     a depth filter", "a trajectory ended in NaN".
-// LDS per wave: B buffers of R records + B counters + B links + 64 scratch records + 64 dummy counters
-// Everything a wave needs to turn a stream of visits into staged records + depth candidates. One visit
-// per lane per step(); all per-visit state lives in registers, the staging buffers in the wave's LDS slice.
-// H is the hint type: unsigned short = 16-bit fixed point (depth_q16; half the cache footprint, but every visit within
-// 2^-14 of the best depth passes stage 1), uint32_t = the sortable image of the f32 depth itself (only true improvements
-// and exact ties pass: 3x fewer waves have to wait for a stage-2 key load). The host picks by image size.
-template <bool DEPTH, uint32_t R, uint32_t U, typename H>
-struct Stager {
+//     a depth filter". A trajectory that ended in NaN is looked for once per checkpoint, not per iteration: until then
+//     its iterations land on pixel (0,0) through the ordinary record path, exactly where the reference counts them.
+//
+// A stager (Stager or PoolStager below) is everything a wave needs to turn a stream of visits into staged records +
+// depth candidates. One visit per lane per step(); all per-visit state lives in registers, the staging buffers in the
+// wave's LDS slice (Stager: B buffers of R records + B counters + B links + 64 scratch records + 64 dummy counters).
+
+// The depth path shared by both stagers: two filters (this XCD's hint, then the chip-wide key) in front of the 64-bit
+// atomic max, as a software pipeline U visits deep — visit t uses slot t % U, whose previous occupant (visit t - U) is
+// settled first. A hint or key load therefore has U whole iterations to arrive, and because the loop is unrolled U times
+// every slot is a fixed set of registers: no copies that would have to wait for a load. A stale or lost hint only costs
+// an extra atomic, never a wrong result. H is the hint type: unsigned short = 16-bit fixed point (depth_q16; half the
+// cache footprint, but every visit within 2^-14 of the best depth passes stage 1), uint32_t = the sortable image of the
+// f32 depth itself (only true improvements and exact ties pass: 3x fewer waves have to wait for a stage-2 key load).
+// The host picks by image size.
+template <bool DEPTH, uint32_t U, typename H>
+struct DepthPipe {
     static constexpr bool kWide = sizeof(H) == 4;
+    H* zhint;
+    unsigned long long* key;
+    uint32_t lo_base;
+    bool pv[U];           // stage-1 candidate, waiting for its hint
+    uint32_t p_idx[U], p_zkey[U], p_lo[U], p_hint[U], p_q[U], n_sent;
+    bool gv[U];           // stage-2 candidate, waiting for the chip-wide key
+    uint32_t g_idx[U], g_q[U];
+    unsigned long long g_mine[U], g_cur[U];
+
+    __device__ __forceinline__ void depth_init(H* zhint_, unsigned long long* key_, uint32_t lo_base_) {
+        zhint = zhint_;
+        key = key_;
+        lo_base = lo_base_;
+        n_sent = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < U; ++k) {
+            pv[k] = gv[k] = false;
+            p_idx[k] = p_zkey[k] = p_lo[k] = p_hint[k] = p_q[k] = 0;
+            g_idx[k] = g_q[k] = 0;
+            g_mine[k] = g_cur[k] = 0;
+        }
+    }
+
+    // Depth candidates go through two filters before they cost a global atomic (the chip retires only ~2.1e10 of those
+    // per second):
+    //   stage 1  this XCD's private hint (L2-resident, loaded U visits ahead);
+    //   stage 2  the chip-wide 64-bit key itself, read at device scope U visits after stage 1 passed: the atomic is sent
+    //            only if this visit beats what ANY XCD has sent — and the private hint learns the chip-wide depth on the way.
+    // k is a compile-time constant after unrolling.
+    __device__ __forceinline__ void settle_depth(uint32_t k) {
+        if (gv[k]) {
+            if (g_mine[k] > g_cur[k]) {
+                atomicMax(key + g_idx[k], g_mine[k]);
+                ++n_sent;
+            }
+            const uint32_t seen = (uint32_t)(g_cur[k] >> 32);  // 0 while nobody has sent this pixel
+            const uint32_t qs = kWide ? seen : (seen ? depth_q16(sortable_f32(seen)) : 0u);
+            zhint[g_idx[k]] = (H)(qs > g_q[k] ? qs : g_q[k]);
+        }
+        // p_hint is the raw dword holding this pixel's hint and its neighbour's: it is unpacked only HERE, U visits
+        // after the load was issued. (Unpacking next to the load makes the compiler wait for the load right there.)
+        const uint32_t hint = kWide ? p_hint[k] : ((p_idx[k] & 1u) ? (p_hint[k] >> 16) : (p_hint[k] & 0xFFFFu));
+        gv[k] = pv[k] && p_q[k] >= hint;
+        if (gv[k]) {
+            g_idx[k] = p_idx[k];
+            g_q[k] = p_q[k];
+            g_mine[k] = ((unsigned long long)p_zkey[k] << 32) | (unsigned long long)p_lo[k];
+            g_cur[k] = __hip_atomic_load(key + p_idx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // Settles the candidate of visit t - U (its hint was requested U whole steps ago) and files this visit's: strict `>`
+    // against the initial -1.0 (:693, :821); NaN fails. Returns whether this visit is a candidate.
+    __device__ __forceinline__ bool depth_candidate(uint32_t k, bool inb, uint32_t idx, float zf, uint32_t t) {
+        if (!DEPTH) return false;
+        settle_depth(k);
+        const bool cand = inb && zf > -1.0f;
+        const float zc = zf + 0.0f;  // -0.0 -> +0.0: integer order == float order
+        p_zkey[k] = f32_sortable(zc);
+        p_q[k] = kWide ? p_zkey[k] : depth_q16(zc);
+        p_idx[k] = idx;
+        p_lo[k] = lo_base - t;
+        pv[k] = cand;
+        return cand;
+    }
+
+    // The hint load is the LAST vector-memory operation of a step: the counter the hardware offers for "has my load
+    // returned" (vmcnt) counts operations in issue order, so anything issued after a load that is still wanted in flight
+    // would have to be waited for as well.
+    __device__ __forceinline__ void depth_request(uint32_t k, bool cand, uint32_t idx) {
+        if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (idx & ~1u)) : 0u));
+    }
+
+    // After the last visit: settle what is in flight.
+    __device__ __forceinline__ void depth_drain(uint32_t lane, unsigned long long* stats) {
+        if (!DEPTH) return;
+#pragma unroll
+        for (uint32_t k = 0; k < U; ++k) {
+            settle_depth(k);  // moves the slot's stage-1 candidate to stage 2
+            pv[k] = false;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < U; ++k) settle_depth(k);  // settles it
+        uint32_t tot = n_sent;  // statistics: depth atomics issued by this wave
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
+        if (lane == 0 && tot) atomicAdd(stats + 1, (unsigned long long)tot);
+    }
+};
+
+template <bool DEPTH, uint32_t R, uint32_t U, typename H>
+struct Stager : DepthPipe<DEPTH, U, H> {
+    using DepthPipe<DEPTH, U, H>::depth_init;
+    using DepthPipe<DEPTH, U, H>::depth_candidate;
+    using DepthPipe<DEPTH, U, H>::depth_request;
+    using DepthPipe<DEPTH, U, H>::depth_drain;
     static constexpr uint32_t Q = kChunkQuads(R);  // 16-byte quads per chunk
     unsigned short* rec;  // [B][R] staged records + 64 scratch slots
     uint32_t* cnt;        // [B] fill counters + 64 dummy counters
@@ -163,17 +266,7 @@ struct Stager {
     uint32_t trash, dummy, lane, n_bins;
     uint4* arena;         // this wave's chunk arena
     uint32_t cursor;      // wave-uniform: next free chunk
-    H* zhint;
-    unsigned long long* key;
-    uint32_t bin_shift, bin_mask, lo_base;
-    // The depth path is a software pipeline U visits deep: visit t uses slot t % U, whose previous occupant (visit
-    // t - U) is settled first. A hint or key load therefore has U whole iterations to arrive, and because the loop
-    // is unrolled U times every slot is a fixed set of registers: no copies that would have to wait for a load.
-    bool pv[U];           // stage-1 candidate, waiting for its hint
-    uint32_t p_idx[U], p_zkey[U], p_lo[U], p_hint[U], p_q[U], n_sent;
-    bool gv[U];           // stage-2 candidate, waiting for the chip-wide key
-    uint32_t g_idx[U], g_q[U];
-    unsigned long long g_mine[U], g_cur[U];
+    uint32_t bin_shift, bin_mask;
     bool b_have;          // previous visit, waiting for its LDS slot
     uint32_t b_bin, b_slot, b_local;
 #ifdef SAR_EXPERIMENT_PROF
@@ -208,20 +301,10 @@ struct Stager {
         dummy = bins + lane;
         arena = arena_;
         cursor = 0;
-        zhint = zhint_;
-        key = key_;
+        depth_init(zhint_, key_, lo_base_);
         bin_shift = shift;
         bin_mask = (1u << shift) - 1u;
-        lo_base = lo_base_;
         b_have = f_on = false;
-        n_sent = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < U; ++k) {
-            pv[k] = gv[k] = false;
-            p_idx[k] = p_zkey[k] = p_lo[k] = p_hint[k] = p_q[k] = 0;
-            g_idx[k] = g_q[k] = 0;
-            g_mine[k] = g_cur[k] = 0;
-        }
         b_bin = b_slot = b_local = 0;
         f_chunk = f_prev = 0;
 #pragma unroll
@@ -310,35 +393,6 @@ struct Stager {
         }
     }
 
-    // Depth candidates go through two filters before they cost a global atomic (the chip retires only
-    // ~2.1e10 of those per second):
-    //   stage 1  this XCD's private 16-bit hint (L2-resident, loaded U visits ahead);
-    //   stage 2  the chip-wide 64-bit key itself, read at device scope U visits after stage 1 passed
-    //            (~5 % of the visits): the atomic is sent only if this visit beats what ANY XCD has sent —
-    //            and the private hint learns the chip-wide depth on the way.
-    // k is a compile-time constant after unrolling.
-    __device__ __forceinline__ void settle_depth(uint32_t k) {
-        if (gv[k]) {
-            if (g_mine[k] > g_cur[k]) {
-                atomicMax(key + g_idx[k], g_mine[k]);
-                ++n_sent;
-            }
-            const uint32_t seen = (uint32_t)(g_cur[k] >> 32);  // 0 while nobody has sent this pixel
-            const uint32_t qs = kWide ? seen : (seen ? depth_q16(sortable_f32(seen)) : 0u);
-            zhint[g_idx[k]] = (H)(qs > g_q[k] ? qs : g_q[k]);
-        }
-        // p_hint is the raw dword holding this pixel's hint and its neighbour's: it is unpacked only HERE, U visits
-        // after the load was issued. (Unpacking next to the load makes the compiler wait for the load right there.)
-        const uint32_t hint = kWide ? p_hint[k] : ((p_idx[k] & 1u) ? (p_hint[k] >> 16) : (p_hint[k] & 0xFFFFu));
-        gv[k] = pv[k] && p_q[k] >= hint;
-        if (gv[k]) {
-            g_idx[k] = p_idx[k];
-            g_q[k] = p_q[k];
-            g_mine[k] = ((unsigned long long)p_zkey[k] << 32) | (unsigned long long)p_lo[k];
-            g_cur[k] = __hip_atomic_load(key + p_idx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-
     // One visit of this lane: inb = the iteration landed inside the image at pixel idx with depth zf
     // (reference src/lib.rs:807-834); t = iteration number (for the visit ordinal); k = t % U, a compile-time
     // constant after unrolling.
@@ -349,18 +403,7 @@ struct Stager {
         // the previous visit's record first: pure LDS work
         place_visit();
         SAR_MARK(1);
-        bool cand = false;
-        if (DEPTH) {
-            settle_depth(k);  // the candidate of visit t - U: its hint was requested U whole steps ago
-            // this visit's candidate: strict `>` against the initial -1.0 (:693, :821); NaN fails
-            cand = inb && zf > -1.0f;
-            const float zc = zf + 0.0f;  // -0.0 -> +0.0: integer order == float order
-            p_zkey[k] = f32_sortable(zc);
-            p_q[k] = kWide ? p_zkey[k] : depth_q16(zc);
-            p_idx[k] = idx;
-            p_lo[k] = lo_base - t;
-            pv[k] = cand;
-        }
+        const bool cand = depth_candidate(k, inb, idx, zf, t);
         SAR_MARK(2);
         // chunk stores of a buffer that filled up (their LDS reads were issued by place_visit above), then this
         // visit's slot request
@@ -369,14 +412,7 @@ struct Stager {
         b_bin = idx >> bin_shift;
         b_local = idx & bin_mask;
         b_slot = atomicAdd(&cnt[inb ? b_bin : dummy], 1u);  // ds_add_rtn_u32
-        // the hint load is the LAST vector-memory operation of the step: the counter the hardware offers for "has
-        // my load returned" (vmcnt) counts operations in issue order, so anything issued after a load that is still
-        // wanted in flight would have to be waited for as well
-#ifdef SAR_X_NO_HINT_LOAD  // timing experiment only: no visit passes stage 1
-        if (DEPTH) p_hint[k] = 0xFFFFFFFFu;
-#else
-        if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (idx & ~1u)) : 0u));
-#endif
+        depth_request(k, cand, idx);
         __builtin_amdgcn_s_setprio(0);
         SAR_MARK(3);
     }
@@ -385,18 +421,7 @@ struct Stager {
     __device__ __forceinline__ void finish(uint32_t* heads, uint32_t n_waves, uint32_t wave, unsigned long long* stats) {
         place_visit();
         flush_store_pending();
-        if (DEPTH) {
-#pragma unroll
-            for (uint32_t k = 0; k < U; ++k) {
-                settle_depth(k);  // moves the slot's stage-1 candidate to stage 2
-                pv[k] = false;
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < U; ++k) settle_depth(k);  // settles it
-            uint32_t tot = n_sent;  // statistics: depth atomics issued by this wave
-            for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
-            if (lane == 0 && tot) atomicAdd(stats + 1, (unsigned long long)tot);
-        }
+        depth_drain(lane, stats);
         for (uint32_t b0 = 0; b0 < n_bins; b0 += 64u) {
             const uint32_t b = b0 + lane;
             const uint32_t have = (b < n_bins) ? cnt[b] : 0u;
@@ -437,8 +462,11 @@ struct Stager {
 // Records that overflow a buffer within one slot request (several lanes, same bin, across the R boundary) are placed
 // in the new buffer by a generation loop, as in Stager (rare).
 template <bool DEPTH, uint32_t R, uint32_t U, typename H>
-struct PoolStager {
-    static constexpr bool kWide = sizeof(H) == 4;
+struct PoolStager : DepthPipe<DEPTH, U, H> {
+    using DepthPipe<DEPTH, U, H>::depth_init;
+    using DepthPipe<DEPTH, U, H>::depth_candidate;
+    using DepthPipe<DEPTH, U, H>::depth_request;
+    using DepthPipe<DEPTH, U, H>::depth_drain;
     static constexpr uint32_t CB = kPoolChunkBytes(R);   // staged chunk == final chunk: 8-byte header + R records
     static constexpr uint32_t Q = CB / 16u;              // 16-byte quads per chunk
     static constexpr uint32_t P = kPoolSpare;            // spare buffers == most chunks that wait for the copy-out
@@ -451,14 +479,7 @@ struct PoolStager {
     uint4* arena;         // this wave's chunk arena
     uint32_t cursor;      // wave-uniform: next chunk number
     uint32_t drained;     // wave-uniform: chunks below this one are in the arena
-    H* zhint;
-    unsigned long long* key;
-    uint32_t bin_shift, bin_mask, lo_base;
-    bool pv[U];
-    uint32_t p_idx[U], p_zkey[U], p_lo[U], p_hint[U], p_q[U], n_sent;
-    bool gv[U];
-    uint32_t g_idx[U], g_q[U];
-    unsigned long long g_mine[U], g_cur[U];
+    uint32_t bin_shift, bin_mask;
     bool b_have;          // previous visit, waiting for its LDS slot
     uint32_t b_bin, b_old, b_local;
 
@@ -486,20 +507,10 @@ struct PoolStager {
         dummy = bins + lane;
         arena = arena_;
         cursor = drained = 0;
-        zhint = zhint_;
-        key = key_;
+        depth_init(zhint_, key_, lo_base_);
         bin_shift = shift;
         bin_mask = (1u << shift) - 1u;
-        lo_base = lo_base_;
         b_have = false;
-        n_sent = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < U; ++k) {
-            pv[k] = gv[k] = false;
-            p_idx[k] = p_zkey[k] = p_lo[k] = p_hint[k] = p_q[k] = 0;
-            g_idx[k] = g_q[k] = 0;
-            g_mine[k] = g_cur[k] = 0;
-        }
         b_bin = b_old = b_local = 0;
     }
 
@@ -569,67 +580,22 @@ struct PoolStager {
         }
     }
 
-    __device__ __forceinline__ void settle_depth(uint32_t k) {
-        if (gv[k]) {
-            if (g_mine[k] > g_cur[k]) {
-                atomicMax(key + g_idx[k], g_mine[k]);
-                ++n_sent;
-            }
-            const uint32_t seen = (uint32_t)(g_cur[k] >> 32);  // 0 while nobody has sent this pixel
-            const uint32_t qs = kWide ? seen : (seen ? depth_q16(sortable_f32(seen)) : 0u);
-            zhint[g_idx[k]] = (H)(qs > g_q[k] ? qs : g_q[k]);
-        }
-        const uint32_t hint = kWide ? p_hint[k] : ((p_idx[k] & 1u) ? (p_hint[k] >> 16) : (p_hint[k] & 0xFFFFu));
-        gv[k] = pv[k] && p_q[k] >= hint;
-        if (gv[k]) {
-            g_idx[k] = p_idx[k];
-            g_q[k] = p_q[k];
-            g_mine[k] = ((unsigned long long)p_zkey[k] << 32) | (unsigned long long)p_lo[k];
-            g_cur[k] = __hip_atomic_load(key + p_idx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-
     __device__ __forceinline__ void step(uint32_t k, bool inb, uint32_t idx, float zf, uint32_t t) {
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(3);  // as in Stager::step
         place_visit();
-        bool cand = false;
-        if (DEPTH) {
-            settle_depth(k);
-            cand = inb && zf > -1.0f;
-            const float zc = zf + 0.0f;
-            p_zkey[k] = f32_sortable(zc);
-            p_q[k] = kWide ? p_zkey[k] : depth_q16(zc);
-            p_idx[k] = idx;
-            p_lo[k] = lo_base - t;
-            pv[k] = cand;
-        }
+        const bool cand = depth_candidate(k, inb, idx, zf, t);
         b_have = inb;
         b_bin = idx >> bin_shift;
         b_local = idx & bin_mask;
         b_old = atomicAdd(&ctl[inb ? b_bin : dummy], 1u);  // ds_add_rtn_u32: slot and buffer in one word
-#ifdef SAR_X_NO_HINT_LOAD  // timing experiment only: no visit passes stage 1
-        if (DEPTH) p_hint[k] = 0xFFFFFFFFu;
-#else
-        if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (idx & ~1u)) : 0u));
-#endif
+        depth_request(k, cand, idx);
         __builtin_amdgcn_s_setprio(0);
     }
 
     __device__ __forceinline__ void finish(uint32_t* heads, uint32_t n_waves, uint32_t wave, unsigned long long* stats) {
         place_visit();
         drain_all();
-        if (DEPTH) {
-#pragma unroll
-            for (uint32_t k = 0; k < U; ++k) {
-                settle_depth(k);
-                pv[k] = false;
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < U; ++k) settle_depth(k);
-            uint32_t tot = n_sent;
-            for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
-            if (lane == 0 && tot) atomicAdd(stats + 1, (unsigned long long)tot);
-        }
+        depth_drain(lane, stats);
         // the partly filled buffers: one lane per bin writes {list head, fill, records} as the list's last chunk
         for (uint32_t b0 = 0; b0 < n_bins; b0 += 64u) {
             const uint32_t b = b0 + lane;
