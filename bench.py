@@ -12,9 +12,9 @@ the one exchange step (all-to-all of the image slices, merge in rank order, 4-sc
 
   --config c2 (default)  BASELINE.json configs[1]: poisson-saturne, 1e9 iterations PER GPU, 2048x2048. WEAK scaling:
                          every GPU renders its own 1e9 iterations of an (N x 1e9)-iteration frame.
-  --config c4            BASELINE.json configs[3]: poisson-saturne, 1e10 iterations, 4096x4096, jobs_total = 524 288
+  --config c4            BASELINE.json configs[3]: poisson-saturne, 1e10 iterations, 4096x4096, jobs_total = 1 048 576
                          sharded over the ranks (shard_jobs). STRONG scaling: the frame is the same at every N; at
-                         N=1 the one GPU runs all 524 288 jobs in launch chunks.
+                         N=1 the one GPU runs all the jobs in launch chunks.
 
 One JSON line on rank 0; see DESIGN.md "Measurement" for how each field is derived.
 """
@@ -30,7 +30,11 @@ sys.path.insert(0, ROOT)
 WIDTH = HEIGHT = 2048
 ITERS_PER_GPU = 1_000_000_000
 DEFAULT_JOBS = 131072            # trajectories per GPU (2 waves per SIMD on 256 CUs); n = floor(1e9 / jobs)
-C4_SIZE, C4_ITERS, C4_JOBS = 4096, 10_000_000_000, 524288   # BASELINE configs[3] (65 536 jobs per GPU at 8)
+# BASELINE configs[3]. SURVEY 8d sketched 524 288 jobs (65 536 per GPU at 8 GPUs) — but 65 536 trajectories are ONE wave per
+# SIMD, and the iterate kernel needs two to hide its latencies (4096^2, 1.25e9 iterations: 17.7 ms with 65 536 jobs, 11.3 ms
+# with 131 072). A strong-scaling frame must be the same frame at every N, so it is cut into 1 048 576 jobs (131 072 per GPU
+# at 8): n = 9536 iterations per job. `--jobs 524288` reproduces SURVEY's split.
+C4_SIZE, C4_ITERS, C4_JOBS = 4096, 10_000_000_000, 1048576
 ALG_BYTES_PER_ITER = 12.0 + 12.0 * 0.0055   # count RMW 8 B + zbuf read 4 B + win-rate * 12 B
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_OPS_PER_ITER = 88           # unfused fp64 ops per counted iteration; FMA is not allowed
@@ -297,7 +301,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: poisson-saturne, 1e9 iterations per GPU, 2048x2048, "
                                     "Gas colorize to RGBA16 in HBM") if a.config == "c2" else
-                                   ("BASELINE configs[3]: poisson-saturne, 1e10 iterations, 4096x4096, 524288 jobs "
+                                   (f"BASELINE configs[3]: poisson-saturne, 1e10 iterations, 4096x4096, {total_jobs} jobs "
                                     "sharded over the GPUs, Gas colorize to RGBA16 in HBM"),
                        "jobs_per_gpu": jobs, "jobs_total": total_jobs,
                        "iterations_per_job": n, "counted_iterations_per_step": n * total_jobs,
