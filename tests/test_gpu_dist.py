@@ -182,3 +182,50 @@ def test_c_abi_multi_device_renderer_equals_single_device_and_oracle(sar, oracle
             sar.exchange_slice_pixels(W * H, len(devices))
     multi.shutdown()
     single.shutdown()
+
+
+def _nccl_single_rank(port, W, H, jobs, n, seed, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import strange_attractor_renderer_amd as S
+    from strange_attractor_renderer_amd import distributed as D
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    cfg = S.Config.poisson_saturne(iterations=jobs * n, width=W, height=H, jobs_total=jobs, seed=seed, transparent=0)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        rt = S.Runtime(cfg, device=0)
+        rt.set_stream(stream.cuda_stream)
+        S.render_job_range(cfg, rt, n, S.start_points(seed, 0, jobs))
+        want = S.colorize(cfg, rt)
+        ex = D.SlicedExchange(S, cfg, rt, 0, 1, "cuda")
+        img = D.exchange_colorize(ex, dist, dst=0)           # all_to_all_single / all_reduce / gather of RCCL itself
+        torch.cuda.synchronize()
+        got = img.cpu().numpy().view(np.uint16).reshape(H, W, 4).copy()
+        key = torch.empty(W * H, dtype=torch.int64, device="cuda")
+        sums = torch.empty(3 * W * H, dtype=torch.int32, device="cuda")
+        before = rt.count().copy()
+        D.exchange_merge(rt, 0, dist, key, sums, dst=0)        # rooted form over RCCL
+        torch.cuda.synchronize()
+        q.put((np.array_equal(got, want), np.array_equal(rt.count(), before), np.array_equal(S.colorize(cfg, rt), want)))
+        rt.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_exchange_runs_over_rccl_itself_with_one_rank(sar, gpu):
+    """A 1-GPU box cannot hold two RCCL ranks, but it can hold one: the device-native branch of distributed.py
+    (all_to_all_single on uint8 blocks, all_reduce MAX on int64, gather, reduce) runs through the real "nccl" backend with
+    world size 1 and must leave the frame unchanged."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single_rank, args=(_free_port(), 200, 150, 300, 800, 3, q))
+    p.start()
+    ok = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and ok == (True, True, True), ok
