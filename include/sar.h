@@ -45,7 +45,7 @@ enum {
     SAR_ERR_NO_DEVICE = 3,    /* no HIP device / HIP runtime unavailable */
     SAR_ERR_HIP = 4,          /* a HIP call failed; see sar_last_error() */
     SAR_ERR_OOM = 5,
-    SAR_ERR_RANGE = 6,        /* a size exceeds what one launch chunk can order (see sar_render_jobs) */
+    SAR_ERR_RANGE = 6,        /* a size is out of range: width*height > 2^31-1, units*jobs_per_unit > 2^32-1 */
     SAR_ERR_IO = 7            /* an image file could not be created or written (ref: File::create(..).unwrap(), main.rs:103) */
 };
 
@@ -319,7 +319,8 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *   "timing_accumulate"  1: the spans of successive render calls add up (sar_timing sums, iterate_launches counts
  *                        them) until sar_runtime_last_timing reads and clears them; 0: last render call only
  *   "measure"            measurement-only kernels: 1 count only, 2 arithmetic only (results are NOT the render)
- *   "debug_chunk_jobs"   test hook: cap on jobs per launch chunk */
+ *   "debug_chunk_jobs"   test hook: cap on jobs per launch chunk
+ *   "debug_max_ordinals" test hook: visits one launch may order (default 2^32-2); jobs with more iterations run as segments */
 int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value);
 
 #ifdef __cplusplus

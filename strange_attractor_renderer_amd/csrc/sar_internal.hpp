@@ -52,7 +52,10 @@ struct IterArgs {
     uint32_t width;            // image width (index = j*width + i)
     uint32_t npix;             // width*height (stride between scratch copies)
     uint32_t ckpt_stride;      // iterations between trajectory checkpoints
-    const double* starts;      // [3][n_jobs] SoA, pre-warm-up start points
+    uint32_t resume;           // 1: `starts` holds the trajectory state a previous segment of this job left (no warm-up)
+    uint32_t _pad_resume;
+    const double* starts;      // [3][n_jobs] SoA, pre-warm-up start points (or, with `resume`, the carried state)
+    double* state_out;         // nullable: [3][n_jobs] SoA, the state after the last iteration (for the job's next segment)
     uint32_t* scratch_count;   // [copies][npix]
     unsigned long long* scratch_key;  // [copies][npix]
     double* ckpt;              // [n_ckpt][3][n_jobs]
@@ -73,6 +76,8 @@ struct BinIterArgs {
     const uint32_t* joblist;     // [n_jobs] job index (within this launch chunk) of every packed slot
     const uint32_t* active;      // number of packed slots
     unsigned long long* nan_count;  // iterations of diverged (NaN) trajectories: all land on pixel (0,0)
+    double* warm_out;            // nullable: the state after the last iteration, by packed slot (== warm: the next segment of
+                                 // jobs with more than 2^32-2 iterations starts from it, without a warm-up)
 };
 
 struct BinAccArgs {

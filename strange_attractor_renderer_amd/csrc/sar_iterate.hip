@@ -56,8 +56,9 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
     double y = a.starts[a.n_jobs + job];
     double z = a.starts[2u * a.n_jobs + job];
 
-    // "skip first 1000 to get good values in the attractor" (:750-752)
-    for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);
+    // "skip first 1000 to get good values in the attractor" (:750-752) — unless this launch continues a trajectory
+    if (!a.resume)
+        for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);
 
     uint32_t* const count = a.scratch_count + (XCD_LOCAL ? (size_t)xcc_id() * a.npix : 0);
     unsigned long long* const key = a.scratch_key + (XCD_LOCAL ? (size_t)xcc_id() * a.npix : 0);
@@ -71,7 +72,8 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
 
     uint32_t t = 0;
     double* ck = a.ckpt + job;
-    while (t < n) {
+    bool ended = false;
+    while (t < n && !ended) {
         // checkpoint: the state BEFORE iteration t (coalesced 512-B rows per wave)
         ck[0] = x;
         ck[cs] = y;
@@ -87,7 +89,8 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
                 // (:800-802) and never wins the depth test. Add them in one go instead of hammering
                 // one address n-t times.
                 if (MODE != 0) bin_count<XCD_LOCAL>(count, n - t);
-                return;
+                ended = true;
+                break;
             }
             double sx, sy, sz;
             screen_space(p, x, y, z, sx, sy, sz);  // :773
@@ -113,6 +116,11 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
                 }
             }
         }
+    }
+    if (a.state_out) {  // a job of more than 2^32-2 iterations continues from here in the next launch (NaN stays NaN)
+        a.state_out[job] = x;
+        a.state_out[a.n_jobs + job] = y;
+        a.state_out[2u * a.n_jobs + job] = z;
     }
     if (MODE == 0) {  // measurement-only variant: keep the arithmetic alive
         if (x + y + z == 12345.678) a.scratch_count[0] = 1;
@@ -759,6 +767,11 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     if (lane == 0)
         for (int i = 0; i < 4; ++i) atomicAdd(a.nan_count + 2 + i, st.prof[i]);
 #endif
+    if (a.warm_out && slot < active) {  // the next segment of a > 2^32-2-iteration job starts here (a NaN state stays NaN
+        a.warm_out[slot] = x;           // and is found again by that segment's first checkpoint)
+        a.warm_out[a.it.n_jobs + slot] = y;
+        a.warm_out[2u * a.it.n_jobs + slot] = z;
+    }
     st.finish(a.heads, a.n_waves, wave, a.nan_count);
 }
 
@@ -899,6 +912,16 @@ uint32_t launch_extent(const MapParams& p, const double* starts, uint32_t n_jobs
 
 void launch_starts_soa(const double* aos, double* soa, uint32_t m, hipStream_t s) {
     hipLaunchKernelGGL(k_starts_soa, dim3((m + 255u) / 256u), dim3(256), 0, s, aos, soa, m);
+}
+
+// a later segment of a long job: the jobs that died in the warm-up (never packed) spend this segment's iterations on
+// pixel (0,0) as well
+__global__ void k_dead_jobs(const uint32_t* active, uint32_t n_jobs, uint64_t iters, unsigned long long* nan_count) {
+    const uint32_t dead = n_jobs - *active;
+    if (dead) atomicAdd(nan_count, iters * (unsigned long long)dead);
+}
+void launch_dead_jobs(const uint32_t* active, uint32_t n_jobs, uint64_t iters, unsigned long long* nan_count, hipStream_t s) {
+    hipLaunchKernelGGL(k_dead_jobs, dim3(1), dim3(1), 0, s, active, n_jobs, iters, nan_count);
 }
 
 void launch_warmup(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* warm, uint32_t* joblist,

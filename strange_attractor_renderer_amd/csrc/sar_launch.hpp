@@ -47,6 +47,7 @@ uint32_t launch_extent(const MapParams& p, const double* starts, uint32_t n_jobs
 void launch_starts_soa(const double* aos, double* soa, uint32_t m, hipStream_t s);
 void launch_warmup(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* warm, uint32_t* joblist,
                    uint32_t* active, unsigned long long* nan_count, hipStream_t s);
+void launch_dead_jobs(const uint32_t* active, uint32_t n_jobs, uint64_t iters, unsigned long long* nan_count, hipStream_t s);
 void launch_exch_export(const unsigned long long* key, uint32_t rank, void* out, uint32_t npix, hipStream_t s);
 void launch_exch_select(const uint32_t* count, const unsigned long long* key, const double* steps, uint32_t rank,
                         const void* reduced, void* out, uint32_t npix, hipStream_t s);

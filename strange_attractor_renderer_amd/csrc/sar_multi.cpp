@@ -201,6 +201,18 @@ int sar_renderer_new_multi(const int* devices, uint32_t n_devices, uint32_t unit
     // GPU — three waves per SIMD — and 8 jobs per unit give 131 072; every job pays 1000 warm-up iterations, so a unit
     // count that multiplied typical jobs_per_unit values into millions of jobs would only add warm-up work
     r->units = units ? units : static_cast<uint32_t>(lanes > 0xFFFFFFFFull ? 0xFFFFFFFFull : lanes);
+    // direct xGMI copies between every pair of distinct devices (hipMemcpyPeerAsync works without peer access too, but
+    // then stages through host memory); "already enabled" is not an error
+    for (uint32_t a = 0; a < n_devices; ++a)
+        for (uint32_t b = 0; b < n_devices; ++b) {
+            if (devices[a] == devices[b]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can && hipSetDevice(devices[a]) == hipSuccess) {
+                const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+        }
     *out = r;
     return SAR_OK;
 }

@@ -325,7 +325,7 @@ int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_
     // lane of one wave, not a full 256-thread block of busy lanes.
     auto lanes_of = [](uint64_t jobs) { return jobs < 64 ? jobs : 64ull; };
     auto chunks_per_wave_of = [&](uint64_t jobs) { return (iters * lanes_of(jobs) + pl.R - 1) / pl.R + pl.geo.bins; };
-    pl.chunk_jobs = kMaxChunkOrdinals / iters;
+    pl.chunk_jobs = (rt->max_ordinals ? rt->max_ordinals : kMaxChunkOrdinals) / iters;  // >= 1: iters is one segment
     if (pl.chunk_jobs > n_jobs) pl.chunk_jobs = n_jobs;
     if (pl.binned && chunks_per_wave_of(pl.chunk_jobs) > 0xFFFFFFF0ull) pl.binned = false;
     // scratch per job: checkpoints (24 B each) + its share of its wave's arena (binned path)
@@ -453,7 +453,8 @@ int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
 }
 
 // One launch chunk of the binned path: warm-up + packing, iterate, accumulate, fold.
-int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& ia, const FoldArgs& fa_in, int mode) {
+// `first`: the first segment of these jobs (warm-up + packing); `carry`: more segments follow (keep the trajectory state).
+int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& ia, const FoldArgs& fa_in, int mode, bool first, bool carry) {
     FoldArgs fa = fa_in;
     fa.bin_shift = pl.geo.shift;
     fa.bin_any = rt->d_bin_any;
@@ -472,10 +473,15 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     ba.joblist = rt->d_joblist;
     ba.active = rt->d_active;
     ba.nan_count = rt->d_nan_count;
+    ba.warm_out = carry ? rt->d_warm : nullptr;
     span_begin(rt, rt->warm_spans, rt->warm_used);
-    HIP_TRY(hipMemsetAsync(rt->d_active, 0, sizeof(uint32_t), rt->stream));
-    launch_warmup(ia.p, ia.starts, m, ia.iters, rt->d_warm, rt->d_joblist, rt->d_active, rt->d_nan_count, rt->stream);
-    if (!rt->active_pending) {  // statistics for the next call; nobody waits for this copy
+    if (first) {
+        HIP_TRY(hipMemsetAsync(rt->d_active, 0, sizeof(uint32_t), rt->stream));
+        launch_warmup(ia.p, ia.starts, m, ia.iters, rt->d_warm, rt->d_joblist, rt->d_active, rt->d_nan_count, rt->stream);
+    } else {
+        launch_dead_jobs(rt->d_active, m, ia.iters, rt->d_nan_count, rt->stream);
+    }
+    if (first && !rt->active_pending) {  // statistics for the next call; nobody waits for this copy
         if (hipMemcpyAsync(rt->h_active, rt->d_active, sizeof(uint32_t), hipMemcpyDeviceToHost, rt->stream) == hipSuccess &&
             hipEventRecord(rt->active_copied, rt->stream) == hipSuccess) {
             rt->active_pending = true;
@@ -525,15 +531,17 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
         rt->warm_used = 0;
     }
     if (n_jobs == 0 || iters == 0) return SAR_OK;
-    if (iters > kMaxChunkOrdinals) {
-        set_error("%llu iterations per job exceed the 32-bit visit ordinal of one launch",
-                  static_cast<unsigned long long>(iters));
-        return SAR_ERR_RANGE;
-    }
     HIP_TRY(hipSetDevice(rt->device));
 
+    // A launch orders its visits with a 32-bit ordinal (job * n + t). Config::iterations is a usize (:267): a job with more
+    // iterations than that runs as SEGMENTS — successive launches that hand the trajectory state on (no second warm-up),
+    // each folded before the next, so that an earlier segment wins depth ties exactly like an earlier iteration.
+    const uint64_t max_ord = rt->max_ordinals ? rt->max_ordinals : kMaxChunkOrdinals;
+    const uint64_t seg = iters <= max_ord ? iters : max_ord;
+    const uint64_t n_seg = (iters + seg - 1) / seg;
+
     LaunchPlan pl;
-    SAR_TRY(plan_launch(cfg, rt, n_jobs, iters, pl));
+    SAR_TRY(plan_launch(cfg, rt, n_jobs, seg, pl));
     SAR_TRY(ensure_scratch(rt, pl.binned ? pl.splits : (pl.xcd_local ? 8u : 1u), (!pl.binned && pl.xcd_local) ? 8u : 1u));
     SAR_TRY(stage_starts(rt, pl, n_jobs, starts, starts_on_device));
     SAR_TRY(grow_device(rt->d_ckpt, rt->ckpt_cap, static_cast<size_t>(pl.n_ckpt) * 3 * pl.chunk_jobs));
@@ -542,7 +550,6 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
     IterArgs ia;
     std::memset(&ia, 0, sizeof(ia));
     fill_map_params(*cfg, ia.p);
-    ia.iters = iters;
     ia.width = rt->W;
     ia.npix = rt->npix;
     ia.ckpt_stride = pl.C;
@@ -554,7 +561,6 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
     std::memset(&fa, 0, sizeof(fa));
     fa.p = ia.p;
     fill_ct_params(*cfg, fa.ct);
-    fa.iters = iters;
     fa.npix = rt->npix;
     fa.ckpt_stride = pl.C;
     fa.copies = rt->copies;
@@ -574,15 +580,23 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
         ia.n_jobs = m;
         ia.starts = rt->d_starts + off * 3;
         fa.n_jobs = m;
-        if (pl.binned) {
-            SAR_TRY(launch_binned_chunk(rt, pl, ia, fa, mode));
-        } else {
-            span_begin(rt, rt->iter_spans, rt->iter_used);
-            launch_iterate(ia, pl.block, pl.xcd_local, mode, rt->stream);
-            span_end(rt, rt->iter_spans, rt->iter_used);
-            span_begin(rt, rt->fold_spans, rt->fold_used);
-            launch_fold_resolve(fa, rt->stream);
-            span_end(rt, rt->fold_spans, rt->fold_used);
+        for (uint64_t s = 0; s < n_seg; ++s) {
+            const uint64_t it = (s + 1 == n_seg) ? iters - s * seg : seg;
+            const bool first = s == 0, carry = s + 1 < n_seg;
+            ia.iters = it;
+            fa.iters = it;
+            if (pl.binned) {
+                SAR_TRY(launch_binned_chunk(rt, pl, ia, fa, mode, first, carry));
+            } else {
+                ia.resume = first ? 0u : 1u;
+                ia.state_out = carry ? rt->d_starts + off * 3 : nullptr;
+                span_begin(rt, rt->iter_spans, rt->iter_used);
+                launch_iterate(ia, pl.block, pl.xcd_local, mode, rt->stream);
+                span_end(rt, rt->iter_spans, rt->iter_used);
+                span_begin(rt, rt->fold_spans, rt->fold_used);
+                launch_fold_resolve(fa, rt->stream);
+                span_end(rt, rt->fold_spans, rt->fold_used);
+            }
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1136,6 +1150,8 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
         rt->warm_used = 0;
     } else if (!std::strcmp(name, "debug_chunk_jobs")) {
         rt->debug_chunk_jobs = v;
+    } else if (!std::strcmp(name, "debug_max_ordinals")) {
+        rt->max_ordinals = value > kMaxChunkOrdinals ? kMaxChunkOrdinals : value;  // test hook: visits one launch may order
     } else {
         set_error("unknown option '%s'", name);
         return SAR_ERR_INVALID;

@@ -84,6 +84,7 @@ struct sar_runtime {
     uint32_t depth_pipe = 0;         // visits of depth pipeline in the iterate kernel (0 = default)
     bool timing_accumulate = false;  // spans of successive render calls add up until sar_runtime_last_timing reads them
     uint32_t debug_chunk_jobs = 0;  // test hook: cap on jobs per launch chunk (0 = none)
+    uint64_t max_ordinals = 0;      // test hook: visits one launch may order (0 = 2^32-2); longer jobs run as segments
     uint32_t bin_shift = 0;         // 0 = automatic
     uint32_t splits = 0;            // 0 = automatic
     uint32_t acc_threads = 0;       // threads per k_bin_accumulate block (0 = automatic)

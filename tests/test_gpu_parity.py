@@ -474,3 +474,22 @@ def test_every_job_diverging_in_the_warm_up(sar, oracle, gpu):
     sar.render_jobs(cfg, rt2, st2)
     oracle.render_jobs(cfg.c, ort2, st2, n)
     assert_state_equal(rt2, ort2, "every third job NaN")
+
+
+@pytest.mark.parametrize("preset,kind", [("poisson_saturne", 0), ("solar_sail", 1)])
+@pytest.mark.parametrize("variant", [1, 3])
+def test_jobs_longer_than_one_launch_can_order_run_as_segments(sar, oracle, gpu, preset, kind, variant):
+    """Config::iterations is a usize (src/lib.rs:267); a launch orders its visits with 32 bits. A job with more iterations
+    runs as successive launches that hand the trajectory state on (no second warm-up) — forced here at a small size
+    through the debug_max_ordinals hook: 3 segments per job (the last one shorter), one job per launch chunk, on the
+    binned path and on the one-atomic-per-visit path, with jobs that diverge in the warm-up and later (solar-sail)."""
+    jobs, n = 9, 12345
+    cfg = _cfg(sar, preset, iterations=jobs * n, width=200, height=160, jobs_total=jobs, render_kind=kind)
+    st = sar.start_points(77, 0, jobs)
+    rt, ort = sar.Runtime(cfg), oracle.Runtime(200, 160)
+    rt.set_tuning(variant=variant)
+    rt.set_option("debug_max_ordinals", 5000)
+    sar.render_jobs(cfg, rt, st)
+    oracle.render_jobs(cfg.c, ort, st, n)
+    assert_state_equal(rt, ort, f"segments {preset} variant={variant}")
+    np.testing.assert_array_equal(sar.colorize(cfg, rt), oracle.colorize(cfg.c, ort))
