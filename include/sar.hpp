@@ -108,6 +108,11 @@ public:
     explicit ParallelRenderer(int device = 0, uint32_t units = 0, uint64_t seed = 0) {
         check(sar_renderer_new(device, units, seed, &r_), "ParallelRenderer::new");
     }
+    // every GPU of the node behind one renderer (jobs sharded over the devices, partial buffers merged over xGMI)
+    explicit ParallelRenderer(const std::vector<int>& devices, uint32_t units = 0, uint64_t seed = 0) {
+        check(sar_renderer_new_multi(devices.data(), static_cast<uint32_t>(devices.size()), units, seed, &r_), "ParallelRenderer::new_multi");
+    }
+    uint32_t num_devices() const { uint32_t n = 0; check(sar_renderer_num_devices(r_, &n), "num_devices"); return n; }
     ~ParallelRenderer() { shutdown(); }
     ParallelRenderer(const ParallelRenderer&) = delete;
     ParallelRenderer& operator=(const ParallelRenderer&) = delete;

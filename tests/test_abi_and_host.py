@@ -174,3 +174,35 @@ def test_graft_entry_build_runs():
     import importlib
     g = importlib.import_module("__graft_entry__")
     g.build()
+
+
+def test_rust_safe_layer_calls_only_what_the_sys_crate_declares():
+    """bindings/rust-safe cannot be compiled here either: at least every `sys::sar_*` call must name a function of the
+    sys crate with the declared number of arguments, and every constant it uses must exist there."""
+    sys_rs = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+    safe_rs = open(os.path.join(ROOT, "bindings", "rust-safe", "src", "lib.rs")).read()
+    decl = {}
+    for m in re.finditer(r"pub fn (sar_[a-z0-9_]+)\s*\(([^)]*)\)", sys_rs, flags=re.S):
+        args = [a for a in m.group(2).split(",") if a.strip()]
+        decl[m.group(1)] = len(args)
+    calls = re.findall(r"sys::(sar_[a-z0-9_]+)\s*\(", safe_rs)
+    assert calls, "the safe layer calls nothing?"
+    for name in set(calls):
+        assert name in decl, f"{name} is not declared in the sys crate"
+    # argument counts: parse each call's parenthesised argument list (no nested commas except inside inner calls)
+    for m in re.finditer(r"sys::(sar_[a-z0-9_]+)\s*\(", safe_rs):
+        i, depth, n, seen = m.end(), 1, 0, False
+        while depth:
+            c = safe_rs[i]
+            if c in "([": depth += 1
+            elif c in ")]": depth -= 1
+            elif c == "," and depth == 1: n += 1
+            elif not c.isspace() and depth >= 1: seen = True
+            i += 1
+        assert (n + 1 if seen else 0) == decl[m.group(1)], f"{m.group(1)}: {n + 1} arguments passed, {decl[m.group(1)]} declared"
+    for const in set(re.findall(r"sys::(SAR_[A-Z0-9_]+)", safe_rs)):
+        assert re.search(rf"pub const {const}\b", sys_rs), f"{const} missing in the sys crate"
+    # the reference items the layer stands in for are all there
+    for item in ("pub struct GpuRuntime", "pub struct GpuRenderer", "pub fn render<", "pub fn colorize<", "pub fn render_parallel<",
+                 "impl Drop for GpuRuntime", "impl Drop for GpuRenderer", "pub fn check(", "pub fn new_multi("):
+        assert item in safe_rs, item
