@@ -15,6 +15,7 @@
 //      it straight into the caller's host image over its own PCIe link.
 // With one device steps 2-3 collapse to a plain colorize.
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -71,7 +72,6 @@ struct sar_renderer {
     uint64_t ahead_jobs = 0;
     Rng rng_mark;
     std::vector<Shard> shards;    // one per device, in fold order
-    uint32_t W = 0, H = 0;
     bool scattered = false;       // shard runtimes hold only their own merged slice (gather before handing one out)
     sar_parallel_timing timing{};
 };
