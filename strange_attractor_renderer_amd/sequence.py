@@ -75,18 +75,26 @@ def render_sequence(config: "api.Config", start: float, end: float, step: float,
     out = []
     if not todo:
         return out
+    from concurrent.futures import ThreadPoolExecutor
     renderer = api.ParallelRenderer(device=device, units=units, seed=seed)
     T = renderer.num_threads()
     total_jobs = T * jobs_per_thread
     per_job = config.iterations // T // jobs_per_thread          # src/lib.rs:1058
     rt = None
+    # the next frame's start points (~1 ms of host time per 2e5 jobs: as long as a frame renders) are drawn on a helper
+    # thread while the GPU works on the current frame (the ctypes call releases the GIL)
+    pool = ThreadPoolExecutor(max_workers=1)
+    draw = lambda k: api.start_points(frame_seed(seed, k), 0, total_jobs)  # noqa: E731
+    pending = pool.submit(draw, todo[0][0])
     try:
-        for k, angle, name in todo:
+        for n, (k, angle, name) in enumerate(todo):
             cfg = config.replace(angle=angle, jobs_total=total_jobs, iterations=per_job * total_jobs, seed=seed)
             if rt is None:
                 rt = api.Runtime(cfg, device=device)
             rt.reset()                                            # :950-951
-            starts = api.start_points(frame_seed(seed, k), 0, total_jobs)
+            starts = pending.result()
+            if n + 1 < len(todo):
+                pending = pool.submit(draw, todo[n + 1][0])
             api.render_jobs(cfg, rt, starts)
             img = api.colorize(cfg, rt) if image_format is None else api.colorize_format(cfg, rt, image_format)  # :1080
             if sink is not None:
@@ -94,6 +102,7 @@ def render_sequence(config: "api.Config", start: float, end: float, step: float,
             else:
                 out.append((k, name, img))
     finally:
+        pool.shutdown(wait=True)
         if rt is not None:
             rt.close()
         renderer.shutdown()
