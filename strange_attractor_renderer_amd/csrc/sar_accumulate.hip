@@ -91,20 +91,8 @@ __global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) {
     __syncthreads();
 
     uint32_t local_max = 0;
-    for (uint32_t k = threadIdx.x; k < FOLD_PIX; k += blockDim.x) {
-        const uint32_t px = base + k;
-        if (px >= a.npix) break;
-        unsigned long long add = 0, kbest = 0;
-        for (uint32_t c = 0; c < a.copies; ++c) {
-            const size_t o = (size_t)c * a.npix + px;
-            const uint32_t sc = a.scratch_count[o];
-            if (sc) { add += sc; a.scratch_count[o] = 0; }
-        }
-        for (uint32_t c = 0; c < a.key_copies; ++c) {
-            const size_t o = (size_t)c * a.npix + px;
-            const unsigned long long sk = a.scratch_key[o];
-            if (sk) { kbest = sk > kbest ? sk : kbest; a.scratch_key[o] = 0; }
-        }
+    // what one pixel does with the hits and the best depth key this launch left for it
+    auto commit = [&](uint32_t px, unsigned long long add, unsigned long long kbest) {
         if (px == 0 && a.nan_count) {  // diverged trajectories: every iteration after the NaN hits (0,0)
             add += *a.nan_count;
             *a.nan_count = 0;
@@ -124,6 +112,52 @@ __global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) {
             const uint32_t pos = atomicAdd(&s_n, 1u);
             s_key[pos] = kbest;
             s_pix[pos] = px;
+        }
+    };
+    if ((a.npix & 3u) == 0u) {
+        // four pixels per thread: 16-byte loads of every partial histogram (the copies are 16-byte aligned when the pixel
+        // count is a multiple of four)
+        for (uint32_t q = threadIdx.x; q < FOLD_PIX / 4u; q += blockDim.x) {
+            const uint32_t px0 = base + 4u * q;
+            if (px0 >= a.npix) break;
+            unsigned long long add[4] = {0, 0, 0, 0}, kb[4] = {0, 0, 0, 0};
+            for (uint32_t c = 0; c < a.copies; ++c) {
+                uint4* sp = (uint4*)(a.scratch_count + (size_t)c * a.npix + px0);
+                const uint4 v = *sp;
+                if (v.x | v.y | v.z | v.w) {
+                    add[0] += v.x; add[1] += v.y; add[2] += v.z; add[3] += v.w;
+                    *sp = make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+            for (uint32_t c = 0; c < a.key_copies; ++c) {
+                ulonglong2* kp = (ulonglong2*)(a.scratch_key + (size_t)c * a.npix + px0);
+                const ulonglong2 k0 = kp[0], k1 = kp[1];
+                if (k0.x | k0.y | k1.x | k1.y) {
+                    kb[0] = k0.x > kb[0] ? k0.x : kb[0]; kb[1] = k0.y > kb[1] ? k0.y : kb[1];
+                    kb[2] = k1.x > kb[2] ? k1.x : kb[2]; kb[3] = k1.y > kb[3] ? k1.y : kb[3];
+                    kp[0] = make_ulonglong2(0ull, 0ull);
+                    kp[1] = make_ulonglong2(0ull, 0ull);
+                }
+            }
+#pragma unroll
+            for (uint32_t e = 0; e < 4u; ++e) commit(px0 + e, add[e], kb[e]);
+        }
+    } else {
+        for (uint32_t k = threadIdx.x; k < FOLD_PIX; k += blockDim.x) {
+            const uint32_t px = base + k;
+            if (px >= a.npix) break;
+            unsigned long long add = 0, kbest = 0;
+            for (uint32_t c = 0; c < a.copies; ++c) {
+                const size_t o = (size_t)c * a.npix + px;
+                const uint32_t sc = a.scratch_count[o];
+                if (sc) { add += sc; a.scratch_count[o] = 0; }
+            }
+            for (uint32_t c = 0; c < a.key_copies; ++c) {
+                const size_t o = (size_t)c * a.npix + px;
+                const unsigned long long sk = a.scratch_key[o];
+                if (sk) { kbest = sk > kbest ? sk : kbest; a.scratch_key[o] = 0; }
+            }
+            commit(px, add, kbest);
         }
     }
     __syncthreads();
