@@ -9,7 +9,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 print(f"# rocprofv3 summary — {os.path.basename(root)}\n")
-print("Command profiled: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` (N=1, BASELINE configs[1]).\n")
+print("Command profiled: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipeline` (N=1, BASELINE configs[1]).\n")
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("## Kernel time (`--kernel-trace --stats`, no counters)\n")
     print("| kernel | calls | total ms | avg ms | % |")
