@@ -112,8 +112,8 @@ constexpr uint32_t kLeanWaveLds(uint32_t bins, uint32_t R) { return bins * (2u *
 constexpr uint32_t kPoolSpare = SAR_POOL_SPARE;
 constexpr uint32_t kPoolChunkBytes(uint32_t R) { return 8u + 2u * R; }
 constexpr uint32_t kPoolWaveLds(uint32_t bins, uint32_t R) {
-    // buffers | ctl words (+64 dummy) | list heads | ring | 64 scratch records; a multiple of 16 bytes
-    return (bins + kPoolSpare) * kPoolChunkBytes(R) + (bins + 64u) * 4u + bins * 4u + kPoolSpare * 4u + 128u;
+    // buffers | ctl words (+64 dummy) | ring | 64 scratch records; a multiple of 16 bytes
+    return (bins + kPoolSpare) * kPoolChunkBytes(R) + (bins + 64u) * 4u + kPoolSpare * 4u + 128u;
 }
 constexpr uint32_t kChunkQuads(uint32_t R) { return (8u + 2u * R) / 16u; }  // 16-byte quads of data per chunk: R = 12, 20, 28
 // Chunks never straddle a 64-byte sector of the arena: the 48-byte chunk (R = 20) is laid out on a 64-byte stride.

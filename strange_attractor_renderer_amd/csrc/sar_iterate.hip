@@ -463,7 +463,8 @@ struct Stager : DepthPipe<DEPTH, U, H> {
 //     buffer, so swapping a buffer is one more atomic add on that word;
 //   * a ring of P = 16 entries holds the spare buffers: the lane that fills a buffer takes the next chunk number c of
 //     the wave (ballot + mbcnt), exchanges ring[c % P] (a free buffer) against its full one — which thereby becomes
-//     "pending chunk c" — writes the chunk header and re-points ctl[bin]: four LDS operations, no copy;
+//     "pending chunk c" — writes the header of the NEXT chunk of this list into the fresh buffer (its predecessor is c)
+//     and re-points ctl[bin]: three LDS operations, one of them returning, no copy, no list-head array;
 //   * when the ring is full (every ~7 iterations) the WHOLE wave copies the pending chunks out: lane l moves quad l % 4
 //     of pending chunk l / 4 — one 16-byte LDS read and one 16-byte store per lane for 16 chunks, to consecutive
 //     addresses of the wave's arena (1 KiB runs) — and the buffers are free again where they stand in the ring.
@@ -480,7 +481,6 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
     static constexpr uint32_t P = kPoolSpare;            // spare buffers == most chunks that wait for the copy-out
     static constexpr uint32_t kFillBits = 7u, kFillMask = 127u;  // fill < R + 64 <= 92
     uint32_t* ctl;        // [B] (LDS address of the records of the bin's buffer << 7) | fill, + 64 dummy words
-    uint32_t* prv;        // [B] previous chunk of this (wave, bin) list
     uint32_t* ring;       // [P] LDS addresses (records) of the spare / pending buffers
     uint32_t pool0;       // LDS address of buffer 0's records
     uint32_t trash, dummy, lane, n_bins;
@@ -498,16 +498,15 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
                                          unsigned long long* key_, uint32_t shift, uint32_t lo_base_) {
         n_bins = bins;
         lane = lane_;
-        // layout: buffers (bins + P) * CB | ctl (bins + 64) | prv bins | ring P | 64 scratch records
+        // layout: buffers (bins + P) * CB | ctl (bins + 64) | ring P | 64 scratch records
         char* pool = wbase;
         ctl = (uint32_t*)(wbase + (bins + P) * CB);
-        prv = ctl + bins + 64u;
-        ring = prv + bins;
+        ring = ctl + bins + 64u;
         unsigned short* scratch = (unsigned short*)(ring + P);
         pool0 = lds_addr(pool) + 8u;
         for (uint32_t b = lane; b < bins; b += 64u) {
             ctl[b] = (pool0 + b * CB) << kFillBits;
-            prv[b] = kNoChunk;
+            *(uint2*)(pool + b * CB) = make_uint2(kNoChunk, R);  // header of the list's first chunk: no predecessor
         }
         ctl[bins + lane] = lds_addr(scratch + lane) << kFillBits;
         if (lane < P) ring[lane] = pool0 + (bins + lane) * CB;
@@ -542,10 +541,12 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
     __device__ __forceinline__ void swap_round(bool mine, uint32_t rank, uint32_t count, uint32_t bin, uint32_t rec) {
         if (cursor - drained + count > P) drain_all();
         if (mine) {
+            // The header of a staged chunk — {previous chunk of this (wave, bin) list, R} — is written when its buffer is
+            // INSTALLED, by the lane that filled the bin's previous buffer: that lane knows the predecessor's number (its
+            // own). So a fill costs one returning LDS operation (the ring exchange), not two, and no list-head array.
             const uint32_t chunk = cursor + rank;
-            const uint32_t prev = __hip_atomic_exchange(&prv[bin], chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const uint32_t fresh = __hip_atomic_exchange(&ring[chunk % P], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            *(uint2*)lds_ptr(rec - 8u) = make_uint2(prev, R);
+            *(uint2*)lds_ptr(fresh - 8u) = make_uint2(chunk, R);
             // buffer address and fill live in one word: re-point the bin and take R off the fill (records that
             // overflowed in the same request keep their count)
             __hip_atomic_fetch_add(&ctl[bin], ((fresh - rec) << kFillBits) - R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -607,16 +608,16 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         // the partly filled buffers: one lane per bin writes {list head, fill, records} as the list's last chunk
         for (uint32_t b0 = 0; b0 < n_bins; b0 += 64u) {
             const uint32_t b = b0 + lane;
-            const uint32_t word = (b < n_bins) ? ctl[b] : 0u;
-            const uint32_t have = word & kFillMask;
+            const uint32_t word = (b < n_bins) ? ctl[b] : (trash << kFillBits);
+            const uint32_t have = (b < n_bins) ? (word & kFillMask) : 0u;
             const bool flusher = have != 0u;
             const unsigned long long fb = wave_ballot(flusher);
-            uint32_t head = (b < n_bins) ? prv[b] : kNoChunk;
+            const uint32_t rec = word >> kFillBits;
+            uint32_t head = (b < n_bins) ? *(const uint32_t*)lds_ptr(rec - 8u) : kNoChunk;  // the list's last full chunk
             if (flusher) {
                 const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
-                const uint32_t rec = word >> kFillBits;
-                *(uint2*)lds_ptr(rec - 8u) = make_uint2(head, have);
+                *(uint32_t*)lds_ptr(rec - 4u) = have;
                 u32x4* dst = (u32x4*)(arena + (size_t)chunk * kChunkStride(R));
 #pragma unroll
                 for (uint32_t q = 0; q < Q; ++q)
