@@ -29,7 +29,6 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     for (uint32_t w = s + a.splits * threadIdx.x; w < a.n_waves; w += a.splits * blockDim.x)
         any |= a.heads[(size_t)b * a.n_waves + w] != kNoChunk;
     if (!__syncthreads_or(any)) return;
-    if (threadIdx.x == 0) a.bin_any[b] = 1u;  // k_fold_resolve skips the pixels of bins nobody flagged
     for (uint32_t k = threadIdx.x; k < bin_px; k += blockDim.x) hist[k] = 0u;
     __syncthreads();
     const uint4* arena = (const uint4*)a.arena;
@@ -61,10 +60,18 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
         }
     }
     __syncthreads();
-    const uint32_t px0 = b << a.bin_shift;
+    // The non-zero counts go out as partial histogram s (the scratch copies are all-zero between launches), at the image
+    // position the map gives (bin, record); 2048 consecutive records are 2048 consecutive pixels under both maps, and a
+    // step of this loop (256 / 512 / 1024 threads) stays inside one such segment: its flag tells k_fold_resolve that the
+    // segment has something to fold.
     uint32_t* out = a.scratch_count + (size_t)s * a.npix;
-    for (uint32_t k = threadIdx.x; k < bin_px; k += blockDim.x)
-        if (px0 + k < a.npix) out[px0 + k] = hist[k];
+    for (uint32_t k = threadIdx.x; k < bin_px; k += blockDim.x) {
+        const uint32_t v = hist[k];
+        const uint32_t px = (k & a.map.low_mask) | (b << a.map.seg_shift) | ((k & ~a.map.low_mask) << a.map.hi_shift);
+        const bool live = v != 0u && px < a.npix;
+        if (live) out[px] = v;
+        if (wave_ballot(live) && (threadIdx.x & 63u) == 0u) a.seg_any[px >> 11] = 1u;  // lane 0 holds the wave's lowest pixel
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -84,10 +91,11 @@ __global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) {
     __shared__ uint32_t s_tmp[4];
     if (threadIdx.x == 0) { s_n = 0; s_wrap = 0; }
     const uint32_t base = blockIdx.x * FOLD_PIX;
-    // Binned path: most bins of a frame are empty (the attractor covers a band of the image). A block of FOLD_PIX pixels
-    // lies inside ONE bin (bins are >= 4096 pixels, a power of two); no visit in the bin means no partial count and no
-    // depth key to fold — only block 0 must always run (the NaN iterations land on pixel 0).
-    if (a.bin_any && blockIdx.x != 0 && a.bin_any[base >> a.bin_shift] == 0u) return;
+    // Binned path: most of a frame is empty (the attractor touches a fifth of the pixels). k_bin_accumulate flags the
+    // 2048-pixel segments that received a count; no visit in the segment means no partial count and no depth key to fold —
+    // only block 0 must always run (the NaN iterations land on pixel 0).
+    static_assert(FOLD_PIX == 2048u, "seg_any is per 2048 pixels");
+    if (a.seg_any && blockIdx.x != 0 && a.seg_any[blockIdx.x] == 0u) return;
     __syncthreads();
 
     uint32_t local_max = 0;

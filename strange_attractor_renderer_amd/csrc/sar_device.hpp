@@ -130,6 +130,13 @@ __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t wave_uniform_b) {
     return r;
 }
 
+// (mask & a) | (~mask & b) as ONE instruction (the compiler splits it into v_and + v_and_or when ~mask is loop-invariant).
+__device__ __forceinline__ uint32_t bfi(uint32_t wave_uniform_mask, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(wave_uniform_mask), "v"(a), "v"(b));
+    return r;
+}
+
 // Lane mask of a predicate. (HIP's __ballot goes through an integer: v_cndmask + v_cmp_ne per call.)
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 

@@ -61,10 +61,21 @@ struct IterArgs {
     double* ckpt;              // [n_ckpt][3][n_jobs]
 };
 
+// Pixel -> (bin, 16-bit record) map of the LDS-binned path. Linear: bin = idx >> k, record = idx & (2^k - 1) — a bin is 2^k
+// consecutive pixels. Interleaved (B = 2^b bins): the image is dealt to the bins in segments of 2^s pixels, round-robin —
+// idx = [hi | bin (b bits) | lo (s bits)], record = [hi | lo] — so that every bin receives the same share of the visits
+// whatever part of the image the attractor covers: the slot requests of a wave spread over all B counters, and the
+// accumulate workgroups (one bin each) get equal work. One formula serves both (linear: s = k, hi_shift = 31):
+//   bin = bfe(idx, seg_shift, bin_bits);  record = (idx & low_mask) | ((idx >> hi_shift) & ~low_mask)
+//   idx = (record & low_mask) | (bin << seg_shift) | ((record & ~low_mask) << hi_shift)
+struct BinMap {
+    uint32_t seg_shift, bin_bits, hi_shift, low_mask;
+};
+
 // LDS-binned iterate kernel (see sar_iterate.hip: k_iterate_lean).
 struct BinIterArgs {
     IterArgs it;                 // scratch_count unused here (counts travel as records)
-    uint32_t bin_shift;          // log2(pixels per bin)
+    BinMap map;                  // pixel -> (bin, record)
     uint32_t n_bins;             // B = ceil(npix / bin_px) <= kMaxBins
     uint32_t chunks_per_wave;    // arena capacity of one wave, in 64-byte chunks
     uint32_t n_waves;            // launched waves (= heads stride)
@@ -81,12 +92,14 @@ struct BinIterArgs {
 };
 
 struct BinAccArgs {
-    uint32_t bin_shift, n_bins, chunks_per_wave, n_waves;
+    uint32_t bin_shift, n_bins, chunks_per_wave, n_waves;   // bin_shift: log2(pixels per bin) = LDS histogram size
     uint32_t npix, splits, _pad0, _pad1;
+    BinMap map;
     const void* arena;
     const uint32_t* heads;
-    uint32_t* scratch_count;     // [splits][npix], fully overwritten
-    uint32_t* bin_any;           // [n_bins] set to 1 by every block that found a chunk (zero before the launch)
+    uint32_t* scratch_count;     // [splits][npix]: all-zero before the launch, the non-zero counts are stored
+    uint32_t* seg_any;           // [ceil(npix / 2048)] set to 1 for every 2048-pixel segment of the image that received a
+                                 // count (zero before the launch)
 };
 
 struct FoldArgs {
@@ -98,8 +111,9 @@ struct FoldArgs {
     uint32_t ckpt_stride;
     uint32_t copies;             // scratch_count copies
     uint32_t key_copies;         // scratch_key copies
-    uint32_t bin_shift;          // binned path: log2(pixels per bin), for bin_any
-    const uint32_t* bin_any;     // binned path: [n_bins] "some visit landed in this bin" (nullptr: fold everything)
+    uint32_t _pad_fold;
+    const uint32_t* seg_any;     // binned path: [ceil(npix / 2048)] "some visit landed in this 2048-pixel segment" (nullptr:
+                                 // fold everything)
     unsigned long long* nan_count;  // nullable; added to pixel 0 and cleared
     uint32_t* count;                 // persistent [npix]
     unsigned long long* key;         // persistent [npix]: hi = sortable(zbuf), lo = 0xFFFFFFFF

@@ -274,7 +274,8 @@ struct Stager : DepthPipe<DEPTH, U, H> {
     uint32_t trash, dummy, lane, n_bins;
     uint4* arena;         // this wave's chunk arena
     uint32_t cursor;      // wave-uniform: next free chunk
-    uint32_t bin_shift, bin_mask;
+    BinMap map;
+    uint32_t bin_bits_v;  // map.bin_bits, held in a vector register
     bool b_have;          // previous visit, waiting for its LDS slot
     uint32_t b_bin, b_slot, b_local;
 #ifdef SAR_EXPERIMENT_PROF
@@ -297,7 +298,7 @@ struct Stager : DepthPipe<DEPTH, U, H> {
     uint2 fpend[R / 4u];
 
     __device__ __forceinline__ void init(char* wbase, uint32_t bins, uint32_t lane_, uint4* arena_, H* zhint_,
-                                         unsigned long long* key_, uint32_t shift, uint32_t lo_base_) {
+                                         unsigned long long* key_, const BinMap& map_, uint32_t lo_base_) {
         n_bins = bins;
         lane = lane_;
         rec = (unsigned short*)wbase;
@@ -310,8 +311,9 @@ struct Stager : DepthPipe<DEPTH, U, H> {
         arena = arena_;
         cursor = 0;
         depth_init(zhint_, key_, lo_base_);
-        bin_shift = shift;
-        bin_mask = (1u << shift) - 1u;
+        map = map_;
+        bin_bits_v = map_.bin_bits;
+        asm volatile("" : "+v"(bin_bits_v));  // stays in a VGPR: v_bfe_u32 takes one scalar operand, the field offset
         b_have = f_on = false;
         b_bin = b_slot = b_local = 0;
         f_chunk = f_prev = 0;
@@ -417,8 +419,8 @@ struct Stager : DepthPipe<DEPTH, U, H> {
         // visit's slot request
         flush_store_pending();
         b_have = inb;
-        b_bin = idx >> bin_shift;
-        b_local = idx & bin_mask;
+        b_bin = __builtin_amdgcn_ubfe(idx, map.seg_shift, bin_bits_v);
+        b_local = bfi(map.low_mask, idx, idx >> map.hi_shift);
         b_slot = atomicAdd(&cnt[inb ? b_bin : dummy], 1u);  // ds_add_rtn_u32
         depth_request(k, cand, idx);
         __builtin_amdgcn_s_setprio(0);
@@ -487,7 +489,8 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
     uint4* arena;         // this wave's chunk arena
     uint32_t cursor;      // wave-uniform: next chunk number
     uint32_t drained;     // wave-uniform: chunks below this one are in the arena
-    uint32_t bin_shift, bin_mask;
+    BinMap map;
+    uint32_t bin_bits_v;  // map.bin_bits, held in a vector register
     bool b_have;          // previous visit, waiting for its LDS slot
     uint32_t b_bin, b_old, b_local;
 
@@ -495,7 +498,7 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
     static __device__ __forceinline__ char* lds_ptr(uint32_t a) { return (char*)(__attribute__((address_space(3))) char*)(uintptr_t)a; }
 
     __device__ __forceinline__ void init(char* wbase, uint32_t bins, uint32_t lane_, uint4* arena_, H* zhint_,
-                                         unsigned long long* key_, uint32_t shift, uint32_t lo_base_) {
+                                         unsigned long long* key_, const BinMap& map_, uint32_t lo_base_) {
         n_bins = bins;
         lane = lane_;
         // layout: buffers (bins + P) * CB | ctl (bins + 64) | ring P | 64 scratch records
@@ -515,8 +518,9 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         arena = arena_;
         cursor = drained = 0;
         depth_init(zhint_, key_, lo_base_);
-        bin_shift = shift;
-        bin_mask = (1u << shift) - 1u;
+        map = map_;
+        bin_bits_v = map_.bin_bits;
+        asm volatile("" : "+v"(bin_bits_v));  // stays in a VGPR: v_bfe_u32 takes one scalar operand, the field offset
         b_have = false;
         b_bin = b_old = b_local = 0;
     }
@@ -594,8 +598,8 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         place_visit();
         const bool cand = depth_candidate(k, inb, idx, zf, t);
         b_have = inb;
-        b_bin = idx >> bin_shift;
-        b_local = idx & bin_mask;
+        b_bin = __builtin_amdgcn_ubfe(idx, map.seg_shift, bin_bits_v);
+        b_local = bfi(map.low_mask, idx, idx >> map.hi_shift);
         b_old = atomicAdd(&ctl[inb ? b_bin : dummy], 1u);  // ds_add_rtn_u32: slot and buffer in one word
         depth_request(k, cand, idx);
         __builtin_amdgcn_s_setprio(0);
@@ -691,7 +695,7 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     // low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie
     st.init((char*)smem + (threadIdx.x >> 6) * (POOL ? kPoolWaveLds(a.n_bins, R) : kLeanWaveLds(a.n_bins, R)), a.n_bins, lane,
             (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkStride(R),
-            (H*)a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.bin_shift, 0xFFFFFFFFu - job * n);
+            (H*)a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n);
 
     MapParams p = a.it.p;
     pin_map_params(p);

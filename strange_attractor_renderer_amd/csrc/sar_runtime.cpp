@@ -124,12 +124,18 @@ int ensure_scratch(sar_runtime* rt, uint32_t copies, uint32_t key_copies) {
     return SAR_OK;
 }
 
-// Bin geometry of the LDS-binned path: bins of 2^shift consecutive pixels, at most kMaxBins of them.
+// Bin geometry of the LDS-binned path: bins of 2^shift pixels, at most kMaxBins of them, and the pixel -> (bin, record)
+// map (BinMap, sar_internal.hpp). Interleaved bins need a power-of-two bin count: used when that costs at most a third
+// more bins (LDS staging is per bin) than consecutive-pixel bins — 2048^2, 1800x2000, 1920x1080, 2560^2, 3840x2160 and
+// 4096^2 all qualify; `interleave` 1 = never, 2 = whenever the count fits kMaxBins.
 struct BinGeometry {
     uint32_t shift = 0, bins = 0, block = 0, splits = 0;
+    BinMap map{};
+    bool interleaved = false;
     bool ok = false;
 };
-BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift, uint32_t want_splits, uint32_t records, bool pool) {
+BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift, uint32_t want_splits, uint32_t records, bool pool,
+                         uint32_t interleave) {
     BinGeometry g;
     uint32_t px = 4096;
     while (px < kMaxBinPx && static_cast<uint64_t>(px) * 256u < npix) px <<= 1;
@@ -137,6 +143,22 @@ BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift
     g.bins = (npix + px - 1) / px;
     if (g.bins > kMaxBins) return g;
     while ((1u << g.shift) < px) ++g.shift;
+    uint32_t b = 0;
+    while ((1u << b) < g.bins) ++b;
+    const uint32_t pow2_bins = 1u << b;
+    g.interleaved = interleave != 1u && pow2_bins <= kMaxBins && (interleave == 2u || 3ull * pow2_bins <= 4ull * g.bins);
+    if (g.interleaved) {
+        g.bins = pow2_bins;
+        g.map.seg_shift = g.shift < 11u ? g.shift : 11u;  // 2048-pixel segments (== k_fold_resolve's blocks)
+        g.map.bin_bits = b;
+        g.map.hi_shift = b;
+        g.map.low_mask = (1u << g.map.seg_shift) - 1u;
+    } else {
+        g.map.seg_shift = g.shift;
+        g.map.bin_bits = 32u - g.shift;
+        g.map.hi_shift = 31u;
+        g.map.low_mask = px - 1u;
+    }
     const uint32_t waves_fit = (160u * 1024u) / lean_wave_lds_bytes(g.bins, records, pool);
     uint32_t block = want_block;
     if (block > waves_fit * 64u) block = waves_fit * 64u;
@@ -271,7 +293,7 @@ struct LaunchPlan {
 // 3-4 % faster where it fits) needs a little more LDS per wave — it is used when it keeps the waves per CU the classic
 // stager reaches with the same chunk size.
 uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool) {
-    const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u, false);
+    const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u, false, rt->bin_interleave);
     if (rt->active_pending && hipEventQuery(rt->active_copied) == hipSuccess) {
         rt->active_pending = false;
         if (rt->active_jobs_launched) rt->survivor_fraction = static_cast<double>(*rt->h_active) / rt->active_jobs_launched;
@@ -301,7 +323,7 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool) {
 
 int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, LaunchPlan& pl) {
     pl.R = choose_chunk_records(rt, n_jobs, pl.pool);
-    pl.geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, pl.R, pl.pool);
+    pl.geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, pl.R, pl.pool, rt->bin_interleave);
     // which accumulate path: LDS-binned records (default) or one global atomic per visit
     pl.binned = (rt->bins_mode == 0 || rt->bins_mode == 3) && rt->measure_mode != 2 && pl.geo.ok;
     if (rt->bins_mode == 3 && !pl.geo.ok) {
@@ -438,7 +460,14 @@ int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
         rt->warm_cap = pl.chunk_jobs;
     }
     if (!rt->d_active) HIP_TRY(hipMalloc(&rt->d_active, sizeof(uint32_t)));
-    if (!rt->d_bin_any) HIP_TRY(hipMalloc(&rt->d_bin_any, kMaxBins * sizeof(uint32_t)));
+    const size_t segs = static_cast<size_t>(rt->npix) / 2048u + 1u;
+    if (rt->seg_any_cap < segs) {
+        if (rt->d_seg_any) hipFree(rt->d_seg_any);
+        rt->d_seg_any = nullptr;
+        rt->seg_any_cap = 0;
+        HIP_TRY(hipMalloc(&rt->d_seg_any, segs * sizeof(uint32_t)));
+        rt->seg_any_cap = segs;
+    }
     if (!rt->h_active) {
         HIP_TRY(hipHostMalloc(&rt->h_active, sizeof(uint32_t), hipHostMallocDefault));
         *rt->h_active = 0;
@@ -456,13 +485,12 @@ int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
 // `first`: the first segment of these jobs (warm-up + packing); `carry`: more segments follow (keep the trajectory state).
 int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& ia, const FoldArgs& fa_in, int mode, bool first, bool carry) {
     FoldArgs fa = fa_in;
-    fa.bin_shift = pl.geo.shift;
-    fa.bin_any = rt->d_bin_any;
+    fa.seg_any = rt->d_seg_any;
     const uint32_t m = ia.n_jobs;
     BinIterArgs ba;
     std::memset(&ba, 0, sizeof(ba));
     ba.it = ia;
-    ba.bin_shift = pl.geo.shift;
+    ba.map = pl.geo.map;
     ba.n_bins = pl.geo.bins;
     ba.chunks_per_wave = static_cast<uint32_t>(pl.chunks_per_wave);
     ba.n_waves = ((m + pl.block - 1) / pl.block) * (pl.block / 64u);
@@ -507,9 +535,10 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     ca.arena = rt->d_arena;
     ca.heads = rt->d_heads;
     ca.scratch_count = rt->d_scratch_count;
-    ca.bin_any = rt->d_bin_any;
+    ca.map = pl.geo.map;
+    ca.seg_any = rt->d_seg_any;
     span_begin(rt, rt->fold_spans, rt->fold_used);
-    HIP_TRY(hipMemsetAsync(rt->d_bin_any, 0, kMaxBins * sizeof(uint32_t), rt->stream));
+    HIP_TRY(hipMemsetAsync(rt->d_seg_any, 0, (static_cast<size_t>(rt->npix) / 2048u + 1u) * sizeof(uint32_t), rt->stream));
     launch_bin_accumulate(ca, rt->acc_threads, pl.R, rt->stream);
     HIP_TRY(hipGetLastError());
     launch_fold_resolve(fa, rt->stream);
@@ -703,7 +732,7 @@ int sar_runtime_free(sar_runtime* rt) {
     if (rt->d_warm) hipFree(rt->d_warm);
     if (rt->d_joblist) hipFree(rt->d_joblist);
     if (rt->d_active) hipFree(rt->d_active);
-    if (rt->d_bin_any) hipFree(rt->d_bin_any);
+    if (rt->d_seg_any) hipFree(rt->d_seg_any);
     if (rt->h_active) hipHostFree(rt->h_active);
     if (rt->active_copied) hipEventDestroy(rt->active_copied);
     if (rt->d_starts) hipFree(rt->d_starts);
@@ -1121,6 +1150,9 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "bin_shift")) {
         if (v && (v < 12 || v > 15)) { set_error("bin_shift must be 12..15"); return SAR_ERR_INVALID; }
         rt->bin_shift = v;
+    } else if (!std::strcmp(name, "bin_interleave")) {
+        if (v > 2) { set_error("bin_interleave must be 0 (automatic), 1 (consecutive-pixel bins) or 2 (interleaved bins)"); return SAR_ERR_INVALID; }
+        rt->bin_interleave = v;
     } else if (!std::strcmp(name, "splits")) {
         if (v > 16) { set_error("splits must be 1..16"); return SAR_ERR_INVALID; }
         rt->splits = v;

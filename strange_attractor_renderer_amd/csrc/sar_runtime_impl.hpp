@@ -56,7 +56,8 @@ struct sar_runtime {
     double* d_warm = nullptr;        // binned path: packed post-warm-up points, job list, survivor count
     uint32_t* d_joblist = nullptr;
     uint32_t* d_active = nullptr;
-    uint32_t* d_bin_any = nullptr;   // [kMaxBins] bins with at least one visit in the current launch (k_fold_resolve skips the rest)
+    uint32_t* d_seg_any = nullptr;   // [npix / 2048 + 1] 2048-pixel segments with a count in the current launch (k_fold_resolve skips the rest)
+    size_t seg_any_cap = 0;
     size_t warm_cap = 0;             // jobs
     // survivor statistics of the last launch, copied back lazily (never waited for): the next render call sizes its
     // staging for the lanes that will really be busy (solar-sail loses 38 % of its jobs in the warm-up)
@@ -86,6 +87,7 @@ struct sar_runtime {
     uint32_t debug_chunk_jobs = 0;  // test hook: cap on jobs per launch chunk (0 = none)
     uint64_t max_ordinals = 0;      // test hook: visits one launch may order (0 = 2^32-2); longer jobs run as segments
     uint32_t bin_shift = 0;         // 0 = automatic
+    uint32_t bin_interleave = 0;    // 0 = automatic, 1 = bins of consecutive pixels, 2 = interleaved bins (BinMap)
     uint32_t splits = 0;            // 0 = automatic
     uint32_t acc_threads = 0;       // threads per k_bin_accumulate block (0 = automatic)
     uint32_t stager = 0;            // 0 automatic, 1 Stager (the filling lane copies its buffer out), 2 PoolStager (sar_iterate.hip)

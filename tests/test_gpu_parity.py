@@ -293,18 +293,40 @@ def test_device_sqrt_div_are_correctly_rounded(sar, oracle, gpu):
         assert_state_equal(rt, ort, preset)
 
 
-@pytest.mark.parametrize("size", [(1920, 1080), (3000, 2500), (4096, 4096), (8192, 6000)])
-def test_bin_geometries(sar, oracle, gpu, size):
-    """Image sizes that exercise every bin geometry of the LDS-binned path (ragged last bin, 512+ bins, and
-    the > 32 Mpx fallback to the atomic path)."""
+@pytest.mark.parametrize("interleave", [0, 1, 2])
+@pytest.mark.parametrize("size", [(1920, 1080), (3000, 2500), (3072, 3072), (4096, 4096), (8192, 6000)])
+def test_bin_geometries(sar, oracle, gpu, size, interleave):
+    """Image sizes that exercise every bin geometry of the LDS-binned path (ragged last bin, 512+ bins, bin counts that
+    are and are not powers of two, and the > 32 Mpx fallback to the atomic path), under both pixel -> (bin, record) maps:
+    bins of consecutive pixels (1) and bins dealt round-robin in 2048-pixel segments (2); 0 = the host's choice."""
     w, h = size
     jobs, n = 2048, 300
     cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=w, height=h, jobs_total=jobs)
     st = sar.start_points(13, 0, jobs)
     rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
+    rt.set_option("bin_interleave", interleave)
     sar.render_jobs(cfg, rt, st)
     oracle.render_jobs(cfg.c, ort, st, n)
-    assert_state_equal(rt, ort, f"{w}x{h}")
+    assert_state_equal(rt, ort, f"{w}x{h} bin_interleave={interleave}")
+
+
+@pytest.mark.parametrize("bin_shift", [12, 13, 14, 15])
+@pytest.mark.parametrize("interleave", [1, 2])
+@pytest.mark.parametrize("size", [(700, 500), (64, 48), (1, 1), (2048, 3)])
+def test_bin_maps_small_and_odd_shapes(sar, oracle, gpu, size, interleave, bin_shift):
+    """Both bin maps with every bin size on images of one bin, of a few bins, of one pixel and of three very long rows
+    (segments of the interleaved map that straddle rows), two render calls into one runtime (the segment flags of the
+    second launch must not hide the first launch's pixels)."""
+    w, h = size
+    jobs, n = 700, 400
+    cfg = _cfg(sar, "solar_sail", iterations=jobs * n, width=w, height=h, jobs_total=jobs, scale=0.9)
+    st = sar.start_points(29, 0, 2 * jobs)
+    rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
+    rt.set_tuning(variant=3, bin_shift=bin_shift, bin_interleave=interleave)
+    for part in (st[:jobs], st[jobs:]):
+        sar.render_jobs(cfg, rt, part)
+        oracle.render_jobs(cfg.c, ort, part, n)
+    assert_state_equal(rt, ort, f"{w}x{h} bin_shift={bin_shift} bin_interleave={interleave}")
 
 
 @pytest.mark.parametrize("preset", ["poisson_saturne", "solar_sail"])
@@ -399,8 +421,9 @@ def test_attractor_extent_bit_exact(sar, oracle, gpu, preset):
 
 @pytest.mark.parametrize("stager", [1, 2])
 @pytest.mark.parametrize("records", [12, 20, 28])
-@pytest.mark.parametrize("splits,acc_threads,pipe,hint_bits", [(0, 0, 0, 0), (1, 256, 1, 16), (5, 512, 2, 16), (16, 1024, 1, 32)])
-def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, splits, acc_threads, pipe, hint_bits, stager):
+@pytest.mark.parametrize("splits,acc_threads,pipe,hint_bits,interleave",
+                         [(0, 0, 0, 0, 0), (1, 256, 1, 16, 1), (5, 512, 2, 16, 2), (16, 1024, 1, 32, 1), (3, 1024, 2, 32, 2)])
+def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, splits, acc_threads, pipe, hint_bits, interleave, stager):
     """Every chunk size of the binned path (32 / 48-on-64 / 64-byte chunks: different lane-group shapes in
     k_bin_accumulate) with several accumulate grids, against the oracle; enough records per (bin, wave) list to chain
     many chunks and to overflow staging buffers within one slot request (all trajectories start close together)."""
@@ -410,10 +433,11 @@ def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, 
     st[:512] = st[0] + np.arange(512)[:, None] * 1e-13  # near-identical trajectories: many lanes hit one bin at once
     rt, ort = sar.Runtime(cfg), oracle.Runtime(256, 192)
     rt.set_tuning(variant=3, chunk_records=records, splits=splits, acc_threads=acc_threads, depth_pipe=pipe, hint_bits=hint_bits,
-                  stager=stager)
+                  stager=stager, bin_interleave=interleave)
     sar.render_jobs(cfg, rt, st)
     oracle.render_jobs(cfg.c, ort, st, n)
-    assert_state_equal(rt, ort, f"records={records} splits={splits} acc_threads={acc_threads} depth_pipe={pipe} hint_bits={hint_bits} stager={stager}")
+    assert_state_equal(rt, ort, f"records={records} splits={splits} acc_threads={acc_threads} depth_pipe={pipe} hint_bits={hint_bits} stager={stager} "
+                               f"bin_interleave={interleave}")
 
 
 @pytest.mark.parametrize("seed", range(32))
