@@ -26,6 +26,7 @@ CONFIGS = {
     # not BASELINE configs: intermediate sizes for choosing size-dependent defaults (select with --only)
     "X2560": dict(preset="poisson_saturne", iters=1e9, w=2560, h=2560, kind=0),
     "X3072": dict(preset="poisson_saturne", iters=1e9, w=3072, h=3072, kind=0),
+    "XC4": dict(preset="poisson_saturne", iters=1e10, w=4096, h=4096, kind=0),  # the whole configs[3] frame: --jobs 1048576
     "XHD": dict(preset="poisson_saturne", iters=1e9, w=1920, h=1080, kind=0),
     "X4K": dict(preset="poisson_saturne", iters=1e9, w=3840, h=2160, kind=0),
 }
