@@ -21,7 +21,7 @@ namespace sar {
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t f32_sortable(float f) {
     const uint32_t b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);  // negative: ~b, else b | sign — three instructions
 }
 __device__ __forceinline__ float sortable_f32(uint32_t s) {
     const uint32_t b = (s & 0x80000000u) ? (s & 0x7fffffffu) : ~s;
@@ -112,8 +112,8 @@ constexpr uint32_t kLeanWaveLds(uint32_t bins, uint32_t R) { return bins * (2u *
 constexpr uint32_t kPoolSpare = SAR_POOL_SPARE;
 constexpr uint32_t kPoolChunkBytes(uint32_t R) { return 8u + 2u * R; }
 constexpr uint32_t kPoolWaveLds(uint32_t bins, uint32_t R) {
-    // buffers | ctl words (+64 dummy) | ring | 64 scratch records; a multiple of 16 bytes
-    return (bins + kPoolSpare) * kPoolChunkBytes(R) + (bins + 64u) * 4u + kPoolSpare * 4u + 128u;
+    // buffers | ctl words | ring, rounded up to a multiple of 16 bytes
+    return ((bins + kPoolSpare) * kPoolChunkBytes(R) + bins * 4u + kPoolSpare * 4u + 15u) & ~15u;
 }
 constexpr uint32_t kChunkQuads(uint32_t R) { return (8u + 2u * R) / 16u; }  // 16-byte quads of data per chunk: R = 12, 20, 28
 // Chunks never straddle a 64-byte sector of the arena: the 48-byte chunk (R = 20) is laid out on a 64-byte stride.
@@ -136,6 +136,11 @@ __device__ __forceinline__ uint32_t bfi(uint32_t wave_uniform_mask, uint32_t a, 
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(wave_uniform_mask), "v"(a), "v"(b));
     return r;
 }
+
+// Lane mask of an unsigned compare, straight from the compare instruction. (wave_ballot of a bool that was combined
+// from several conditions costs v_cndmask + v_cmp_ne on top of them.)
+__device__ __forceinline__ unsigned long long lanes_eq(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 32); }
+__device__ __forceinline__ unsigned long long lanes_ge(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 35); }
 
 // Lane mask of a predicate. (HIP's __ballot goes through an integer: v_cndmask + v_cmp_ne per call.)
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }

@@ -242,7 +242,7 @@ struct DepthPipe {
     // returned" (vmcnt) counts operations in issue order, so anything issued after a load that is still wanted in flight
     // would have to be waited for as well.
     __device__ __forceinline__ void depth_request(uint32_t k, bool cand, uint32_t idx) {
-        if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (idx & ~1u)) : 0u));
+        if (DEPTH && cand) p_hint[k] = *(const uint32_t*)(zhint + (kWide ? idx : (idx & ~1u)));
     }
 
     // After the last visit: settle what is in flight.
@@ -482,10 +482,10 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
     static constexpr uint32_t Q = CB / 16u;              // 16-byte quads per chunk
     static constexpr uint32_t P = kPoolSpare;            // spare buffers == most chunks that wait for the copy-out
     static constexpr uint32_t kFillBits = 7u, kFillMask = 127u;  // fill < R + 64 <= 92
-    uint32_t* ctl;        // [B] (LDS address of the records of the bin's buffer << 7) | fill, + 64 dummy words
+    uint32_t* ctl;        // [B] (LDS address of the records of the bin's buffer << 7) | fill
     uint32_t* ring;       // [P] LDS addresses (records) of the spare / pending buffers
     uint32_t pool0;       // LDS address of buffer 0's records
-    uint32_t trash, dummy, lane, n_bins;
+    uint32_t lane, n_bins;
     uint4* arena;         // this wave's chunk arena
     uint32_t cursor;      // wave-uniform: next chunk number
     uint32_t drained;     // wave-uniform: chunks below this one are in the arena
@@ -501,20 +501,16 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
                                          unsigned long long* key_, const BinMap& map_, uint32_t lo_base_) {
         n_bins = bins;
         lane = lane_;
-        // layout: buffers (bins + P) * CB | ctl (bins + 64) | ring P | 64 scratch records
+        // layout: buffers (bins + P) * CB | ctl bins | ring P (lanes without a visit are masked off, not redirected)
         char* pool = wbase;
         ctl = (uint32_t*)(wbase + (bins + P) * CB);
-        ring = ctl + bins + 64u;
-        unsigned short* scratch = (unsigned short*)(ring + P);
+        ring = ctl + bins;
         pool0 = lds_addr(pool) + 8u;
         for (uint32_t b = lane; b < bins; b += 64u) {
             ctl[b] = (pool0 + b * CB) << kFillBits;
             *(uint2*)(pool + b * CB) = make_uint2(kNoChunk, R);  // header of the list's first chunk: no predecessor
         }
-        ctl[bins + lane] = lds_addr(scratch + lane) << kFillBits;
         if (lane < P) ring[lane] = pool0 + (bins + lane) * CB;
-        trash = lds_addr(scratch + lane);
-        dummy = bins + lane;
         arena = arena_;
         cursor = drained = 0;
         depth_init(zhint_, key_, lo_base_);
@@ -573,14 +569,16 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         uint32_t slot = b_old & kFillMask;
         uint32_t rec = b_old >> kFillBits;
         const bool w0 = b_have && slot < R;
-        *(unsigned short*)lds_ptr(w0 ? rec + 2u * slot : trash) = (unsigned short)b_local;
-        bool fl = w0 && slot == R - 1u;
-        unsigned long long fb = wave_ballot(fl);
+        if (w0) *(unsigned short*)lds_ptr(rec + 2u * slot) = (unsigned short)b_local;
+        // lanes that took the last slot: the mask comes straight from one compare (lanes without a visit compare ~0)
+        const uint32_t slot_m = b_have ? slot : 0xFFFFFFFFu;
+        bool fl = slot_m == R - 1u;
+        unsigned long long fb = lanes_eq(slot_m, R - 1u);
         if (fb) {
             bool over = b_have && slot >= R;  // overflowed into a later generation of a buffer that filled within this request
             for (;;) {
                 swap_full(fl, fb, b_bin, rec);
-                if (!wave_ballot(over)) break;  // the common case
+                if (!lanes_ge(over ? slot : 0u, R)) break;  // the common case
                 slot -= over ? R : 0u;
                 if (over) rec = ctl[b_bin] >> kFillBits;  // the buffer the swap installed
                 const bool w = over && slot < R;
@@ -600,7 +598,7 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         b_have = inb;
         b_bin = __builtin_amdgcn_ubfe(idx, map.seg_shift, bin_bits_v);
         b_local = bfi(map.low_mask, idx, idx >> map.hi_shift);
-        b_old = atomicAdd(&ctl[inb ? b_bin : dummy], 1u);  // ds_add_rtn_u32: slot and buffer in one word
+        if (inb) b_old = atomicAdd(&ctl[b_bin], 1u);  // ds_add_rtn_u32: slot and buffer in one word
         depth_request(k, cand, idx);
         __builtin_amdgcn_s_setprio(0);
     }
@@ -612,7 +610,7 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         // the partly filled buffers: one lane per bin writes {list head, fill, records} as the list's last chunk
         for (uint32_t b0 = 0; b0 < n_bins; b0 += 64u) {
             const uint32_t b = b0 + lane;
-            const uint32_t word = (b < n_bins) ? ctl[b] : (trash << kFillBits);
+            const uint32_t word = (b < n_bins) ? ctl[b] : (pool0 << kFillBits);
             const uint32_t have = (b < n_bins) ? (word & kFillMask) : 0u;
             const bool flusher = have != 0u;
             const unsigned long long fb = wave_ballot(flusher);
