@@ -308,6 +308,9 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *   "path"               accumulate path: 0 default (= 3 when the image fits), 1 one global atomic per
  *                        visit at agent scope, 2 the same into one scratch copy per XCD, 3 LDS-binned records
  *   "bin_shift"          log2(pixels per bin) of the binned path (12..15)
+ *   "bin_interleave"     which pixels form a bin: 1 consecutive pixels, 2 every B-th 2048-pixel segment of the image
+ *                        (B bins, a power of two: every bin carries the same share of the visits whatever the attractor
+ *                        covers); 0 = 2 when the power-of-two bin count costs at most a third more bins, else 1
  *   "splits"             workgroups per bin in the record-accumulate kernel (1..16)
  *   "chunk_records"      u16 records per chunk: 12, 20 or 28 (32/48/64-byte chunks; fewer = less LDS per wave)
  *   "stager"             how the iterate kernel copies full staging buffers out: 1 the lane that filled one copies it,
