@@ -16,7 +16,7 @@ namespace sar {
 template <uint32_t R>
 __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     constexpr uint32_t Q = kChunkQuads(R);       // 16-byte quads per chunk
-    constexpr uint32_t G = Q == 2u ? 2u : 4u;    // lanes that share one list: lane q of a group reads quad q
+    constexpr uint32_t G = kChunkLanes(R);       // lanes that share one list: lane q of a group reads quad q
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     const uint32_t b = blockIdx.x, s = blockIdx.y;
     const uint32_t bin_px = 1u << a.bin_shift;
@@ -206,6 +206,7 @@ int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t record
         case 12: hipLaunchKernelGGL(k_bin_accumulate<12u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
         case 20: hipLaunchKernelGGL(k_bin_accumulate<20u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
         case 28: hipLaunchKernelGGL(k_bin_accumulate<28u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
+        case 60: hipLaunchKernelGGL(k_bin_accumulate<60u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
         default: return 1;
     }
     return 0;
@@ -219,6 +220,7 @@ int accumulate_kernel_attributes() {
     SAR_ATTR(12u);
     SAR_ATTR(20u);
     SAR_ATTR(28u);
+    SAR_ATTR(60u);
 #undef SAR_ATTR
     return (int)e;
 }

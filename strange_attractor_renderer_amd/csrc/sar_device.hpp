@@ -109,17 +109,20 @@ constexpr uint32_t kLeanWaveLds(uint32_t bins, uint32_t R) { return bins * (2u *
 #ifndef SAR_POOL_SPARE
 #define SAR_POOL_SPARE 16u  // a test build shrinks it (SAR_EXTRA_FLAGS=-DSAR_POOL_SPARE=2u) to force the many-fillers rounds
 #endif
-constexpr uint32_t kPoolSpare = SAR_POOL_SPARE;
 constexpr uint32_t kPoolChunkBytes(uint32_t R) { return 8u + 2u * R; }
+constexpr uint32_t kChunkQuads(uint32_t R) { return (8u + 2u * R) / 16u; }  // 16-byte quads of data per chunk: R = 12, 20, 28, 60
+// lanes that move one chunk (one quad each): 2, 4 or 8
+constexpr uint32_t kChunkLanes(uint32_t R) { return kChunkQuads(R) <= 2u ? 2u : (kChunkQuads(R) <= 4u ? 4u : 8u); }
+// spare buffers of the pool stager: as many as one cooperative copy-out of the wave moves (64 lanes), at most SAR_POOL_SPARE
+constexpr uint32_t kPoolSpareOf(uint32_t R) { return SAR_POOL_SPARE < 64u / kChunkLanes(R) ? SAR_POOL_SPARE : 64u / kChunkLanes(R); }
 constexpr uint32_t kPoolWaveLds(uint32_t bins, uint32_t R) {
     // buffers | ctl words | ring, rounded up to a multiple of 16 bytes
-    return ((bins + kPoolSpare) * kPoolChunkBytes(R) + bins * 4u + kPoolSpare * 4u + 15u) & ~15u;
+    return ((bins + kPoolSpareOf(R)) * kPoolChunkBytes(R) + bins * 4u + kPoolSpareOf(R) * 4u + 15u) & ~15u;
 }
-constexpr uint32_t kChunkQuads(uint32_t R) { return (8u + 2u * R) / 16u; }  // 16-byte quads of data per chunk: R = 12, 20, 28
 // Chunks never straddle a 64-byte sector of the arena: the 48-byte chunk (R = 20) is laid out on a 64-byte stride.
 // The accumulate kernel's chunk reads are isolated, and an isolated read moves whole sectors (measured, tools/ubench/
 // gather_runs.hip: 3.4 TB/s for 64-byte pieces) — a straddling chunk would cost two.
-constexpr uint32_t kChunkStride(uint32_t R) { return R == 12u ? 2u : 4u; }
+constexpr uint32_t kChunkStride(uint32_t R) { return R == 12u ? 2u : (R == 60u ? 8u : 4u); }
 
 
 // a * b for operands below 2^24 as ONE full-rate instruction. (Through the __umul24 builtin the optimiser knows the

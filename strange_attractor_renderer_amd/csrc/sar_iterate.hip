@@ -242,7 +242,9 @@ struct DepthPipe {
     // returned" (vmcnt) counts operations in issue order, so anything issued after a load that is still wanted in flight
     // would have to be waited for as well.
     __device__ __forceinline__ void depth_request(uint32_t k, bool cand, uint32_t idx) {
-        if (DEPTH && cand) p_hint[k] = *(const uint32_t*)(zhint + (kWide ? idx : (idx & ~1u)));
+        // every lane loads (the others from entry 0): a load under the candidates' exec mask instead costs 8 % at 4096^2,
+        // where the hints miss the L2 — the partial register write makes the previous load of that register a dependency
+        if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (idx & ~1u)) : 0u));
     }
 
     // After the last visit: settle what is in flight.
@@ -480,7 +482,7 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
     using DepthPipe<DEPTH, U, H>::depth_drain;
     static constexpr uint32_t CB = kPoolChunkBytes(R);   // staged chunk == final chunk: 8-byte header + R records
     static constexpr uint32_t Q = CB / 16u;              // 16-byte quads per chunk
-    static constexpr uint32_t P = kPoolSpare;            // spare buffers == most chunks that wait for the copy-out
+    static constexpr uint32_t P = kPoolSpareOf(R);       // spare buffers == most chunks that wait for the copy-out
     static constexpr uint32_t kFillBits = 7u, kFillMask = 127u;  // fill < R + 64 <= 92
     uint32_t* ctl;        // [B] (LDS address of the records of the bin's buffer << 7) | fill
     uint32_t* ring;       // [P] LDS addresses (records) of the spare / pending buffers
@@ -521,10 +523,10 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         b_bin = b_old = b_local = 0;
     }
 
-    // The whole wave copies the pending chunks [drained, cursor) out — at most P = 16 of them, so one pass: lane l moves
-    // quad l % G of pending chunk l / G (G = 4 lanes per chunk; 2 for the 32-byte chunk).
+    // The whole wave copies the pending chunks [drained, cursor) out — at most P of them (16; 8 of the 128-byte chunks), so
+    // one pass: lane l moves quad l % G of pending chunk l / G (G = 2 / 4 / 8 lanes per chunk).
     __device__ __forceinline__ void drain_all() {
-        constexpr uint32_t G = Q == 2u ? 2u : 4u;
+        constexpr uint32_t G = kChunkLanes(R);
         static_assert(P <= 64u / G, "one pass must cover the ring");
         const uint32_t q = lane % G;
         const uint32_t e = drained + lane / G;
@@ -875,6 +877,10 @@ uint32_t chunk_bytes(uint32_t records) { return kChunkStride(records) * 16u; }
     X(true, 28u, 1u, uint32_t) X(true, 28u, 2u, uint32_t)                                                              \
     X(false, 12u, 1u, unsigned short) X(false, 20u, 1u, unsigned short) X(false, 28u, 1u, unsigned short)
 #endif
+// 128-byte chunks: pool stager only (the classic stager would hold a chunk's 120 bytes in registers)
+#define SAR_FOR_EACH_LEAN_POOL(X)                                                                                     \
+    X(true, 60u, 1u, unsigned short) X(true, 60u, 2u, unsigned short) X(true, 60u, 1u, uint32_t) X(true, 60u, 2u, uint32_t) \
+    X(false, 60u, 1u, unsigned short)
 
 int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
                         bool pool, hipStream_t s) {
@@ -893,6 +899,13 @@ int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, 
     }
     SAR_FOR_EACH_LEAN(SAR_LAUNCH_LEAN)
 #undef SAR_LAUNCH_LEAN
+#define SAR_LAUNCH_LEAN_POOL(DD, RR, UU, HH)                                                               \
+    if (!launched && pool && depth == DD && records == RR && pipe == UU && hint_bytes == sizeof(HH)) {     \
+        hipLaunchKernelGGL((k_iterate_lean<DD, RR, UU, HH, true>), dim3(grid), dim3(block), lds, s, a);    \
+        launched = true;                                                                                   \
+    }
+    SAR_FOR_EACH_LEAN_POOL(SAR_LAUNCH_LEAN_POOL)
+#undef SAR_LAUNCH_LEAN_POOL
     return launched ? 0 : 1;
 }
 
@@ -904,6 +917,10 @@ int iterate_kernel_attributes() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU, HH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SAR_FOR_EACH_LEAN(SAR_ATTR_LEAN)
 #undef SAR_ATTR_LEAN
+#define SAR_ATTR_LEAN_POOL(DD, RR, UU, HH) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU, HH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    SAR_FOR_EACH_LEAN_POOL(SAR_ATTR_LEAN_POOL)
+#undef SAR_ATTR_LEAN_POOL
     return (int)e;
 }
 

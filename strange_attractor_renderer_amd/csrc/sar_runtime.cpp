@@ -292,8 +292,8 @@ struct LaunchPlan {
 // Also picks the stager: the pool stager (sar_iterate.hip: full buffers swapped against spares, cooperative copy-out;
 // 3-4 % faster where it fits) needs a little more LDS per wave — it is used when it keeps the waves per CU the classic
 // stager reaches with the same chunk size.
-uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool) {
-    const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u, false, rt->bin_interleave);
+uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool, uint32_t& shift) {
+    shift = rt->bin_shift;
     if (rt->active_pending && hipEventQuery(rt->active_copied) == hipSuccess) {
         rt->active_pending = false;
         if (rt->active_jobs_launched) rt->survivor_fraction = static_cast<double>(*rt->h_active) / rt->active_jobs_launched;
@@ -303,6 +303,23 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool) {
     uint64_t want = (busy + 64u * cus - 1) / (64u * cus);  // waves per CU if all surviving jobs were resident
     want = ((want + 3) / 4) * 4;  // workgroups are four waves: residency comes in steps of four waves per CU
     want = want < 8 ? 8 : (want > 12 ? 12 : want);
+    // Interleaved bins carry equal loads, so few LARGE bins cost the slot requests nothing (with bins of consecutive
+    // pixels half the bins idle and the rest collide) and k_bin_accumulate's 128 KiB histograms (one workgroup per CU) get
+    // equal work. 128 bins of 32768 pixels leave the pool stager room for 128-byte chunks at two waves per SIMD — half
+    // the buffer swaps, whole cache lines for k_bin_accumulate — or for 64-byte chunks at three. (2048^2, 1e9 iterations:
+    // 131072 jobs 7.0 -> 6.x ms per frame)
+    if (rt->bin_shift == 0 && rt->chunk_records == 0 && rt->stager != 1 && rt->bin_interleave != 1) {
+        const BinGeometry big = bin_geometry(rt->npix, rt->block_threads, 15u, rt->splits, 12u, true, rt->bin_interleave);
+        if (big.ok && big.interleaved) {
+            for (uint32_t cand : {60u, 28u})
+                if (lean_wave_lds_bytes(big.bins, cand, true) * want <= 160u * 1024u) {
+                    pool = true;
+                    shift = 15u;
+                    return cand;
+                }
+        }
+    }
+    const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u, false, rt->bin_interleave);
     uint32_t R = rt->chunk_records, need_waves = 8;
     if (R == 0 && !probe.ok) R = kDefaultChunkRecords;
     if (R == 0) {
@@ -314,16 +331,18 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool) {
             if (found) break;
         }
     } else if (probe.ok) {
-        need_waves = (lean_wave_lds_bytes(probe.bins, R, false) * want <= 160u * 1024u) ? static_cast<uint32_t>(want) : 8u;
+        need_waves = (lean_wave_lds_bytes(probe.bins, R == 60u ? 28u : R, false) * want <= 160u * 1024u) ? static_cast<uint32_t>(want) : 8u;
     }
-    pool = rt->stager == 2 || (rt->stager == 0 && probe.ok && lean_wave_lds_bytes(probe.bins, R, true) * need_waves <= 160u * 1024u &&
-                               lean_wave_lds_bytes(probe.bins, R, false) * need_waves <= 160u * 1024u);
+    pool = rt->stager == 2 || R == 60u ||
+           (rt->stager == 0 && probe.ok && lean_wave_lds_bytes(probe.bins, R, true) * need_waves <= 160u * 1024u &&
+            lean_wave_lds_bytes(probe.bins, R, false) * need_waves <= 160u * 1024u);
     return R;
 }
 
 int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, LaunchPlan& pl) {
-    pl.R = choose_chunk_records(rt, n_jobs, pl.pool);
-    pl.geo = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, pl.R, pl.pool, rt->bin_interleave);
+    uint32_t shift = 0;
+    pl.R = choose_chunk_records(rt, n_jobs, pl.pool, shift);
+    pl.geo = bin_geometry(rt->npix, rt->block_threads, shift, rt->splits, pl.R, pl.pool, rt->bin_interleave);
     // which accumulate path: LDS-binned records (default) or one global atomic per visit
     pl.binned = (rt->bins_mode == 0 || rt->bins_mode == 3) && rt->measure_mode != 2 && pl.geo.ok;
     if (rt->bins_mode == 3 && !pl.geo.ok) {
@@ -374,9 +393,16 @@ int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_
         // k_bin_accumulate walks one (bin, wave) list per group of lanes (4, or 2 with 32-byte chunks): aim at one
         // list per group, and at enough blocks to cover the chip when only a band of bins is populated
         const uint32_t threads = rt->acc_threads ? rt->acc_threads : 1024u;
-        const uint32_t groups = threads / (pl.R == 12u ? 2u : 4u);
+        const uint32_t groups = threads / (pl.R == 12u ? 2u : (pl.R == 60u ? 8u : 4u));
         pl.splits = (pl.max_waves + groups - 1u) / groups;
-        const uint32_t cover = 2048u / pl.geo.bins;
+        uint32_t cover = 2048u / pl.geo.bins;
+        if (pl.geo.shift == 15u && pl.geo.interleaved) {
+            // 128 KiB histograms: one workgroup per CU is resident, and with interleaved bins all of them carry the same
+            // load — two rounds of workgroups over the chip, up to a few lists per lane group (measured, 2048^2: 4
+            // workgroups per bin 0.85 ms, 8 or 16 1.2 ms)
+            cover = 512u / pl.geo.bins;
+            pl.splits = (pl.max_waves + 8u * groups - 1u) / (8u * groups);
+        }
         if (pl.splits < cover) pl.splits = cover;
         if (pl.splits < 1) pl.splits = 1;
         if (pl.splits > 16) pl.splits = 16;
@@ -1157,7 +1183,7 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
         if (v > 16) { set_error("splits must be 1..16"); return SAR_ERR_INVALID; }
         rt->splits = v;
     } else if (!std::strcmp(name, "chunk_records")) {
-        if (v && v != 12 && v != 20 && v != 28) { set_error("chunk_records must be 12, 20 or 28"); return SAR_ERR_INVALID; }
+        if (v && v != 12 && v != 20 && v != 28 && v != 60) { set_error("chunk_records must be 12, 20, 28 or 60"); return SAR_ERR_INVALID; }
         rt->chunk_records = v;
     } else if (!std::strcmp(name, "stager")) {
         if (v > 2) { set_error("stager must be 0 (automatic), 1 (copy-out by the filling lane) or 2 (buffer pool, cooperative copy-out)"); return SAR_ERR_INVALID; }

@@ -322,7 +322,8 @@ def test_bin_maps_small_and_odd_shapes(sar, oracle, gpu, size, interleave, bin_s
     cfg = _cfg(sar, "solar_sail", iterations=jobs * n, width=w, height=h, jobs_total=jobs, scale=0.9)
     st = sar.start_points(29, 0, 2 * jobs)
     rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
-    rt.set_tuning(variant=3, bin_shift=bin_shift, bin_interleave=interleave)
+    rt.set_tuning(variant=3, bin_shift=bin_shift, bin_interleave=interleave, chunk_records=60 if bin_shift == 15 else 0,
+                  stager=2 if bin_shift == 15 else 0)
     for part in (st[:jobs], st[jobs:]):
         sar.render_jobs(cfg, rt, part)
         oracle.render_jobs(cfg.c, ort, part, n)
@@ -420,13 +421,16 @@ def test_attractor_extent_bit_exact(sar, oracle, gpu, preset):
 
 
 @pytest.mark.parametrize("stager", [1, 2])
-@pytest.mark.parametrize("records", [12, 20, 28])
+@pytest.mark.parametrize("records", [12, 20, 28, 60])
 @pytest.mark.parametrize("splits,acc_threads,pipe,hint_bits,interleave",
                          [(0, 0, 0, 0, 0), (1, 256, 1, 16, 1), (5, 512, 2, 16, 2), (16, 1024, 1, 32, 1), (3, 1024, 2, 32, 2)])
 def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, splits, acc_threads, pipe, hint_bits, interleave, stager):
-    """Every chunk size of the binned path (32 / 48-on-64 / 64-byte chunks: different lane-group shapes in
-    k_bin_accumulate) with several accumulate grids, against the oracle; enough records per (bin, wave) list to chain
-    many chunks and to overflow staging buffers within one slot request (all trajectories start close together)."""
+    """Every chunk size of the binned path (32 / 48-on-64 / 64 / 128-byte chunks: different lane-group shapes in
+    k_bin_accumulate; the 128-byte chunk exists for the pool stager only) with several accumulate grids, against the
+    oracle; enough records per (bin, wave) list to chain many chunks and to overflow staging buffers within one slot
+    request (all trajectories start close together)."""
+    if records == 60 and stager == 1:
+        pytest.skip("128-byte chunks: pool stager only")
     jobs, n = 2048 + 64, 1201  # odd: the depth pipeline's pass of 2 leaves a last single iteration
     cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=256, height=192, jobs_total=jobs)
     st = sar.start_points(23, 0, jobs)
