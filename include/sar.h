@@ -312,7 +312,8 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *                        (B bins, a power of two: every bin carries the same share of the visits whatever the attractor
  *                        covers); 0 = 2 when the power-of-two bin count costs at most a third more bins, else 1
  *   "splits"             workgroups per bin in the record-accumulate kernel (1..16)
- *   "chunk_records"      u16 records per chunk: 12, 20 or 28 (32/48/64-byte chunks; fewer = less LDS per wave)
+ *   "chunk_records"      u16 records per chunk: 12, 20, 28 or 60 (32/48/64/128-byte chunks; fewer = less LDS per wave;
+ *                        60: pool stager only)
  *   "stager"             how the iterate kernel copies full staging buffers out: 1 the lane that filled one copies it,
  *                        2 full buffers are swapped against spares and the whole wave copies them out in batches
  *                        (needs slightly more LDS); 0 = 2 where it keeps the waves per CU, else 1
