@@ -320,6 +320,7 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *   "hint_bits"          per-XCD depth hints of the iterate kernel: 16 (fixed point) or 32 (sortable f32); 0 = by image size
  *   "depth_pipe"         visits between a depth-hint (or depth-key) load and its use in the iterate kernel: 1 or 2 (default 2)
  *   "acc_threads"        threads per block of the record-accumulate kernel (256, 512, 1024)
+ *   "acc_lists"          (bin, wave) record lists a lane group of that kernel walks at the same time: 1, 2 or 4
  *   "timing_accumulate"  1: the spans of successive render calls add up (sar_timing sums, iterate_launches counts
  *                        them) until sar_runtime_last_timing reads and clears them; 0: last render call only
  *   "measure"            measurement-only kernels: 1 count only, 2 arithmetic only (results are NOT the render)

@@ -13,7 +13,7 @@ namespace sar {
 // whole (bin, wave) chunk lists (64-byte loads, newest chunk first) and adds the records into the
 // bin's LDS histogram with LDS atomics; the histogram is then written — plainly, fully — as copy s of
 // the scratch count bins, which k_fold_resolve sums into Runtime::count.
-template <uint32_t R>
+template <uint32_t R, uint32_t K>
 __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     constexpr uint32_t Q = kChunkQuads(R);       // 16-byte quads per chunk
     constexpr uint32_t G = kChunkLanes(R);       // lanes that share one list: lane q of a group reads quad q
@@ -34,29 +34,49 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     const uint4* arena = (const uint4*)a.arena;
     // One (bin, wave) list per group of G lanes: a chunk is ONE 16-byte load per lane and one cache line per
     // group (a lane that walked a list alone needed Q loads over 64 different lines per wave instruction).
-    for (uint32_t w = s + a.splits * group; w < a.n_waves; w += a.splits * groups) {
-        uint32_t chunk = a.heads[(size_t)b * a.n_waves + w];
-        const uint4* base = arena + (size_t)w * a.chunks_per_wave * kChunkStride(R);
-        while (chunk != kNoChunk) {
-            uint4 v = make_uint4(kNoChunk, 0u, 0u, 0u);
-            if (q < Q) v = base[(size_t)chunk * kChunkStride(R) + q];
-            // the chunk header {previous chunk of the list, record count} sits in lane 0's quad
-            const uint32_t prev = __shfl(v.x, 0, G);
-            const uint32_t nrec = __shfl(v.y, 0, G);
-            // records held by this lane: lane 0 -> records 0..3 (its .z/.w), lane q -> 8q-4 .. 8q+3
-            const uint32_t first = q == 0u ? 0u : 8u * q - 4u;
-            const uint32_t w0 = q == 0u ? v.z : v.x, w1 = q == 0u ? v.w : v.y;
-            if (first < nrec) atomicAdd(&hist[w0 & 0xFFFFu], 1u);
-            if (first + 1u < nrec) atomicAdd(&hist[w0 >> 16], 1u);
-            if (first + 2u < nrec) atomicAdd(&hist[w1 & 0xFFFFu], 1u);
-            if (first + 3u < nrec) atomicAdd(&hist[w1 >> 16], 1u);
-            if (q != 0u) {
-                if (first + 4u < nrec) atomicAdd(&hist[v.z & 0xFFFFu], 1u);
-                if (first + 5u < nrec) atomicAdd(&hist[v.z >> 16], 1u);
-                if (first + 6u < nrec) atomicAdd(&hist[v.w & 0xFFFFu], 1u);
-                if (first + 7u < nrec) atomicAdd(&hist[v.w >> 16], 1u);
+    // A list is a chain of dependent loads (the next chunk's number is in this chunk's header): a group walks K lists at
+    // the same time — K loads in flight per lane. (One workgroup per CU with the 128 KiB histogram: K = 2.)
+    const uint32_t stride = a.splits * groups;
+    for (uint32_t w0 = s + a.splits * group; w0 < a.n_waves; w0 += K * stride) {
+        uint32_t chunk[K];
+        const uint4* base[K];
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint32_t w = w0 + k * stride;
+            chunk[k] = w < a.n_waves ? a.heads[(size_t)b * a.n_waves + w] : kNoChunk;
+            base[k] = arena + (size_t)(w < a.n_waves ? w : 0u) * a.chunks_per_wave * kChunkStride(R) + (q < Q ? q : 0u);
+        }
+        for (;;) {
+            bool live = false;
+#pragma unroll
+            for (uint32_t k = 0; k < K; ++k) live |= chunk[k] != kNoChunk;
+            if (!live) break;
+            uint4 v[K];
+#pragma unroll
+            for (uint32_t k = 0; k < K; ++k) {
+                v[k] = make_uint4(kNoChunk, 0u, 0u, 0u);  // an ended list: no predecessor, no record
+                if (chunk[k] != kNoChunk) v[k] = base[k][(size_t)chunk[k] * kChunkStride(R)];
             }
-            chunk = prev;
+#pragma unroll
+            for (uint32_t k = 0; k < K; ++k) {
+                // the chunk header {previous chunk of the list, record count} sits in lane 0's quad
+                const uint32_t prev = __shfl(v[k].x, 0, G);
+                const uint32_t nrec = q < Q ? __shfl(v[k].y, 0, G) : 0u;
+                // records held by this lane: lane 0 -> records 0..3 (its .z/.w), lane q -> 8q-4 .. 8q+3
+                const uint32_t first = q == 0u ? 0u : 8u * q - 4u;
+                const uint32_t r0 = q == 0u ? v[k].z : v[k].x, r1 = q == 0u ? v[k].w : v[k].y;
+                if (first < nrec) atomicAdd(&hist[r0 & 0xFFFFu], 1u);
+                if (first + 1u < nrec) atomicAdd(&hist[r0 >> 16], 1u);
+                if (first + 2u < nrec) atomicAdd(&hist[r1 & 0xFFFFu], 1u);
+                if (first + 3u < nrec) atomicAdd(&hist[r1 >> 16], 1u);
+                if (q != 0u) {
+                    if (first + 4u < nrec) atomicAdd(&hist[v[k].z & 0xFFFFu], 1u);
+                    if (first + 5u < nrec) atomicAdd(&hist[v[k].z >> 16], 1u);
+                    if (first + 6u < nrec) atomicAdd(&hist[v[k].w & 0xFFFFu], 1u);
+                    if (first + 7u < nrec) atomicAdd(&hist[v[k].w >> 16], 1u);
+                }
+                chunk[k] = prev;
+            }
         }
     }
     __syncthreads();
@@ -198,30 +218,42 @@ __global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) {
     }
 }
 
-int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, hipStream_t s) {
+int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, uint32_t lists, hipStream_t s) {
     const size_t lds = (size_t)4u << a.bin_shift;
-    // a list takes a group of 2 or 4 lanes: 1024 threads walk 256..512 lists per block
+    // a list takes a group of 2, 4 or 8 lanes: 1024 threads walk 128..512 lists per block, `lists` per group at a time
     if (threads == 0) threads = 1024u;
+#define SAR_ACC(RR, KK) hipLaunchKernelGGL((k_bin_accumulate<RR, KK>), dim3(a.n_bins, a.splits), dim3(threads), lds, s, a)
+#define SAR_ACC_R(RR)                   \
+    switch (lists) {                    \
+        case 1: SAR_ACC(RR, 1u); break; \
+        case 2: SAR_ACC(RR, 2u); break; \
+        case 4: SAR_ACC(RR, 4u); break; \
+        default: return 1;              \
+    }
     switch (records) {
-        case 12: hipLaunchKernelGGL(k_bin_accumulate<12u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
-        case 20: hipLaunchKernelGGL(k_bin_accumulate<20u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
-        case 28: hipLaunchKernelGGL(k_bin_accumulate<28u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
-        case 60: hipLaunchKernelGGL(k_bin_accumulate<60u>, dim3(a.n_bins, a.splits), dim3(threads), lds, s, a); break;
+        case 12: SAR_ACC_R(12u); break;
+        case 20: SAR_ACC_R(20u); break;
+        case 28: SAR_ACC_R(28u); break;
+        case 60: SAR_ACC_R(60u); break;
         default: return 1;
     }
+#undef SAR_ACC_R
+#undef SAR_ACC
     return 0;
 }
 
 int accumulate_kernel_attributes() {
     // a bin's histogram needs more dynamic LDS than the 64 KiB default window when the bin has 32768 pixels
     hipError_t e = hipSuccess;
-#define SAR_ATTR(RR) \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)
+#define SAR_ATTR1(RR, KK) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)
+#define SAR_ATTR(RR) SAR_ATTR1(RR, 1u); SAR_ATTR1(RR, 2u); SAR_ATTR1(RR, 4u)
     SAR_ATTR(12u);
     SAR_ATTR(20u);
     SAR_ATTR(28u);
     SAR_ATTR(60u);
 #undef SAR_ATTR
+#undef SAR_ATTR1
     return (int)e;
 }
 
