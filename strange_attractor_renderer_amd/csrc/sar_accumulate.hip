@@ -228,6 +228,7 @@ int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t record
         case 1: SAR_ACC(RR, 1u); break; \
         case 2: SAR_ACC(RR, 2u); break; \
         case 4: SAR_ACC(RR, 4u); break; \
+        case 8: SAR_ACC(RR, 8u); break; \
         default: return 1;              \
     }
     switch (records) {
@@ -247,7 +248,7 @@ int accumulate_kernel_attributes() {
     hipError_t e = hipSuccess;
 #define SAR_ATTR1(RR, KK) \
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)
-#define SAR_ATTR(RR) SAR_ATTR1(RR, 1u); SAR_ATTR1(RR, 2u); SAR_ATTR1(RR, 4u)
+#define SAR_ATTR(RR) SAR_ATTR1(RR, 1u); SAR_ATTR1(RR, 2u); SAR_ATTR1(RR, 4u); SAR_ATTR1(RR, 8u)
     SAR_ATTR(12u);
     SAR_ATTR(20u);
     SAR_ATTR(28u);

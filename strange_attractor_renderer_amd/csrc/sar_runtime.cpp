@@ -1198,7 +1198,7 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
         if (v > 2) { set_error("depth_pipe must be 1 or 2"); return SAR_ERR_INVALID; }
         rt->depth_pipe = v;
     } else if (!std::strcmp(name, "acc_lists")) {
-        if (v && v != 1 && v != 2 && v != 4) { set_error("acc_lists must be 1, 2 or 4"); return SAR_ERR_INVALID; }
+        if (v && v != 1 && v != 2 && v != 4 && v != 8) { set_error("acc_lists must be 1, 2, 4 or 8"); return SAR_ERR_INVALID; }
         rt->acc_lists = v;
     } else if (!std::strcmp(name, "acc_threads")) {
         if (v && v != 256 && v != 512 && v != 1024) { set_error("acc_threads must be 256, 512 or 1024"); return SAR_ERR_INVALID; }
