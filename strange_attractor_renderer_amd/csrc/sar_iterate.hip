@@ -577,19 +577,25 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         bool fl = slot_m == R - 1u;
         unsigned long long fb = lanes_eq(slot_m, R - 1u);
         if (fb) {
-            bool over = b_have && slot >= R;  // overflowed into a later generation of a buffer that filled within this request
-            for (;;) {
-                swap_full(fl, fb, b_bin, rec);
-                if (!lanes_ge(over ? slot : 0u, R)) break;  // the common case
-                slot -= over ? R : 0u;
-                if (over) rec = ctl[b_bin] >> kFillBits;  // the buffer the swap installed
-                const bool w = over && slot < R;
-                if (w) *(unsigned short*)lds_ptr(rec + 2u * slot) = (unsigned short)b_local;
-                fl = w && slot == R - 1u;
-                over = over && slot >= R;
-                fb = wave_ballot(fl);
-                if (!fb) break;
-            }
+            swap_full(fl, fb, b_bin, rec);
+            // Lanes whose slot lies beyond the buffer: it filled within this very request, and their record belongs to a later
+            // generation of it. Rare — kept out of the path above, which 2 of 3 iterations take.
+            if (__builtin_expect(lanes_ge(b_have ? slot : 0u, R) != 0ull, 0)) place_overflow(slot, rec);
+        }
+    }
+    __device__ __forceinline__ void place_overflow(uint32_t slot, uint32_t rec) {
+        bool over = b_have && slot >= R;
+        for (;;) {
+            slot -= over ? R : 0u;
+            if (over) rec = ctl[b_bin] >> kFillBits;  // the buffer the swap installed
+            const bool w = over && slot < R;
+            if (w) *(unsigned short*)lds_ptr(rec + 2u * slot) = (unsigned short)b_local;
+            const bool fl = w && slot == R - 1u;
+            over = over && slot >= R;
+            const unsigned long long fb = wave_ballot(fl);
+            if (!fb) break;
+            swap_full(fl, fb, b_bin, rec);
+            if (!wave_ballot(over)) break;
         }
     }
 
