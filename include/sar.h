@@ -307,7 +307,7 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *   "checkpoint_stride"  iterations between trajectory checkpoints used by the payload resolve
  *   "path"               accumulate path: 0 default (= 3 when the image fits), 1 one global atomic per
  *                        visit at agent scope, 2 the same into one scratch copy per XCD, 3 LDS-binned records
- *   "bin_shift"          log2(pixels per bin) of the binned path (12..15)
+ *   "bin_shift"          log2(pixels per bin) of the binned path (12..16; 16: the accumulate kernel counts a bin in two halves)
  *   "bin_interleave"     which pixels form a bin: 1 consecutive pixels, 2 every B-th 2048-pixel segment of the image
  *                        (B bins, a power of two: every bin carries the same share of the visits whatever the attractor
  *                        covers); 0 = 2 when the power-of-two bin count costs at most a third more bins, else 1

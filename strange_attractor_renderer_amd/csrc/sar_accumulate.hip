@@ -13,13 +13,20 @@ namespace sar {
 // whole (bin, wave) chunk lists (64-byte loads, newest chunk first) and adds the records into the
 // bin's LDS histogram with LDS atomics; the histogram is then written — plainly, fully — as copy s of
 // the scratch count bins, which k_fold_resolve sums into Runtime::count.
-template <uint32_t R, uint32_t K>
+// HALF (bins of 65536 pixels, the most a 16-bit record addresses — 4096^2 in 256 bins): two workgroups per (bin, split), each
+// reads the lists and counts the records of its half of the bin (record bit 15) in a 32768-entry histogram.
+template <uint32_t R, uint32_t K, bool HALF>
 __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     constexpr uint32_t Q = kChunkQuads(R);       // 16-byte quads per chunk
     constexpr uint32_t G = kChunkLanes(R);       // lanes that share one list: lane q of a group reads quad q
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
-    const uint32_t b = blockIdx.x, s = blockIdx.y;
-    const uint32_t bin_px = 1u << a.bin_shift;
+    // HALF: the two workgroups of a bin read the same lists — give them block numbers 8 apart, so that they run on the same
+    // XCD (workgroups go to the XCDs round-robin) at the same time and the second reader finds the chunks in that L2
+    const bool swz = HALF && (a.n_bins & 7u) == 0u;
+    const uint32_t b = !HALF ? blockIdx.x : (swz ? ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7u) : blockIdx.x >> 1);
+    const uint32_t s = blockIdx.y;
+    const uint32_t half_base = !HALF ? 0u : (swz ? (blockIdx.x >> 3) & 1u : blockIdx.x & 1u) << 15;
+    const uint32_t hist_px = HALF ? 32768u : 1u << a.bin_shift;
     const uint32_t q = threadIdx.x % G;
     const uint32_t group = threadIdx.x / G, groups = blockDim.x / G;
     // Most bins of a frame are empty (the attractor covers a band of the image): a block with no chunk at all
@@ -29,7 +36,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     for (uint32_t w = s + a.splits * threadIdx.x; w < a.n_waves; w += a.splits * blockDim.x)
         any |= a.heads[(size_t)b * a.n_waves + w] != kNoChunk;
     if (!__syncthreads_or(any)) return;
-    for (uint32_t k = threadIdx.x; k < bin_px; k += blockDim.x) hist[k] = 0u;
+    for (uint32_t k = threadIdx.x; k < hist_px; k += blockDim.x) hist[k] = 0u;
     __syncthreads();
     const uint4* arena = (const uint4*)a.arena;
     // One (bin, wave) list per group of G lanes: a chunk is ONE 16-byte load per lane and one cache line per
@@ -65,15 +72,22 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
                 // records held by this lane: lane 0 -> records 0..3 (its .z/.w), lane q -> 8q-4 .. 8q+3
                 const uint32_t first = q == 0u ? 0u : 8u * q - 4u;
                 const uint32_t r0 = q == 0u ? v[k].z : v[k].x, r1 = q == 0u ? v[k].w : v[k].y;
-                if (first < nrec) atomicAdd(&hist[r0 & 0xFFFFu], 1u);
-                if (first + 1u < nrec) atomicAdd(&hist[r0 >> 16], 1u);
-                if (first + 2u < nrec) atomicAdd(&hist[r1 & 0xFFFFu], 1u);
-                if (first + 3u < nrec) atomicAdd(&hist[r1 >> 16], 1u);
+                auto count = [&](bool valid, uint32_t rec) {  // rec: 16 bits
+                    if (HALF) {
+                        if (valid && (rec & 0x8000u) == half_base) atomicAdd(&hist[rec & 0x7FFFu], 1u);
+                    } else if (valid) {
+                        atomicAdd(&hist[rec], 1u);
+                    }
+                };
+                count(first < nrec, r0 & 0xFFFFu);
+                count(first + 1u < nrec, r0 >> 16);
+                count(first + 2u < nrec, r1 & 0xFFFFu);
+                count(first + 3u < nrec, r1 >> 16);
                 if (q != 0u) {
-                    if (first + 4u < nrec) atomicAdd(&hist[v[k].z & 0xFFFFu], 1u);
-                    if (first + 5u < nrec) atomicAdd(&hist[v[k].z >> 16], 1u);
-                    if (first + 6u < nrec) atomicAdd(&hist[v[k].w & 0xFFFFu], 1u);
-                    if (first + 7u < nrec) atomicAdd(&hist[v[k].w >> 16], 1u);
+                    count(first + 4u < nrec, v[k].z & 0xFFFFu);
+                    count(first + 5u < nrec, v[k].z >> 16);
+                    count(first + 6u < nrec, v[k].w & 0xFFFFu);
+                    count(first + 7u < nrec, v[k].w >> 16);
                 }
                 chunk[k] = prev;
             }
@@ -85,9 +99,10 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     // step of this loop (256 / 512 / 1024 threads) stays inside one such segment: its flag tells k_fold_resolve that the
     // segment has something to fold.
     uint32_t* out = a.scratch_count + (size_t)s * a.npix;
-    for (uint32_t k = threadIdx.x; k < bin_px; k += blockDim.x) {
+    for (uint32_t k = threadIdx.x; k < hist_px; k += blockDim.x) {
         const uint32_t v = hist[k];
-        const uint32_t px = (k & a.map.low_mask) | (b << a.map.seg_shift) | ((k & ~a.map.low_mask) << a.map.hi_shift);
+        const uint32_t rec = k | half_base;
+        const uint32_t px = (rec & a.map.low_mask) | (b << a.map.seg_shift) | ((rec & ~a.map.low_mask) << a.map.hi_shift);
         const bool live = v != 0u && px < a.npix;
         if (live) out[px] = v;
         if (wave_ballot(live) && (threadIdx.x & 63u) == 0u) a.seg_any[px >> 11] = 1u;  // lane 0 holds the wave's lowest pixel
@@ -219,17 +234,21 @@ __global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) {
 }
 
 int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, uint32_t lists, hipStream_t s) {
-    const size_t lds = (size_t)4u << a.bin_shift;
+    const bool half = a.bin_shift == 16u;
+    const size_t lds = (size_t)4u << (half ? 15u : a.bin_shift);
     // a list takes a group of 2, 4 or 8 lanes: 1024 threads walk 128..512 lists per block, `lists` per group at a time
     if (threads == 0) threads = 1024u;
-#define SAR_ACC(RR, KK) hipLaunchKernelGGL((k_bin_accumulate<RR, KK>), dim3(a.n_bins, a.splits), dim3(threads), lds, s, a)
-#define SAR_ACC_R(RR)                   \
-    switch (lists) {                    \
-        case 1: SAR_ACC(RR, 1u); break; \
-        case 2: SAR_ACC(RR, 2u); break; \
-        case 4: SAR_ACC(RR, 4u); break; \
-        case 8: SAR_ACC(RR, 8u); break; \
-        default: return 1;              \
+    const dim3 grid(half ? 2u * a.n_bins : a.n_bins, a.splits);
+#define SAR_ACC(RR, KK)                                                                                     \
+    if (half) hipLaunchKernelGGL((k_bin_accumulate<RR, KK, true>), grid, dim3(threads), lds, s, a);         \
+    else hipLaunchKernelGGL((k_bin_accumulate<RR, KK, false>), grid, dim3(threads), lds, s, a)
+#define SAR_ACC_R(RR)                     \
+    switch (lists) {                      \
+        case 1: { SAR_ACC(RR, 1u); } break; \
+        case 2: { SAR_ACC(RR, 2u); } break; \
+        case 4: { SAR_ACC(RR, 4u); } break; \
+        case 8: { SAR_ACC(RR, 8u); } break; \
+        default: return 1;                \
     }
     switch (records) {
         case 12: SAR_ACC_R(12u); break;
@@ -247,7 +266,8 @@ int accumulate_kernel_attributes() {
     // a bin's histogram needs more dynamic LDS than the 64 KiB default window when the bin has 32768 pixels
     hipError_t e = hipSuccess;
 #define SAR_ATTR1(RR, KK) \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)
 #define SAR_ATTR(RR) SAR_ATTR1(RR, 1u); SAR_ATTR1(RR, 2u); SAR_ATTR1(RR, 4u); SAR_ATTR1(RR, 8u)
     SAR_ATTR(12u);
     SAR_ATTR(20u);

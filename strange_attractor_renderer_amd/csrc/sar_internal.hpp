@@ -92,7 +92,8 @@ struct BinIterArgs {
 };
 
 struct BinAccArgs {
-    uint32_t bin_shift, n_bins, chunks_per_wave, n_waves;   // bin_shift: log2(pixels per bin) = LDS histogram size
+    uint32_t bin_shift, n_bins, chunks_per_wave, n_waves;   // bin_shift: log2(pixels per bin); 16: two workgroups per (bin, split),
+                                                            // one per half of the bin's pixels (the histogram holds 32768)
     uint32_t npix, splits, _pad0, _pad1;
     BinMap map;
     const void* arena;
@@ -152,6 +153,7 @@ constexpr uint32_t kDefaultChunkRecords = 28;
 constexpr double kWideHintMaxSpan2 = 11.0e6;  // (width * scale)^2 up to which 32-bit depth hints are used
 constexpr uint32_t kDefaultDepthPipe = 2;   // visits between a depth-hint load and its use in the iterate kernel  // u16 records per chunk (8-byte header): 12, 20 or 28 -> 32/48/64-byte chunks
 constexpr uint32_t kMaxBins = 1024;      // LDS staging is 64 B per bin per wave
-constexpr uint32_t kMaxBinPx = 32768;    // phase-2 LDS histogram: 4 B per pixel of the bin
+constexpr uint32_t kMaxBinPx = 65536;    // a record is 16 bits; k_bin_accumulate counts a bin of 65536 pixels in two halves
+constexpr uint32_t kMaxHistPx = 32768;   // its LDS histogram: 4 B per pixel, 128 KiB
 
 }  // namespace sar

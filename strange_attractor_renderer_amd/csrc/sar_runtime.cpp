@@ -138,7 +138,8 @@ BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift
                          uint32_t interleave) {
     BinGeometry g;
     uint32_t px = 4096;
-    while (px < kMaxBinPx && static_cast<uint64_t>(px) * 256u < npix) px <<= 1;
+    while (px < kMaxHistPx && static_cast<uint64_t>(px) * 256u < npix) px <<= 1;
+    if (static_cast<uint64_t>(px) * kMaxBins < npix) px = kMaxBinPx;  // 32..64 Mpx: bins of 65536 pixels
     if (want_shift) px = 1u << want_shift;
     g.bins = (npix + px - 1) / px;
     if (g.bins > kMaxBins) return g;
@@ -308,16 +309,19 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool, uint
     // equal work. 128 bins of 32768 pixels leave the pool stager room for 128-byte chunks at two waves per SIMD — half
     // the buffer swaps, whole cache lines for k_bin_accumulate — or for 64-byte chunks at three. (2048^2, 1e9 iterations:
     // 131072 jobs 7.0 -> 6.x ms per frame)
+    // Beyond 4 Mpx the same with bins of 65536 pixels (all a 16-bit record addresses; k_bin_accumulate counts such a bin in
+    // two halves, reading its lists twice): 4096^2 in 256 bins keeps 64-byte chunks where 512 bins allowed 32-byte ones
+    // (1.25e9 iterations there: 13.5 -> 12.3 ms; 2560^2 and 3840x2160 take 128-byte chunks on 128 such bins: -2..3 %).
     if (rt->bin_shift == 0 && rt->chunk_records == 0 && rt->stager != 1 && rt->bin_interleave != 1) {
-        const BinGeometry big = bin_geometry(rt->npix, rt->block_threads, 15u, rt->splits, 12u, true, rt->bin_interleave);
-        if (big.ok && big.interleaved) {
-            for (uint32_t cand : {60u, 28u})
-                if (lean_wave_lds_bytes(big.bins, cand, true) * want <= 160u * 1024u) {
+        for (uint32_t cand : {60u, 28u})  // the larger chunk first, the smaller bin first
+            for (uint32_t sh : {15u, 16u}) {
+                const BinGeometry big = bin_geometry(rt->npix, rt->block_threads, sh, rt->splits, 12u, true, rt->bin_interleave);
+                if (big.ok && big.interleaved && lean_wave_lds_bytes(big.bins, cand, true) * want <= 160u * 1024u) {
                     pool = true;
-                    shift = 15u;
+                    shift = sh;
                     return cand;
                 }
-        }
+            }
     }
     const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u, false, rt->bin_interleave);
     uint32_t R = rt->chunk_records, need_waves = 8;
@@ -396,11 +400,11 @@ int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_
         const uint32_t groups = threads / (pl.R == 12u ? 2u : (pl.R == 60u ? 8u : 4u));
         pl.splits = (pl.max_waves + groups - 1u) / groups;
         uint32_t cover = 2048u / pl.geo.bins;
-        if (pl.geo.shift == 15u && pl.geo.interleaved) {
+        if (pl.geo.shift >= 15u && pl.geo.interleaved) {
             // 128 KiB histograms: one workgroup per CU is resident, and with interleaved bins all of them carry the same
             // load — two rounds of workgroups over the chip, up to a few lists per lane group (measured, 2048^2: 4
             // workgroups per bin 0.85 ms, 8 or 16 1.2 ms)
-            cover = 512u / pl.geo.bins;
+            cover = 512u / (pl.geo.shift == 16u ? 2u * pl.geo.bins : pl.geo.bins);  // two workgroups per bin and split at 65536 pixels
             pl.splits = (pl.max_waves + 8u * groups - 1u) / (8u * groups);
         }
         if (pl.splits < cover) pl.splits = cover;
@@ -568,7 +572,7 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     // lists a lane group walks at the same time: with the 128 KiB histogram one workgroup per CU is resident — four loads
     // in flight per lane make up for the missing second workgroup (2048^2: 0.61 -> 0.46 ms); with two workgroups per CU
     // (64 KiB) more loads in flight change nothing
-    launch_bin_accumulate(ca, rt->acc_threads, pl.R, rt->acc_lists ? rt->acc_lists : (pl.geo.shift == 15u ? 4u : 1u), rt->stream);
+    launch_bin_accumulate(ca, rt->acc_threads, pl.R, rt->acc_lists ? rt->acc_lists : (pl.geo.shift >= 15u ? 4u : 1u), rt->stream);
     HIP_TRY(hipGetLastError());
     launch_fold_resolve(fa, rt->stream);
     span_end(rt, rt->fold_spans, rt->fold_used);
@@ -1177,7 +1181,7 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
         if (v > 3) { set_error("path must be 0..3"); return SAR_ERR_INVALID; }
         rt->bins_mode = v;
     } else if (!std::strcmp(name, "bin_shift")) {
-        if (v && (v < 12 || v > 15)) { set_error("bin_shift must be 12..15"); return SAR_ERR_INVALID; }
+        if (v && (v < 12 || v > 16)) { set_error("bin_shift must be 12..16"); return SAR_ERR_INVALID; }
         rt->bin_shift = v;
     } else if (!std::strcmp(name, "bin_interleave")) {
         if (v > 2) { set_error("bin_interleave must be 0 (automatic), 1 (consecutive-pixel bins) or 2 (interleaved bins)"); return SAR_ERR_INVALID; }

@@ -297,7 +297,7 @@ def test_device_sqrt_div_are_correctly_rounded(sar, oracle, gpu):
 @pytest.mark.parametrize("size", [(1920, 1080), (3000, 2500), (3072, 3072), (4096, 4096), (8192, 6000)])
 def test_bin_geometries(sar, oracle, gpu, size, interleave):
     """Image sizes that exercise every bin geometry of the LDS-binned path (ragged last bin, 512+ bins, bin counts that
-    are and are not powers of two, and the > 32 Mpx fallback to the atomic path), under both pixel -> (bin, record) maps:
+    are and are not powers of two, bins of 65536 pixels counted in two halves at 4096^2 and at 49 Mpx), under both pixel -> (bin, record) maps:
     bins of consecutive pixels (1) and bins dealt round-robin in 2048-pixel segments (2); 0 = the host's choice."""
     w, h = size
     jobs, n = 2048, 300
@@ -310,7 +310,7 @@ def test_bin_geometries(sar, oracle, gpu, size, interleave):
     assert_state_equal(rt, ort, f"{w}x{h} bin_interleave={interleave}")
 
 
-@pytest.mark.parametrize("bin_shift", [12, 13, 14, 15])
+@pytest.mark.parametrize("bin_shift", [12, 13, 14, 15, 16])
 @pytest.mark.parametrize("interleave", [1, 2])
 @pytest.mark.parametrize("size", [(700, 500), (64, 48), (1, 1), (2048, 3)])
 def test_bin_maps_small_and_odd_shapes(sar, oracle, gpu, size, interleave, bin_shift):
@@ -322,8 +322,8 @@ def test_bin_maps_small_and_odd_shapes(sar, oracle, gpu, size, interleave, bin_s
     cfg = _cfg(sar, "solar_sail", iterations=jobs * n, width=w, height=h, jobs_total=jobs, scale=0.9)
     st = sar.start_points(29, 0, 2 * jobs)
     rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
-    rt.set_tuning(variant=3, bin_shift=bin_shift, bin_interleave=interleave, chunk_records=60 if bin_shift == 15 else 0,
-                  stager=2 if bin_shift == 15 else 0)
+    rt.set_tuning(variant=3, bin_shift=bin_shift, bin_interleave=interleave, chunk_records=60 if bin_shift >= 15 else 0,
+                  stager=2 if bin_shift >= 15 else 0)
     for part in (st[:jobs], st[jobs:]):
         sar.render_jobs(cfg, rt, part)
         oracle.render_jobs(cfg.c, ort, part, n)
