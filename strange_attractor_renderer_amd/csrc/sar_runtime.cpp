@@ -313,15 +313,16 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool, uint
     // two halves, reading its lists twice): 4096^2 in 256 bins keeps 64-byte chunks where 512 bins allowed 32-byte ones
     // (1.25e9 iterations there: 13.5 -> 12.3 ms; 2560^2 and 3840x2160 take 128-byte chunks on 128 such bins: -2..3 %).
     if (rt->bin_shift == 0 && rt->chunk_records == 0 && rt->stager != 1 && rt->bin_interleave != 1) {
-        for (uint32_t cand : {60u, 28u})  // the larger chunk first, the smaller bin first
-            for (uint32_t sh : {15u, 16u}) {
-                const BinGeometry big = bin_geometry(rt->npix, rt->block_threads, sh, rt->splits, 12u, true, rt->bin_interleave);
-                if (big.ok && big.interleaved && lean_wave_lds_bytes(big.bins, cand, true) * want <= 160u * 1024u) {
-                    pool = true;
-                    shift = sh;
-                    return cand;
+        for (uint64_t need : {want, static_cast<uint64_t>(8)})  // three waves per SIMD if the launch has the jobs, else two
+            for (uint32_t cand : {60u, 28u})                      // the larger chunk first, the smaller bin first
+                for (uint32_t sh : {15u, 16u}) {
+                    const BinGeometry big = bin_geometry(rt->npix, rt->block_threads, sh, rt->splits, 12u, true, rt->bin_interleave);
+                    if (big.ok && big.interleaved && lean_wave_lds_bytes(big.bins, cand, true) * need <= 160u * 1024u) {
+                        pool = true;
+                        shift = sh;
+                        return cand;
+                    }
                 }
-            }
     }
     const BinGeometry probe = bin_geometry(rt->npix, rt->block_threads, rt->bin_shift, rt->splits, 12u, false, rt->bin_interleave);
     uint32_t R = rt->chunk_records, need_waves = 8;
