@@ -293,8 +293,9 @@ struct LaunchPlan {
 // Also picks the stager: the pool stager (sar_iterate.hip: full buffers swapped against spares, cooperative copy-out;
 // 3-4 % faster where it fits) needs a little more LDS per wave — it is used when it keeps the waves per CU the classic
 // stager reaches with the same chunk size.
-uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool, uint32_t& shift) {
+uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool, uint32_t& shift, uint32_t& interleave) {
     shift = rt->bin_shift;
+    interleave = rt->bin_interleave;
     if (rt->active_pending && hipEventQuery(rt->active_copied) == hipSuccess) {
         rt->active_pending = false;
         if (rt->active_jobs_launched) rt->survivor_fraction = static_cast<double>(*rt->h_active) / rt->active_jobs_launched;
@@ -316,10 +317,12 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool, uint
         for (uint64_t need : {want, static_cast<uint64_t>(8)})  // three waves per SIMD if the launch has the jobs, else two
             for (uint32_t cand : {60u, 28u})                      // the larger chunk first, the smaller bin first
                 for (uint32_t sh : {15u, 16u}) {
-                    const BinGeometry big = bin_geometry(rt->npix, rt->block_threads, sh, rt->splits, 12u, true, rt->bin_interleave);
+                    // interleaved whatever the power-of-two bin count costs: the staging is checked to fit right here
+                    const BinGeometry big = bin_geometry(rt->npix, rt->block_threads, sh, rt->splits, 12u, true, 2u);
                     if (big.ok && big.interleaved && lean_wave_lds_bytes(big.bins, cand, true) * need <= 160u * 1024u) {
                         pool = true;
                         shift = sh;
+                        interleave = 2u;
                         return cand;
                     }
                 }
@@ -345,9 +348,9 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool, uint
 }
 
 int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, LaunchPlan& pl) {
-    uint32_t shift = 0;
-    pl.R = choose_chunk_records(rt, n_jobs, pl.pool, shift);
-    pl.geo = bin_geometry(rt->npix, rt->block_threads, shift, rt->splits, pl.R, pl.pool, rt->bin_interleave);
+    uint32_t shift = 0, interleave = 0;
+    pl.R = choose_chunk_records(rt, n_jobs, pl.pool, shift, interleave);
+    pl.geo = bin_geometry(rt->npix, rt->block_threads, shift, rt->splits, pl.R, pl.pool, interleave);
     // which accumulate path: LDS-binned records (default) or one global atomic per visit
     pl.binned = (rt->bins_mode == 0 || rt->bins_mode == 3) && rt->measure_mode != 2 && pl.geo.ok;
     if (rt->bins_mode == 3 && !pl.geo.ok) {
