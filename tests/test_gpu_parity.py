@@ -330,6 +330,24 @@ def test_bin_maps_small_and_odd_shapes(sar, oracle, gpu, size, interleave, bin_s
     assert_state_equal(rt, ort, f"{w}x{h} bin_shift={bin_shift} bin_interleave={interleave}")
 
 
+@pytest.mark.parametrize("stager", [1, 2])
+@pytest.mark.parametrize("records", [12, 20, 28])
+@pytest.mark.parametrize("acc_lists", [1, 4])
+def test_two_half_accumulate_with_every_chunk_size(sar, oracle, gpu, records, stager, acc_lists):
+    """Bins of 65536 pixels (k_bin_accumulate counts them in two halves, the records' top bit) under both stagers and the
+    small chunk sizes, on an image of 5 such bins whose last one is ragged, interleaved (8 bins) and not."""
+    w, h = 640, 480
+    jobs, n = 1500, 500
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=w, height=h, jobs_total=jobs)
+    st = sar.start_points(37, 0, jobs)
+    for interleave in (1, 2):
+        rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
+        rt.set_tuning(variant=3, bin_shift=16, chunk_records=records, stager=stager, acc_lists=acc_lists, bin_interleave=interleave)
+        sar.render_jobs(cfg, rt, st)
+        oracle.render_jobs(cfg.c, ort, st, n)
+        assert_state_equal(rt, ort, f"records={records} stager={stager} acc_lists={acc_lists} bin_interleave={interleave}")
+
+
 @pytest.mark.parametrize("preset", ["poisson_saturne", "solar_sail"])
 def test_ragged_job_count_both_presets_both_kinds(sar, oracle, gpu, preset):
     """A job count that leaves a ragged last workgroup, NaN-absorbing trajectories (solar_sail) and both render
