@@ -787,6 +787,133 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_iterate_split — the hot loop cut in two by FUNCTION: a producer wave and a consumer wave per 64 trajectories
+// ---------------------------------------------------------------------------------------------------
+// k_iterate_lean keeps two waves per SIMD resident (the staging buffers fill the LDS), and each wave alternates between a
+// long run of dependent fp64 arithmetic and a short run of LDS / memory round trips: a quarter of the time both waves of a
+// SIMD wait. Here a workgroup is TWO waves for one set of 64 trajectories: wave 0 runs the map and the projection —
+// arithmetic only, it never waits for memory — and hands {pixel, depth} of every visit to wave 1 through 1 KiB of LDS
+// (double-buffered, one s_barrier per iteration); wave 1 owns the staging buffers and does what k_iterate_lean's stager
+// does. The LDS holds the same eight staging sets per CU, but the SIMD now has four waves to pick from, two of which are
+// always ready to issue arithmetic. Same arithmetic, same visit order, same records.
+template <bool DEPTH, uint32_t R, uint32_t U, typename H>
+__global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool producer = threadIdx.x < 64u;  // wave-uniform
+    const uint32_t wave = blockIdx.x;          // one set of 64 trajectories per workgroup
+    const uint32_t slot = wave * 64u + lane;
+    const uint32_t active = *a.active;
+    if (wave * 64u >= active) {  // nothing left for this workgroup: publish empty lists
+        if (!producer)
+            for (uint32_t b = lane; b < a.n_bins; b += 64u) a.heads[(size_t)b * a.n_waves + wave] = kNoChunk;
+        return;
+    }
+    bool alive = slot < active;
+    const uint32_t job = alive ? a.joblist[slot] : 0u;
+    const uint32_t n = (uint32_t)a.it.iters;
+    // visits in flight between the two waves: [2 phases][U visits][64 lanes] {pixel index or ~0 (no visit), depth as f32 bits};
+    // a phase is U iterations (the consumer's depth pipeline pass), one s_barrier per phase
+    uint2* hand = (uint2*)((char*)smem + kPoolWaveLds(a.n_bins, R));
+    const uint32_t n_full = n - n % U;  // whole phases; the last n % U iterations form a short one
+    if (producer) {
+        MapParams p = a.it.p;
+        pin_map_params(p);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) p.cy[k] = vgpr_pin(p.cy[k]);
+        double x = 0., y = 0., z = 0.;
+        if (alive) {  // the point after the warm-up (:750-752), from k_warmup
+            x = a.warm[slot];
+            y = a.warm[a.it.n_jobs + slot];
+            z = a.warm[2u * a.it.n_jobs + slot];
+        }
+        const uint32_t C = a.it.ckpt_stride;  // a multiple of U (the host rounds it)
+        const size_t cs = a.it.n_jobs;
+        double* ck = a.it.ckpt + job;
+        uint32_t t = 0;
+        auto checkpoint = [&]() {  // as in k_iterate_lean: the state BEFORE iteration t; NaN is looked for here
+            const bool ended = alive && x != x;
+            if (wave_ballot(ended)) {
+                if (ended) atomicAdd(a.nan_count, (unsigned long long)(n - t));
+                alive = alive && !ended;
+            }
+            if (alive) {
+                __builtin_nontemporal_store(x, ck);
+                __builtin_nontemporal_store(y, ck + cs);
+                __builtin_nontemporal_store(z, ck + 2 * cs);
+            }
+            ck += 3 * cs;
+        };
+        auto produce = [&](uint2* dst) {
+            bool inb;
+            uint32_t idx;
+            float zf;
+            iterate_once(p, a.it.width, x, y, z, inb, idx, zf);
+            inb = inb && alive;
+            *dst = make_uint2(inb ? idx : 0xFFFFFFFFu, __float_as_uint(zf));
+            ++t;
+        };
+        uint32_t phase = 0;
+        while (t < n_full) {
+            checkpoint();
+            const uint32_t tend = (n_full - t > C) ? t + C : n_full;
+            while (t < tend) {
+                uint2* dst = hand + (phase & 1u) * (U * 64u) + lane;
+#pragma unroll
+                for (uint32_t k = 0; k < U; ++k) produce(dst + k * 64u);
+                // the visits are in LDS before the consumer is let past the barrier
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                ++phase;
+            }
+        }
+        if (t < n) {  // the last n % U iterations of the job
+            if (t % C == 0u) checkpoint();
+            uint2* dst = hand + (phase & 1u) * (U * 64u) + lane;
+#pragma unroll
+            for (uint32_t k = 0; k + 1 < U; ++k)
+                if (t < n) produce(dst + k * 64u);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (a.warm_out && slot < active) {
+            a.warm_out[slot] = x;
+            a.warm_out[a.it.n_jobs + slot] = y;
+            a.warm_out[2u * a.it.n_jobs + slot] = z;
+        }
+    } else {
+        PoolStager<DEPTH, R, U, H> st;
+        st.init((char*)smem, a.n_bins, lane, (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkStride(R),
+                (H*)a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n);
+        uint32_t t = 0, phase = 0;
+        while (t < n_full) {
+            // phase `phase` is in its half of `hand`; the producer writes that half again after the NEXT barrier
+            asm volatile("s_barrier" ::: "memory");
+            const uint2* src = hand + (phase & 1u) * (U * 64u) + lane;
+            uint2 v[U];
+#pragma unroll
+            for (uint32_t k = 0; k < U; ++k) v[k] = src[k * 64u];
+#pragma unroll
+            for (uint32_t k = 0; k < U; ++k) {
+                st.step(k, v[k].x != 0xFFFFFFFFu, v[k].x, __uint_as_float(v[k].y), t);
+                ++t;
+            }
+            ++phase;
+        }
+        if (t < n) {
+            asm volatile("s_barrier" ::: "memory");
+            const uint2* src = hand + (phase & 1u) * (U * 64u) + lane;
+#pragma unroll
+            for (uint32_t k = 0; k + 1 < U; ++k)
+                if (t < n) {
+                    const uint2 v = src[k * 64u];
+                    st.step(k, v.x != 0xFFFFFFFFu, v.x, __uint_as_float(v.y), t);
+                    ++t;
+                }
+        }
+        st.finish(a.heads, a.n_waves, wave, a.nan_count);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k_extent — the "first pass" the reference leaves as a TODO (src/lib.rs:326-333): bounds of the attractor in screen
 // space (what the comment at :329-333 lists) and in raw coordinates. One trajectory per lane: 1000 warm-up
 // iterations, then `iters` iterations with 12 running bounds in registers; a bound moves through `<` / `>` only, so NaN
@@ -889,7 +1016,15 @@ uint32_t chunk_bytes(uint32_t records) { return kChunkStride(records) * 16u; }
     X(false, 60u, 1u, unsigned short)
 
 int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
-                        bool pool, hipStream_t s) {
+                        bool pool, bool split, hipStream_t s) {
+    if (split) {  // producer / consumer wave pairs: one workgroup of 128 threads per launched wave (a.n_waves of them)
+        const size_t lds2 = lean_wave_lds_bytes(a.n_bins, records, true) + 2048u;  // + the visits in flight
+        if (!pool || !depth || records != 60u) return 1;
+        if (pipe == 2 && hint_bytes == 4) hipLaunchKernelGGL((k_iterate_split<true, 60u, 2u, uint32_t>), dim3(a.n_waves), dim3(128), lds2, s, a);
+        else if (pipe == 2 && hint_bytes == 2) hipLaunchKernelGGL((k_iterate_split<true, 60u, 2u, unsigned short>), dim3(a.n_waves), dim3(128), lds2, s, a);
+        else return 1;
+        return 0;
+    }
     const uint32_t grid = (a.it.n_jobs + block - 1) / block;
     const size_t lds = (size_t)(block / 64u) * lean_wave_lds_bytes(a.n_bins, records, pool);
     if (!depth) {
@@ -927,6 +1062,8 @@ int iterate_kernel_attributes() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU, HH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SAR_FOR_EACH_LEAN_POOL(SAR_ATTR_LEAN_POOL)
 #undef SAR_ATTR_LEAN_POOL
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_split<true, 60u, 2u, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_split<true, 60u, 2u, unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return (int)e;
 }
 

@@ -15,7 +15,7 @@ uint32_t chunk_bytes(uint32_t records);
 // hint_bytes: 2 (16-bit fixed-point hints) or 4 (sortable f32 hints)
 // pool: PoolStager (full buffers swapped against spares, cooperative copy-out) instead of Stager
 int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
-                        bool pool, hipStream_t s);
+                        bool pool, bool split, hipStream_t s);
 int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, uint32_t lists, hipStream_t s);
 int iterate_kernel_attributes();     // sar_iterate.hip
 int accumulate_kernel_attributes();  // sar_accumulate.hip

@@ -552,7 +552,9 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     }
     span_end(rt, rt->warm_spans, rt->warm_used);
     span_begin(rt, rt->iter_spans, rt->iter_used);
-    if (launch_iterate_lean(ba, pl.block, pl.R, pl.pipe, pl.hint_bytes, mode == 2, pl.pool, rt->stream) != 0) {
+    const bool split = rt->split_waves == 2 && pl.pool && pl.R == 60u && mode == 2 && pl.pipe == 2 &&
+                       (lean_wave_lds_bytes(pl.geo.bins, pl.R, true) + 2048u) * 8u <= 160u * 1024u;
+    if (launch_iterate_lean(ba, pl.block, pl.R, pl.pipe, pl.hint_bytes, mode == 2, pl.pool, split, rt->stream) != 0) {
         set_error("bad chunk_records / depth_pipe");
         return SAR_ERR_INVALID;
     }
@@ -740,6 +742,7 @@ int sar_runtime_new(const sar_config* cfg, int device, sar_runtime** out) {
     if (!rt) return SAR_ERR_OOM;
     rt->device = device;
     if (const char* e = std::getenv("SAR_STAGER")) rt->stager = (e[0] == '1') ? 1u : (e[0] == '2' ? 2u : 0u);  // test / A-B hook
+    if (const char* e = std::getenv("SAR_SPLIT")) rt->split_waves = (e[0] == '2') ? 2u : (e[0] == '1' ? 1u : 0u);  // test / A-B hook
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) rt->sm_count = static_cast<uint32_t>(prop.multiProcessorCount);
     int st = SAR_OK;
@@ -1205,6 +1208,9 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "depth_pipe")) {
         if (v > 2) { set_error("depth_pipe must be 1 or 2"); return SAR_ERR_INVALID; }
         rt->depth_pipe = v;
+    } else if (!std::strcmp(name, "split_waves")) {
+        if (v > 2) { set_error("split_waves must be 0, 1 or 2"); return SAR_ERR_INVALID; }
+        rt->split_waves = v;
     } else if (!std::strcmp(name, "acc_lists")) {
         if (v && v != 1 && v != 2 && v != 4 && v != 8) { set_error("acc_lists must be 1, 2, 4 or 8"); return SAR_ERR_INVALID; }
         rt->acc_lists = v;
