@@ -317,6 +317,9 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *   "stager"             how the iterate kernel copies full staging buffers out: 1 the lane that filled one copies it,
  *                        2 full buffers are swapped against spares and the whole wave copies them out in batches
  *                        (needs slightly more LDS); 0 = 2 where it keeps the waves per CU, else 1
+ *   "split_waves"        the iterate kernel as producer / consumer wave pairs (one wave runs the map, its partner stages the
+ *                        visits): 1 never, 2 wherever the kernel exists (pool stager, 64- or 128-byte chunks); 0 = 2 for
+ *                        launches whose jobs are all resident at once (512 per CU), 1 for larger ones
  *   "hint_bits"          per-XCD depth hints of the iterate kernel: 16 (fixed point) or 32 (sortable f32); 0 = by image size
  *   "depth_pipe"         visits between a depth-hint (or depth-key) load and its use in the iterate kernel: 1 or 2 (default 2)
  *   "acc_threads"        threads per block of the record-accumulate kernel (256, 512, 1024)

@@ -796,8 +796,10 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
 // (double-buffered, one s_barrier per iteration); wave 1 owns the staging buffers and does what k_iterate_lean's stager
 // does. The LDS holds the same eight staging sets per CU, but the SIMD now has four waves to pick from, two of which are
 // always ready to issue arithmetic. Same arithmetic, same visit order, same records.
-template <bool DEPTH, uint32_t R, uint32_t U, typename H>
+// PH = iterations per barrier phase: U (2 KiB of visits in flight) or 1 (1 KiB, where the staging leaves no more).
+template <bool DEPTH, uint32_t R, uint32_t U, typename H, uint32_t PH>
 __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
+    static_assert(PH == 1u || PH == U, "a phase is one iteration or one pass of the depth pipeline");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const bool producer = threadIdx.x < 64u;  // wave-uniform
@@ -812,8 +814,8 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
     bool alive = slot < active;
     const uint32_t job = alive ? a.joblist[slot] : 0u;
     const uint32_t n = (uint32_t)a.it.iters;
-    // visits in flight between the two waves: [2 phases][U visits][64 lanes] {pixel index or ~0 (no visit), depth as f32 bits};
-    // a phase is U iterations (the consumer's depth pipeline pass), one s_barrier per phase
+    // visits in flight between the two waves: [2 phases][PH visits][64 lanes] {pixel index or ~0 (no visit), depth as f32 bits};
+    // one s_barrier per phase
     uint2* hand = (uint2*)((char*)smem + kPoolWaveLds(a.n_bins, R));
     const uint32_t n_full = n - n % U;  // whole phases; the last n % U iterations form a short one
     if (producer) {
@@ -858,21 +860,26 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
             checkpoint();
             const uint32_t tend = (n_full - t > C) ? t + C : n_full;
             while (t < tend) {
-                uint2* dst = hand + (phase & 1u) * (U * 64u) + lane;
 #pragma unroll
-                for (uint32_t k = 0; k < U; ++k) produce(dst + k * 64u);
-                // the visits are in LDS before the consumer is let past the barrier
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                ++phase;
+                for (uint32_t h = 0; h < U / PH; ++h) {
+                    uint2* dst = hand + (phase & 1u) * (PH * 64u) + lane;
+#pragma unroll
+                    for (uint32_t k = 0; k < PH; ++k) produce(dst + k * 64u);
+                    // the visits are in LDS before the consumer is let past the barrier
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    ++phase;
+                }
             }
         }
         if (t < n) {  // the last n % U iterations of the job
             if (t % C == 0u) checkpoint();
-            uint2* dst = hand + (phase & 1u) * (U * 64u) + lane;
 #pragma unroll
-            for (uint32_t k = 0; k + 1 < U; ++k)
-                if (t < n) produce(dst + k * 64u);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            for (uint32_t k = 0; k + 1 < U; ++k)  // one iteration per phase here, whatever PH
+                if (t < n) {
+                    produce(hand + (phase & 1u) * (PH * 64u) + lane);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    ++phase;
+                }
         }
         if (a.warm_out && slot < active) {
             a.warm_out[slot] = x;
@@ -885,30 +892,31 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
                 (H*)a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n);
         uint32_t t = 0, phase = 0;
         while (t < n_full) {
-            // phase `phase` is in its half of `hand`; the producer writes that half again after the NEXT barrier
-            asm volatile("s_barrier" ::: "memory");
-            const uint2* src = hand + (phase & 1u) * (U * 64u) + lane;
-            uint2 v[U];
 #pragma unroll
-            for (uint32_t k = 0; k < U; ++k) v[k] = src[k * 64u];
+            for (uint32_t h = 0; h < U / PH; ++h) {
+                // phase `phase` is in its half of `hand`; the producer writes that half again after the NEXT barrier
+                asm volatile("s_barrier" ::: "memory");
+                const uint2* src = hand + (phase & 1u) * (PH * 64u) + lane;
+                uint2 v[PH];
 #pragma unroll
-            for (uint32_t k = 0; k < U; ++k) {
-                st.step(k, v[k].x != 0xFFFFFFFFu, v[k].x, __uint_as_float(v[k].y), t);
-                ++t;
-            }
-            ++phase;
-        }
-        if (t < n) {
-            asm volatile("s_barrier" ::: "memory");
-            const uint2* src = hand + (phase & 1u) * (U * 64u) + lane;
+                for (uint32_t k = 0; k < PH; ++k) v[k] = src[k * 64u];
 #pragma unroll
-            for (uint32_t k = 0; k + 1 < U; ++k)
-                if (t < n) {
-                    const uint2 v = src[k * 64u];
-                    st.step(k, v.x != 0xFFFFFFFFu, v.x, __uint_as_float(v.y), t);
+                for (uint32_t k = 0; k < PH; ++k) {
+                    st.step(h * PH + k, v[k].x != 0xFFFFFFFFu, v[k].x, __uint_as_float(v[k].y), t);
                     ++t;
                 }
+                ++phase;
+            }
         }
+#pragma unroll
+        for (uint32_t k = 0; k + 1 < U; ++k)
+            if (t < n) {
+                asm volatile("s_barrier" ::: "memory");
+                const uint2 v = hand[(phase & 1u) * (PH * 64u) + lane];
+                st.step(k, v.x != 0xFFFFFFFFu, v.x, __uint_as_float(v.y), t);
+                ++t;
+                ++phase;
+            }
         st.finish(a.heads, a.n_waves, wave, a.nan_count);
     }
 }
@@ -1018,11 +1026,21 @@ uint32_t chunk_bytes(uint32_t records) { return kChunkStride(records) * 16u; }
 int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
                         bool pool, bool split, hipStream_t s) {
     if (split) {  // producer / consumer wave pairs: one workgroup of 128 threads per launched wave (a.n_waves of them)
-        const size_t lds2 = lean_wave_lds_bytes(a.n_bins, records, true) + 2048u;  // + the visits in flight
-        if (!pool || !depth || records != 60u) return 1;
-        if (pipe == 2 && hint_bytes == 4) hipLaunchKernelGGL((k_iterate_split<true, 60u, 2u, uint32_t>), dim3(a.n_waves), dim3(128), lds2, s, a);
-        else if (pipe == 2 && hint_bytes == 2) hipLaunchKernelGGL((k_iterate_split<true, 60u, 2u, unsigned short>), dim3(a.n_waves), dim3(128), lds2, s, a);
+        if (!pool || !depth || pipe != 2u) return 1;
+        const uint32_t stage = lean_wave_lds_bytes(a.n_bins, records, true);
+        const uint32_t ph = (stage + 2048u) * 8u <= 160u * 1024u ? 2u : 1u;  // visits in flight: two iterations if they fit
+        const size_t lds2 = stage + ph * 1024u;
+#define SAR_SPLIT(RR, HH, PP) hipLaunchKernelGGL((k_iterate_split<true, RR, 2u, HH, PP>), dim3(a.n_waves), dim3(128), lds2, s, a)
+#define SAR_SPLIT_R(RR)                                                                                        \
+    if (hint_bytes == 4 && ph == 2) SAR_SPLIT(RR, uint32_t, 2u);                                               \
+    else if (hint_bytes == 4) SAR_SPLIT(RR, uint32_t, 1u);                                                     \
+    else if (ph == 2) SAR_SPLIT(RR, unsigned short, 2u);                                                       \
+    else SAR_SPLIT(RR, unsigned short, 1u)
+        if (records == 60u) { SAR_SPLIT_R(60u); }
+        else if (records == 28u) { SAR_SPLIT_R(28u); }
         else return 1;
+#undef SAR_SPLIT_R
+#undef SAR_SPLIT
         return 0;
     }
     const uint32_t grid = (a.it.n_jobs + block - 1) / block;
@@ -1062,8 +1080,11 @@ int iterate_kernel_attributes() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU, HH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SAR_FOR_EACH_LEAN_POOL(SAR_ATTR_LEAN_POOL)
 #undef SAR_ATTR_LEAN_POOL
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_split<true, 60u, 2u, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_split<true, 60u, 2u, unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define SAR_ATTR_SPLIT(RR, HH, PP) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_split<true, RR, 2u, HH, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    SAR_ATTR_SPLIT(60u, uint32_t, 2u) SAR_ATTR_SPLIT(60u, uint32_t, 1u) SAR_ATTR_SPLIT(60u, unsigned short, 2u) SAR_ATTR_SPLIT(60u, unsigned short, 1u)
+    SAR_ATTR_SPLIT(28u, uint32_t, 2u) SAR_ATTR_SPLIT(28u, uint32_t, 1u) SAR_ATTR_SPLIT(28u, unsigned short, 2u) SAR_ATTR_SPLIT(28u, unsigned short, 1u)
+#undef SAR_ATTR_SPLIT
     return (int)e;
 }
 

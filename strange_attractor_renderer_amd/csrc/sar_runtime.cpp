@@ -274,6 +274,8 @@ int grow_device(T*& ptr, size_t& cap, size_t need) {
 // scratch inside kCkptBytesCap).
 struct LaunchPlan {
     bool binned = false, xcd_local = false, pool = false;
+    bool split = false;                 // the iterate kernel as producer / consumer wave pairs (k_iterate_split)
+    uint64_t resident_jobs = 0;         // trajectories resident at once under this plan: launch chunks are whole rounds of them
     BinGeometry geo;
     uint32_t R = kDefaultChunkRecords;  // records per chunk
     uint32_t block = 0;                 // trajectories per workgroup of the iterate kernel
@@ -293,7 +295,8 @@ struct LaunchPlan {
 // Also picks the stager: the pool stager (sar_iterate.hip: full buffers swapped against spares, cooperative copy-out;
 // 3-4 % faster where it fits) needs a little more LDS per wave — it is used when it keeps the waves per CU the classic
 // stager reaches with the same chunk size.
-uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool, uint32_t& shift, uint32_t& interleave) {
+uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool, uint32_t& shift, uint32_t& interleave, bool& split,
+                              uint64_t& resident_jobs) {
     shift = rt->bin_shift;
     interleave = rt->bin_interleave;
     if (rt->active_pending && hipEventQuery(rt->active_copied) == hipSuccess) {
@@ -305,6 +308,18 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool, uint
     uint64_t want = (busy + 64u * cus - 1) / (64u * cus);  // waves per CU if all surviving jobs were resident
     want = ((want + 3) / 4) * 4;  // workgroups are four waves: residency comes in steps of four waves per CU
     want = want < 8 ? 8 : (want > 12 ? 12 : want);
+    // k_iterate_split (producer / consumer wave pairs) keeps 8 staging sets per CU busy with 16 waves: for launches whose
+    // jobs are all resident at once (512 per CU). A launch of several rounds of workgroups desynchronises by itself —
+    // workgroups of different rounds are in different phases — and the whole kernel is the faster one there (configs[3] on
+    // one GPU, 8 rounds: 81.7 against 89.9 ms).
+    {
+        const uint64_t cap = 512u * cus;
+        const bool fills = busy <= cap;
+        split = rt->split_waves == 2 || (rt->split_waves == 0 && fills);
+        if (rt->measure_mode || rt->stager == 1 || (rt->depth_pipe && rt->depth_pipe != 2)) split = false;
+        if (split) want = 8;
+    }
+    resident_jobs = 64u * cus * want;  // trajectories the chip holds at once under this plan
     // Interleaved bins carry equal loads, so few LARGE bins cost the slot requests nothing (with bins of consecutive
     // pixels half the bins idle and the rest collide) and k_bin_accumulate's 128 KiB histograms (one workgroup per CU) get
     // equal work. 128 bins of 32768 pixels leave the pool stager room for 128-byte chunks at two waves per SIMD — half
@@ -349,7 +364,7 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool, uint
 
 int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, LaunchPlan& pl) {
     uint32_t shift = 0, interleave = 0;
-    pl.R = choose_chunk_records(rt, n_jobs, pl.pool, shift, interleave);
+    pl.R = choose_chunk_records(rt, n_jobs, pl.pool, shift, interleave, pl.split, pl.resident_jobs);
     pl.geo = bin_geometry(rt->npix, rt->block_threads, shift, rt->splits, pl.R, pl.pool, interleave);
     // which accumulate path: LDS-binned records (default) or one global atomic per visit
     pl.binned = (rt->bins_mode == 0 || rt->bins_mode == 3) && rt->measure_mode != 2 && pl.geo.ok;
@@ -393,6 +408,8 @@ int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_
     if (pl.binned && scratch_bytes(1) > kCkptBytesCap) pl.binned = false;  // one job alone overflows the arena cap: atomics path
     if (rt->debug_chunk_jobs && rt->debug_chunk_jobs < pl.chunk_jobs) pl.chunk_jobs = rt->debug_chunk_jobs;
     if (pl.chunk_jobs > pl.block) pl.chunk_jobs -= pl.chunk_jobs % pl.block;
+    // a launch that needs several rounds of resident workgroups: whole rounds, so that no round runs half empty
+    if (pl.binned && pl.resident_jobs && pl.chunk_jobs > pl.resident_jobs && !rt->debug_chunk_jobs) pl.chunk_jobs -= pl.chunk_jobs % pl.resident_jobs;
     pl.chunks_per_wave = chunks_per_wave_of(pl.chunk_jobs);
     pl.max_waves = static_cast<uint32_t>(((pl.chunk_jobs + pl.block - 1) / pl.block) * (pl.block / 64u));
     pl.arena_waves = static_cast<uint32_t>((pl.chunk_jobs + 63) / 64);  // waves that hold a job (the others exit at once)
@@ -552,8 +569,8 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     }
     span_end(rt, rt->warm_spans, rt->warm_used);
     span_begin(rt, rt->iter_spans, rt->iter_used);
-    const bool split = rt->split_waves == 2 && pl.pool && pl.R == 60u && mode == 2 && pl.pipe == 2 &&
-                       (lean_wave_lds_bytes(pl.geo.bins, pl.R, true) + 2048u) * 8u <= 160u * 1024u;
+    const bool split = pl.split && pl.pool && (pl.R == 60u || pl.R == 28u) && mode == 2 && pl.pipe == 2 &&
+                       (lean_wave_lds_bytes(pl.geo.bins, pl.R, true) + 1024u) * 8u <= 160u * 1024u;
     if (launch_iterate_lean(ba, pl.block, pl.R, pl.pipe, pl.hint_bytes, mode == 2, pl.pool, split, rt->stream) != 0) {
         set_error("bad chunk_records / depth_pipe");
         return SAR_ERR_INVALID;

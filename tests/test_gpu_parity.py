@@ -440,12 +440,14 @@ def test_attractor_extent_bit_exact(sar, oracle, gpu, preset):
 
 @pytest.mark.parametrize("stager", [1, 2])
 @pytest.mark.parametrize("records", [12, 20, 28, 60])
-@pytest.mark.parametrize("splits,acc_threads,pipe,hint_bits,interleave,acc_lists",
-                         [(0, 0, 0, 0, 0, 0), (1, 256, 1, 16, 1, 2), (5, 512, 2, 16, 2, 4), (16, 1024, 1, 32, 1, 1), (3, 1024, 2, 32, 2, 2)])
+@pytest.mark.parametrize("splits,acc_threads,pipe,hint_bits,interleave,acc_lists,split_waves",
+                         [(0, 0, 0, 0, 0, 0, 0), (1, 256, 1, 16, 1, 2, 1), (5, 512, 2, 16, 2, 4, 2), (16, 1024, 1, 32, 1, 1, 2),
+                          (3, 1024, 2, 32, 2, 2, 1), (2, 1024, 2, 32, 2, 4, 2)])
 def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, splits, acc_threads, pipe, hint_bits, interleave, acc_lists,
-                                                     stager):
+                                                     split_waves, stager):
     """Every chunk size of the binned path (32 / 48-on-64 / 64 / 128-byte chunks: different lane-group shapes in
-    k_bin_accumulate; the 128-byte chunk exists for the pool stager only) with several accumulate grids, against the
+    k_bin_accumulate; the 128-byte chunk exists for the pool stager only), the iterate kernel whole (split_waves 1) and as
+    producer / consumer wave pairs (2: 64- and 128-byte chunks of the pool stager), with several accumulate grids, against the
     oracle; enough records per (bin, wave) list to chain many chunks and to overflow staging buffers within one slot
     request (all trajectories start close together)."""
     if records == 60 and stager == 1:
@@ -456,11 +458,11 @@ def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, 
     st[:512] = st[0] + np.arange(512)[:, None] * 1e-13  # near-identical trajectories: many lanes hit one bin at once
     rt, ort = sar.Runtime(cfg), oracle.Runtime(256, 192)
     rt.set_tuning(variant=3, chunk_records=records, splits=splits, acc_threads=acc_threads, depth_pipe=pipe, hint_bits=hint_bits,
-                  stager=stager, bin_interleave=interleave, acc_lists=acc_lists)
+                  stager=stager, bin_interleave=interleave, acc_lists=acc_lists, split_waves=split_waves)
     sar.render_jobs(cfg, rt, st)
     oracle.render_jobs(cfg.c, ort, st, n)
     assert_state_equal(rt, ort, f"records={records} splits={splits} acc_threads={acc_threads} depth_pipe={pipe} hint_bits={hint_bits} stager={stager} "
-                               f"bin_interleave={interleave} acc_lists={acc_lists}")
+                               f"bin_interleave={interleave} acc_lists={acc_lists} split_waves={split_waves}")
 
 
 @pytest.mark.parametrize("seed", range(32))
