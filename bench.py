@@ -50,7 +50,7 @@ def pmc_traffic_bytes():
         return None
     try:
         d = json.load(open(files[-1]))
-        d = d.get("k_iterate_lean") or d["k_iterate_binned"]
+        d = d.get("k_iterate_split") or d.get("k_iterate_lean") or d["k_iterate_binned"]
         return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
     except Exception:
         return None
@@ -329,7 +329,10 @@ def main():
     counted = n * total_jobs * a.steps
     value = counted / elapsed
     if rank == 0:
-        kern_s = iter_ms * 1e-3 / max(launches, 1)             # average duration of one k_iterate_lean launch
+        kern_s = iter_ms * 1e-3 / max(launches, 1)             # average duration of one launch of the iterate kernel
+        # launches whose jobs are all resident at once (512 per CU) run it as producer / consumer wave pairs
+        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        iterate_kernel = "k_iterate_split" if jobs <= 512 * cus and not a.variant else "k_iterate_lean"
         per_launch = n * jobs * a.steps / max(launches, 1)      # counted iterations one launch processes
         ach = ALG_BYTES_PER_ITER * per_launch / kern_s / 1e9
         out = {
@@ -356,7 +359,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic_bytes() if (a.config == "c2" and int(a.iters) == ITERS_PER_GPU and jobs == DEFAULT_JOBS) else None,
-                         "kernel": "k_iterate_lean", "kernel_ms": kern_s * 1e3,
+                         "kernel": iterate_kernel, "kernel_ms": kern_s * 1e3,
                          "alg_bytes_per_iteration": ALG_BYTES_PER_ITER,
                          "launches_timed": launches,
                          "valu_frac": FP64_OPS_PER_ITER * per_launch / kern_s / FP64_PEAK_OPS,

@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if "k_iterate" in r["Kernel_Name"]]
     if d:
-        print("`k_iterate_lean` per dispatch (ms): " + ", ".join(f"{x:.3f}" for x in d) +
+        print("the iterate kernel per dispatch (ms): " + ", ".join(f"{x:.3f}" for x in d) +
               f" — the first dispatch is bench.py's warm-up step (cold caches, first-touch of the arena); mean of the timed "
               f"ones {sum(d[1:]) / max(len(d) - 1, 1):.3f} ms, which is what bench.py's HIP events average.\n")
 try:
@@ -51,7 +51,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     for k, cs in agg.items():
         if not any(t in k for t in ("k_iterate", "k_bin_accumulate", "k_fold", "k_colorize")):
             continue
-        short = next(t for t in ("k_iterate_lean", "k_iterate_binned", "k_iterate", "k_bin_accumulate", "k_fold_resolve", "k_colorize_gas", "k_colorize") if t in k)
+        short = next(t for t in ("k_iterate_split", "k_iterate_lean", "k_iterate_binned", "k_iterate", "k_bin_accumulate", "k_fold_resolve", "k_colorize_gas", "k_colorize") if t in k)
         for c, v in cs.items():
             print(f"| `{k[:48]}` | {c} | {len(v)} | {sum(v)/len(v):.6g} |")
             pmc_json.setdefault(short, {})[c] = sum(v) / len(v)
