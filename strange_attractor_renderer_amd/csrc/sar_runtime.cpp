@@ -319,7 +319,8 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, bool& pool, uint
         if (rt->measure_mode || rt->stager == 1 || (rt->depth_pipe && rt->depth_pipe != 2)) split = false;
         if (split) want = 8;
     }
-    resident_jobs = 64u * cus * want;  // trajectories the chip holds at once under this plan
+    // jobs (dead ones included: they are launched and dropped by the warm-up) whose survivors the chip holds at once
+    resident_jobs = static_cast<uint64_t>(64.0 * cus * want / (rt->survivor_fraction > 0.05 ? rt->survivor_fraction : 0.05));
     // Interleaved bins carry equal loads, so few LARGE bins cost the slot requests nothing (with bins of consecutive
     // pixels half the bins idle and the rest collide) and k_bin_accumulate's 128 KiB histograms (one workgroup per CU) get
     // equal work. 128 bins of 32768 pixels leave the pool stager room for 128-byte chunks at two waves per SIMD — half
