@@ -409,8 +409,10 @@ int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_
     if (pl.binned && scratch_bytes(1) > kCkptBytesCap) pl.binned = false;  // one job alone overflows the arena cap: atomics path
     if (rt->debug_chunk_jobs && rt->debug_chunk_jobs < pl.chunk_jobs) pl.chunk_jobs = rt->debug_chunk_jobs;
     if (pl.chunk_jobs > pl.block) pl.chunk_jobs -= pl.chunk_jobs % pl.block;
-    // a launch that needs several rounds of resident workgroups: whole rounds, so that no round runs half empty
-    if (pl.binned && pl.resident_jobs && pl.chunk_jobs > pl.resident_jobs && !rt->debug_chunk_jobs) pl.chunk_jobs -= pl.chunk_jobs % pl.resident_jobs;
+    // jobs that need several launches anyway (the 2^32 visit ordinals, the scratch cap): launches of whole rounds of resident
+    // workgroups, so that no launch ends on a nearly empty round. (Jobs that fit ONE launch stay one launch: its rounds overlap.)
+    if (pl.binned && pl.resident_jobs && n_jobs > pl.chunk_jobs && pl.chunk_jobs > pl.resident_jobs && !rt->debug_chunk_jobs)
+        pl.chunk_jobs -= pl.chunk_jobs % pl.resident_jobs;
     pl.chunks_per_wave = chunks_per_wave_of(pl.chunk_jobs);
     pl.max_waves = static_cast<uint32_t>(((pl.chunk_jobs + pl.block - 1) / pl.block) * (pl.block / 64u));
     pl.arena_waves = static_cast<uint32_t>((pl.chunk_jobs + 63) / 64);  // waves that hold a job (the others exit at once)
