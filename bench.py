@@ -30,9 +30,9 @@ sys.path.insert(0, ROOT)
 WIDTH = HEIGHT = 2048
 ITERS_PER_GPU = 1_000_000_000
 DEFAULT_JOBS = 131072            # trajectories per GPU (2 waves per SIMD on 256 CUs); n = floor(1e9 / jobs)
-# BASELINE configs[3]. SURVEY 8d sketched 524 288 jobs (65 536 per GPU at 8 GPUs) — but 65 536 trajectories are ONE wave per
-# SIMD, and the iterate kernel needs two to hide its latencies (4096^2, 1.25e9 iterations: 17.7 ms with 65 536 jobs, 11.3 ms
-# with 131 072). A strong-scaling frame must be the same frame at every N, so it is cut into 1 048 576 jobs (131 072 per GPU
+# BASELINE configs[3]. SURVEY 8d sketched 524 288 jobs (65 536 per GPU at 8 GPUs) — but 65 536 trajectories are one per lane
+# of the chip and no more, and the iterate kernel wants two per lane to hide its latencies (4096^2, 1.25e9 iterations: 14.2 ms
+# with 65 536 jobs, 11.9 ms with 131 072). A strong-scaling frame must be the same frame at every N, so it is cut into 1 048 576 jobs (131 072 per GPU
 # at 8): n = 9536 iterations per job. `--jobs 524288` reproduces SURVEY's split.
 C4_SIZE, C4_ITERS, C4_JOBS = 4096, 10_000_000_000, 1048576
 ALG_BYTES_PER_ITER = 12.0 + 12.0 * 0.0055   # count RMW 8 B + zbuf read 4 B + win-rate * 12 B
