@@ -170,4 +170,5 @@ extern "C" {
     pub fn sar_runtime_enable_timing(rt: *mut SarRuntime, enabled: c_int) -> c_int;
     pub fn sar_runtime_last_timing(rt: *mut SarRuntime, out: *mut SarTiming) -> c_int;
     pub fn sar_runtime_set_option(rt: *mut SarRuntime, name: *const c_char, value: u64) -> c_int;
+    pub fn sar_bin_geometry(width: u32, height: u32, bin_shift: u32, bin_interleave: u32, out: *mut u32) -> c_int;
 }

@@ -330,6 +330,13 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *   "debug_chunk_jobs"   test hook: cap on jobs per launch chunk
  *   "debug_max_ordinals" test hook: visits one launch may order (default 2^32-2); jobs with more iterations run as segments */
 int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value);
+/* Diagnostic (host arithmetic only, no device needed): the pixel -> (bin, 16-bit record) map the LDS-binned path uses for
+ * a width x height image with "bin_shift" / "bin_interleave" as given (0 = the defaults of a runtime without forced
+ * options and 131072 jobs). out = {ok, bins, bin_shift, interleaved, seg_shift, bin_bits, hi_shift, low_mask}:
+ *   bin = (idx >> seg_shift) & ((1 << bin_bits) - 1);  record = (idx & low_mask) | ((idx >> hi_shift) & ~low_mask)
+ *   idx = (record & low_mask) | (bin << seg_shift) | ((record & ~low_mask) << hi_shift)
+ * ok = 0: the image has no binned geometry (the one-atomic-per-visit path renders it). */
+int sar_bin_geometry(uint32_t width, uint32_t height, uint32_t bin_shift, uint32_t bin_interleave, uint32_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -152,6 +152,7 @@ PROTOTYPES = {
     "sar_runtime_enable_timing": (C.c_int, [_vp, C.c_int]),
     "sar_runtime_last_timing": (C.c_int, [_vp, _P(SarTiming)]),
     "sar_runtime_set_option": (C.c_int, [_vp, C.c_char_p, C.c_uint64]),
+    "sar_bin_geometry": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32)]),
 }
 
 LIB_NAME = "libsar_hip.so"

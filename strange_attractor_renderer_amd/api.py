@@ -285,6 +285,14 @@ def exchange_slice_pixels(npix: int, world: int) -> int:
     return int(s.value)
 
 
+def bin_geometry(width: int, height: int, bin_shift: int = 0, bin_interleave: int = 0) -> dict:
+    """The pixel -> (bin, record) map of the LDS-binned path for this image shape (host arithmetic, no device needed)."""
+    out = (C.c_uint32 * 8)()
+    _check(_lib().sar_bin_geometry(width, height, bin_shift, bin_interleave, out), "sar_bin_geometry")
+    keys = ("ok", "bins", "bin_shift", "interleaved", "seg_shift", "bin_bits", "hi_shift", "low_mask")
+    return dict(zip(keys, (int(v) for v in out)))
+
+
 def colorize_range_device(config: Config, runtime: Runtime, first_px: int, n_px: int, rgba_dev_ptr: int):
     """colorize of a pixel range with the max / depth range the runtime's scalars hold (n_px*8 bytes out); stream-ordered."""
     _check(_lib().sar_colorize_range_device(C.byref(config.c), runtime.handle, first_px, n_px, C.c_void_p(rgba_dev_ptr)),

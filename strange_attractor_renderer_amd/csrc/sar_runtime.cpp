@@ -1092,6 +1092,35 @@ int sar_runtime_exchange_import(sar_runtime* rt, const void* key_i64_reduced_dev
     return SAR_OK;
 }
 
+int sar_bin_geometry(uint32_t width, uint32_t height, uint32_t bin_shift, uint32_t bin_interleave, uint32_t out[8]) {
+    if (!out || width == 0 || height == 0 || (bin_shift && (bin_shift < 12 || bin_shift > 16)) || bin_interleave > 2) return SAR_ERR_INVALID;
+    const uint64_t npix64 = static_cast<uint64_t>(width) * height;
+    if (npix64 > 0xFFFFFFFFull) return SAR_ERR_RANGE;
+    BinGeometry g;
+    if (bin_shift == 0 && bin_interleave == 0) {  // what choose_chunk_records picks for a launch that wants two waves per SIMD
+        bool found = false;
+        for (uint32_t cand : {60u, 28u}) {
+            for (uint32_t sh : {15u, 16u}) {
+                g = bin_geometry(static_cast<uint32_t>(npix64), 256u, sh, 0u, 12u, true, 2u);
+                if (g.ok && g.interleaved && lean_wave_lds_bytes(g.bins, cand, true) * 8u <= 160u * 1024u) { found = true; break; }
+            }
+            if (found) break;
+        }
+        if (!found) g = bin_geometry(static_cast<uint32_t>(npix64), 256u, 0u, 0u, 12u, false, 0u);
+    } else {
+        g = bin_geometry(static_cast<uint32_t>(npix64), 256u, bin_shift, 0u, 12u, false, bin_interleave);
+    }
+    out[0] = g.ok ? 1u : 0u;
+    out[1] = g.bins;
+    out[2] = g.shift;
+    out[3] = g.interleaved ? 1u : 0u;
+    out[4] = g.map.seg_shift;
+    out[5] = g.map.bin_bits;
+    out[6] = g.map.hi_shift;
+    out[7] = g.map.low_mask;
+    return SAR_OK;
+}
+
 // ---- sliced exchange (all-to-all of pixel slices; see include/sar.h) ---------------------------------------
 
 int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice_pixels) {

@@ -206,3 +206,38 @@ def test_rust_safe_layer_calls_only_what_the_sys_crate_declares():
     for item in ("pub struct GpuRuntime", "pub struct GpuRenderer", "pub fn render<", "pub fn colorize<", "pub fn render_parallel<",
                  "impl Drop for GpuRuntime", "impl Drop for GpuRenderer", "pub fn check(", "pub fn new_multi("):
         assert item in safe_rs, item
+
+
+@pytest.mark.parametrize("size", [(2048, 2048), (1800, 2000), (1920, 1080), (2560, 2560), (3072, 3072), (3840, 2160), (4096, 4096),
+                                  (8192, 8192), (700, 500), (64, 48), (1, 1), (2048, 3), (8192, 6000), (9000, 9000)])
+@pytest.mark.parametrize("bin_shift,interleave", [(0, 0), (12, 2), (14, 1), (14, 2), (15, 2), (16, 1), (16, 2)])
+def test_bin_map_is_a_bijection_onto_bins_and_records(sar, size, bin_shift, interleave):
+    """The pixel -> (bin, 16-bit record) map of the LDS-binned path (host arithmetic behind sar_bin_geometry, the same
+    BinGeometry the launches use): every pixel gets a bin below the bin count and a record below the bin's size, the
+    inverse formula of k_bin_accumulate / k_fold_resolve gives the pixel back, no two pixels share (bin, record), and with
+    interleaved bins every bin gets the same number of 2048-pixel segments (+-1). Images without a binned geometry
+    (too many bins) say so."""
+    w, h = size
+    g = sar.bin_geometry(w, h, bin_shift, interleave)
+    npix = w * h
+    if not g["ok"]:
+        assert (npix + (1 << g["bin_shift"]) - 1) >> g["bin_shift"] > 1024 or g["bins"] > 1024
+        return
+    assert 12 <= g["bin_shift"] <= 16 and 1 <= g["bins"] <= 1024
+    step = max(1, npix // 3_000_000)  # every pixel of the small shapes, a dense sample (plus the edges) of the 64-Mpx ones
+    idx = np.unique(np.concatenate([np.arange(0, npix, step, dtype=np.int64), np.arange(max(0, npix - 70000), npix, dtype=np.int64),
+                                    np.arange(0, min(npix, 70000), dtype=np.int64)]))
+    low, seg, hi, bits = g["low_mask"], g["seg_shift"], g["hi_shift"], g["bin_bits"]
+    b = (idx >> seg) & ((1 << bits) - 1)
+    rec = (idx & low) | ((idx >> hi) & ~np.int64(low) & 0xFFFFFFFF)
+    assert b.max() < g["bins"] and rec.max() < (1 << g["bin_shift"]) and rec.max() < 65536
+    back = (rec & low) | (b << seg) | ((rec & ~np.int64(low)) << hi)
+    np.testing.assert_array_equal(back, idx)
+    if step == 1:
+        key = b * 65536 + rec
+        assert np.unique(key).size == idx.size
+        if g["interleaved"] and npix >= 2048 * g["bins"]:
+            segs = np.bincount(((np.arange(0, npix, 2048) >> seg) & ((1 << bits) - 1)).astype(np.int64), minlength=g["bins"])
+            assert segs.max() - segs.min() <= 1
+    if bin_shift == 0 and interleave == 0 and npix <= 16 << 20:
+        assert g["interleaved"], "every shape up to 4096^2 gets interleaved bins by default"
