@@ -4,7 +4,7 @@ import math
 
 import numpy as np
 
-CASES = ("c2_131072", "c2_65536", "c3_solar_depth", "c4_rank5_share", "c5_frame37")
+CASES = ("c2_131072", "c2_65536", "c3_solar_depth", "c4_rank5_share", "c4_all_jobs", "c5_frame37")
 
 
 def frame_seed(seed: int, k: int) -> int:   # strange_attractor_renderer_amd.sequence.frame_seed, restated
@@ -31,6 +31,11 @@ def build_case(name: str, O):
         cfg = O.poisson_saturne()
         cfg.width = cfg.height = 4096
         return _fin(cfg, jobs, n), O.start_points(3, 5 * jobs, jobs), n
+    if name == "c4_all_jobs":                      # configs[3]'s whole job list on ONE GPU (bench.py --config c4: 1 048 576 jobs,
+        jobs, n = 1048576, 953                     # 8 rounds of resident workgroups in a launch), 1e9 iterations instead of 1e10
+        cfg = O.poisson_saturne()
+        cfg.width = cfg.height = 4096
+        return _fin(cfg, jobs, n), O.start_points(3, 0, jobs), n
     if name == "c5_frame37":                       # configs[4]: frame 37 of the 360-frame solar-sail sweep, 1e8 iterations
         units, jpt, k = 16384, 12, 37              # (CLI defaults: 12 jobs per thread, scale 1, Gas)
         jobs = units * jpt
