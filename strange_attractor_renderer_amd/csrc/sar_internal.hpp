@@ -81,12 +81,14 @@ struct BinIterArgs {
     uint32_t n_waves;            // launched waves (= heads stride)
     void* arena;                 // [n_waves][chunks_per_wave] chunks {prev, n, R x u16}, R = 12 / 20 / 28
     uint32_t* heads;             // [n_bins][n_waves] last chunk of each (bin, wave) list, or kNoChunk
-    void* zhint;                 // [8][npix(+1)] per-XCD depth hints: u16 fixed point (depth_q16) or u32 sortable f32
+    void* zhint;                 // [8][npix(+1)] per-XCD depth hints: u16 fixed point (depth_q16) or the depth itself as f32 bits
     // k_warmup's output: the trajectories that are still finite after the warm-up, packed densely
     const double* warm;          // [3][n_jobs] SoA by packed slot: the point after 1000 warm-up iterations
     const uint32_t* joblist;     // [n_jobs] job index (within this launch chunk) of every packed slot
     const uint32_t* active;      // number of packed slots
     unsigned long long* nan_count;  // iterations of diverged (NaN) trajectories: all land on pixel (0,0)
+    const uint32_t* hint_range;  // nullable: {~sortable(min z), sortable(max z)} of the view, from k_warmup: the range the narrow
+                                 // depth hints quantise (fixed from the first launch after the hints were cleared)
     double* warm_out;            // nullable: the state after the last iteration, by packed slot (== warm: the next segment of
                                  // jobs with more than 2^32-2 iterations starts from it, without a warm-up)
 };

@@ -175,21 +175,29 @@ struct DepthPipe {
     H* zhint;
     unsigned long long* key;
     uint32_t lo_base;
-    bool pv[U];           // stage-1 candidate, waiting for its hint
-    uint32_t p_idx[U], p_zkey[U], p_lo[U], p_hint[U], p_q[U], n_sent;
+    HintQuant hq;         // narrow hints: the quantiser (wave-uniform)
+    // Stage-1 slot of a visit that waits for its hint. Per visit only what the filter itself needs is computed: the wide
+    // hint is the f32 depth itself and stage 1 is ONE float compare (the hints start at the largest float below -1.0, so
+    // `z >= hint` is the reference's strict `z > -1.0` while nobody has been there, and NaN fails); the sortable key, the
+    // visit ordinal and the -0.0 fix are only formed for the ~1 % that pass. (Round 2 formed all of them for every visit:
+    // six vector instructions on the consumer wave of k_iterate_split, which is that kernel's critical path.)
+    bool pv[U];           // wide hints: the visit exists; narrow hints: it is a candidate (z > -1)
+    uint32_t p_idx[U], p_zf[U], p_hint[U], p_q[U], n_sent;
+    uint32_t p_t[U];      // wave-uniform: the visit's iteration
     bool gv[U];           // stage-2 candidate, waiting for the chip-wide key
     uint32_t g_idx[U], g_q[U];
     unsigned long long g_mine[U], g_cur[U];
 
-    __device__ __forceinline__ void depth_init(H* zhint_, unsigned long long* key_, uint32_t lo_base_) {
+    __device__ __forceinline__ void depth_init(H* zhint_, unsigned long long* key_, uint32_t lo_base_, const uint32_t* hint_range_) {
         zhint = zhint_;
         key = key_;
         lo_base = lo_base_;
+        hq = hint_quant(kWide ? nullptr : hint_range_);
         n_sent = 0;
 #pragma unroll
         for (uint32_t k = 0; k < U; ++k) {
             pv[k] = gv[k] = false;
-            p_idx[k] = p_zkey[k] = p_lo[k] = p_hint[k] = p_q[k] = 0;
+            p_idx[k] = p_zf[k] = p_hint[k] = p_q[k] = p_t[k] = 0;
             g_idx[k] = g_q[k] = 0;
             g_mine[k] = g_cur[k] = 0;
         }
@@ -208,32 +216,49 @@ struct DepthPipe {
                 ++n_sent;
             }
             const uint32_t seen = (uint32_t)(g_cur[k] >> 32);  // 0 while nobody has sent this pixel
-            const uint32_t qs = kWide ? seen : (seen ? depth_q16(sortable_f32(seen)) : 0u);
-            zhint[g_idx[k]] = (H)(qs > g_q[k] ? qs : g_q[k]);
+            uint32_t learnt;
+            if (kWide) {  // the hint is the depth as f32: the larger of this visit's and the chip-wide best
+                const float mine = __uint_as_float(g_q[k]), theirs = sortable_f32(seen);
+                learnt = (seen && theirs > mine) ? __float_as_uint(theirs) : g_q[k];
+            } else {
+                const uint32_t qs = seen ? depth_q16(sortable_f32(seen), hq) : 0u;
+                learnt = qs > g_q[k] ? qs : g_q[k];
+            }
+            zhint[g_idx[k]] = (H)learnt;
         }
         // p_hint is the raw dword holding this pixel's hint and its neighbour's: it is unpacked only HERE, U visits
         // after the load was issued. (Unpacking next to the load makes the compiler wait for the load right there.)
-        const uint32_t hint = kWide ? p_hint[k] : ((p_idx[k] & 1u) ? (p_hint[k] >> 16) : (p_hint[k] & 0xFFFFu));
-        gv[k] = pv[k] && p_q[k] >= hint;
+        if (kWide) {
+            gv[k] = pv[k] && __uint_as_float(p_zf[k]) >= __uint_as_float(p_hint[k]);
+        } else {
+            const uint32_t hint = (p_idx[k] & 1u) ? (p_hint[k] >> 16) : (p_hint[k] & 0xFFFFu);
+            gv[k] = pv[k] && p_q[k] >= hint;
+        }
         if (gv[k]) {
+            const float zc = __uint_as_float(p_zf[k]) + 0.0f;  // -0.0 -> +0.0: integer order == float order
             g_idx[k] = p_idx[k];
-            g_q[k] = p_q[k];
-            g_mine[k] = ((unsigned long long)p_zkey[k] << 32) | (unsigned long long)p_lo[k];
+            g_q[k] = kWide ? __float_as_uint(zc) : p_q[k];
+            // visit ordinal = job*n + t; the key's low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a tie
+            g_mine[k] = ((unsigned long long)f32_sortable(zc) << 32) | (unsigned long long)(lo_base - p_t[k]);
             g_cur[k] = __hip_atomic_load(key + p_idx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 
-    // Settles the candidate of visit t - U (its hint was requested U whole steps ago) and files this visit's: strict `>`
-    // against the initial -1.0 (:693, :821); NaN fails. Returns whether this visit is a candidate.
+    // Settles the candidate of visit t - U (its hint was requested U whole steps ago) and files this visit's. Returns
+    // whether the hint of this visit's pixel is wanted.
     __device__ __forceinline__ bool depth_candidate(uint32_t k, bool inb, uint32_t idx, float zf, uint32_t t) {
         if (!DEPTH) return false;
         settle_depth(k);
-        const bool cand = inb && zf > -1.0f;
-        const float zc = zf + 0.0f;  // -0.0 -> +0.0: integer order == float order
-        p_zkey[k] = f32_sortable(zc);
-        p_q[k] = kWide ? p_zkey[k] : depth_q16(zc);
         p_idx[k] = idx;
-        p_lo[k] = lo_base - t;
+        p_zf[k] = __float_as_uint(zf);
+        p_t[k] = t;
+        if (kWide) {
+            pv[k] = inb;  // z > -1 is what stage 1's compare against the hint says (:693, :821)
+            return inb;
+        }
+        // strict `>` against the initial -1.0 (:693, :821); NaN fails
+        const bool cand = inb && zf > -1.0f;
+        p_q[k] = depth_q16(zf + 0.0f, hq);
         pv[k] = cand;
         return cand;
     }
@@ -300,7 +325,7 @@ struct Stager : DepthPipe<DEPTH, U, H> {
     uint2 fpend[R / 4u];
 
     __device__ __forceinline__ void init(char* wbase, uint32_t bins, uint32_t lane_, uint4* arena_, H* zhint_,
-                                         unsigned long long* key_, const BinMap& map_, uint32_t lo_base_) {
+                                         unsigned long long* key_, const BinMap& map_, uint32_t lo_base_, const uint32_t* hint_range_) {
         n_bins = bins;
         lane = lane_;
         rec = (unsigned short*)wbase;
@@ -312,7 +337,7 @@ struct Stager : DepthPipe<DEPTH, U, H> {
         dummy = bins + lane;
         arena = arena_;
         cursor = 0;
-        depth_init(zhint_, key_, lo_base_);
+        depth_init(zhint_, key_, lo_base_, hint_range_);
         map = map_;
         bin_bits_v = map_.bin_bits;
         asm volatile("" : "+v"(bin_bits_v));  // stays in a VGPR: v_bfe_u32 takes one scalar operand, the field offset
@@ -495,12 +520,23 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
     uint32_t bin_bits_v;  // map.bin_bits, held in a vector register
     bool b_have;          // previous visit, waiting for its LDS slot
     uint32_t b_bin, b_old, b_local;
+#ifdef SAR_EXPERIMENT_PROF
+    // timing experiment (k_iterate_split's consumer wave): wave-cycles per segment, see Stager::mark
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0;
+    __device__ __forceinline__ void mark(int i) {
+        asm volatile("" ::: "memory");
+        const unsigned long long now = __builtin_readcyclecounter();
+        asm volatile("" ::: "memory");
+        prof[i] += now - prof_last;
+        prof_last = now;
+    }
+#endif
 
     static __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
     static __device__ __forceinline__ char* lds_ptr(uint32_t a) { return (char*)(__attribute__((address_space(3))) char*)(uintptr_t)a; }
 
     __device__ __forceinline__ void init(char* wbase, uint32_t bins, uint32_t lane_, uint4* arena_, H* zhint_,
-                                         unsigned long long* key_, const BinMap& map_, uint32_t lo_base_) {
+                                         unsigned long long* key_, const BinMap& map_, uint32_t lo_base_, const uint32_t* hint_range_) {
         n_bins = bins;
         lane = lane_;
         // layout: buffers (bins + P) * CB | ctl bins | ring P (lanes without a visit are masked off, not redirected)
@@ -515,7 +551,7 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         if (lane < P) ring[lane] = pool0 + (bins + lane) * CB;
         arena = arena_;
         cursor = drained = 0;
-        depth_init(zhint_, key_, lo_base_);
+        depth_init(zhint_, key_, lo_base_, hint_range_);
         map = map_;
         bin_bits_v = map_.bin_bits;
         asm volatile("" : "+v"(bin_bits_v));  // stays in a VGPR: v_bfe_u32 takes one scalar operand, the field offset
@@ -572,10 +608,10 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         uint32_t rec = b_old >> kFillBits;
         const bool w0 = b_have && slot < R;
         if (w0) *(unsigned short*)lds_ptr(rec + 2u * slot) = (unsigned short)b_local;
-        // lanes that took the last slot: the mask comes straight from one compare (lanes without a visit compare ~0)
-        const uint32_t slot_m = b_have ? slot : 0xFFFFFFFFu;
-        bool fl = slot_m == R - 1u;
-        unsigned long long fb = lanes_eq(slot_m, R - 1u);
+        // lanes that took the last slot: the mask comes straight from one compare, the lanes without a visit drop out of it
+        // in the scalar unit
+        const unsigned long long fb = lanes_eq(slot, R - 1u) & wave_ballot(b_have);
+        const bool fl = b_have && slot == R - 1u;
         if (fb) {
             swap_full(fl, fb, b_bin, rec);
             // Lanes whose slot lies beyond the buffer: it filled within this very request, and their record belongs to a later
@@ -602,13 +638,16 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
     __device__ __forceinline__ void step(uint32_t k, bool inb, uint32_t idx, float zf, uint32_t t) {
         __builtin_amdgcn_s_setprio(3);  // as in Stager::step
         place_visit();
+        SAR_MARK(2);
         const bool cand = depth_candidate(k, inb, idx, zf, t);
+        SAR_MARK(3);
         b_have = inb;
         b_bin = __builtin_amdgcn_ubfe(idx, map.seg_shift, bin_bits_v);
         b_local = bfi(map.low_mask, idx, idx >> map.hi_shift);
         if (inb) b_old = atomicAdd(&ctl[b_bin], 1u);  // ds_add_rtn_u32: slot and buffer in one word
         depth_request(k, cand, idx);
         __builtin_amdgcn_s_setprio(0);
+        SAR_MARK(4);
     }
 
     __device__ __forceinline__ void finish(uint32_t* heads, uint32_t n_waves, uint32_t wave, unsigned long long* stats) {
@@ -647,9 +686,11 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
 // job never occupies a lane of the hot kernel. The packed order depends on which wave's atomic lands first; results
 // do not (the visit ordinal is formed from the job index, which travels in `joblist`).
 // ---------------------------------------------------------------------------------------------------
+constexpr int kWarmupRangeIters = 64;  // the last warm-up iterations whose depths k_warmup looks at for the hint quantiser
 __global__ void __launch_bounds__(256) k_warmup(const MapParams pin, const double* __restrict__ starts, uint32_t n_jobs,
                                                 uint64_t iters, double* __restrict__ warm, uint32_t* __restrict__ joblist,
-                                                uint32_t* active, unsigned long long* nan_count) {
+                                                uint32_t* active, unsigned long long* nan_count, uint32_t width,
+                                                uint32_t* hint_range) {
     const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = job < n_jobs;
     MapParams p = pin;
@@ -659,7 +700,32 @@ __global__ void __launch_bounds__(256) k_warmup(const MapParams pin, const doubl
         x = starts[job];
         y = starts[n_jobs + job];
         z = starts[2u * n_jobs + job];
-        for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);
+        if (!hint_range) {
+            for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);
+        } else {
+            // the same 1000 iterations; the last ones also project the point and note the depth of every visit that could
+            // win a depth test (in bounds, z > -1): the range the narrow depth hints quantise (HintQuant)
+            for (int w = 0; w < 1000 - kWarmupRangeIters; ++w) next_point(p, x, y, z);
+            float zlo = __builtin_inff(), zhi = -__builtin_inff();
+            for (int w = 0; w < kWarmupRangeIters; ++w) {
+                bool inb;
+                uint32_t idx;
+                float zf;
+                iterate_once(p, width, x, y, z, inb, idx, zf);
+                if (inb && zf > -1.0f) {
+                    zlo = fminf(zlo, zf);
+                    zhi = fmaxf(zhi, zf);
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                zlo = fminf(zlo, __shfl_down(zlo, off));
+                zhi = fmaxf(zhi, __shfl_down(zhi, off));
+            }
+            if ((threadIdx.x & 63u) == 0u && zhi >= zlo) {
+                atomicMax(hint_range, ~f32_sortable(zlo + 0.0f));
+                atomicMax(hint_range + 1, f32_sortable(zhi + 0.0f));
+            }
+        }
     }
     const bool live = valid && x == x;
     const unsigned long long lm = wave_ballot(live), dm = wave_ballot(valid && !live);
@@ -701,7 +767,7 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     // low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie
     st.init((char*)smem + (threadIdx.x >> 6) * (POOL ? kPoolWaveLds(a.n_bins, R) : kLeanWaveLds(a.n_bins, R)), a.n_bins, lane,
             (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkStride(R),
-            (H*)a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n);
+            (H*)a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n, a.hint_range);
 
     MapParams p = a.it.p;
     pin_map_params(p);
@@ -776,7 +842,7 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     }
 #ifdef SAR_EXPERIMENT_PROF
     if (lane == 0)
-        for (int i = 0; i < 4; ++i) atomicAdd(a.nan_count + 2 + i, st.prof[i]);
+        for (int i = 0; i < 4; ++i) atomicAdd(a.nan_count + 2 + i, st.prof[(POOL && i) ? i + 1 : i]);  // PoolStager marks 0, 2, 3, 4
 #endif
     if (a.warm_out && slot < active) {  // the next segment of a > 2^32-2-iteration job starts here (a NaN state stays NaN
         a.warm_out[slot] = x;           // and is found again by that segment's first checkpoint)
@@ -856,6 +922,12 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
             ++t;
         };
         uint32_t phase = 0;
+#ifdef SAR_EXPERIMENT_PROF  // wave-cycles of the producer: [0] map + projection + hand-over write, [1] waiting at the barrier
+        unsigned long long pp[2] = {0, 0}, pl = __builtin_readcyclecounter();
+#define SAR_PMARK(i) do { asm volatile("" ::: "memory"); const unsigned long long now_ = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); pp[i] += now_ - pl; pl = now_; } while (0)
+#else
+#define SAR_PMARK(i)
+#endif
         while (t < n_full) {
             checkpoint();
             const uint32_t tend = (n_full - t > C) ? t + C : n_full;
@@ -866,11 +938,17 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
 #pragma unroll
                     for (uint32_t k = 0; k < PH; ++k) produce(dst + k * 64u);
                     // the visits are in LDS before the consumer is let past the barrier
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    SAR_PMARK(0);
+                    asm volatile("s_barrier" ::: "memory");
+                    SAR_PMARK(1);
                     ++phase;
                 }
             }
         }
+#ifdef SAR_EXPERIMENT_PROF
+        if (lane == 0) { atomicAdd(a.nan_count + 6, pp[0]); atomicAdd(a.nan_count + 7, pp[1]); }
+#endif
         if (t < n) {  // the last n % U iterations of the job
             if (t % C == 0u) checkpoint();
 #pragma unroll
@@ -889,17 +967,28 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
     } else {
         PoolStager<DEPTH, R, U, H> st;
         st.init((char*)smem, a.n_bins, lane, (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkStride(R),
-                (H*)a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n);
+                (H*)a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n, a.hint_range);
         uint32_t t = 0, phase = 0;
+#ifdef SAR_EXPERIMENT_PROF  // wave-cycles of the consumer: [0] barrier, [1] hand-over read, [2] place_visit, [3] depth, [4] requests
+        st.prof_last = __builtin_readcyclecounter();
+#endif
         while (t < n_full) {
 #pragma unroll
             for (uint32_t h = 0; h < U / PH; ++h) {
                 // phase `phase` is in its half of `hand`; the producer writes that half again after the NEXT barrier
                 asm volatile("s_barrier" ::: "memory");
+#ifdef SAR_EXPERIMENT_PROF
+                st.mark(0);
+#endif
                 const uint2* src = hand + (phase & 1u) * (PH * 64u) + lane;
                 uint2 v[PH];
 #pragma unroll
                 for (uint32_t k = 0; k < PH; ++k) v[k] = src[k * 64u];
+#ifdef SAR_EXPERIMENT_PROF
+#pragma unroll
+                for (uint32_t k = 0; k < PH; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y));
+                st.mark(1);
+#endif
 #pragma unroll
                 for (uint32_t k = 0; k < PH; ++k) {
                     st.step(h * PH + k, v[k].x != 0xFFFFFFFFu, v[k].x, __uint_as_float(v[k].y), t);
@@ -917,6 +1006,10 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
                 ++t;
                 ++phase;
             }
+#ifdef SAR_EXPERIMENT_PROF
+        if (lane == 0)
+            for (int i = 0; i < 5; ++i) atomicAdd(a.nan_count + 8 + i, st.prof[i]);
+#endif
         st.finish(a.heads, a.n_waves, wave, a.nan_count);
     }
 }
@@ -1109,9 +1202,9 @@ void launch_dead_jobs(const uint32_t* active, uint32_t n_jobs, uint64_t iters, u
 }
 
 void launch_warmup(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* warm, uint32_t* joblist,
-                   uint32_t* active, unsigned long long* nan_count, hipStream_t s) {
+                   uint32_t* active, unsigned long long* nan_count, uint32_t width, uint32_t* hint_range, hipStream_t s) {
     hipLaunchKernelGGL(k_warmup, dim3((n_jobs + 255u) / 256u), dim3(256), 0, s, p, starts, n_jobs, iters, warm, joblist, active,
-                       nan_count);
+                       nan_count, width, hint_range);
 }
 
 }  // namespace sar

@@ -46,7 +46,7 @@ int launch_convert(const void* rgba16, int format, void* out, uint32_t npix, hip
 uint32_t launch_extent(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* out, hipStream_t s);
 void launch_starts_soa(const double* aos, double* soa, uint32_t m, hipStream_t s);
 void launch_warmup(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* warm, uint32_t* joblist,
-                   uint32_t* active, unsigned long long* nan_count, hipStream_t s);
+                   uint32_t* active, unsigned long long* nan_count, uint32_t width, uint32_t* hint_range, hipStream_t s);
 void launch_dead_jobs(const uint32_t* active, uint32_t n_jobs, uint64_t iters, unsigned long long* nan_count, hipStream_t s);
 void launch_exch_export(const unsigned long long* key, uint32_t rank, void* out, uint32_t npix, hipStream_t s);
 void launch_exch_select(const uint32_t* count, const unsigned long long* key, const double* steps, uint32_t rank,

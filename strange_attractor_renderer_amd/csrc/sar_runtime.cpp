@@ -173,7 +173,13 @@ BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift
 
 int clear_hints(sar_runtime* rt) {
     // hints are lower bounds of depths already accumulated; anything that can lower zbuf voids them
-    if (rt->d_zhint) HIP_TRY(hipMemsetAsync(rt->d_zhint, 0, (static_cast<size_t>(rt->npix) + 2u) * 8u * rt->zhint_bytes, rt->stream));
+    // Wide hints hold the depth itself as f32 and start at the largest float below -1.0: stage 1's `z >= hint` is then the
+    // reference's strict `z > -1.0` (:693, :821) for a pixel nobody has reached. Narrow hints are 16-bit fixed point from 0.
+    if (rt->d_zhint && rt->zhint_bytes == 4)
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(rt->d_zhint), static_cast<int>(0xBF7FFFFFu), (static_cast<size_t>(rt->npix) + 2u) * 8u, rt->stream));
+    else if (rt->d_zhint)
+        HIP_TRY(hipMemsetAsync(rt->d_zhint, 0, (static_cast<size_t>(rt->npix) + 2u) * 8u * rt->zhint_bytes, rt->stream));
+    rt->hint_range_set = false;  // empty hints: the next launch may measure the view's depth range anew
     return SAR_OK;
 }
 
@@ -527,10 +533,15 @@ int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
         *rt->h_active = 0;
         HIP_TRY(hipEventCreateWithFlags(&rt->active_copied, hipEventDisableTiming));
     }
+    if (!rt->d_hint_range) {
+        HIP_TRY(hipMalloc(&rt->d_hint_range, 2 * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(rt->d_hint_range, 0, 2 * sizeof(uint32_t), rt->stream));
+    }
     if (!rt->d_nan_count) {
         // [0] NaN iterations, [1] depth atomics (stat), [2..5] segment cycles of the SAR_EXPERIMENT_PROF build
-        HIP_TRY(hipMalloc(&rt->d_nan_count, 8 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, 8 * sizeof(unsigned long long), rt->stream));
+        // [6..7] producer wave, [8..12] consumer wave of k_iterate_split in that build
+        HIP_TRY(hipMalloc(&rt->d_nan_count, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, 16 * sizeof(unsigned long long), rt->stream));
     }
     return SAR_OK;
 }
@@ -555,11 +566,19 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     ba.joblist = rt->d_joblist;
     ba.active = rt->d_active;
     ba.nan_count = rt->d_nan_count;
+    ba.hint_range = pl.hint_bytes == 2 ? rt->d_hint_range : nullptr;
     ba.warm_out = carry ? rt->d_warm : nullptr;
     span_begin(rt, rt->warm_spans, rt->warm_used);
     if (first) {
         HIP_TRY(hipMemsetAsync(rt->d_active, 0, sizeof(uint32_t), rt->stream));
-        launch_warmup(ia.p, ia.starts, m, ia.iters, rt->d_warm, rt->d_joblist, rt->d_active, rt->d_nan_count, rt->stream);
+        // narrow hints: the first warm-up after the hints were cleared also measures the depth range they quantise
+        uint32_t* measure = nullptr;
+        if (pl.hint_bytes == 2 && !rt->hint_range_set) {
+            HIP_TRY(hipMemsetAsync(rt->d_hint_range, 0, 2 * sizeof(uint32_t), rt->stream));
+            measure = rt->d_hint_range;
+            rt->hint_range_set = true;
+        }
+        launch_warmup(ia.p, ia.starts, m, ia.iters, rt->d_warm, rt->d_joblist, rt->d_active, rt->d_nan_count, ia.width, measure, rt->stream);
     } else {
         launch_dead_jobs(rt->d_active, m, ia.iters, rt->d_nan_count, rt->stream);
     }
@@ -801,6 +820,7 @@ int sar_runtime_free(sar_runtime* rt) {
     if (rt->d_arena) hipFree(rt->d_arena);
     if (rt->d_heads) hipFree(rt->d_heads);
     if (rt->d_nan_count) hipFree(rt->d_nan_count);
+    if (rt->d_hint_range) hipFree(rt->d_hint_range);
     if (rt->starts_copied) hipEventDestroy(rt->starts_copied);
     for (auto& s : rt->iter_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto& s : rt->fold_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
@@ -1204,13 +1224,21 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
         HIP_TRY(hipMemcpy(&sent, rt->d_nan_count + 1, sizeof(sent), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(rt->d_nan_count + 1, 0, sizeof(sent)));
 #ifdef SAR_EXPERIMENT_PROF
-        unsigned long long seg[4];
+        unsigned long long seg[11];
         HIP_TRY(hipMemcpy(seg, rt->d_nan_count + 2, sizeof(seg), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(rt->d_nan_count + 2, 0, sizeof(seg)));
         const double tot = static_cast<double>(seg[0] + seg[1] + seg[2] + seg[3]);
         if (tot > 0)
             std::fprintf(stderr, "[prof] wave-cycles: map+projection %.1f%%  place_visit %.1f%%  depth %.1f%%  stores+requests %.1f%%  (total %.3g)\n",
                          100. * seg[0] / tot, 100. * seg[1] / tot, 100. * seg[2] / tot, 100. * seg[3] / tot, tot);
+        const double ptot = static_cast<double>(seg[4] + seg[5]);
+        double ctot = 0;
+        for (int i = 6; i < 11; ++i) ctot += static_cast<double>(seg[i]);
+        if (ptot > 0 && ctot > 0)
+            std::fprintf(stderr, "[prof-split] producer: map+projection+hand-over %.1f%%  barrier %.1f%% (total %.4g) | consumer: barrier %.1f%%  hand-over read %.1f%%  "
+                                 "place_visit %.1f%%  depth settle %.1f%%  slot+hint request %.1f%% (total %.4g)\n",
+                         100. * seg[4] / ptot, 100. * seg[5] / ptot, ptot, 100. * seg[6] / ctot, 100. * seg[7] / ctot, 100. * seg[8] / ctot,
+                         100. * seg[9] / ctot, 100. * seg[10] / ctot, ctot);
 #endif
         out->depth_atomics = sent;
     }

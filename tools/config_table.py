@@ -28,6 +28,8 @@ CONFIGS = {
     "X3072": dict(preset="poisson_saturne", iters=1e9, w=3072, h=3072, kind=0),
     "XC4": dict(preset="poisson_saturne", iters=1e10, w=4096, h=4096, kind=0),  # the whole configs[3] frame: --jobs 1048576
     "X8192": dict(preset="poisson_saturne", iters=1e9, w=8192, h=8192, kind=0),  # 64 Mpx: 1024 bins of 65536 pixels
+    "X1024": dict(preset="poisson_saturne", iters=1e9, w=1024, h=1024, kind=0),
+    "X1448": dict(preset="poisson_saturne", iters=1e9, w=1448, h=1448, kind=0),
     "XHD": dict(preset="poisson_saturne", iters=1e9, w=1920, h=1080, kind=0),
     "X4K": dict(preset="poisson_saturne", iters=1e9, w=3840, h=2160, kind=0),
 }
