@@ -307,7 +307,8 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *   "checkpoint_stride"  iterations between trajectory checkpoints used by the payload resolve
  *   "path"               accumulate path: 0 default (= 3 when the image fits), 1 one global atomic per
  *                        visit at agent scope, 2 the same into one scratch copy per XCD, 3 LDS-binned records
- *   "bin_shift"          log2(pixels per bin) of the binned path (12..16; 16: the accumulate kernel counts a bin in two halves)
+ *   "bin_shift"          log2(pixels per bin) of the binned path (12..16; 16: the accumulate kernel packs two 16-bit counters
+ *                        into an LDS word, see "acc_halves")
  *   "bin_interleave"     which pixels form a bin: 1 consecutive pixels, 2 every B-th 2048-pixel segment of the image
  *                        (B bins, a power of two: every bin carries the same share of the visits whatever the attractor
  *                        covers); 0 = 2 when the power-of-two bin count costs at most a third more bins, else 1
@@ -320,10 +321,13 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *   "split_waves"        the iterate kernel as producer / consumer wave pairs (one wave runs the map, its partner stages the
  *                        visits): 1 never, 2 wherever the kernel exists (pool stager, 64- or 128-byte chunks); 0 = 2 for
  *                        launches whose jobs are all resident at once (512 per CU), 1 for larger ones
- *   "hint_bits"          per-XCD depth hints of the iterate kernel: 16 (fixed point) or 32 (sortable f32); 0 = by image size
+ *   "hint_bits"          per-XCD depth hints of the iterate kernel: 16 (fixed point over the depth range the warm-up saw) or
+ *                        32 (the depth itself as f32); 0 = by image size
  *   "depth_pipe"         visits between a depth-hint (or depth-key) load and its use in the iterate kernel: 1 or 2 (default 2)
  *   "acc_threads"        threads per block of the record-accumulate kernel (256, 512, 1024)
- *   "acc_lists"          (bin, wave) record lists a lane group of that kernel walks at the same time: 1, 2 or 4
+ *   "acc_lists"          (bin, wave) record lists a lane group of that kernel walks at the same time: 1, 2, 4 or 8
+ *   "acc_halves"         bins of 65536 pixels: 1 = two workgroups per bin count one half each with 32-bit counters (every
+ *                        list is read twice; round 2), 0 = one workgroup, 16-bit counters with a guard bit (default)
  *   "timing_accumulate"  1: the spans of successive render calls add up (sar_timing sums, iterate_launches counts
  *                        them) until sar_runtime_last_timing reads and clears them; 0: last render call only
  *   "measure"            measurement-only kernels: 1 count only, 2 arithmetic only (results are NOT the render)

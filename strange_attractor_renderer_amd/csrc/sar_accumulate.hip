@@ -13,13 +13,27 @@ namespace sar {
 // whole (bin, wave) chunk lists (64-byte loads, newest chunk first) and adds the records into the
 // bin's LDS histogram with LDS atomics; the histogram is then written — plainly, fully — as copy s of
 // the scratch count bins, which k_fold_resolve sums into Runtime::count.
-// HALF (bins of 65536 pixels, the most a 16-bit record addresses — 4096^2 in 256 bins): two workgroups per (bin, split), each
-// reads the lists and counts the records of its half of the bin (record bit 15) in a 32768-entry histogram.
-template <uint32_t R, uint32_t K, bool HALF>
+// Bins of 65536 pixels (the most a 16-bit record addresses — 4096^2 in 256 bins) do not fit 32-bit counters into the LDS:
+//   MODE 2, PACKED (default): two 16-bit counters per LDS word, 128 KiB for the whole bin, ONE workgroup reads the lists
+//     once. A counter is 15 bits plus a guard bit: the lane whose (returning) add sets the guard bit takes 32768 out again
+//     and notes the pixel in a short event list; every event is worth 32768 hits when the histogram is written out. No
+//     carry ever reaches the neighbouring counter: between the add that sets the guard bit and the subtraction by the same
+//     lane at most 16 waves x 15 outstanding LDS operations x 64 lanes = 15360 more adds can land on that counter.
+//   MODE 1, HALF (round 2; `acc_packed` 2 selects it for A/B runs and tests): two workgroups per (bin, split), each reads the
+//     lists and counts the records of its half of the bin (record bit 15) in a 32768-entry histogram of 32-bit counters —
+//     every list is read twice: 4.35 ms per launch of configs[3] on one GPU against 2.82 ms (which is the rate of isolated
+//     64-byte reads, 2.7 of the 3.4 TB/s MI355X serves).
+constexpr uint32_t kAccEvents = 2040u;  // event list of the PACKED mode (u16 records), next to two counters
+template <uint32_t R, uint32_t K, uint32_t MODE>
 __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
+    constexpr bool HALF = MODE == 1u, PACKED = MODE == 2u;
     constexpr uint32_t Q = kChunkQuads(R);       // 16-byte quads per chunk
     constexpr uint32_t G = kChunkLanes(R);       // lanes that share one list: lane q of a group reads quad q
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    // PACKED: behind the 32768 words of counters: [0] events noted, [1] "an event went straight to memory", then the events
+    uint32_t* const ev_ctl = hist + 32768u;
+    unsigned short* const ev = (unsigned short*)(ev_ctl + 2);
+    uint32_t* const out = a.scratch_count + (size_t)blockIdx.y * a.npix;
     // HALF: the two workgroups of a bin read the same lists — give them block numbers 8 apart, so that they run on the same
     // XCD (workgroups go to the XCDs round-robin) at the same time and the second reader finds the chunks in that L2
     const bool swz = HALF && (a.n_bins & 7u) == 0u;
@@ -27,6 +41,10 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     const uint32_t s = blockIdx.y;
     const uint32_t half_base = !HALF ? 0u : (swz ? (blockIdx.x >> 3) & 1u : blockIdx.x & 1u) << 15;
     const uint32_t hist_px = HALF ? 32768u : 1u << a.bin_shift;
+    const uint32_t hist_words = PACKED ? hist_px / 2u : hist_px;
+    auto pixel_of = [&](uint32_t rec) {  // (bin, record) -> image position (BinMap)
+        return (rec & a.map.low_mask) | (b << a.map.seg_shift) | ((rec & ~a.map.low_mask) << a.map.hi_shift);
+    };
     const uint32_t q = threadIdx.x % G;
     const uint32_t group = threadIdx.x / G, groups = blockDim.x / G;
     // Most bins of a frame are empty (the attractor covers a band of the image): a block with no chunk at all
@@ -36,7 +54,8 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     for (uint32_t w = s + a.splits * threadIdx.x; w < a.n_waves; w += a.splits * blockDim.x)
         any |= a.heads[(size_t)b * a.n_waves + w] != kNoChunk;
     if (!__syncthreads_or(any)) return;
-    for (uint32_t k = threadIdx.x; k < hist_px; k += blockDim.x) hist[k] = 0u;
+    for (uint32_t k = threadIdx.x; k < hist_words; k += blockDim.x) hist[k] = 0u;
+    if (PACKED && threadIdx.x < 2u) ev_ctl[threadIdx.x] = 0u;
     __syncthreads();
     const uint4* arena = (const uint4*)a.arena;
     // One (bin, wave) list per group of G lanes: a chunk is ONE 16-byte load per lane and one cache line per
@@ -72,8 +91,43 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
                 // records held by this lane: lane 0 -> records 0..3 (its .z/.w), lane q -> 8q-4 .. 8q+3
                 const uint32_t first = q == 0u ? 0u : 8u * q - 4u;
                 const uint32_t r0 = q == 0u ? v[k].z : v[k].x, r1 = q == 0u ? v[k].w : v[k].y;
+                // PACKED: one returning add per record; the counter's 15 bits were all set before it <=> this add set the
+                // guard bit (inc = 1 or 1 << 16, so inc * 0x7FFF masks the counter)
+                auto packed_add = [&](uint32_t rec) {
+                    const uint32_t inc = __umul24(rec & 1u, 0xFFFFu) + 1u;
+                    const uint32_t full = __umul24(inc, 0x7FFFu);
+                    const uint32_t old = atomicAdd(&hist[rec >> 1], inc);
+                    if (__builtin_expect((old & full) == full, 0)) {
+                        atomicSub(&hist[rec >> 1], inc << 15);
+                        const uint32_t e = atomicAdd(&ev_ctl[0], 1u);
+                        if (e < kAccEvents) {
+                            ev[e] = (unsigned short)rec;
+                        } else {  // more than 2040 x 32768 hits on a handful of pixels in one block: straight to memory
+                            atomicAdd(&out[pixel_of(rec)], 32768u);
+                            ev_ctl[1] = 1u;
+                        }
+                    }
+                };
+                if (PACKED && nrec == R) {  // a full chunk (all but the last of a list): every record of this lane's quad counts
+                    if (q < Q) {
+                        packed_add(r0 & 0xFFFFu);
+                        packed_add(r0 >> 16);
+                        packed_add(r1 & 0xFFFFu);
+                        packed_add(r1 >> 16);
+                        if (q != 0u) {
+                            packed_add(v[k].z & 0xFFFFu);
+                            packed_add(v[k].z >> 16);
+                            packed_add(v[k].w & 0xFFFFu);
+                            packed_add(v[k].w >> 16);
+                        }
+                    }
+                    chunk[k] = prev;
+                    continue;
+                }
                 auto count = [&](bool valid, uint32_t rec) {  // rec: 16 bits
-                    if (HALF) {
+                    if (PACKED) {
+                        if (valid) packed_add(rec);
+                    } else if (HALF) {
                         if (valid && (rec & 0x8000u) == half_base) atomicAdd(&hist[rec & 0x7FFFu], 1u);
                     } else if (valid) {
                         atomicAdd(&hist[rec], 1u);
@@ -98,14 +152,26 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     // position the map gives (bin, record); 2048 consecutive records are 2048 consecutive pixels under both maps, and a
     // step of this loop (256 / 512 / 1024 threads) stays inside one such segment: its flag tells k_fold_resolve that the
     // segment has something to fold.
-    uint32_t* out = a.scratch_count + (size_t)s * a.npix;
+    const bool direct = PACKED && ev_ctl[1] != 0u;  // (wave-uniform) some events are already in `out`: add, do not overwrite
+    if (direct) __threadfence();
     for (uint32_t k = threadIdx.x; k < hist_px; k += blockDim.x) {
-        const uint32_t v = hist[k];
+        uint32_t v = PACKED ? (hist[k >> 1] >> ((k & 1u) << 4)) & 0xFFFFu : hist[k];
         const uint32_t rec = k | half_base;
-        const uint32_t px = (rec & a.map.low_mask) | (b << a.map.seg_shift) | ((rec & ~a.map.low_mask) << a.map.hi_shift);
+        const uint32_t px = pixel_of(rec);
+        if (direct && px < a.npix) v += __hip_atomic_load(&out[px], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool live = v != 0u && px < a.npix;
         if (live) out[px] = v;
         if (wave_ballot(live) && (threadIdx.x & 63u) == 0u) a.seg_any[px >> 11] = 1u;  // lane 0 holds the wave's lowest pixel
+    }
+    if (PACKED && ev_ctl[0] != 0u) {  // (block-uniform) 32768 hits per event, on top of what was just stored
+        __threadfence();
+        __syncthreads();
+        const uint32_t n_ev = ev_ctl[0] < kAccEvents ? ev_ctl[0] : kAccEvents;
+        for (uint32_t e = threadIdx.x; e < n_ev; e += blockDim.x) {
+            const uint32_t px = pixel_of(ev[e]);
+            atomicAdd(&out[px], 32768u);
+            a.seg_any[px >> 11] = 1u;
+        }
     }
 }
 
@@ -233,15 +299,16 @@ __global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) {
     }
 }
 
-int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, uint32_t lists, hipStream_t s) {
-    const bool half = a.bin_shift == 16u;
-    const size_t lds = (size_t)4u << (half ? 15u : a.bin_shift);
+int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, uint32_t lists, bool halves, hipStream_t s) {
+    const bool half = a.bin_shift == 16u && halves, packed = a.bin_shift == 16u && !halves;
+    const size_t lds = packed ? (size_t)(32768u + 2u) * 4u + kAccEvents * 2u : (size_t)4u << (half ? 15u : a.bin_shift);
     // a list takes a group of 2, 4 or 8 lanes: 1024 threads walk 128..512 lists per block, `lists` per group at a time
     if (threads == 0) threads = 1024u;
     const dim3 grid(half ? 2u * a.n_bins : a.n_bins, a.splits);
 #define SAR_ACC(RR, KK)                                                                                     \
-    if (half) hipLaunchKernelGGL((k_bin_accumulate<RR, KK, true>), grid, dim3(threads), lds, s, a);         \
-    else hipLaunchKernelGGL((k_bin_accumulate<RR, KK, false>), grid, dim3(threads), lds, s, a)
+    if (half) hipLaunchKernelGGL((k_bin_accumulate<RR, KK, 1u>), grid, dim3(threads), lds, s, a);           \
+    else if (packed) hipLaunchKernelGGL((k_bin_accumulate<RR, KK, 2u>), grid, dim3(threads), lds, s, a);    \
+    else hipLaunchKernelGGL((k_bin_accumulate<RR, KK, 0u>), grid, dim3(threads), lds, s, a)
 #define SAR_ACC_R(RR)                     \
     switch (lists) {                      \
         case 1: { SAR_ACC(RR, 1u); } break; \
@@ -266,8 +333,9 @@ int accumulate_kernel_attributes() {
     // a bin's histogram needs more dynamic LDS than the 64 KiB default window when the bin has 32768 pixels
     hipError_t e = hipSuccess;
 #define SAR_ATTR1(RR, KK) \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK, 0u>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK, 2u>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)
 #define SAR_ATTR(RR) SAR_ATTR1(RR, 1u); SAR_ATTR1(RR, 2u); SAR_ATTR1(RR, 4u); SAR_ATTR1(RR, 8u)
     SAR_ATTR(12u);
     SAR_ATTR(20u);

@@ -16,7 +16,8 @@ uint32_t chunk_bytes(uint32_t records);
 // pool: PoolStager (full buffers swapped against spares, cooperative copy-out) instead of Stager
 int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
                         bool pool, bool split, hipStream_t s);
-int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, uint32_t lists, hipStream_t s);
+// halves: bins of 65536 pixels counted by two workgroups with 32-bit counters (round 2) instead of one with packed 16-bit ones
+int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, uint32_t lists, bool halves, hipStream_t s);
 int iterate_kernel_attributes();     // sar_iterate.hip
 int accumulate_kernel_attributes();  // sar_accumulate.hip
 int binned_kernel_attributes();      // both

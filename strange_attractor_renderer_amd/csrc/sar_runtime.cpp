@@ -434,7 +434,7 @@ int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_
             // 128 KiB histograms: one workgroup per CU is resident, and with interleaved bins all of them carry the same
             // load — two rounds of workgroups over the chip, up to a few lists per lane group (measured, 2048^2: 4
             // workgroups per bin 0.85 ms, 8 or 16 1.2 ms)
-            cover = 512u / (pl.geo.shift == 16u ? 2u * pl.geo.bins : pl.geo.bins);  // two workgroups per bin and split at 65536 pixels
+            cover = 512u / ((pl.geo.shift == 16u && rt->acc_halves) ? 2u * pl.geo.bins : pl.geo.bins);  // counted in halves: two workgroups per bin and split
             pl.splits = (pl.max_waves + 8u * groups - 1u) / (8u * groups);
         }
         if (pl.splits < cover) pl.splits = cover;
@@ -617,7 +617,7 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     // lists a lane group walks at the same time: with the 128 KiB histogram one workgroup per CU is resident — four loads
     // in flight per lane make up for the missing second workgroup (2048^2: 0.61 -> 0.46 ms); with two workgroups per CU
     // (64 KiB) more loads in flight change nothing
-    launch_bin_accumulate(ca, rt->acc_threads, pl.R, rt->acc_lists ? rt->acc_lists : (pl.geo.shift >= 15u ? 4u : 1u), rt->stream);
+    launch_bin_accumulate(ca, rt->acc_threads, pl.R, rt->acc_lists ? rt->acc_lists : (pl.geo.shift >= 15u ? 4u : 1u), rt->acc_halves != 0, rt->stream);
     HIP_TRY(hipGetLastError());
     launch_fold_resolve(fa, rt->stream);
     span_end(rt, rt->fold_spans, rt->fold_used);
@@ -1291,6 +1291,8 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "acc_lists")) {
         if (v && v != 1 && v != 2 && v != 4 && v != 8) { set_error("acc_lists must be 1, 2, 4 or 8"); return SAR_ERR_INVALID; }
         rt->acc_lists = v;
+    } else if (!std::strcmp(name, "acc_halves")) {
+        rt->acc_halves = v ? 1u : 0u;
     } else if (!std::strcmp(name, "acc_threads")) {
         if (v && v != 256 && v != 512 && v != 1024) { set_error("acc_threads must be 256, 512 or 1024"); return SAR_ERR_INVALID; }
         rt->acc_threads = v;

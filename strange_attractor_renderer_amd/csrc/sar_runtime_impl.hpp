@@ -92,6 +92,7 @@ struct sar_runtime {
     uint32_t bin_interleave = 0;    // 0 = automatic, 1 = bins of consecutive pixels, 2 = interleaved bins (BinMap)
     uint32_t splits = 0;            // 0 = automatic
     uint32_t acc_threads = 0;       // threads per k_bin_accumulate block (0 = automatic)
+    uint32_t acc_halves = 0;        // 1: bins of 65536 pixels are counted in two halves (32-bit counters, lists read twice) instead of packed
     uint32_t split_waves = 0;       // 2: the iterate kernel as producer / consumer wave pairs (k_iterate_split) where it applies
     uint32_t acc_lists = 0;         // (bin, wave) lists a lane group of k_bin_accumulate walks at the same time: 1, 2, 4 (0 = automatic)
     uint32_t stager = 0;            // 0 automatic, 1 Stager (the filling lane copies its buffer out), 2 PoolStager (sar_iterate.hip)

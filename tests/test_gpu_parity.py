@@ -330,22 +330,78 @@ def test_bin_maps_small_and_odd_shapes(sar, oracle, gpu, size, interleave, bin_s
     assert_state_equal(rt, ort, f"{w}x{h} bin_shift={bin_shift} bin_interleave={interleave}")
 
 
+@pytest.mark.parametrize("halves", [0, 1])
 @pytest.mark.parametrize("stager", [1, 2])
 @pytest.mark.parametrize("records", [12, 20, 28])
 @pytest.mark.parametrize("acc_lists", [1, 4])
-def test_two_half_accumulate_with_every_chunk_size(sar, oracle, gpu, records, stager, acc_lists):
-    """Bins of 65536 pixels (k_bin_accumulate counts them in two halves, the records' top bit) under both stagers and the
-    small chunk sizes, on an image of 5 such bins whose last one is ragged, interleaved (8 bins) and not."""
+def test_two_half_accumulate_with_every_chunk_size(sar, oracle, gpu, records, stager, acc_lists, halves):
+    """Bins of 65536 pixels — k_bin_accumulate counts them with packed 16-bit counters (halves=0, the default) or in two
+    halves by the records' top bit (halves=1) — under both stagers and the small chunk sizes, on an image of 5 such bins
+    whose last one is ragged, interleaved (8 bins) and not."""
     w, h = 640, 480
     jobs, n = 1500, 500
     cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=w, height=h, jobs_total=jobs)
     st = sar.start_points(37, 0, jobs)
     for interleave in (1, 2):
         rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
-        rt.set_tuning(variant=3, bin_shift=16, chunk_records=records, stager=stager, acc_lists=acc_lists, bin_interleave=interleave)
+        rt.set_tuning(variant=3, bin_shift=16, chunk_records=records, stager=stager, acc_lists=acc_lists, bin_interleave=interleave,
+                      acc_halves=halves)
         sar.render_jobs(cfg, rt, st)
         oracle.render_jobs(cfg.c, ort, st, n)
-        assert_state_equal(rt, ort, f"records={records} stager={stager} acc_lists={acc_lists} bin_interleave={interleave}")
+        assert_state_equal(rt, ort, f"records={records} stager={stager} acc_lists={acc_lists} bin_interleave={interleave} halves={halves}")
+
+
+def _fixed_point_config(sar, **kw):
+    """A contrived coefficient set: every coordinate's polynomial is a constant, so every trajectory sits on ONE point from
+    its first iteration on and every visit of every job lands on ONE pixel (a point of the poisson-saturne attractor, so the
+    preset's view shows it)."""
+    pt = (float.fromhex("0x1.d37397ce5279dp-3"), float.fromhex("0x1.494519191dfdbp-3"), float.fromhex("-0x1.ff8befd61a1b4p-3"))
+    coef = lambda c: [c] + [0.0] * 9
+    return _cfg(sar, "poisson_saturne", coeff_x=coef(pt[0]), coeff_y=coef(pt[1]), coeff_z=coef(pt[2]), **kw)
+
+
+def _expect_hot_pixel(sar, oracle, cfg, w, h, total):
+    """What `total` visits of the one pixel leave: depth and payload of the FIRST visit (later ones tie: strict `>`, :821),
+    count = total mod 2^32 (:811), max = u32::MAX once the count has wrapped (:813-815)."""
+    small = cfg.replace(iterations=64 * 8, jobs_total=64)
+    st = sar.start_points(5, 0, 64)
+    ort = oracle.Runtime(w, h)
+    oracle.render_jobs(small.c, ort, st, 8)
+    (ys, xs) = np.nonzero(ort.count)
+    assert len(ys) == 1 and ort.count[ys[0], xs[0]] == 64 * 8
+    ort.count[ys[0], xs[0]] = total & 0xFFFFFFFF
+    ort.set_max(0xFFFFFFFF if total >> 32 else total)
+    return ort, (int(ys[0]), int(xs[0]))
+
+
+@pytest.mark.parametrize("halves", [0, 1])
+def test_hot_pixel_through_the_packed_counters(sar, oracle, gpu, halves):
+    """3e8 visits of ONE pixel through bins of 65536 pixels: with one workgroup per bin the packed 16-bit counter of that
+    pixel overflows ~9000 times — more events than the workgroup's list holds, so both the event list and the
+    straight-to-memory path of k_bin_accumulate's PACKED mode carry hits. (halves=1: the 32-bit counters of round 2.)"""
+    w = h = 1024
+    jobs, n = 65536, 4578
+    cfg = _fixed_point_config(sar, iterations=jobs * n, width=w, height=h, jobs_total=jobs)
+    rt = sar.Runtime(cfg)
+    rt.set_tuning(variant=3, bin_shift=16, splits=1, acc_halves=halves)
+    sar.render_jobs(cfg, rt, sar.start_points(5, 0, jobs))
+    ort, _ = _expect_hot_pixel(sar, oracle, cfg, w, h, jobs * n)
+    assert_state_equal(rt, ort, f"hot pixel, halves={halves}")
+
+
+def test_hot_pixel_past_u32_through_the_binned_path(sar, oracle, gpu):
+    """One real pixel driven past 2^32 hits by the default path (reference src/lib.rs:811-815, 860): the fold's wrap flag
+    makes `max` read u32::MAX, the count is the total mod 2^32, and colorize takes ln(max + 1) = ln(0)."""
+    w = h = 2048
+    jobs, n = 131072, 32769            # 4 295 098 368 = 2^32 + 131072 visits
+    cfg = _fixed_point_config(sar, iterations=jobs * n, width=w, height=h, jobs_total=jobs, transparent=1)
+    rt = sar.Runtime(cfg)
+    sar.render_jobs(cfg, rt, sar.start_points(5, 0, jobs))
+    ort, (y, x) = _expect_hot_pixel(sar, oracle, cfg, w, h, jobs * n)
+    assert ort.count[y, x] == 131072
+    assert_state_equal(rt, ort, "hot pixel past 2^32")
+    assert rt.max() == 0xFFFFFFFF
+    np.testing.assert_array_equal(sar.colorize(cfg, rt), oracle.colorize(cfg.c, ort))
 
 
 @pytest.mark.parametrize("preset", ["poisson_saturne", "solar_sail"])
