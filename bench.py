@@ -121,6 +121,8 @@ def main():
                     "c4: BASELINE configs[3] (1e10 iterations, 4096^2, 524288 jobs sharded over the ranks), strong scaling")
     ap.add_argument("--exchange", default="sliced", choices=["sliced", "rooted"], help="N>1: all-to-all of image slices + "
                     "sharded colorize (default) or all-reduce MAX + reduce SUM onto rank 0")
+    ap.add_argument("--no-prefetch", dest="prefetch", action="store_false", help="do not announce the next frame "
+                    "(sar_runtime_prefetch_device): every frame runs its warm-up inside its own render call")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="skip the two-stream pipelined-throughput "
                     "measurement that is reported next to `value` at N=1")
     ap.add_argument("--variant", type=lambda s: int(s, 0), default=0)
@@ -208,12 +210,17 @@ def main():
         # timed region starts (with host start points each frame uploads 3 MiB: +0.1 ms)
         starts_dev = torch.from_numpy(np.ascontiguousarray(starts)).cuda()
 
-        def step():
+        def step(more=True):
             rt.reset()
             if a.host_starts:
                 S.render_job_range(cfg, rt, n, starts)
             else:
                 S.render_job_range_device(cfg, rt, jobs, n, starts_dev.data_ptr())
+                # the frame loop knows its next frame (src/bin/main.rs:493-517): announce it, so that its 1000 uncounted
+                # warm-up iterations per job run under THIS frame's accumulate / fold / colorize. Every frame still does
+                # all of its work inside the timed region; the last one announces nothing.
+                if a.prefetch and more:
+                    S.prefetch_device(cfg, rt, jobs, n, starts_dev.data_ptr())
             if world > 1:
                 ev = evs[step_no[0] % len(evs)]
                 step_no[0] += 1
@@ -239,8 +246,8 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
-        for _ in range(a.warmup):
-            step()
+        for k in range(a.warmup):
+            step(more=k + 1 < a.warmup)  # the last untimed frame announces nothing: no work of the timed region runs before it
         fence()
         if world > 1 and a.check:
             # each rank's own (un-merged) count summed over ranks must equal the merged count on rank 0
@@ -273,8 +280,8 @@ def main():
         rt.set_option("timing_accumulate", 1)
         t0 = time.perf_counter()
         step_no[0] = 0
-        for _ in range(a.steps):
-            step()
+        for k in range(a.steps):
+            step(more=k + 1 < a.steps)
         fence()
         elapsed = time.perf_counter() - t0
         for ev in evs[:a.steps]:
@@ -349,6 +356,8 @@ def main():
                        "jobs_per_gpu": jobs, "jobs_total": total_jobs,
                        "iterations_per_job": n, "counted_iterations_per_step": n * total_jobs,
                        "warmup_iterations_per_job_uncounted": 1000,
+                       "counted_over_executed_iterations": round(n / (n + 1000.0), 4),
+                       "next_frame_announced": bool(a.prefetch and not a.host_starts),
                        "start_points": "uploaded from host memory every step" if a.host_starts else "resident in HBM",
                        "parallelism": f"trajectories sharded over {world} GPU(s)"
                                       + ((f"; all-to-all of image slices (16 B/px) + merge in rank order + sharded "

@@ -122,6 +122,8 @@ extern "C" {
     pub fn sar_colorize(cfg: *const SarConfig, rt: *mut SarRuntime, rgba_out_host: *mut u16) -> c_int; // colorize (:841)
     pub fn sar_render_job_range_device(cfg: *const SarConfig, rt: *mut SarRuntime, n_jobs: u32, iters_per_job: u64,
                                        starts_xyz_dev: *const f64) -> c_int;
+    pub fn sar_runtime_prefetch_device(cfg: *const SarConfig, rt: *mut SarRuntime, n_jobs: u32, iters_per_job: u64,
+                                       starts_xyz_dev: *const f64) -> c_int;
     pub fn sar_colorize_device(cfg: *const SarConfig, rt: *mut SarRuntime, rgba_out_dev: *mut c_void) -> c_int;
 
     pub fn sar_runtime_extent(cfg: *const SarConfig, rt: *mut SarRuntime, n_jobs: u32, iters_per_job: u64,

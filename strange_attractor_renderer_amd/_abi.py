@@ -117,6 +117,7 @@ PROTOTYPES = {
     "sar_render_jobs": (C.c_int, [_cfg_p, _vp, _P(C.c_double)]),
     "sar_render_job_range": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _P(C.c_double)]),
     "sar_render_job_range_device": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _vp]),
+    "sar_runtime_prefetch_device": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _vp]),
     "sar_colorize": (C.c_int, [_cfg_p, _vp, _P(C.c_uint16)]),
     "sar_colorize_device": (C.c_int, [_cfg_p, _vp, _vp]),
     "sar_runtime_extent": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _P(C.c_double), _P(C.c_double)]),

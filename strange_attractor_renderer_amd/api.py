@@ -334,6 +334,13 @@ def render_job_range_device(config: Config, runtime: Runtime, n_jobs: int, iters
                                               C.c_void_p(starts_dev_ptr)), "sar_render_job_range_device")
 
 
+def prefetch_device(config: Config, runtime: Runtime, n_jobs: int, iters_per_job: int, starts_dev_ptr: int):
+    """Announces the next render_job_range_device call (same arguments): its warm-up may run ahead, under the tail of
+    the frame in flight. Results do not depend on it."""
+    _check(_lib().sar_runtime_prefetch_device(C.byref(config.c), runtime.handle, n_jobs, iters_per_job,
+                                              C.c_void_p(starts_dev_ptr)), "sar_runtime_prefetch_device")
+
+
 def colorize(config: Config, runtime: Runtime) -> np.ndarray:
     """``colorize(&config, &runtime) -> FinalImage`` as an (H, W, 4) uint16 array (src/lib.rs:841)."""
     out = np.empty((config.c.height, config.c.width, 4), dtype=np.uint16)

@@ -19,7 +19,7 @@ namespace sar {
 //     and notes the pixel in a short event list; every event is worth 32768 hits when the histogram is written out. No
 //     carry ever reaches the neighbouring counter: between the add that sets the guard bit and the subtraction by the same
 //     lane at most 16 waves x 15 outstanding LDS operations x 64 lanes = 15360 more adds can land on that counter.
-//   MODE 1, HALF (round 2; `acc_packed` 2 selects it for A/B runs and tests): two workgroups per (bin, split), each reads the
+//   MODE 1, HALF (round 2; `acc_halves` 1 selects it for A/B runs and tests): two workgroups per (bin, split), each reads the
 //     lists and counts the records of its half of the bin (record bit 15) in a 32768-entry histogram of 32-bit counters —
 //     every list is read twice: 4.35 ms per launch of configs[3] on one GPU against 2.82 ms (which is the rate of isolated
 //     64-byte reads, 2.7 of the 3.4 TB/s MI355X serves).

@@ -86,6 +86,8 @@ struct BinIterArgs {
     const double* warm;          // [3][n_jobs] SoA by packed slot: the point after 1000 warm-up iterations
     const uint32_t* joblist;     // [n_jobs] job index (within this launch chunk) of every packed slot
     const uint32_t* active;      // number of packed slots
+    const unsigned long long* warm_nan;  // nullable: iterations of the jobs that died in the warm-up (from k_warmup; the first
+                                 // workgroup adds them to nan_count — the warm-up may have run ahead, under the previous frame)
     unsigned long long* nan_count;  // iterations of diverged (NaN) trajectories: all land on pixel (0,0)
     const uint32_t* hint_range;  // nullable: {~sortable(min z), sortable(max z)} of the view, from k_warmup: the range the narrow
                                  // depth hints quantise (fixed from the first launch after the hints were cleared)

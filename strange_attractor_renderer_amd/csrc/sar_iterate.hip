@@ -754,6 +754,10 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t wave = slot >> 6;
     const uint32_t active = *a.active;
+    if (a.warm_nan && slot == 0u) {  // the jobs the warm-up dropped (k_warmup): their iterations all land on pixel (0,0)
+        const unsigned long long dead = *a.warm_nan;
+        if (dead) atomicAdd(a.nan_count, dead);
+    }
     if ((slot & ~63u) >= active) {  // nothing left for this wave: publish empty lists
         for (uint32_t b = lane; b < a.n_bins; b += 64u) a.heads[(size_t)b * a.n_waves + wave] = kNoChunk;
         return;
@@ -872,6 +876,10 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
     const uint32_t wave = blockIdx.x;          // one set of 64 trajectories per workgroup
     const uint32_t slot = wave * 64u + lane;
     const uint32_t active = *a.active;
+    if (a.warm_nan && blockIdx.x == 0u && threadIdx.x == 0u) {  // as in k_iterate_lean
+        const unsigned long long dead = *a.warm_nan;
+        if (dead) atomicAdd(a.nan_count, dead);
+    }
     if (wave * 64u >= active) {  // nothing left for this workgroup: publish empty lists
         if (!producer)
             for (uint32_t b = lane; b < a.n_bins; b += 64u) a.heads[(size_t)b * a.n_waves + wave] = kNoChunk;

@@ -519,7 +519,7 @@ int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
         SAR_TRY(grow_device(rt->d_joblist, cap1, static_cast<size_t>(pl.chunk_jobs)));
         rt->warm_cap = pl.chunk_jobs;
     }
-    if (!rt->d_active) HIP_TRY(hipMalloc(&rt->d_active, sizeof(uint32_t)));
+    if (!rt->d_active) HIP_TRY(hipMalloc(&rt->d_active, 4 * sizeof(uint32_t)));
     const size_t segs = static_cast<size_t>(rt->npix) / 2048u + 1u;
     if (rt->seg_any_cap < segs) {
         if (rt->d_seg_any) hipFree(rt->d_seg_any);
@@ -548,7 +548,8 @@ int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
 
 // One launch chunk of the binned path: warm-up + packing, iterate, accumulate, fold.
 // `first`: the first segment of these jobs (warm-up + packing); `carry`: more segments follow (keep the trajectory state).
-int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& ia, const FoldArgs& fa_in, int mode, bool first, bool carry) {
+int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& ia, const FoldArgs& fa_in, int mode, bool first, bool carry,
+                        bool use_prefetch) {
     FoldArgs fa = fa_in;
     fa.seg_any = rt->d_seg_any;
     const uint32_t m = ia.n_jobs;
@@ -562,15 +563,27 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     ba.arena = rt->d_arena;
     ba.heads = rt->d_heads;
     ba.zhint = rt->d_zhint;
-    ba.warm = rt->d_warm;
-    ba.joblist = rt->d_joblist;
-    ba.active = rt->d_active;
     ba.nan_count = rt->d_nan_count;
     ba.hint_range = pl.hint_bytes == 2 ? rt->d_hint_range : nullptr;
     ba.warm_out = carry ? rt->d_warm : nullptr;
     span_begin(rt, rt->warm_spans, rt->warm_used);
-    if (first) {
-        HIP_TRY(hipMemsetAsync(rt->d_active, 0, sizeof(uint32_t), rt->stream));
+    const sar_runtime::Prefetch& pf = rt->pf;
+    const bool ahead = first && !carry && use_prefetch && pf.valid && pf.m == m && pf.iters == ia.iters && pf.width == ia.width &&
+                       std::memcmp(&pf.p, &ia.p, sizeof(ia.p)) == 0;
+    if (ahead) {
+        // this chunk's warm-up ran ahead (sar_runtime_prefetch_device): its buffers become the current ones
+        HIP_TRY(hipStreamWaitEvent(rt->stream, rt->pf_done, 0));
+        std::swap(rt->d_warm, rt->d_warm_alt);
+        std::swap(rt->d_joblist, rt->d_joblist_alt);
+        std::swap(rt->d_active, rt->d_active_alt);
+        std::swap(rt->warm_cap, rt->warm_alt_cap);
+        if (pl.hint_bytes == 2 && !rt->hint_range_set && pf.range_measured) {
+            HIP_TRY(hipMemcpyAsync(rt->d_hint_range, rt->d_hint_range_alt, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, rt->stream));
+            rt->hint_range_set = true;
+        }
+        ++rt->prefetch_used;
+    } else if (first) {
+        HIP_TRY(hipMemsetAsync(rt->d_active, 0, 4 * sizeof(uint32_t), rt->stream));
         // narrow hints: the first warm-up after the hints were cleared also measures the depth range they quantise
         uint32_t* measure = nullptr;
         if (pl.hint_bytes == 2 && !rt->hint_range_set) {
@@ -578,10 +591,16 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
             measure = rt->d_hint_range;
             rt->hint_range_set = true;
         }
-        launch_warmup(ia.p, ia.starts, m, ia.iters, rt->d_warm, rt->d_joblist, rt->d_active, rt->d_nan_count, ia.width, measure, rt->stream);
+        launch_warmup(ia.p, ia.starts, m, ia.iters, rt->d_warm, rt->d_joblist, rt->d_active,
+                      reinterpret_cast<unsigned long long*>(rt->d_active + 2), ia.width, measure, rt->stream);
     } else {
         launch_dead_jobs(rt->d_active, m, ia.iters, rt->d_nan_count, rt->stream);
     }
+    if (first) rt->pf.valid = false;  // used, or announced for another call: either way it is spent
+    ba.warm = rt->d_warm;
+    ba.joblist = rt->d_joblist;
+    ba.active = rt->d_active;
+    ba.warm_nan = first ? reinterpret_cast<const unsigned long long*>(rt->d_active + 2) : nullptr;
     if (first && !rt->active_pending) {  // statistics for the next call; nobody waits for this copy
         if (hipMemcpyAsync(rt->h_active, rt->d_active, sizeof(uint32_t), hipMemcpyDeviceToHost, rt->stream) == hipSuccess &&
             hipEventRecord(rt->active_copied, rt->stream) == hipSuccess) {
@@ -599,6 +618,10 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     }
     HIP_TRY(hipGetLastError());
     span_end(rt, rt->iter_spans, rt->iter_used);
+    if (rt->iter_done) {  // an announced call's warm-up starts here, under this launch's accumulate and fold
+        HIP_TRY(hipEventRecord(rt->iter_done, rt->stream));
+        rt->iter_done_recorded = true;
+    }
     BinAccArgs ca;
     std::memset(&ca, 0, sizeof(ca));
     ca.bin_shift = pl.geo.shift;
@@ -693,7 +716,9 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
             ia.iters = it;
             fa.iters = it;
             if (pl.binned) {
-                SAR_TRY(launch_binned_chunk(rt, pl, ia, fa, mode, first, carry));
+                // the announced call: same start points, same job count; the first chunk's warm-up may already be done
+                const bool announced = off == 0 && starts_on_device && rt->pf.valid && rt->pf.starts == starts && rt->pf.n_jobs == n_jobs;
+                SAR_TRY(launch_binned_chunk(rt, pl, ia, fa, mode, first, carry, announced));
             } else {
                 ia.resume = first ? 0u : 1u;
                 ia.state_out = carry ? rt->d_starts + off * 3 : nullptr;
@@ -808,9 +833,17 @@ int sar_runtime_free(sar_runtime* rt) {
     free_device_buffers(rt);
     if (rt->d_scalars) hipFree(rt->d_scalars);
     if (rt->d_lnlut) hipFree(rt->d_lnlut);
+    if (rt->side) { hipStreamSynchronize(rt->side); hipStreamDestroy(rt->side); }
+    if (rt->iter_done) hipEventDestroy(rt->iter_done);
+    if (rt->pf_done) hipEventDestroy(rt->pf_done);
     if (rt->d_warm) hipFree(rt->d_warm);
     if (rt->d_joblist) hipFree(rt->d_joblist);
     if (rt->d_active) hipFree(rt->d_active);
+    if (rt->d_warm_alt) hipFree(rt->d_warm_alt);
+    if (rt->d_joblist_alt) hipFree(rt->d_joblist_alt);
+    if (rt->d_active_alt) hipFree(rt->d_active_alt);
+    if (rt->d_hint_range_alt) hipFree(rt->d_hint_range_alt);
+    if (rt->d_starts_alt) hipFree(rt->d_starts_alt);
     if (rt->d_seg_any) hipFree(rt->d_seg_any);
     if (rt->h_active) hipHostFree(rt->h_active);
     if (rt->active_copied) hipEventDestroy(rt->active_copied);
@@ -950,6 +983,60 @@ int sar_render_job_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t
     SAR_TRY(check_cfg_matches(cfg, rt));
     if (n_jobs && !starts_xyz_dev) { set_error("starts_xyz_dev is NULL"); return SAR_ERR_INVALID; }
     return render_chunked(cfg, rt, n_jobs, iters_per_job, starts_xyz_dev, true);
+}
+
+int sar_runtime_prefetch_device(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters_per_job,
+                                const double* starts_xyz_dev) {
+    SAR_TRY(check_cfg_matches(cfg, rt));
+    if (!starts_xyz_dev) { set_error("starts_xyz_dev is NULL"); return SAR_ERR_INVALID; }
+    rt->pf.valid = false;
+    if (n_jobs == 0 || iters_per_job == 0) return SAR_OK;
+    HIP_TRY(hipSetDevice(rt->device));
+    const uint64_t max_ord = rt->max_ordinals ? rt->max_ordinals : kMaxChunkOrdinals;
+    if (iters_per_job > max_ord) return SAR_OK;  // a job of several segments: nothing to run ahead
+    LaunchPlan pl;
+    SAR_TRY(plan_launch(cfg, rt, n_jobs, iters_per_job, pl));
+    if (!pl.binned) return SAR_OK;
+    const uint32_t m = static_cast<uint32_t>(n_jobs < pl.chunk_jobs ? n_jobs : pl.chunk_jobs);
+    if (!rt->side) {
+        HIP_TRY(hipStreamCreateWithFlags(&rt->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&rt->iter_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&rt->pf_done, hipEventDisableTiming));
+    }
+    if (m > rt->warm_alt_cap) {
+        // nothing reads the second set while no announced call is pending; what wrote it last ran on this side stream
+        HIP_TRY(hipStreamSynchronize(rt->side));
+        for (void* q : {static_cast<void*>(rt->d_warm_alt), static_cast<void*>(rt->d_joblist_alt), static_cast<void*>(rt->d_starts_alt)})
+            if (q) hipFree(q);
+        rt->d_warm_alt = nullptr; rt->d_joblist_alt = nullptr; rt->d_starts_alt = nullptr;
+        rt->warm_alt_cap = 0;
+        HIP_TRY(hipMalloc(&rt->d_warm_alt, static_cast<size_t>(m) * 3 * sizeof(double)));
+        HIP_TRY(hipMalloc(&rt->d_joblist_alt, static_cast<size_t>(m) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&rt->d_starts_alt, static_cast<size_t>(m) * 3 * sizeof(double)));
+        rt->warm_alt_cap = m;
+    }
+    if (!rt->d_active_alt) HIP_TRY(hipMalloc(&rt->d_active_alt, 4 * sizeof(uint32_t)));
+    if (!rt->d_hint_range_alt) HIP_TRY(hipMalloc(&rt->d_hint_range_alt, 2 * sizeof(uint32_t)));
+    sar_runtime::Prefetch& pf = rt->pf;
+    fill_map_params(*cfg, pf.p);
+    pf.n_jobs = n_jobs;
+    pf.m = m;
+    pf.width = rt->W;
+    pf.iters = iters_per_job;
+    pf.starts = starts_xyz_dev;
+    pf.range_measured = pl.hint_bytes == 2;
+    // after the iterate kernel of the frame in flight (its accumulate / fold / colorize are what this runs under); with no
+    // frame in flight, at once
+    if (rt->iter_done_recorded) HIP_TRY(hipStreamWaitEvent(rt->side, rt->iter_done, 0));
+    launch_starts_soa(starts_xyz_dev, rt->d_starts_alt, m, rt->side);
+    HIP_TRY(hipMemsetAsync(rt->d_active_alt, 0, 4 * sizeof(uint32_t), rt->side));
+    if (pf.range_measured) HIP_TRY(hipMemsetAsync(rt->d_hint_range_alt, 0, 2 * sizeof(uint32_t), rt->side));
+    launch_warmup(pf.p, rt->d_starts_alt, m, iters_per_job, rt->d_warm_alt, rt->d_joblist_alt, rt->d_active_alt,
+                  reinterpret_cast<unsigned long long*>(rt->d_active_alt + 2), rt->W, pf.range_measured ? rt->d_hint_range_alt : nullptr, rt->side);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(rt->pf_done, rt->side));
+    pf.valid = true;
+    return SAR_OK;
 }
 
 int sar_runtime_extent(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters_per_job,

@@ -57,7 +57,27 @@ struct sar_runtime {
     double* d_starts = nullptr;
     double* d_warm = nullptr;        // binned path: packed post-warm-up points, job list, survivor count
     uint32_t* d_joblist = nullptr;
-    uint32_t* d_active = nullptr;
+    uint32_t* d_active = nullptr;    // [4]: survivors, pad, iterations of the jobs that died in the warm-up (u64)
+    // The warm-up of an ANNOUNCED render call (sar_runtime_prefetch_device) runs ahead on a side stream, under the current
+    // frame's accumulate / fold / colorize, into a second set of these buffers; the announced call swaps the sets.
+    double* d_warm_alt = nullptr;
+    uint32_t* d_joblist_alt = nullptr;
+    uint32_t* d_active_alt = nullptr;
+    uint32_t* d_hint_range_alt = nullptr;
+    double* d_starts_alt = nullptr;
+    size_t warm_alt_cap = 0;         // jobs
+    hipStream_t side = nullptr;
+    hipEvent_t iter_done = nullptr, pf_done = nullptr;
+    bool iter_done_recorded = false;
+    struct Prefetch {
+        bool valid = false;
+        sar::MapParams p;
+        uint32_t n_jobs = 0, m = 0, width = 0;
+        uint64_t iters = 0;
+        const double* starts = nullptr;
+        bool range_measured = false;
+    } pf;
+    uint32_t prefetch_used = 0;      // statistic: render calls that found their warm-up done
     uint32_t* d_seg_any = nullptr;   // [npix / 2048 + 1] 2048-pixel segments with a count in the current launch (k_fold_resolve skips the rest)
     size_t seg_any_cap = 0;
     size_t warm_cap = 0;             // jobs

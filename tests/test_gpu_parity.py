@@ -561,6 +561,35 @@ def test_device_resident_start_points_give_the_same_bits(sar, oracle, gpu):
         assert_state_equal(rt, ort, f"device starts, chunk cap {cap}")
 
 
+@pytest.mark.parametrize("preset", ["poisson_saturne", "solar_sail"])
+def test_announced_frames_whose_warm_up_ran_ahead(sar, oracle, gpu, preset):
+    """sar_runtime_prefetch_device: the warm-up of the announced call runs on a second stream under the previous frame's
+    tail. Three frames on one runtime (reset in between) — announced and matched, announced with other start points (the
+    announcement is dropped), not announced — all equal the oracle; solar-sail's dead jobs reach count[0] exactly once."""
+    import torch
+    jobs, n = 4096, 300
+    w, h = 640, 480
+    cfg = _cfg(sar, preset, iterations=jobs * n, width=w, height=h, jobs_total=jobs)
+    sts = [sar.start_points(40 + k, 0, jobs) for k in range(3)]
+    devs = [torch.from_numpy(s).cuda() for s in sts]
+    torch.cuda.synchronize()
+    rt = sar.Runtime(cfg)
+    sar.prefetch_device(cfg, rt, jobs, n, devs[0].data_ptr())            # nothing in flight: runs at once
+    for k, announce in enumerate([1, 0, None]):                           # frame 0 announces 1; frame 1 announces frame 0's points
+        rt.reset()
+        sar.render_job_range_device(cfg, rt, jobs, n, devs[k].data_ptr())
+        if announce is not None:
+            sar.prefetch_device(cfg, rt, jobs, n, devs[announce].data_ptr())
+        ort = oracle.Runtime(w, h)
+        oracle.render_jobs(cfg.c, ort, sts[k], n)
+        assert_state_equal(rt, ort, f"{preset} frame {k}")
+    # an announced call on an un-reset runtime continues the image (src/lib.rs:742-744)
+    sar.prefetch_device(cfg, rt, jobs, n, devs[0].data_ptr())
+    sar.render_job_range_device(cfg, rt, jobs, n, devs[0].data_ptr())
+    oracle.render_jobs(cfg.c, ort, sts[0], n)
+    assert_state_equal(rt, ort, f"{preset} continued")
+
+
 def test_every_job_diverging_in_the_warm_up(sar, oracle, gpu):
     """No trajectory survives the warm-up (start points far outside the basin): the hot kernel has nothing to do, every
     counted iteration lands on pixel (0,0) (reference src/lib.rs:789, 800-802) and the depth buffer stays empty."""
