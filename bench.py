@@ -16,6 +16,13 @@ the one exchange step (all-to-all of the image slices, merge in rank order, 4-sc
                          sharded over the ranks (shard_jobs). STRONG scaling: the frame is the same at every N; at
                          N=1 the one GPU runs all the jobs in launch chunks.
 
+With N > 1 and no --config the ONE command answers both scaling questions: `value` is the weak-scaling c2 line, and the
+same ranks then render the c4 frame (strong scaling) — reported under `strong_c4` — and rank 0 drives the same two
+workloads through the C-ABI-only multi-device renderer (sar_renderer_new_multi: host threads + hipMemcpyPeerAsync, no
+torch.distributed) — reported under `native`.
+
+    python bench.py --native --gpus N [--config c2|c4]   only the C-ABI multi-device renderer, one process
+
 One JSON line on rank 0; see DESIGN.md "Measurement" for how each field is derived.
 """
 import argparse
@@ -47,13 +54,13 @@ def pmc_traffic_bytes():
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
-        return None
+        return None, None
     try:
         d = json.load(open(files[-1]))
         d = d.get("k_iterate_split") or d.get("k_iterate_lean") or d["k_iterate_binned"]
-        return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+        return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(seconds_hint: float):
@@ -102,6 +109,42 @@ def cpu_baseline(seconds_hint: float):
     }
 
 
+def native_measure(S, torch, devices, config, steps, warmup):
+    """The same frame through the C ABI alone: sar_renderer_new_multi over `devices` (one host thread + one stream per
+    device, slices exchanged with hipMemcpyPeerAsync, colorized per slice into a pinned host image). A step is one
+    sar_render_parallel call: start points drawn on the host (the next frame's while the GPUs work), uploaded, reset,
+    render, exchange, colorize, image in host memory."""
+    g = len(devices)
+    if config == "c4":
+        width, total_jobs, iters = C4_SIZE, C4_JOBS, C4_ITERS
+    else:
+        width, total_jobs, iters = WIDTH, DEFAULT_JOBS * g, ITERS_PER_GPU * g
+    jpu = 8
+    units = total_jobs // jpu
+    n = iters // units // jpu
+    cfg = S.Config.poisson_saturne(iterations=iters, width=width, height=width, transparent=0, seed=1)
+    r = S.ParallelRenderer(devices=devices, units=units, seed=1)
+    img = torch.empty((width, width, 4), dtype=torch.int16).pin_memory()
+    phases = {"render_ms": 0.0, "exchange_ms": 0.0, "colorize_ms": 0.0}
+    for _ in range(warmup):
+        S.render_parallel_into(r, cfg, jpu, img.data_ptr())
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        S.render_parallel_into(r, cfg, jpu, img.data_ptr())
+        t = r.last_timing()
+        for k in phases:
+            phases[k] += t[k]
+    el = time.perf_counter() - t0
+    t = r.last_timing()
+    r.shutdown()
+    return {"value": n * total_jobs * steps / el, "unit": "iterations/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+            "scaling": "strong" if config == "c4" else "weak", "devices": list(devices), "jobs_total": total_jobs,
+            "iterations_per_job": n, "image": f"{width}x{width}",
+            "phase_ms_per_step_slowest_device": {k: v / steps for k, v in phases.items()},
+            "exchange_bytes_per_device": int(t["exchange_bytes_per_device"]), "peer_access_failures": int(t["peer_access_failures"]),
+            "note": "sar_render_parallel end to end, image in pinned host memory (PCIe and the host-side job list included)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,8 +160,14 @@ def main():
                     "the per-rank buffers (debug; not timed)")
     ap.add_argument("--host-starts", action="store_true", help="hand the start points over from host memory every step "
                     "(PCIe-inclusive rate; the default keeps them resident in HBM)")
-    ap.add_argument("--config", default="c2", choices=["c2", "c4"], help="c2: BASELINE configs[1], weak scaling (default); "
-                    "c4: BASELINE configs[3] (1e10 iterations, 4096^2, 524288 jobs sharded over the ranks), strong scaling")
+    ap.add_argument("--config", default=None, choices=["c2", "c4", "c5"], help="c2: BASELINE configs[1], weak scaling (default); "
+                    "c4: BASELINE configs[3] (1e10 iterations, 4096^2, 1048576 jobs sharded over the ranks), strong scaling. "
+                    "c5: BASELINE configs[4], the solar-sail `sequence` sweep, 1e8 iterations per frame at 1800x2000, frame k on "
+                    "rank k mod N, --steps frames per rank, no collective (replicas only). "
+                    "With N > 1 and no --config: c2 as `value`, then c4 under `strong_c4` and both through the C ABI under `native`")
+    ap.add_argument("--native", action="store_true", help="only the C-ABI multi-device renderer (sar_renderer_new_multi) over "
+                    "--gpus devices in ONE process (device ordinals wrap around on a box with fewer GPUs)")
+    ap.add_argument("--sustained-seconds", type=float, default=3.0, help="N=1: length of the extra sustained-rate loop (0 = skip)")
     ap.add_argument("--exchange", default="sliced", choices=["sliced", "rooted"], help="N>1: all-to-all of image slices + "
                     "sharded colorize (default) or all-reduce MAX + reduce SUM onto rank 0")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false", help="do not announce the next frame "
@@ -129,6 +178,19 @@ def main():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--stride", type=int, default=0)
     a = ap.parse_args()
+    both_curves = a.config is None and not a.native  # the driver's SCALE command: N > 1 and nothing else said
+    a.config = a.config or "c2"
+
+    if a.native:
+        import torch
+        import strange_attractor_renderer_amd as S
+        ndev = max(S.device_count(), 1)
+        res = native_measure(S, torch, [k % ndev for k in range(a.gpus)], a.config, a.steps, a.warmup)
+        res.update({"metric": "attractor iterations/sec through sar_render_parallel (C ABI, multi-device)", "n_gpus": a.gpus,
+                    "physical_gpus": ndev, "higher_is_better": True, "dtype": "f64", "data": "synthetic", "vs_baseline": None,
+                    "config": {"workload": f"BASELINE configs[{1 if a.config == 'c2' else 3}] through sar_renderer_new_multi"}})
+        print(json.dumps(res), flush=True)
+        return
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU) and relay their output
@@ -168,228 +230,348 @@ def main():
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
 
-    if a.config == "c4":
-        # STRONG scaling: the frame (1e10 iterations, 524 288 jobs, 4096^2) is the same at every N; rank r renders the
-        # contiguous job slice shard_jobs gives it (src/lib.rs:1056-1062 split)
-        width = height = C4_SIZE
-        total_jobs = C4_JOBS if a.jobs == DEFAULT_JOBS else a.jobs
-        n = int(a.iters if a.iters != ITERS_PER_GPU else C4_ITERS) // total_jobs
-        first_job, jobs = shard_jobs(total_jobs, world, rank)
-    else:
-        # WEAK scaling: world*jobs trajectories of n iterations; this rank owns jobs [rank*jobs, (rank+1)*jobs)
-        width = height = WIDTH
-        jobs = a.jobs
-        n = int(a.iters) // jobs
-        total_jobs = jobs * world
-        first_job = rank * jobs
-    iters_gpu = n * jobs
-    cfg = S.Config.poisson_saturne(iterations=n * total_jobs, width=width, height=height,
-                                   jobs_total=total_jobs, transparent=0, seed=1)
-    starts = S.start_points(1, first_job, jobs)
+    if a.config == "c5":
+        # BASELINE configs[4]: `sequence --start 0 --end 360 --step 1` (src/bin/main.rs:107-176, 493-517), frame k -> rank k mod N.
+        # A step is one frame: reset, render_parallel's job split with a fresh start-point stream per frame, colorize, RGB16
+        # conversion on the device, read-back into host memory. The PNG encoder (the CLI runs it on other threads) is excluded.
+        from strange_attractor_renderer_amd.sequence import render_sequence
+        frame_jobs = 65536 if a.jobs == DEFAULT_JOBS else a.jobs
+        units, jpt = frame_jobs // 4, 4
+        scfg = S.Config.solar_sail(iterations=100_000_000, width=1800, height=2000, scale=1.0, transparent=0)
+        per_job = scfg.iterations // units // jpt
+        done = [0]
 
-    stream = torch.cuda.Stream()
-    with torch.cuda.stream(stream):
-        rt = S.Runtime(cfg, device=local_rank)
-        rt.set_stream(stream.cuda_stream)
-        rt.enable_timing(True)
-        rt.set_tuning(block_threads=a.block, checkpoint_stride=a.stride, variant=a.variant)
-        npix = width * height
-        rgba = torch.empty(npix * 4, dtype=torch.int16, device="cuda")
-        ex = None
-        if world > 1 and a.exchange == "sliced":
-            ex = SlicedExchange(S, cfg, rt, rank, world, "cuda")
-        elif world > 1:
-            key = torch.empty(npix, dtype=torch.int64, device="cuda")
-            sums = torch.empty(3 * npix, dtype=torch.int32, device="cuda")
-        # per timed step: render end / exchange end / colorize end (read after the closing fence, never inside the region)
-        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(max(a.steps, a.warmup, 1))] if world > 1 else []
-        exch_ms = [0.0, 0.0]
-        step_no = [0]
+        def sink(k, name, img):
+            done[0] += 1
 
-        # the inputs of the path — the start points of this rank's trajectories — are resident in HBM before the
-        # timed region starts (with host start points each frame uploads 3 MiB: +0.1 ms)
-        starts_dev = torch.from_numpy(np.ascontiguousarray(starts)).cuda()
-
-        def step(more=True):
-            rt.reset()
-            if a.host_starts:
-                S.render_job_range(cfg, rt, n, starts)
-            else:
-                S.render_job_range_device(cfg, rt, jobs, n, starts_dev.data_ptr())
-                # the frame loop knows its next frame (src/bin/main.rs:493-517): announce it, so that its 1000 uncounted
-                # warm-up iterations per job run under THIS frame's accumulate / fold / colorize. Every frame still does
-                # all of its work inside the timed region; the last one announces nothing.
-                if a.prefetch and more:
-                    S.prefetch_device(cfg, rt, jobs, n, starts_dev.data_ptr())
-            if world > 1:
-                ev = evs[step_no[0] % len(evs)]
-                step_no[0] += 1
-                ev[0].record()
-                if ex is not None:
-                    # Runtime::merge folded in rank order, sliced: all-to-all of the image slices (16 B/px), the owner
-                    # folds its slice, 4 scalars all-reduced, every rank colorizes its slice, RGBA16 gathered on rank 0
-                    ex.merge(dist)
-                    ev[1].record()
-                    ex.colorize(dist, dst=0)
-                else:
-                    # rooted: depth keys -> all-reduce MAX; counts + winner's steps -> reduce SUM; rank 0 colorizes
-                    exchange_merge(rt, rank, dist, key, sums, dst=0)
-                    ev[1].record()
-                    if rank == 0:
-                        S.colorize_device(cfg, rt, rgba.data_ptr())
-                ev[2].record()
-            else:
-                S.colorize_device(cfg, rt, rgba.data_ptr())
-
-        def fence():
-            if world > 1:
-                dist.barrier()
+        def sweep(frames_per_rank):
+            done[0] = 0
+            render_sequence(scfg, 0.0, float(frames_per_rank * world), 1.0, units=units, jobs_per_thread=jpt, rank=rank, world=world,
+                            device=local_rank, seed=4, sink=sink, image_format=S.SAR_FMT_RGB16)
             torch.cuda.synchronize()
 
-        for k in range(a.warmup):
-            step(more=k + 1 < a.warmup)  # the last untimed frame announces nothing: no work of the timed region runs before it
-        fence()
-        if world > 1 and a.check:
-            # each rank's own (un-merged) count summed over ranks must equal the merged count on rank 0
-            def reduce_sum(a_np):  # int64 SUM onto rank 0, through whatever the backend can move
-                t = torch.from_numpy(np.ascontiguousarray(a_np))
-                t = t.cuda() if a.backend == "nccl" else t
-                dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
-                return t.cpu().numpy()
-
-            rt.reset()
-            S.render_job_range(cfg, rt, n, starts)
-            own = reduce_sum(rt.count().ravel().astype(np.int64))
-            if ex is not None:
-                ex.merge(dist)
-                torch.cuda.synchronize()
-                mine = np.zeros(npix, np.int64)  # every rank holds the merged frame inside its own slice: assemble them
-                mine[ex.first:ex.first + ex.count] = rt.count().ravel()[ex.first:ex.first + ex.count]
-                merged = reduce_sum(mine)
-            else:
-                exchange_merge(rt, rank, dist, key, sums, dst=0)
-                torch.cuda.synchronize()
-                merged = rt.count().ravel().astype(np.int64)
-            if rank == 0:
-                assert np.array_equal(merged, own % (1 << 32)), "merged count != sum of rank counts"
-                assert int(merged.sum()) == n * total_jobs
-                print(f"[check] merged count over {world} ranks == sum of per-rank counts == {n * total_jobs}", file=sys.stderr)
-            fence()
-        # HIP events around every launch of the timed region, recorded on the launch stream by the library and
-        # summed until they are read after the closing fence (reading them synchronises, so not inside the region)
-        rt.set_option("timing_accumulate", 1)
+        sweep(max(a.warmup, 1))
+        if world > 1:
+            dist.barrier()
         t0 = time.perf_counter()
-        step_no[0] = 0
-        for k in range(a.steps):
-            step(more=k + 1 < a.steps)
-        fence()
+        sweep(a.steps)
+        if world > 1:
+            dist.barrier()
         elapsed = time.perf_counter() - t0
-        for ev in evs[:a.steps]:
-            exch_ms[0] += ev[0].elapsed_time(ev[1])
-            exch_ms[1] += ev[1].elapsed_time(ev[2])
-        tm = rt.last_timing()
-        iter_ms, fold_ms, launches = tm.iterate_ms, tm.resolve_ms, tm.iterate_launches
-        col_ms = tm.colorize_ms
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-
-    # Pipelined throughput (reported NEXT to `value`, never as it): the same frames on two runtimes and two streams,
-    # alternating, so that frame k's tail (accumulate, fold, colorize — memory-bound) and frame k+1's head (reset, warm-up
-    # — no LDS, arithmetic-bound) may share the chip. `value` above is the one-stream number: a frame's latency.
-    pipelined = None
-    if world == 1 and a.pipeline:
-        try:
-            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-            rts, bufs = [], []
-            for st in streams:
-                with torch.cuda.stream(st):
-                    r2 = S.Runtime(cfg, device=local_rank)
-                    r2.set_stream(st.cuda_stream)
-                    r2.set_tuning(block_threads=a.block, checkpoint_stride=a.stride, variant=a.variant)
-                    rts.append(r2)
-                    bufs.append(torch.empty(npix * 4, dtype=torch.int16, device="cuda"))
-
-            def frame(i):
-                r2, st = rts[i & 1], streams[i & 1]
-                with torch.cuda.stream(st):
-                    r2.reset()
-                    S.render_job_range_device(cfg, r2, jobs, n, starts_dev.data_ptr())
-                    S.colorize_device(cfg, r2, bufs[i & 1].data_ptr())
-
-            for i in range(max(a.warmup, 2)):
-                frame(i)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(a.steps):
-                frame(i)
-            torch.cuda.synchronize()
-            el2 = time.perf_counter() - t0
-            pipelined = {"value": n * total_jobs * a.steps / el2, "unit": "iterations/s", "ms_per_step": el2 / a.steps * 1e3,
-                         "streams": 2, "note": "two runtimes on two streams, frames alternating; every frame does the full work"}
-            for r2 in rts:
-                r2.close()
-        except Exception as e:  # an optional extra: never lose the bench line over it
-            pipelined = {"error": repr(e)}
-
-    counted = n * total_jobs * a.steps
-    value = counted / elapsed
-    if rank == 0:
-        kern_s = iter_ms * 1e-3 / max(launches, 1)             # average duration of one launch of the iterate kernel
-        # launches whose jobs are all resident at once (512 per CU) run it as producer / consumer wave pairs
-        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
-        iterate_kernel = "k_iterate_split" if jobs <= 512 * cus and not a.variant else "k_iterate_lean"
-        per_launch = n * jobs * a.steps / max(launches, 1)      # counted iterations one launch processes
-        ach = ALG_BYTES_PER_ITER * per_launch / kern_s / 1e9
-        out = {
-            "metric": ("attractor iterations/sec at 1e9 iters, 2048x2048 buffer (poisson-saturne), per-GPU frame" if a.config == "c2"
-                       else "attractor iterations/sec at 1e10 iters, 4096x4096 buffer (poisson-saturne), whole frame"),
-            "value": value, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak" if a.config == "c2" else "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: poisson-saturne, 1e9 iterations per GPU, 2048x2048, "
-                                    "Gas colorize to RGBA16 in HBM") if a.config == "c2" else
-                                   (f"BASELINE configs[3]: poisson-saturne, 1e10 iterations, 4096x4096, {total_jobs} jobs "
-                                    "sharded over the GPUs, Gas colorize to RGBA16 in HBM"),
-                       "jobs_per_gpu": jobs, "jobs_total": total_jobs,
-                       "iterations_per_job": n, "counted_iterations_per_step": n * total_jobs,
-                       "warmup_iterations_per_job_uncounted": 1000,
-                       "counted_over_executed_iterations": round(n / (n + 1000.0), 4),
-                       "next_frame_announced": bool(a.prefetch and not a.host_starts),
-                       "start_points": "uploaded from host memory every step" if a.host_starts else "resident in HBM",
-                       "parallelism": f"trajectories sharded over {world} GPU(s)"
-                                      + ((f"; all-to-all of image slices (16 B/px) + merge in rank order + sharded "
-                                          f"colorize + RGBA16 gather (8 B/px)" if a.exchange == "sliced" else
-                                          f"; all-reduce MAX (depth keys) + reduce SUM (count, steps)")
-                                         + f" over {'RCCL/xGMI' if a.backend == 'nccl' else a.backend + ' (ranks share GPUs: staged through host)'}"
-                                         if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes() if (a.config == "c2" and int(a.iters) == ITERS_PER_GPU and jobs == DEFAULT_JOBS) else None,
-                         "kernel": iterate_kernel, "kernel_ms": kern_s * 1e3,
-                         "alg_bytes_per_iteration": ALG_BYTES_PER_ITER,
-                         "launches_timed": launches,
-                         "valu_frac": FP64_OPS_PER_ITER * per_launch / kern_s / FP64_PEAK_OPS,
-                         "note": "judged roofline per SURVEY 8(d) is HBM with 12.07 algorithmic B/iteration; the "
-                                 "kernel's binding resource is fp64 VALU issue (88 unfused ops/iteration, no FMA "
-                                 "allowed): valu_frac = 88*it/s / 39.3e12 op/s. traffic = PMC bytes/launch "
-                                 "(profiles/), below the algorithmic bytes because the scatter state lives in LDS/L2"},
-            "kernel_ms_per_step": {"warmup_and_pack": tm.warmup_ms / a.steps, "iterate": iter_ms / a.steps,
-                                   "accumulate_fold_resolve": fold_ms / a.steps,
-                                   "colorize_last": col_ms},
-        }
-        if pipelined is not None:
-            out["pipelined"] = pipelined
+        if rank == 0:
+            frames = a.steps * world
+            print(json.dumps({
+                "metric": "attractor iterations/sec over the solar-sail sequence sweep (1e8 iterations per frame, 1800x2000), one frame per GPU",
+                "value": per_job * units * jpt * frames / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": elapsed / a.steps * 1e3, "ms_per_frame_per_gpu": elapsed / a.steps * 1e3, "frames_per_second": frames / elapsed,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "BASELINE configs[4]: sequence --start 0 --end 360 --step 1 (the first steps*N frames), solar-sail, "
+                                       "1e8 iterations per frame, 1800x2000, scale 1, frame k on rank k mod N; RGB16 conversion on the "
+                                       "device + read-back included, PNG encoder excluded",
+                           "jobs_per_frame": units * jpt, "iterations_per_job": per_job, "frames": frames,
+                           "counted_over_executed_iterations": round(per_job / (per_job + 1000.0), 4),
+                           "parallelism": f"{world} replica(s), no collective"}}), flush=True)
         if world > 1:
-            out["exchange_ms_per_step"] = {"merge": exch_ms[0] / a.steps, "colorize_and_gather": exch_ms[1] / a.steps,
-                                           "form": a.exchange, "backend": a.backend}
-            if ex is not None:
-                out["exchange_ms_per_step"]["bytes_on_the_wire_per_rank"] = ex.bytes_on_the_wire()
-        if world == 1 and not a.no_cpu_baseline and a.config == "c2":
-            out["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    def run_config(config, steps, warmup, extras):
+        result = None
+        if config == "c4":
+            # STRONG scaling: the frame (1e10 iterations, 524 288 jobs, 4096^2) is the same at every N; rank r renders the
+            # contiguous job slice shard_jobs gives it (src/lib.rs:1056-1062 split)
+            width = height = C4_SIZE
+            total_jobs = C4_JOBS if a.jobs == DEFAULT_JOBS else a.jobs
+            n = int(a.iters if a.iters != ITERS_PER_GPU else C4_ITERS) // total_jobs
+            first_job, jobs = shard_jobs(total_jobs, world, rank)
+        else:
+            # WEAK scaling: world*jobs trajectories of n iterations; this rank owns jobs [rank*jobs, (rank+1)*jobs)
+            width = height = WIDTH
+            jobs = a.jobs
+            n = int(a.iters) // jobs
+            total_jobs = jobs * world
+            first_job = rank * jobs
+        iters_gpu = n * jobs
+        cfg = S.Config.poisson_saturne(iterations=n * total_jobs, width=width, height=height,
+                                       jobs_total=total_jobs, transparent=0, seed=1)
+        starts = S.start_points(1, first_job, jobs)
+
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            rt = S.Runtime(cfg, device=local_rank)
+            rt.set_stream(stream.cuda_stream)
+            rt.enable_timing(True)
+            rt.set_tuning(block_threads=a.block, checkpoint_stride=a.stride, variant=a.variant)
+            npix = width * height
+            rgba = torch.empty(npix * 4, dtype=torch.int16, device="cuda")
+            ex = None
+            if world > 1 and a.exchange == "sliced":
+                ex = SlicedExchange(S, cfg, rt, rank, world, "cuda")
+            elif world > 1:
+                key = torch.empty(npix, dtype=torch.int64, device="cuda")
+                sums = torch.empty(3 * npix, dtype=torch.int32, device="cuda")
+            # per timed step: render end / exchange end / colorize end (read after the closing fence, never inside the region)
+            evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(max(steps, warmup, 1))] if world > 1 else []
+            exch_ms = [0.0, 0.0]
+            step_no = [0]
+
+            # the inputs of the path — the start points of this rank's trajectories — are resident in HBM before the
+            # timed region starts (with host start points each frame uploads 3 MiB: +0.1 ms)
+            starts_dev = torch.from_numpy(np.ascontiguousarray(starts)).cuda()
+
+            def step(more=True):
+                rt.reset()
+                if a.host_starts:
+                    S.render_job_range(cfg, rt, n, starts)
+                else:
+                    S.render_job_range_device(cfg, rt, jobs, n, starts_dev.data_ptr())
+                    # the frame loop knows its next frame (src/bin/main.rs:493-517): announce it, so that its 1000 uncounted
+                    # warm-up iterations per job run under THIS frame's accumulate / fold / colorize. Every frame still does
+                    # all of its work inside the timed region; the last one announces nothing.
+                    if a.prefetch and more:
+                        S.prefetch_device(cfg, rt, jobs, n, starts_dev.data_ptr())
+                if world > 1:
+                    ev = evs[step_no[0] % len(evs)]
+                    step_no[0] += 1
+                    ev[0].record()
+                    if ex is not None:
+                        # Runtime::merge folded in rank order, sliced: all-to-all of the image slices (16 B/px), the owner
+                        # folds its slice, 4 scalars all-reduced, every rank colorizes its slice, RGBA16 gathered on rank 0
+                        ex.merge(dist)
+                        ev[1].record()
+                        ex.colorize(dist, dst=0)
+                    else:
+                        # rooted: depth keys -> all-reduce MAX; counts + winner's steps -> reduce SUM; rank 0 colorizes
+                        exchange_merge(rt, rank, dist, key, sums, dst=0)
+                        ev[1].record()
+                        if rank == 0:
+                            S.colorize_device(cfg, rt, rgba.data_ptr())
+                    ev[2].record()
+                else:
+                    S.colorize_device(cfg, rt, rgba.data_ptr())
+
+            def fence():
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+
+            for k in range(warmup):
+                step(more=k + 1 < warmup)  # the last untimed frame announces nothing: no work of the timed region runs before it
+            fence()
+            if world > 1 and a.check:
+                # each rank's own (un-merged) count summed over ranks must equal the merged count on rank 0
+                def reduce_sum(a_np):  # int64 SUM onto rank 0, through whatever the backend can move
+                    t = torch.from_numpy(np.ascontiguousarray(a_np))
+                    t = t.cuda() if a.backend == "nccl" else t
+                    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+                    return t.cpu().numpy()
+
+                rt.reset()
+                S.render_job_range(cfg, rt, n, starts)
+                own = reduce_sum(rt.count().ravel().astype(np.int64))
+                if ex is not None:
+                    ex.merge(dist)
+                    torch.cuda.synchronize()
+                    mine = np.zeros(npix, np.int64)  # every rank holds the merged frame inside its own slice: assemble them
+                    mine[ex.first:ex.first + ex.count] = rt.count().ravel()[ex.first:ex.first + ex.count]
+                    merged = reduce_sum(mine)
+                else:
+                    exchange_merge(rt, rank, dist, key, sums, dst=0)
+                    torch.cuda.synchronize()
+                    merged = rt.count().ravel().astype(np.int64)
+                if rank == 0:
+                    assert np.array_equal(merged, own % (1 << 32)), "merged count != sum of rank counts"
+                    assert int(merged.sum()) == n * total_jobs
+                    print(f"[check] merged count over {world} ranks == sum of per-rank counts == {n * total_jobs}", file=sys.stderr)
+                fence()
+            # HIP events around every launch of the timed region, recorded on the launch stream by the library and
+            # summed until they are read after the closing fence (reading them synchronises, so not inside the region)
+            rt.set_option("timing_accumulate", 1)
+            t0 = time.perf_counter()
+            step_no[0] = 0
+            for k in range(steps):
+                step(more=k + 1 < steps)
+            fence()
+            elapsed = time.perf_counter() - t0
+            for ev in evs[:steps]:
+                exch_ms[0] += ev[0].elapsed_time(ev[1])
+                exch_ms[1] += ev[1].elapsed_time(ev[2])
+            tm = rt.last_timing()
+            iter_ms, fold_ms, launches = tm.iterate_ms, tm.resolve_ms, tm.iterate_launches
+            col_ms = tm.colorize_ms
+            if world > 1:
+                t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+
+        # Sustained rate (reported NEXT to `value`): the same step loop for a few seconds, every frame timed by HIP events on
+        # the launch stream — min / median / max per frame, so that clock droop under a seconds-long fp64 load is on record.
+        sustained = None
+        if world == 1 and extras and a.sustained_seconds > 0:
+            try:
+                rt.enable_timing(False)  # no per-launch events in this loop: thousands of frames
+                with torch.cuda.stream(stream):
+                    per = elapsed / steps
+                    frames = int(min(4000, max(steps, a.sustained_seconds / per)))
+                    marks = [torch.cuda.Event(enable_timing=True) for _ in range(frames + 1)]
+                    marks[0].record()
+                    t0s = time.perf_counter()
+                    for k in range(frames):
+                        step(more=k + 1 < frames)
+                        marks[k + 1].record()
+                    torch.cuda.synchronize()
+                    els = time.perf_counter() - t0s
+                ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(frames))
+                third = max(frames // 3, 1)
+                order = [marks[k].elapsed_time(marks[k + 1]) for k in range(frames)]
+                sustained = {"seconds": els, "frames": frames, "value": n * total_jobs * frames / els, "unit": "iterations/s",
+                             "ms_per_frame": {"min": ms[0], "median": ms[frames // 2], "max": ms[-1],
+                                              "mean_first_third": sum(order[:third]) / third, "mean_last_third": sum(order[-third:]) / third},
+                             "note": "frame k's event-to-event time on the launch stream (the first frame runs its own warm-up, "
+                                     "the others were announced)"}
+            except Exception as e:
+                sustained = {"error": repr(e)}
+
+        # Pipelined throughput (reported NEXT to `value`, never as it): the same frames on two runtimes and two streams,
+        # alternating, so that frame k's tail (accumulate, fold, colorize — memory-bound) and frame k+1's head (reset, warm-up
+        # — no LDS, arithmetic-bound) may share the chip. `value` above is the one-stream number: a frame's latency.
+        pipelined = None
+        if world == 1 and a.pipeline and extras:
+            try:
+                streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+                rts, bufs = [], []
+                for st in streams:
+                    with torch.cuda.stream(st):
+                        r2 = S.Runtime(cfg, device=local_rank)
+                        r2.set_stream(st.cuda_stream)
+                        r2.set_tuning(block_threads=a.block, checkpoint_stride=a.stride, variant=a.variant)
+                        rts.append(r2)
+                        bufs.append(torch.empty(npix * 4, dtype=torch.int16, device="cuda"))
+
+                def frame(i):
+                    r2, st = rts[i & 1], streams[i & 1]
+                    with torch.cuda.stream(st):
+                        r2.reset()
+                        S.render_job_range_device(cfg, r2, jobs, n, starts_dev.data_ptr())
+                        S.colorize_device(cfg, r2, bufs[i & 1].data_ptr())
+
+                for i in range(max(warmup, 2)):
+                    frame(i)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    frame(i)
+                torch.cuda.synchronize()
+                el2 = time.perf_counter() - t0
+                pipelined = {"value": n * total_jobs * steps / el2, "unit": "iterations/s", "ms_per_step": el2 / steps * 1e3,
+                             "streams": 2, "note": "two runtimes on two streams, frames alternating; every frame does the full work"}
+                for r2 in rts:
+                    r2.close()
+            except Exception as e:  # an optional extra: never lose the bench line over it
+                pipelined = {"error": repr(e)}
+
+        counted = n * total_jobs * steps
+        value = counted / elapsed
+        if rank == 0:
+            kern_s = iter_ms * 1e-3 / max(launches, 1)             # average duration of one launch of the iterate kernel
+            launch_desc = rt.describe_last_launch()                # what the library really launched (not a guess made here)
+            iterate_kernel = launch_desc.split(" ")[0]
+            traffic, traffic_src = pmc_traffic_bytes()
+            if not (config == "c2" and int(a.iters) == ITERS_PER_GPU and jobs == DEFAULT_JOBS):
+                traffic, traffic_src = None, None
+            per_launch = n * jobs * steps / max(launches, 1)      # counted iterations one launch processes
+            ach = ALG_BYTES_PER_ITER * per_launch / kern_s / 1e9
+            out = {
+                "metric": ("attractor iterations/sec at 1e9 iters, 2048x2048 buffer (poisson-saturne), per-GPU frame" if config == "c2"
+                           else "attractor iterations/sec at 1e10 iters, 4096x4096 buffer (poisson-saturne), whole frame"),
+                "value": value, "unit": "iterations/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+                "scaling": "weak" if config == "c2" else "strong",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": ("BASELINE configs[1]: poisson-saturne, 1e9 iterations per GPU, 2048x2048, "
+                                        "Gas colorize to RGBA16 in HBM") if config == "c2" else
+                                       (f"BASELINE configs[3]: poisson-saturne, 1e10 iterations, 4096x4096, {total_jobs} jobs "
+                                        "sharded over the GPUs, Gas colorize to RGBA16 in HBM"),
+                           "jobs_per_gpu": jobs, "jobs_total": total_jobs,
+                           "iterations_per_job": n, "counted_iterations_per_step": n * total_jobs,
+                           "warmup_iterations_per_job_uncounted": 1000,
+                           "counted_over_executed_iterations": round(n / (n + 1000.0), 4),
+                           "next_frame_announced": bool(a.prefetch and not a.host_starts),
+                           "start_points": "uploaded from host memory every step" if a.host_starts else "resident in HBM",
+                           "parallelism": f"trajectories sharded over {world} GPU(s)"
+                                          + ((f"; all-to-all of image slices (16 B/px) + merge in rank order + sharded "
+                                              f"colorize + RGBA16 gather (8 B/px)" if a.exchange == "sliced" else
+                                              f"; all-reduce MAX (depth keys) + reduce SUM (count, steps)")
+                                             + f" over {'RCCL/xGMI' if a.backend == 'nccl' else a.backend + ' (ranks share GPUs: staged through host)'}"
+                                             if world > 1 else "")},
+                "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ach / HBM_PEAK_GBS,
+                             "traffic": traffic,
+                             "traffic_source": (f"{traffic_src}: PMC passes of this workload committed with the round "
+                                                "((2*FETCH_SIZE + WRITE_SIZE)*1024 per launch), NOT measured by this run") if traffic_src else None,
+                             "kernel": iterate_kernel, "launch": launch_desc, "kernel_ms": kern_s * 1e3,
+                             "alg_bytes_per_iteration": ALG_BYTES_PER_ITER,
+                             "launches_timed": launches,
+                             "valu_frac": FP64_OPS_PER_ITER * per_launch / kern_s / FP64_PEAK_OPS,
+                             "note": "judged roofline per SURVEY 8(d) is HBM with 12.07 algorithmic B/iteration; the "
+                                     "kernel's binding resource is fp64 VALU issue (88 unfused ops/iteration, no FMA "
+                                     "allowed): valu_frac = 88*it/s / 39.3e12 op/s. traffic = PMC bytes/launch "
+                                     "(profiles/), below the algorithmic bytes because the scatter state lives in LDS/L2"},
+                "sustained": sustained,
+                "kernel_ms_per_step": {"warmup_and_pack": tm.warmup_ms / steps, "iterate": iter_ms / steps,
+                                       "accumulate_fold_resolve": fold_ms / steps,
+                                       "colorize_last": col_ms},
+            }
+            if pipelined is not None:
+                out["pipelined"] = pipelined
+            if world > 1:
+                out["exchange_ms_per_step"] = {"merge": exch_ms[0] / steps, "colorize_and_gather": exch_ms[1] / steps,
+                                               "form": a.exchange, "backend": a.backend}
+                if ex is not None:
+                    out["exchange_ms_per_step"]["bytes_on_the_wire_per_rank"] = ex.bytes_on_the_wire()
+            if world == 1 and not a.no_cpu_baseline and config == "c2" and extras:
+                out["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
+                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            result = out
+        if ex is not None:
+            del ex
+        rt.close()
+        return result
+
+    out = run_config(a.config, a.steps, a.warmup, True)
+    if world > 1 and both_curves:
+        # the strong-scaling frame on the same ranks: BASELINE configs[3], the same frame at every N
+        c4 = run_config("c4", max(2, min(a.steps, 6)), 1, False)
+        if rank == 0:
+            ref = None
+            try:
+                ref = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_c4_n1.json")))
+            except Exception:
+                pass
+            out["strong_c4"] = {"value": c4["value"], "unit": c4["unit"], "ms_per_step": c4["ms_per_step"], "steps": c4["steps"],
+                                "scaling": "strong", "workload": c4["config"]["workload"], "jobs_total": c4["config"]["jobs_total"],
+                                "exchange_ms_per_step": c4.get("exchange_ms_per_step"), "kernel_ms_per_step": c4["kernel_ms_per_step"],
+                                "launch": c4["roofline"]["kernel"],
+                                "n1_profile": ({"file": "profiles/r03_bench_c4_n1.json", "value": ref["value"], "ms_per_step": ref["ms_per_step"]}
+                                               if ref else None),
+                                "speedup_vs_n1_profile": (c4["value"] / ref["value"]) if ref else None}
+        # ... and both workloads through the C ABI alone (one process, rank 0, every GPU of the job; the other ranks wait)
+        dist.barrier()
+        if rank == 0:
+            try:
+                devs = list(range(min(world, max(torch.cuda.device_count(), 1))))
+                devs = [devs[k % len(devs)] for k in range(world)]
+                out["native"] = {"c2": native_measure(S, torch, devs, "c2", max(2, min(a.steps, 6)), 1),
+                                 "c4": native_measure(S, torch, devs, "c4", max(2, min(a.steps, 4)), 1)}
+            except Exception as e:  # an extra: never lose the line over it
+                out["native"] = {"error": repr(e)}
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

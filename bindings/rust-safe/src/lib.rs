@@ -261,11 +261,25 @@ impl GpuRenderer {
             self.raw = std::ptr::null_mut();
         }
     }
-    /// The renderer's merged runtime (borrowed: freed with the renderer), e.g. to read `count` after a frame.
-    pub fn runtime(&mut self) -> GpuRuntime {
+    /// The renderer's merged runtime, e.g. to read `count` after a frame. It lives inside the renderer: the borrow keeps
+    /// the renderer from being shut down, dropped or rendered into again while the view is alive.
+    pub fn runtime(&mut self) -> BorrowedRuntime<'_> {
         let mut rt = std::ptr::null_mut();
         check(unsafe { sys::sar_renderer_runtime(self.raw, &mut rt) });
-        GpuRuntime { raw: rt, owned: false, opts: self.opts.clone() }
+        BorrowedRuntime { rt: GpuRuntime { raw: rt, owned: false, opts: self.opts.clone() }, _renderer: std::marker::PhantomData }
+    }
+}
+
+/// A `GpuRuntime` that belongs to a `GpuRenderer` (`GpuRenderer::runtime`): usable like `&GpuRuntime` for as long as the
+/// renderer stays mutably borrowed, never freed through this handle.
+pub struct BorrowedRuntime<'a> {
+    rt: GpuRuntime,
+    _renderer: std::marker::PhantomData<&'a mut GpuRenderer>,
+}
+impl<'a> std::ops::Deref for BorrowedRuntime<'a> {
+    type Target = GpuRuntime;
+    fn deref(&self) -> &GpuRuntime {
+        &self.rt
     }
 }
 impl Drop for GpuRenderer {

@@ -79,7 +79,7 @@ pub struct SarParallelTiming {
     pub exchange_ms: f32,
     pub colorize_ms: f32,
     pub n_devices: u32,
-    pub _pad: u32,
+    pub peer_access_failures: u32,
     pub exchange_bytes_per_device: u64,
 }
 
@@ -125,6 +125,7 @@ extern "C" {
     pub fn sar_runtime_prefetch_device(cfg: *const SarConfig, rt: *mut SarRuntime, n_jobs: u32, iters_per_job: u64,
                                        starts_xyz_dev: *const f64) -> c_int;
     pub fn sar_colorize_device(cfg: *const SarConfig, rt: *mut SarRuntime, rgba_out_dev: *mut c_void) -> c_int;
+    pub fn sar_runtime_describe_last_launch(rt: *const SarRuntime, out: *mut c_char, cap: usize) -> c_int;
 
     pub fn sar_runtime_extent(cfg: *const SarConfig, rt: *mut SarRuntime, n_jobs: u32, iters_per_job: u64,
                               starts_xyz_host: *const f64, out12: *mut f64) -> c_int;

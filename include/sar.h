@@ -282,8 +282,11 @@ int sar_renderer_new(int device, uint32_t units, uint64_t seed, sar_renderer** o
  * summed over the devices. render_parallel then cuts the units*jobs_per_unit jobs into contiguous slices, one per
  * device, renders them concurrently (one host thread + one stream per device), lets every device own one slice of
  * the image, moves the partial buffers point-to-point (hipMemcpyPeerAsync: every pair of GPUs over its own xGMI link,
- * 16 B/px), folds them with Runtime::merge in device order, colorizes each slice where it lives and copies it
- * straight into rgba_out_host. The result is bit-identical to the single-device renderer's for the same units. */
+ * 16 B/px; an owner's G-1 pulls run on G-1 copy streams, so they use their links at the same time), folds them with
+ * Runtime::merge in device order, colorizes each slice where it lives and copies it into rgba_out_host (straight into it
+ * when that memory is pinned, through a pinned staging buffer per device otherwise). The result is bit-identical to the
+ * single-device renderer's for the same units. (Validated with one physical GPU listed several times; a node with several
+ * GPUs has not been available to this build.) */
 int sar_renderer_new_multi(const int* devices, uint32_t n_devices, uint32_t units, uint64_t seed, sar_renderer** out);
 int sar_renderer_num_devices(const sar_renderer* r, uint32_t* out_devices);
 int sar_renderer_num_units(const sar_renderer* r, uint32_t* out_units);
@@ -303,7 +306,9 @@ typedef struct sar_parallel_timing {
     float    exchange_ms;   /* peer copies + merge of the owned slice (includes waiting for the slowest peer) */
     float    colorize_ms;   /* scalars + colorize of the slice + its copy to the host image */
     uint32_t n_devices;
-    uint32_t _pad;
+    uint32_t peer_access_failures;  /* ordered pairs of distinct devices WITHOUT direct peer access (hipDeviceCanAccessPeer said
+                                       no, or hipDeviceEnablePeerAccess failed; sar_last_error keeps the last reason): their
+                                       copies are staged through host memory by the HIP runtime */
     uint64_t exchange_bytes_per_device;  /* bytes every device pulls over xGMI per frame */
 } sar_parallel_timing;
 int sar_renderer_last_timing(const sar_renderer* r, sar_parallel_timing* out);
@@ -311,6 +316,12 @@ int sar_renderer_last_timing(const sar_renderer* r, sar_parallel_timing* out);
 /* ---- measurement ----------------------------------------------------------------------------------- */
 int sar_runtime_enable_timing(sar_runtime* rt, int enabled);
 int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
+/* What the last render call launched, as one line of text for logs and bench records — e.g.
+ * "k_iterate_split R=60 bins=128x32768px interleaved hints=f32 pipe=2 | k_bin_accumulate splits=4 lists=4 counters=u32 |
+ * chunks=1 warmup_ahead=19": the iterate kernel the library really chose (not a guess of the caller), its chunk size and
+ * bin geometry, the accumulate mode, the launch chunks of the call and how many render calls so far found their warm-up
+ * already done (sar_runtime_prefetch_device). Writes at most cap bytes including the terminating 0. */
+int sar_runtime_describe_last_launch(const sar_runtime* rt, char* out, size_t cap);
 /* Tuning / test options by name (value 0 restores the default unless noted):
  *   "block_threads"      lanes per workgroup of the iterate kernel (64, 128, 192, 256)
  *   "checkpoint_stride"  iterations between trajectory checkpoints used by the payload resolve
@@ -341,7 +352,14 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  *                        them) until sar_runtime_last_timing reads and clears them; 0: last render call only
  *   "measure"            measurement-only kernels: 1 count only, 2 arithmetic only (results are NOT the render)
  *   "debug_chunk_jobs"   test hook: cap on jobs per launch chunk
- *   "debug_max_ordinals" test hook: visits one launch may order (default 2^32-2); jobs with more iterations run as segments */
+ *   "debug_max_ordinals" test hook: visits one launch may order (default 2^32-2); jobs with more iterations run as segments
+ *
+ * Jobs of more than 2^32-2 iterations (Config::iterations is a usize, :267): a launch orders its visits with a 32-bit
+ * ordinal, so such a job runs as successive launches that hand its state on — and it runs them ALONE, one lane of the
+ * chip at ~1e6 iterations per second: the reference's tie rule is job-major (an earlier JOB wins an exact depth tie
+ * whatever the iteration), and two jobs advancing through their segments side by side would fold a later job's early
+ * visit before an earlier job's late one. Correct, but ~1e5 times slower than the same iterations cut into more jobs;
+ * use jobs_total / jobs_per_unit so that a job stays below 2^32-2 iterations. */
 int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value);
 /* Diagnostic (host arithmetic only, no device needed): the pixel -> (bin, 16-bit record) map the LDS-binned path uses for
  * a width x height image with "bin_shift" / "bin_interleave" as given (0 = the defaults of a runtime without forced

@@ -70,7 +70,7 @@ class SarParallelTiming(C.Structure):
         ("exchange_ms", C.c_float),
         ("colorize_ms", C.c_float),
         ("n_devices", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("peer_access_failures", C.c_uint32),
         ("exchange_bytes_per_device", C.c_uint64),
     ]
 
@@ -118,6 +118,7 @@ PROTOTYPES = {
     "sar_render_job_range": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _P(C.c_double)]),
     "sar_render_job_range_device": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _vp]),
     "sar_runtime_prefetch_device": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _vp]),
+    "sar_runtime_describe_last_launch": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "sar_colorize": (C.c_int, [_cfg_p, _vp, _P(C.c_uint16)]),
     "sar_colorize_device": (C.c_int, [_cfg_p, _vp, _vp]),
     "sar_runtime_extent": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _P(C.c_double), _P(C.c_double)]),

@@ -147,6 +147,11 @@ class Runtime:
             h = C.c_void_p()
             _check(_lib().sar_runtime_new(C.byref(config.c), device, C.byref(h)), "sar_runtime_new")
             self._h = h
+            # A/B and whole-suite test hook of THIS harness (the library itself reads no environment): SAR_STAGER=1|2 and
+            # SAR_SPLIT=1|2 force one stager / the whole or the split iterate kernel on every runtime created through it
+            for env, opt in (("SAR_STAGER", "stager"), ("SAR_SPLIT", "split_waves")):
+                if os.environ.get(env, "") in ("1", "2"):
+                    _check(_lib().sar_runtime_set_option(self._h, opt.encode(), int(os.environ[env])), "sar_runtime_set_option")
         self.device = device
 
     def close(self):
@@ -238,6 +243,12 @@ class Runtime:
         self.set_option("debug_chunk_jobs", variant >> 8)
         for k, v in more.items():
             self.set_option(k, v)
+
+    def describe_last_launch(self) -> str:
+        """Which kernels the last render call really launched (sar_runtime_describe_last_launch)."""
+        buf = C.create_string_buffer(512)
+        _check(_lib().sar_runtime_describe_last_launch(self._h, buf, 512), "sar_runtime_describe_last_launch")
+        return buf.value.decode()
 
     def stream(self) -> int:
         s = C.c_void_p()
@@ -449,7 +460,7 @@ class ParallelRenderer:
     def last_timing(self) -> dict:
         t = SarParallelTiming()
         _check(_lib().sar_renderer_last_timing(self._h, C.byref(t)), "sar_renderer_last_timing")
-        return {k: getattr(t, k) for k, _ in SarParallelTiming._fields_ if k != "_pad"}
+        return {k: getattr(t, k) for k, _ in SarParallelTiming._fields_}
 
     def num_threads(self) -> int:
         n = C.c_uint32()
@@ -479,3 +490,10 @@ def render_parallel(renderer: ParallelRenderer, config: Config, jobs_per_thread:
     _check(_lib().sar_render_parallel(renderer._h, C.byref(config.c), jobs_per_thread,
                                       out.ctypes.data_as(C.POINTER(C.c_uint16))), "sar_render_parallel")
     return out
+
+
+def render_parallel_into(renderer: ParallelRenderer, config: Config, jobs_per_thread: int, rgba_host_ptr: int):
+    """render_parallel into caller-owned host memory (width*height*4 uint16; e.g. pinned memory: every device then
+    copies its slice straight into it)."""
+    _check(_lib().sar_render_parallel(renderer._h, C.byref(config.c), jobs_per_thread,
+                                      C.cast(C.c_void_p(rgba_host_ptr), C.POINTER(C.c_uint16))), "sar_render_parallel")

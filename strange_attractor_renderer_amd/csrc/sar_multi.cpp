@@ -9,10 +9,12 @@
 //      points and enqueues the render on that device's stream (no data-path traffic between devices);
 //   2. every device OWNS one slice of S consecutive pixels of the image: it packs its partial buffers into one block per
 //      owner (16 B/px), the owners PULL their blocks with hipMemcpyPeerAsync — G*(G-1) copies, every pair over its own
-//      xGMI link — and fold them with Runtime::merge in device order (k_exch_merge_slices: device 0 is the accumulator,
-//      the earlier device wins depth ties, the running max sees every intermediate sum);
+//      xGMI link, an owner's G-1 pulls on G-1 copy streams so that the links work at the same time (on ONE stream they
+//      ran one after the other, each at single-link speed: round 2) — and fold them with Runtime::merge in device order
+//      (k_exch_merge_slices: device 0 is the accumulator, the earlier device wins depth ties, the running max sees every
+//      intermediate sum);
 //   3. four scalars (max, wrap flag, depth range) are combined on the host, every device colorizes ITS slice and copies
-//      it straight into the caller's host image over its own PCIe link.
+//      it into the caller's host image over its own PCIe link (through a pinned staging buffer if that image is pageable).
 // With one device steps 2-3 collapse to a plain colorize.
 #include <chrono>
 #include <cstdio>
@@ -51,6 +53,9 @@ struct Shard {
     void* d_rgba = nullptr;   // [S*8] colorized slice
     void* d_sc = nullptr;     // int64[4] scalars in / out
     long long* h_sc = nullptr;  // pinned int64[4]
+    uint16_t* h_rgba = nullptr;  // pinned [S*4]: the colorized slice on its way into a pageable host image
+    std::vector<hipStream_t> pull_streams;  // one per source device: this owner's pulls run side by side
+    std::vector<hipEvent_t> pulled;         // ... and are joined to the owner's stream through these
     size_t slice_cap = 0;     // S the buffers were sized for
     hipEvent_t packed = nullptr, merged = nullptr, begin = nullptr, end = nullptr;
     // job slice of the current frame
@@ -73,6 +78,7 @@ struct sar_renderer {
     Rng rng_mark;
     std::vector<Shard> shards;    // one per device, in fold order
     bool scattered = false;       // shard runtimes hold only their own merged slice (gather before handing one out)
+    uint32_t peer_access_failures = 0;  // ordered device pairs whose copies cannot go peer to peer
     sar_parallel_timing timing{};
 };
 
@@ -88,6 +94,8 @@ int free_shard_buffers(Shard& sh) {
     if (sh.d_pack) hipFree(sh.d_pack);
     if (sh.d_recv) hipFree(sh.d_recv);
     if (sh.d_rgba) hipFree(sh.d_rgba);
+    if (sh.h_rgba) hipHostFree(sh.h_rgba);
+    sh.h_rgba = nullptr;
     sh.d_pack = sh.d_recv = sh.d_rgba = nullptr;
     sh.slice_cap = 0;
     return SAR_OK;
@@ -110,6 +118,12 @@ int ensure_shard(sar_renderer* r, Shard& sh, const sar_config* cfg, uint32_t S) 
         HIP_TRY(hipEventCreate(&sh.end));
         HIP_TRY(hipMalloc(&sh.d_sc, 4 * sizeof(long long)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sh.h_sc), 4 * sizeof(long long), hipHostMallocDefault));
+        sh.pull_streams.assign(G, nullptr);
+        sh.pulled.assign(G, nullptr);
+        for (uint32_t k = 0; k < G; ++k) {
+            HIP_TRY(hipStreamCreateWithFlags(&sh.pull_streams[k], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&sh.pulled[k], hipEventDisableTiming));
+        }
     }
     if (sh.slice_cap != S) {
         HIP_TRY(hipStreamSynchronize(sh.rt->stream));
@@ -117,6 +131,7 @@ int ensure_shard(sar_renderer* r, Shard& sh, const sar_config* cfg, uint32_t S) 
         HIP_TRY(hipMalloc(&sh.d_pack, static_cast<size_t>(G) * S * 16u));
         HIP_TRY(hipMalloc(&sh.d_recv, static_cast<size_t>(G) * S * 16u));
         HIP_TRY(hipMalloc(&sh.d_rgba, static_cast<size_t>(S) * 8u));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sh.h_rgba), static_cast<size_t>(S) * 8u, hipHostMallocDefault));
         sh.slice_cap = S;
     }
     return SAR_OK;
@@ -207,10 +222,17 @@ int sar_renderer_new_multi(const int* devices, uint32_t n_devices, uint32_t unit
         for (uint32_t b = 0; b < n_devices; ++b) {
             if (devices[a] == devices[b]) continue;
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can && hipSetDevice(devices[a]) == hipSuccess) {
-                const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-                else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            hipError_t e = hipDeviceCanAccessPeer(&can, devices[a], devices[b]);
+            if (e == hipSuccess && can) e = hipSetDevice(devices[a]);
+            if (e == hipSuccess && can) {
+                e = hipDeviceEnablePeerAccess(devices[b], 0);
+                if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+            }
+            if (e != hipSuccess || !can) {  // not fatal (the copies are then staged through the host), but not silent either
+                (void)hipGetLastError();
+                ++r->peer_access_failures;
+                set_error("no direct peer access from device %d to device %d (%s): their exchange is staged through host memory",
+                          devices[a], devices[b], e != hipSuccess ? hipGetErrorString(e) : "hipDeviceCanAccessPeer: no");
             }
         }
     *out = r;
@@ -243,6 +265,8 @@ int sar_renderer_shutdown(sar_renderer* r) {
         free_shard_buffers(sh);
         if (sh.d_sc) hipFree(sh.d_sc);
         if (sh.h_sc) hipHostFree(sh.h_sc);
+        for (hipStream_t st : sh.pull_streams) if (st) hipStreamDestroy(st);
+        for (hipEvent_t ev : sh.pulled) if (ev) hipEventDestroy(ev);
         if (sh.packed) hipEventDestroy(sh.packed);
         if (sh.merged) hipEventDestroy(sh.merged);
         if (sh.begin) hipEventDestroy(sh.begin);
@@ -289,6 +313,7 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
 
     // fresh start points for every job, in job order, from the renderer's stream (the reference's workers draw from
     // per-thread RNGs as they pick jobs up, :748; here the stream is one and the job -> point map is deterministic)
+    const Rng rng_before = r->ahead_jobs ? r->rng_mark : r->rng;  // the stream as the PREVIOUS frame left it
     std::vector<double> starts;
     if (r->ahead_jobs == total_jobs && !r->ahead.empty()) {
         starts.swap(r->ahead);              // drawn during the previous frame
@@ -303,6 +328,26 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
         r->ahead.resize(static_cast<size_t>(total_jobs) * 3);
         for (uint64_t k = 0; k < total_jobs; ++k) r->rng.start_point(&r->ahead[3 * static_cast<size_t>(k)]);
         r->ahead_jobs = total_jobs;
+    };
+    // A frame that fails leaves the renderer as it found it: the start-point stream is wound back (the next frame draws
+    // the points this one would have used), nothing drawn ahead survives, every device has finished what it was given,
+    // and no shard claims to hold merged slices.
+    auto failed = [&](int status) {
+        char keep[512];
+        std::snprintf(keep, sizeof(keep), "%s", sar_last_error());
+        for (Shard& sh : r->shards) {
+            if (!sh.rt) continue;
+            hipSetDevice(sh.device);
+            hipStreamSynchronize(sh.rt->stream);
+            for (hipStream_t st : sh.pull_streams) if (st) hipStreamSynchronize(st);
+        }
+        (void)hipGetLastError();
+        r->rng = rng_before;
+        r->ahead_jobs = 0;
+        r->ahead.clear();
+        r->scattered = false;
+        set_error("%s", keep);
+        return status;
     };
 
     // contiguous job slices, sizes differ by at most one (the same partition as distributed.shard_jobs)
@@ -319,12 +364,12 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
     if (G == 1) {
         Shard& sh = r->shards[0];
         render_shard(r, &sh, cfg, per_job, starts.data(), S);
-        if (sh.status != SAR_OK) { set_error("%s", sh.error); return sh.status; }
+        if (sh.status != SAR_OK) { set_error("%s", sh.error); return failed(sh.status); }
         int st = SAR_OK;
         draw_ahead();
         if (rgba_out_host) st = sar_colorize(cfg, sh.rt, rgba_out_host);  // :1080
         r->timing.total_ms = static_cast<float>(now_ms() - t0);
-        return st;
+        return st == SAR_OK ? st : failed(st);
     }
 
     // 1. one host thread per device (as the reference has one per core): stage, render, pack
@@ -335,68 +380,103 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
         for (auto& w : workers) w.join();
     }
     for (Shard& sh : r->shards)
-        if (sh.status != SAR_OK) { set_error("device %d: %s", sh.device, sh.error); return sh.status; }
+        if (sh.status != SAR_OK) { set_error("device %d: %s", sh.device, sh.error); return failed(sh.status); }
     draw_ahead();
 
-    // 2. the owners pull their blocks (every pair of devices over its own link) and fold them in device order
     const size_t blk = static_cast<size_t>(S) * 16u;
-    for (uint32_t d = 0; d < G; ++d) {
-        Shard& dst = r->shards[d];
-        HIP_TRY(hipSetDevice(dst.device));
-        hipStream_t st = dst.rt->stream;
-        for (uint32_t k = 0; k < G; ++k) {
-            const uint32_t s = (d + k) % G;  // start with the local block; stagger the sources over the links
-            Shard& src = r->shards[s];
-            if (s != d) HIP_TRY(hipStreamWaitEvent(st, src.packed, 0));
-            HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(dst.d_recv) + s * blk, dst.device,
-                                       static_cast<const char*>(src.d_pack) + d * blk, src.device, blk, st));
-        }
-        const uint64_t first = static_cast<uint64_t>(d) * S;
-        const uint32_t n = first >= npix ? 0u : static_cast<uint32_t>((npix - first < S) ? npix - first : S);
-        launch_exch_merge_slices(dst.rt->d_count, dst.rt->d_key, dst.rt->d_steps, static_cast<uint32_t>(first >= npix ? 0 : first), n, S, G,
-                                 dst.d_recv, dst.rt->d_scalars, d == 0, st);
-        launch_exch_scalars_export(dst.rt->d_scalars, dst.d_sc, st);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(dst.h_sc, dst.d_sc, 4 * sizeof(long long), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(dst.merged, st));
+    // Is the caller's image pinned memory (then every device copies its slice straight into it), or pageable (an async copy
+    // into pageable memory is staged by the HIP runtime and serialises the devices: each goes through its own pinned buffer
+    // and a host thread moves the slice on)?
+    bool pinned_out = false;
+    if (rgba_out_host) {
+        hipPointerAttribute_t attr;
+        std::memset(&attr, 0, sizeof(attr));
+        if (hipPointerGetAttributes(&attr, rgba_out_host) == hipSuccess) pinned_out = attr.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();
     }
-    r->scattered = true;
+    auto exchange = [&]() -> int {
+        // 2. the owners pull their blocks (every pair of devices over its own link, all links at the same time) and fold them
+        // in device order
+        for (uint32_t d = 0; d < G; ++d) {
+            Shard& dst = r->shards[d];
+            HIP_TRY(hipSetDevice(dst.device));
+            hipStream_t st = dst.rt->stream;
+            for (uint32_t k = 0; k < G; ++k) {
+                const uint32_t s = (d + k) % G;  // start with the local block; stagger the sources over the links
+                Shard& src = r->shards[s];
+                hipStream_t cs = s == d ? st : dst.pull_streams[s];
+                if (s != d) HIP_TRY(hipStreamWaitEvent(cs, src.packed, 0));
+                HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(dst.d_recv) + s * blk, dst.device,
+                                           static_cast<const char*>(src.d_pack) + d * blk, src.device, blk, cs));
+                if (s != d) {
+                    HIP_TRY(hipEventRecord(dst.pulled[s], cs));
+                    HIP_TRY(hipStreamWaitEvent(st, dst.pulled[s], 0));
+                }
+            }
+            const uint64_t first = static_cast<uint64_t>(d) * S;
+            const uint32_t n = first >= npix ? 0u : static_cast<uint32_t>((npix - first < S) ? npix - first : S);
+            launch_exch_merge_slices(dst.rt->d_count, dst.rt->d_key, dst.rt->d_steps, static_cast<uint32_t>(first >= npix ? 0 : first), n, S, G,
+                                     dst.d_recv, dst.rt->d_scalars, d == 0, st);
+            launch_exch_scalars_export(dst.rt->d_scalars, dst.d_sc, st);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(dst.h_sc, dst.d_sc, 4 * sizeof(long long), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(dst.merged, st));
+        }
+        r->scattered = true;
 
-    // 3. the four scalars become global on the host; every device colorizes its slice into the caller's image
-    long long red[4] = {0, 0, 0, 0};
-    for (uint32_t d = 0; d < G; ++d) {
-        Shard& sh = r->shards[d];
-        HIP_TRY(hipSetDevice(sh.device));
-        HIP_TRY(hipEventSynchronize(sh.merged));
-        for (int k = 0; k < 4; ++k) red[k] = sh.h_sc[k] > red[k] ? sh.h_sc[k] : red[k];
-    }
-    const double t_merged = now_ms();
-    for (uint32_t d = 0; d < G; ++d) {
-        Shard& sh = r->shards[d];
-        HIP_TRY(hipSetDevice(sh.device));
-        hipStream_t st = sh.rt->stream;
-        for (int k = 0; k < 4; ++k) sh.h_sc[k] = red[k];
-        HIP_TRY(hipMemcpyAsync(sh.d_sc, sh.h_sc, 4 * sizeof(long long), hipMemcpyHostToDevice, st));
-        launch_exch_scalars_import(sh.rt->d_scalars, sh.d_sc, st);
-        const uint64_t first = static_cast<uint64_t>(d) * S;
-        const uint32_t n = first >= npix ? 0u : static_cast<uint32_t>((npix - first < S) ? npix - first : S);
-        if (rgba_out_host && n) {
-            SAR_TRY(colorize_range(cfg, sh.rt, static_cast<uint32_t>(first), n, sh.d_rgba, true));  // :1080, sharded
-            HIP_TRY(hipMemcpyAsync(rgba_out_host + first * 4u, sh.d_rgba, static_cast<size_t>(n) * 8u, hipMemcpyDeviceToHost, st));
+        // 3. the four scalars become global on the host; every device colorizes its slice into the caller's image
+        long long red[4] = {0, 0, 0, 0};
+        for (uint32_t d = 0; d < G; ++d) {
+            Shard& sh = r->shards[d];
+            HIP_TRY(hipSetDevice(sh.device));
+            HIP_TRY(hipEventSynchronize(sh.merged));
+            for (int k = 0; k < 4; ++k) red[k] = sh.h_sc[k] > red[k] ? sh.h_sc[k] : red[k];
         }
-        HIP_TRY(hipEventRecord(sh.end, st));
-    }
-    (void)t_merged;
-    for (Shard& sh : r->shards) {
-        HIP_TRY(hipSetDevice(sh.device));
-        HIP_TRY(hipStreamSynchronize(sh.rt->stream));
-        float ms = 0.f;  // per-device stream time of the three phases; the frame is as slow as the slowest device
-        if (hipEventElapsedTime(&ms, sh.begin, sh.packed) == hipSuccess && ms > r->timing.render_ms) r->timing.render_ms = ms;
-        if (hipEventElapsedTime(&ms, sh.packed, sh.merged) == hipSuccess && ms > r->timing.exchange_ms) r->timing.exchange_ms = ms;
-        if (hipEventElapsedTime(&ms, sh.merged, sh.end) == hipSuccess && ms > r->timing.colorize_ms) r->timing.colorize_ms = ms;
-    }
+        for (uint32_t d = 0; d < G; ++d) {
+            Shard& sh = r->shards[d];
+            HIP_TRY(hipSetDevice(sh.device));
+            hipStream_t st = sh.rt->stream;
+            for (int k = 0; k < 4; ++k) sh.h_sc[k] = red[k];
+            HIP_TRY(hipMemcpyAsync(sh.d_sc, sh.h_sc, 4 * sizeof(long long), hipMemcpyHostToDevice, st));
+            launch_exch_scalars_import(sh.rt->d_scalars, sh.d_sc, st);
+            const uint64_t first = static_cast<uint64_t>(d) * S;
+            const uint32_t n = first >= npix ? 0u : static_cast<uint32_t>((npix - first < S) ? npix - first : S);
+            if (rgba_out_host && n) {
+                SAR_TRY(colorize_range(cfg, sh.rt, static_cast<uint32_t>(first), n, sh.d_rgba, true));  // :1080, sharded
+                HIP_TRY(hipMemcpyAsync(pinned_out ? rgba_out_host + first * 4u : sh.h_rgba, sh.d_rgba, static_cast<size_t>(n) * 8u,
+                                       hipMemcpyDeviceToHost, st));
+            }
+            HIP_TRY(hipEventRecord(sh.end, st));
+        }
+        // wait for every device; a pageable image gets its slices from the staging buffers, one host thread per device
+        std::vector<std::thread> movers;
+        std::vector<int> sync_status(G, SAR_OK);
+        for (uint32_t d = 0; d < G; ++d) {
+            movers.emplace_back([&, d]() {
+                Shard& sh = r->shards[d];
+                if (hipSetDevice(sh.device) != hipSuccess || hipStreamSynchronize(sh.rt->stream) != hipSuccess) { sync_status[d] = SAR_ERR_HIP; return; }
+                const uint64_t first = static_cast<uint64_t>(d) * S;
+                const uint32_t n = first >= npix ? 0u : static_cast<uint32_t>((npix - first < S) ? npix - first : S);
+                if (rgba_out_host && n && !pinned_out) std::memcpy(rgba_out_host + first * 4u, sh.h_rgba, static_cast<size_t>(n) * 8u);
+            });
+        }
+        for (auto& m : movers) m.join();
+        for (uint32_t d = 0; d < G; ++d)
+            if (sync_status[d] != SAR_OK) { set_error("device %d: stream synchronisation failed after the exchange", r->shards[d].device); return sync_status[d]; }
+        for (Shard& sh : r->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            float ms = 0.f;  // per-device stream time of the three phases; the frame is as slow as the slowest device
+            if (hipEventElapsedTime(&ms, sh.begin, sh.packed) == hipSuccess && ms > r->timing.render_ms) r->timing.render_ms = ms;
+            if (hipEventElapsedTime(&ms, sh.packed, sh.merged) == hipSuccess && ms > r->timing.exchange_ms) r->timing.exchange_ms = ms;
+            if (hipEventElapsedTime(&ms, sh.merged, sh.end) == hipSuccess && ms > r->timing.colorize_ms) r->timing.colorize_ms = ms;
+        }
+        return SAR_OK;
+    };
+    const int st = exchange();
+    if (st != SAR_OK) return failed(st);
     r->timing.total_ms = static_cast<float>(now_ms() - t0);
     r->timing.exchange_bytes_per_device = static_cast<uint64_t>(G - 1) * blk;
+    r->timing.peer_access_failures = r->peer_access_failures;
     return SAR_OK;
 }
 

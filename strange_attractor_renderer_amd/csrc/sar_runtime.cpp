@@ -618,6 +618,13 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     }
     HIP_TRY(hipGetLastError());
     span_end(rt, rt->iter_spans, rt->iter_used);
+    ++rt->last_chunks;
+    std::snprintf(rt->last_launch, sizeof(rt->last_launch),
+                  "%s R=%u bins=%ux%upx %s hints=%s pipe=%u | k_bin_accumulate splits=%u lists=%u counters=%s",
+                  split ? "k_iterate_split" : "k_iterate_lean", pl.R, pl.geo.bins, 1u << pl.geo.shift, pl.geo.interleaved ? "interleaved" : "consecutive",
+                  mode != 2 ? "none" : (pl.hint_bytes == 4 ? "f32" : "q16"), pl.pipe, pl.splits,
+                  rt->acc_lists ? rt->acc_lists : (pl.geo.shift >= 15u ? 4u : 1u),
+                  pl.geo.shift == 16u ? (rt->acc_halves ? "u32-halves" : "u16-packed") : "u32");
     if (rt->iter_done) {  // an announced call's warm-up starts here, under this launch's accumulate and fold
         HIP_TRY(hipEventRecord(rt->iter_done, rt->stream));
         rt->iter_done_recorded = true;
@@ -662,6 +669,8 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
     }
     if (n_jobs == 0 || iters == 0) return SAR_OK;
     HIP_TRY(hipSetDevice(rt->device));
+    rt->last_chunks = 0;
+    rt->last_launch[0] = 0;
 
     // A launch orders its visits with a 32-bit ordinal (job * n + t). Config::iterations is a usize (:267): a job with more
     // iterations than that runs as SEGMENTS — successive launches that hand the trajectory state on (no second warm-up),
@@ -725,6 +734,8 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
                 span_begin(rt, rt->iter_spans, rt->iter_used);
                 launch_iterate(ia, pl.block, pl.xcd_local, mode, rt->stream);
                 span_end(rt, rt->iter_spans, rt->iter_used);
+                ++rt->last_chunks;
+                std::snprintf(rt->last_launch, sizeof(rt->last_launch), "k_iterate (one global atomic per visit%s)", pl.xcd_local ? ", per-XCD copies" : "");
                 span_begin(rt, rt->fold_spans, rt->fold_used);
                 launch_fold_resolve(fa, rt->stream);
                 span_end(rt, rt->fold_spans, rt->fold_used);
@@ -805,8 +816,6 @@ int sar_runtime_new(const sar_config* cfg, int device, sar_runtime** out) {
     sar_runtime* rt = new (std::nothrow) sar_runtime();
     if (!rt) return SAR_ERR_OOM;
     rt->device = device;
-    if (const char* e = std::getenv("SAR_STAGER")) rt->stager = (e[0] == '1') ? 1u : (e[0] == '2' ? 2u : 0u);  // test / A-B hook
-    if (const char* e = std::getenv("SAR_SPLIT")) rt->split_waves = (e[0] == '2') ? 2u : (e[0] == '1' ? 1u : 0u);  // test / A-B hook
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) rt->sm_count = static_cast<uint32_t>(prop.multiProcessorCount);
     int st = SAR_OK;
@@ -983,6 +992,13 @@ int sar_render_job_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t
     SAR_TRY(check_cfg_matches(cfg, rt));
     if (n_jobs && !starts_xyz_dev) { set_error("starts_xyz_dev is NULL"); return SAR_ERR_INVALID; }
     return render_chunked(cfg, rt, n_jobs, iters_per_job, starts_xyz_dev, true);
+}
+
+int sar_runtime_describe_last_launch(const sar_runtime* rt, char* out, size_t cap) {
+    if (!rt || !out || cap == 0) return SAR_ERR_INVALID;
+    std::snprintf(out, cap, "%s | chunks=%u warmup_ahead=%u", rt->last_launch[0] ? rt->last_launch : "nothing launched", rt->last_chunks,
+                  rt->prefetch_used);
+    return SAR_OK;
 }
 
 int sar_runtime_prefetch_device(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters_per_job,
@@ -1202,7 +1218,7 @@ int sar_runtime_exchange_import(sar_runtime* rt, const void* key_i64_reduced_dev
 int sar_bin_geometry(uint32_t width, uint32_t height, uint32_t bin_shift, uint32_t bin_interleave, uint32_t out[8]) {
     if (!out || width == 0 || height == 0 || (bin_shift && (bin_shift < 12 || bin_shift > 16)) || bin_interleave > 2) return SAR_ERR_INVALID;
     const uint64_t npix64 = static_cast<uint64_t>(width) * height;
-    if (npix64 > 0xFFFFFFFFull) return SAR_ERR_RANGE;
+    if (npix64 > 0x7FFFFFFFull) return SAR_ERR_RANGE;  // what a runtime accepts (alloc_image_buffers)
     BinGeometry g;
     if (bin_shift == 0 && bin_interleave == 0) {  // what choose_chunk_records picks for a launch that wants two waves per SIMD
         bool found = false;

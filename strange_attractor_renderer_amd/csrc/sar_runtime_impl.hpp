@@ -78,6 +78,8 @@ struct sar_runtime {
         bool range_measured = false;
     } pf;
     uint32_t prefetch_used = 0;      // statistic: render calls that found their warm-up done
+    char last_launch[256] = {0};     // sar_runtime_describe_last_launch
+    uint32_t last_chunks = 0;
     uint32_t* d_seg_any = nullptr;   // [npix / 2048 + 1] 2048-pixel segments with a count in the current launch (k_fold_resolve skips the rest)
     size_t seg_any_cap = 0;
     size_t warm_cap = 0;             // jobs

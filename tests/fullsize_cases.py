@@ -4,7 +4,7 @@ import math
 
 import numpy as np
 
-CASES = ("c2_131072", "c2_65536", "c3_solar_depth", "c4_rank5_share", "c4_all_jobs", "c5_frame37")
+CASES = ("c2_131072", "c2_65536", "c3_solar_depth", "c4_rank5_share", "c4_all_jobs", "c4_full_1e10", "c5_frame37")
 
 
 def frame_seed(seed: int, k: int) -> int:   # strange_attractor_renderer_amd.sequence.frame_seed, restated
@@ -33,6 +33,11 @@ def build_case(name: str, O):
         return _fin(cfg, jobs, n), O.start_points(3, 5 * jobs, jobs), n
     if name == "c4_all_jobs":                      # configs[3]'s whole job list on ONE GPU (bench.py --config c4: 1 048 576 jobs,
         jobs, n = 1048576, 953                     # 8 rounds of resident workgroups in a launch), 1e9 iterations instead of 1e10
+        cfg = O.poisson_saturne()
+        cfg.width = cfg.height = 4096
+        return _fin(cfg, jobs, n), O.start_points(3, 0, jobs), n
+    if name == "c4_full_1e10":                     # configs[3] itself: 1e10 iterations as bench.py --config c4 cuts them (1 048 576 jobs
+        jobs, n = 1048576, 9536                    # x 9536), the whole frame on ONE GPU: three launch chunks of whole rounds
         cfg = O.poisson_saturne()
         cfg.width = cfg.height = 4096
         return _fin(cfg, jobs, n), O.start_points(3, 0, jobs), n

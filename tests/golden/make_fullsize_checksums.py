@@ -43,7 +43,11 @@ if __name__ == "__main__":
         assert np.array_equal(a.zbuf.view(np.uint32), b.zbuf.view(np.uint32))
         assert np.array_equal(a.steps.view(np.uint64), b.steps.view(np.uint64))
     out = {}
-    for name in CASES:
+    only = sys.argv[1:]   # `make_fullsize_checksums.py <case> ...`: (re)generate these cases only, keep the others
+    path = os.path.join(HERE, "fullsize_checksums.json")
+    if only and os.path.exists(path):
+        out = json.load(open(path))
+    for name in (only or CASES):
         cfg, starts, n = build_case(name, O)
         rt = O.Runtime(cfg.width, cfg.height)
         t0 = time.time()

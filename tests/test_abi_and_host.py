@@ -202,6 +202,18 @@ def test_rust_safe_layer_calls_only_what_the_sys_crate_declares():
         assert (n + 1 if seen else 0) == decl[m.group(1)], f"{m.group(1)}: {n + 1} arguments passed, {decl[m.group(1)]} declared"
     for const in set(re.findall(r"sys::(SAR_[A-Z0-9_]+)", safe_rs)):
         assert re.search(rf"pub const {const}\b", sys_rs), f"{const} missing in the sys crate"
+    # to_abi fills every field of sar_config the header declares (padding aside): a field added to the ABI and forgotten
+    # here would reach the library as zero
+    from strange_attractor_renderer_amd._abi import SarConfig, SarParallelTiming
+    body = safe_rs[safe_rs.index("fn to_abi<"):]
+    body = body[:body.index("\n}\n")]
+    filled = set(re.findall(r"\bs\.(\w+)(?:\[\w+\])?\s*=", body))
+    assert filled == {f for f, _ in SarConfig._fields_ if not f.startswith("_pad")}, filled ^ {f for f, _ in SarConfig._fields_ if not f.startswith("_pad")}
+    tbody = sys_rs[sys_rs.index("pub struct SarParallelTiming {"):]
+    tbody = tbody[:tbody.index("}")]
+    assert re.findall(r"pub (\w+):", tbody) == [f for f, _ in SarParallelTiming._fields_]
+    # a runtime handed out by the renderer is tied to the renderer's lifetime (it is freed with it)
+    assert "pub fn runtime(&mut self) -> BorrowedRuntime<'_>" in safe_rs and "PhantomData<&'a mut GpuRenderer>" in safe_rs
     # the reference items the layer stands in for are all there
     for item in ("pub struct GpuRuntime", "pub struct GpuRenderer", "pub fn render<", "pub fn colorize<", "pub fn render_parallel<",
                  "impl Drop for GpuRuntime", "impl Drop for GpuRenderer", "pub fn check(", "pub fn new_multi("):
