@@ -9,7 +9,8 @@ from collections import defaultdict
 
 root = sys.argv[1]
 print(f"# rocprofv3 summary — {os.path.basename(root)}\n")
-print("Command profiled: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipeline` (N=1, BASELINE configs[1]).\n")
+print("Commands profiled (N=1, BASELINE configs[1]): `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pipeline --sustained-seconds 0` "
+      "under `--kernel-trace --stats`; the same with `--steps 3 --warmup 1` under each `--pmc` pass.\n")
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("## Kernel time (`--kernel-trace --stats`, no counters)\n")
     print("| kernel | calls | total ms | avg ms | % |")
@@ -21,8 +22,8 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if "k_iterate" in r["Kernel_Name"]]
     if d:
         print("the iterate kernel per dispatch (ms): " + ", ".join(f"{x:.3f}" for x in d) +
-              f" — the first dispatch is bench.py's warm-up step (cold caches, first-touch of the arena); mean of the timed "
-              f"ones {sum(d[1:]) / max(len(d) - 1, 1):.3f} ms, which is what bench.py's HIP events average.\n")
+              f" — the first three dispatches are bench.py's untimed warm-up steps (cold caches, first touch of the arena); mean of "
+              f"the 20 timed ones {sum(d[3:]) / max(len(d) - 3, 1):.3f} ms, which is what bench.py's HIP events average.\n")
 try:
     line = [l for l in open(os.path.join(root, "trace_bench.json")) if l.startswith("{")][-1]
     b = json.loads(line)
