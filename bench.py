@@ -167,6 +167,8 @@ def main():
                     "With N > 1 and no --config: c2 as `value`, then c4 under `strong_c4` and both through the C ABI under `native`")
     ap.add_argument("--native", action="store_true", help="only the C-ABI multi-device renderer (sar_renderer_new_multi) over "
                     "--gpus devices in ONE process (device ordinals wrap around on a box with fewer GPUs)")
+    ap.add_argument("--extras-seconds", type=float, default=420.0, help="N > 1 without --config: time the strong_c4 + native "
+                    "extras may take before the line is printed without them")
     ap.add_argument("--sustained-seconds", type=float, default=3.0, help="N=1: length of the extra sustained-rate loop (0 = skip)")
     ap.add_argument("--exchange", default="sliced", choices=["sliced", "rooted"], help="N>1: all-to-all of image slices + "
                     "sharded colorize (default) or all-reduce MAX + reduce SUM onto rank 0")
@@ -545,33 +547,68 @@ def main():
 
     out = run_config(a.config, a.steps, a.warmup, True)
     if world > 1 and both_curves:
-        # the strong-scaling frame on the same ranks: BASELINE configs[3], the same frame at every N
-        c4 = run_config("c4", max(2, min(a.steps, 6)), 1, False)
-        if rank == 0:
-            ref = None
-            try:
-                ref = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_c4_n1.json")))
-            except Exception:
-                pass
-            out["strong_c4"] = {"value": c4["value"], "unit": c4["unit"], "ms_per_step": c4["ms_per_step"], "steps": c4["steps"],
-                                "scaling": "strong", "workload": c4["config"]["workload"], "jobs_total": c4["config"]["jobs_total"],
-                                "exchange_ms_per_step": c4.get("exchange_ms_per_step"), "kernel_ms_per_step": c4["kernel_ms_per_step"],
-                                "launch": c4["roofline"]["kernel"],
-                                "n1_profile": ({"file": "profiles/r03_bench_c4_n1.json", "value": ref["value"], "ms_per_step": ref["ms_per_step"]}
-                                               if ref else None),
-                                "speedup_vs_n1_profile": (c4["value"] / ref["value"]) if ref else None}
-        # ... and both workloads through the C ABI alone (one process, rank 0, every GPU of the job; the other ranks wait)
+        # The extras must never cost the line itself. They have never run on more than one physical GPU, so every rank arms
+        # the same watchdog once the configs[1] measurement is done: if the extras are not through in time (a hang in a
+        # collective, a dead peer), rank 0 prints the line it has — with what went wrong — and every rank leaves.
+        import threading
+        state = {"printed": False}
+        lock = threading.Lock()
+
+        def emit():
+            with lock:
+                if rank == 0 and not state["printed"]:
+                    print(json.dumps(out), flush=True)
+                state["printed"] = True
+
+        def give_up():
+            if rank == 0:
+                out.setdefault("strong_c4", {"error": f"not finished within {a.extras_seconds:.0f} s: given up"})
+                out.setdefault("native", {"error": f"not reached within {a.extras_seconds:.0f} s"})
+            emit()
+            sys.stdout.flush()
+            os._exit(0)
+
+        dog = threading.Timer(a.extras_seconds, give_up)
+        dog.daemon = True
         dist.barrier()
-        if rank == 0:
-            try:
-                devs = list(range(min(world, max(torch.cuda.device_count(), 1))))
-                devs = [devs[k % len(devs)] for k in range(world)]
-                out["native"] = {"c2": native_measure(S, torch, devs, "c2", max(2, min(a.steps, 6)), 1),
-                                 "c4": native_measure(S, torch, devs, "c4", max(2, min(a.steps, 4)), 1)}
-            except Exception as e:  # an extra: never lose the line over it
-                out["native"] = {"error": repr(e)}
-        dist.barrier()
-    if rank == 0:
+        dog.start()
+        try:
+            # the strong-scaling frame on the same ranks: BASELINE configs[3], the same frame at every N
+            c4 = run_config("c4", max(2, min(a.steps, 6)), 1, False)
+            if rank == 0:
+                ref = None
+                try:
+                    ref = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_c4_n1.json")))
+                except Exception:
+                    pass
+                out["strong_c4"] = {"value": c4["value"], "unit": c4["unit"], "ms_per_step": c4["ms_per_step"], "steps": c4["steps"],
+                                    "scaling": "strong", "workload": c4["config"]["workload"], "jobs_total": c4["config"]["jobs_total"],
+                                    "exchange_ms_per_step": c4.get("exchange_ms_per_step"), "kernel_ms_per_step": c4["kernel_ms_per_step"],
+                                    "launch": c4["roofline"]["kernel"],
+                                    "n1_profile": ({"file": "profiles/r03_bench_c4_n1.json", "value": ref["value"], "ms_per_step": ref["ms_per_step"]}
+                                                   if ref else None),
+                                    "speedup_vs_n1_profile": (c4["value"] / ref["value"]) if ref else None}
+        except Exception as e:
+            if rank == 0:
+                out["strong_c4"] = {"error": repr(e)}
+        try:
+            # ... and both workloads through the C ABI alone (one process, rank 0, every GPU of the job; the other ranks wait)
+            dist.barrier()
+            if rank == 0:
+                try:
+                    devs = list(range(min(world, max(torch.cuda.device_count(), 1))))
+                    devs = [devs[k % len(devs)] for k in range(world)]
+                    out["native"] = {"c2": native_measure(S, torch, devs, "c2", max(2, min(a.steps, 6)), 1),
+                                     "c4": native_measure(S, torch, devs, "c4", max(2, min(a.steps, 4)), 1)}
+                except Exception as e:  # an extra: never lose the line over it
+                    out["native"] = {"error": repr(e)}
+            dist.barrier()
+        except Exception as e:
+            if rank == 0:
+                out.setdefault("native", {"error": repr(e)})
+        dog.cancel()
+        emit()
+    elif rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
