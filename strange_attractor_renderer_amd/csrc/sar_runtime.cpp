@@ -577,8 +577,13 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
         std::swap(rt->d_joblist, rt->d_joblist_alt);
         std::swap(rt->d_active, rt->d_active_alt);
         std::swap(rt->warm_cap, rt->warm_alt_cap);
-        if (pl.hint_bytes == 2 && !rt->hint_range_set && pf.range_measured) {
-            HIP_TRY(hipMemcpyAsync(rt->d_hint_range, rt->d_hint_range_alt, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, rt->stream));
+        if (pl.hint_bytes == 2 && !rt->hint_range_set) {
+            // the quantiser of the narrow hints is fixed here for as long as the hints live: the range the announced warm-up
+            // measured — or, if it did not measure one (the options changed in between), the default quantiser (an empty range)
+            if (pf.range_measured)
+                HIP_TRY(hipMemcpyAsync(rt->d_hint_range, rt->d_hint_range_alt, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, rt->stream));
+            else
+                HIP_TRY(hipMemsetAsync(rt->d_hint_range, 0, 2 * sizeof(uint32_t), rt->stream));
             rt->hint_range_set = true;
         }
         ++rt->prefetch_used;
@@ -667,6 +672,8 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
         rt->fold_used = 0;
         rt->warm_used = 0;
     }
+    // an announcement is good for the very next render call only, and only if that call is the announced one
+    if (!(starts_on_device && rt->pf.valid && rt->pf.starts == starts && rt->pf.n_jobs == n_jobs && rt->pf.iters == iters)) rt->pf.valid = false;
     if (n_jobs == 0 || iters == 0) return SAR_OK;
     HIP_TRY(hipSetDevice(rt->device));
     rt->last_chunks = 0;

@@ -590,6 +590,39 @@ def test_announced_frames_whose_warm_up_ran_ahead(sar, oracle, gpu, preset):
     assert_state_equal(rt, ort, f"{preset} continued")
 
 
+def test_announced_frames_with_narrow_hints_and_launch_chunks(sar, oracle, gpu):
+    """The announced warm-up also measures the depth range the 16-bit hints quantise (and hands it over with the buffers);
+    an announced call of several launch chunks finds its FIRST chunk's warm-up done; an announcement does not survive
+    another render call; sar_runtime_describe_last_launch says what ran."""
+    import torch
+    jobs, n = 6144, 250   # a multiple of the workgroup size: one launch chunk unless capped
+    w, h = 700, 500
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=w, height=h, jobs_total=jobs)
+    st = sar.start_points(77, 0, jobs)
+    dev = torch.from_numpy(st).cuda()
+    other = torch.from_numpy(sar.start_points(78, 0, jobs)).cuda()
+    torch.cuda.synchronize()
+    ort = oracle.Runtime(w, h)
+    oracle.render_jobs(cfg.c, ort, st, n)
+    for chunk_cap in (0, 2500):
+        rt = sar.Runtime(cfg)
+        rt.set_tuning(variant=3 | (chunk_cap << 8), hint_bits=16)
+        sar.prefetch_device(cfg, rt, jobs, n, dev.data_ptr())
+        sar.render_job_range_device(cfg, rt, jobs, n, dev.data_ptr())
+        assert_state_equal(rt, ort, f"announced, narrow hints, chunk cap {chunk_cap}")
+        d = rt.describe_last_launch()
+        assert "hints=q16" in d and "warmup_ahead=1" in d and f"chunks={1 if chunk_cap == 0 else 3}" in d, d
+        # an announcement is spent by the next render call, whatever that call renders
+        rt.reset()
+        sar.prefetch_device(cfg, rt, jobs, n, dev.data_ptr())
+        sar.render_job_range_device(cfg, rt, jobs, n, other.data_ptr())
+        rt.reset()
+        sar.render_job_range_device(cfg, rt, jobs, n, dev.data_ptr())
+        assert_state_equal(rt, ort, "after a dropped announcement")
+        assert "warmup_ahead=1" in rt.describe_last_launch()
+        rt.close()
+
+
 def test_every_job_diverging_in_the_warm_up(sar, oracle, gpu):
     """No trajectory survives the warm-up (start points far outside the basin): the hot kernel has nothing to do, every
     counted iteration lands on pixel (0,0) (reference src/lib.rs:789, 800-802) and the depth buffer stays empty."""
