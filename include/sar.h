@@ -343,6 +343,9 @@ int sar_runtime_describe_last_launch(const sar_runtime* rt, char* out, size_t ca
  *                        launches whose jobs are all resident at once (512 per CU), 1 for larger ones
  *   "hint_bits"          per-XCD depth hints of the iterate kernel: 16 (fixed point over the depth range the warm-up saw) or
  *                        32 (the depth itself as f32); 0 = by image size
+ *   "hint_shared"        1: one array of depth hints per XCD, 2: one array for the whole chip (each XCD's L2 then sees the
+ *                        others' updates late — more visits pass the filter, none wrongly); 0 = per XCD unless the eight
+ *                        copies exceed 200 MB (then they would not fit the Infinity Cache)
  *   "depth_pipe"         visits between a depth-hint (or depth-key) load and its use in the iterate kernel: 1 or 2 (default 2)
  *   "acc_threads"        threads per block of the record-accumulate kernel (256, 512, 1024)
  *   "acc_lists"          (bin, wave) record lists a lane group of that kernel walks at the same time: 1, 2, 4 or 8

@@ -89,6 +89,8 @@ struct BinIterArgs {
     const unsigned long long* warm_nan;  // nullable: iterations of the jobs that died in the warm-up (from k_warmup; the first
                                  // workgroup adds them to nan_count — the warm-up may have run ahead, under the previous frame)
     unsigned long long* nan_count;  // iterations of diverged (NaN) trajectories: all land on pixel (0,0)
+    uint32_t hint_copy_mask;     // 7: one array of hints per XCD (index = XCC id); 0: one array for the whole chip
+    uint32_t _pad_hint;
     const uint32_t* hint_range;  // nullable: {~sortable(min z), sortable(max z)} of the view, from k_warmup: the range the narrow
                                  // depth hints quantise (fixed from the first launch after the hints were cleared)
     double* warm_out;            // nullable: the state after the last iteration, by packed slot (== warm: the next segment of

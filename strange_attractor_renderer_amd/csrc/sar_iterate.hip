@@ -771,7 +771,7 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     // low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie
     st.init((char*)smem + (threadIdx.x >> 6) * (POOL ? kPoolWaveLds(a.n_bins, R) : kLeanWaveLds(a.n_bins, R)), a.n_bins, lane,
             (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkStride(R),
-            (H*)a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n, a.hint_range);
+            (H*)a.zhint + (size_t)(xcc_id() & a.hint_copy_mask) * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n, a.hint_range);
 
     MapParams p = a.it.p;
     pin_map_params(p);
@@ -975,7 +975,7 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
     } else {
         PoolStager<DEPTH, R, U, H> st;
         st.init((char*)smem, a.n_bins, lane, (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkStride(R),
-                (H*)a.zhint + (size_t)xcc_id() * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n, a.hint_range);
+                (H*)a.zhint + (size_t)(xcc_id() & a.hint_copy_mask) * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n, a.hint_range);
         uint32_t t = 0, phase = 0;
 #ifdef SAR_EXPERIMENT_PROF  // wave-cycles of the consumer: [0] barrier, [1] hand-over read, [2] place_visit, [3] depth, [4] requests
         st.prof_last = __builtin_readcyclecounter();

@@ -565,6 +565,13 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     ba.zhint = rt->d_zhint;
     ba.nan_count = rt->d_nan_count;
     ba.hint_range = pl.hint_bytes == 2 ? rt->d_hint_range : nullptr;
+    // One hint array per XCD lets every XCD's L2 serve its own hints coherently; but eight copies of a 4096^2 image's hints
+    // (268 MB at 16 bits) no longer fit the 256 MB Infinity Cache behind the L2s, and the misses go to HBM. From 200 MB on
+    // the XCDs share ONE array: an XCD then sees another's updates only when its own L2 drops the line — a stale hint lets
+    // more visits through stage 1, never a wrong one — and the misses stay on chip (4096^2 share: 9.15 -> 8.85 ms; below
+    // that size sharing costs: 2048^2 5.90 -> 6.05 ms).
+    const bool share = rt->hint_shared == 2 || (rt->hint_shared == 0 && static_cast<uint64_t>(rt->npix) * pl.hint_bytes * 8u > (200ull << 20));
+    ba.hint_copy_mask = share ? 0u : 7u;
     ba.warm_out = carry ? rt->d_warm : nullptr;
     span_begin(rt, rt->warm_spans, rt->warm_used);
     const sar_runtime::Prefetch& pf = rt->pf;
@@ -627,7 +634,7 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     std::snprintf(rt->last_launch, sizeof(rt->last_launch),
                   "%s R=%u bins=%ux%upx %s hints=%s pipe=%u | k_bin_accumulate splits=%u lists=%u counters=%s",
                   split ? "k_iterate_split" : "k_iterate_lean", pl.R, pl.geo.bins, 1u << pl.geo.shift, pl.geo.interleaved ? "interleaved" : "consecutive",
-                  mode != 2 ? "none" : (pl.hint_bytes == 4 ? "f32" : "q16"), pl.pipe, pl.splits,
+                  mode != 2 ? "none" : (pl.hint_bytes == 4 ? (share ? "f32/chip" : "f32") : (share ? "q16/chip" : "q16")), pl.pipe, pl.splits,
                   rt->acc_lists ? rt->acc_lists : (pl.geo.shift >= 15u ? 4u : 1u),
                   pl.geo.shift == 16u ? (rt->acc_halves ? "u32-halves" : "u16-packed") : "u32");
     if (rt->iter_done) {  // an announced call's warm-up starts here, under this launch's accumulate and fold
@@ -1401,6 +1408,9 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "acc_lists")) {
         if (v && v != 1 && v != 2 && v != 4 && v != 8) { set_error("acc_lists must be 1, 2, 4 or 8"); return SAR_ERR_INVALID; }
         rt->acc_lists = v;
+    } else if (!std::strcmp(name, "hint_shared")) {
+        if (v > 2) { set_error("hint_shared must be 0, 1 or 2"); return SAR_ERR_INVALID; }
+        rt->hint_shared = v;
     } else if (!std::strcmp(name, "acc_halves")) {
         rt->acc_halves = v ? 1u : 0u;
     } else if (!std::strcmp(name, "acc_threads")) {
