@@ -160,6 +160,7 @@ def main():
                     "the per-rank buffers (debug; not timed)")
     ap.add_argument("--host-starts", action="store_true", help="hand the start points over from host memory every step "
                     "(PCIe-inclusive rate; the default keeps them resident in HBM)")
+    ap.add_argument("--lanes", type=int, default=2, help="--config c5: runtimes (streams) per GPU the frames are rendered on in turn")
     ap.add_argument("--config", default=None, choices=["c2", "c4", "c5"], help="c2: BASELINE configs[1], weak scaling (default); "
                     "c4: BASELINE configs[3] (1e10 iterations, 4096^2, 1048576 jobs sharded over the ranks), strong scaling. "
                     "c5: BASELINE configs[4], the solar-sail `sequence` sweep, 1e8 iterations per frame at 1800x2000, frame k on "
@@ -249,7 +250,7 @@ def main():
         def sweep(frames_per_rank):
             done[0] = 0
             render_sequence(scfg, 0.0, float(frames_per_rank * world), 1.0, units=units, jobs_per_thread=jpt, rank=rank, world=world,
-                            device=local_rank, seed=4, sink=sink, image_format=S.SAR_FMT_RGB16)
+                            device=local_rank, seed=4, sink=sink, image_format=S.SAR_FMT_RGB16, lanes=a.lanes)
             torch.cuda.synchronize()
 
         sweep(max(a.warmup, 1))
@@ -275,6 +276,7 @@ def main():
                                        "1e8 iterations per frame, 1800x2000, scale 1, frame k on rank k mod N; RGB16 conversion on the "
                                        "device + read-back included, PNG encoder excluded",
                            "jobs_per_frame": units * jpt, "iterations_per_job": per_job, "frames": frames,
+                           "frames_in_flight_per_gpu": a.lanes,
                            "counted_over_executed_iterations": round(per_job / (per_job + 1000.0), 4),
                            "parallelism": f"{world} replica(s), no collective"}}), flush=True)
         if world > 1:

@@ -134,6 +134,10 @@ extern "C" {
     pub fn sar_image_bytes(format: c_int, width: u32, height: u32) -> usize;
     pub fn sar_image_convert_device(rt: *mut SarRuntime, rgba16_dev: *const c_void, format: c_int, out_dev: *mut c_void) -> c_int;
     pub fn sar_colorize_format(cfg: *const SarConfig, rt: *mut SarRuntime, format: c_int, out_host: *mut c_void) -> c_int;
+    pub fn sar_colorize_format_async(cfg: *const SarConfig, rt: *mut SarRuntime, format: c_int, out_host: *mut c_void, ticket_out: *mut u64) -> c_int;
+    pub fn sar_runtime_wait_image(rt: *mut SarRuntime, ticket: u64) -> c_int;
+    pub fn sar_host_alloc(bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn sar_host_free(p: *mut c_void) -> c_int;
     pub fn sar_write_png(path: *const c_char, format: c_int, width: u32, height: u32, pixels: *const c_void) -> c_int;
     pub fn sar_write_bmp(path: *const c_char, format: c_int, width: u32, height: u32, pixels: *const c_void) -> c_int;
     pub fn sar_write_pam(path: *const c_char, format: c_int, width: u32, height: u32, pixels: *const c_void) -> c_int;

@@ -218,6 +218,16 @@ int sar_image_convert_device(sar_runtime* rt, const void* rgba16_dev, int format
 /* colorize + conversion on the device, then ONE device-to-host copy of the converted image
  * (sar_image_bytes(format) bytes: 12 MiB instead of 32 MiB for RGB8 at 2048x2048). Samples are host-endian. */
 int sar_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host);
+/* The same, returning as soon as the work is ENQUEUED on rt's stream: the image is in out_host once
+ * sar_runtime_wait_image(rt, ticket) has returned. A `sequence` sweep (src/bin/main.rs:493-517 hands frame k to its
+ * writer threads and goes on with frame k+1) reads frame k back while frame k+1 renders. out_host should be page-locked
+ * (sar_host_alloc); with pageable memory the copy is staged by the HIP runtime and the call may block. The runtime may be
+ * reset and rendered into again before the ticket is waited for; out_host must stay untouched until then. */
+int sar_colorize_format_async(const sar_config* cfg, sar_runtime* rt, int format, void* out_host, uint64_t* ticket_out);
+int sar_runtime_wait_image(sar_runtime* rt, uint64_t ticket);
+/* Page-locked host memory for those read-backs. */
+int sar_host_alloc(size_t bytes, void** out);
+int sar_host_free(void* p);
 /* Encoders (host only; no device needed). `pixels` is a host image in `format`, host-endian samples.
  * PNG: 8/16-bit RGB(A), zlib default compression, per-row adaptive filter (minimum sum of absolute differences).
  * BMP / PAM: SAR_FMT_RGBA8 or SAR_FMT_RGB8 only (the CLI requires --8bit for them); BMP 24 bpp BI_RGB or

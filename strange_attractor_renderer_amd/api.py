@@ -402,6 +402,47 @@ def colorize_format(config: Config, runtime: Runtime, fmt: int) -> np.ndarray:
     return out
 
 
+class HostImage:
+    """A page-locked host image of (height, width, channels-of-fmt) for ``colorize_format_async``; `array` is a numpy
+    view of it, valid until ``close``."""
+
+    def __init__(self, width: int, height: int, fmt: int):
+        if fmt not in _FMT_SHAPE:
+            raise ValueError(f"unknown image format {fmt}")
+        ch, dt = _FMT_SHAPE[fmt]
+        self.fmt = fmt
+        nbytes = int(_lib().sar_image_bytes(fmt, width, height))
+        p = C.c_void_p()
+        _check(_lib().sar_host_alloc(nbytes, C.byref(p)), "sar_host_alloc")
+        self.ptr = p.value
+        self.array = np.frombuffer((C.c_ubyte * nbytes).from_address(self.ptr), dtype=dt).reshape(height, width, ch)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            _check(_lib().sar_host_free(C.c_void_p(self.ptr)), "sar_host_free")
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def colorize_format_async(config: Config, runtime: Runtime, image: HostImage) -> int:
+    """``colorize_format`` into a page-locked image, enqueued only: returns the ticket ``wait_image`` takes. The runtime
+    may be reset and rendered into again meanwhile (the `sequence` sweep reads frame k back under frame k+1)."""
+    t = C.c_uint64()
+    _check(_lib().sar_colorize_format_async(C.byref(config.c), runtime.handle, image.fmt, C.c_void_p(image.ptr), C.byref(t)),
+           "sar_colorize_format_async")
+    return int(t.value)
+
+
+def wait_image(runtime: Runtime, ticket: int):
+    _check(_lib().sar_runtime_wait_image(runtime.handle, ticket), "sar_runtime_wait_image")
+
+
 def convert_device(runtime: Runtime, rgba16_dev_ptr: int, fmt: int, out_dev_ptr: int):
     """RGBA16 -> fmt between two device buffers, ordered on the runtime's stream."""
     _check(_lib().sar_image_convert_device(runtime.handle, C.c_void_p(rgba16_dev_ptr), fmt, C.c_void_p(out_dev_ptr)),

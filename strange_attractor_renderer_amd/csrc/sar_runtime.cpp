@@ -859,6 +859,7 @@ int sar_runtime_free(sar_runtime* rt) {
     if (rt->side) { hipStreamSynchronize(rt->side); hipStreamDestroy(rt->side); }
     if (rt->iter_done) hipEventDestroy(rt->iter_done);
     if (rt->pf_done) hipEventDestroy(rt->pf_done);
+    for (hipEvent_t e : rt->img_events) if (e) hipEventDestroy(e);
     if (rt->d_warm) hipFree(rt->d_warm);
     if (rt->d_joblist) hipFree(rt->d_joblist);
     if (rt->d_active) hipFree(rt->d_active);
@@ -1131,7 +1132,7 @@ int sar_image_convert_device(sar_runtime* rt, const void* rgba16_dev, int format
     return SAR_OK;
 }
 
-int sar_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host) {
+static int enqueue_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host) {
     SAR_TRY(check_cfg_matches(cfg, rt));
     const size_t bytes = sar_image_bytes(format, rt->W, rt->H);
     if (!out_host || bytes == 0) { set_error("sar_colorize_format: bad format or NULL output"); return SAR_ERR_INVALID; }
@@ -1144,8 +1145,42 @@ int sar_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void
         SAR_TRY(sar_image_convert_device(rt, rt->d_rgba, format, rt->d_export));
         src = rt->d_export;
     }
+    // d_rgba / d_export are written again by the next frame's colorize, which the stream orders behind this copy
     HIP_TRY(hipMemcpyAsync(out_host, src, bytes, hipMemcpyDeviceToHost, rt->stream));
+    return SAR_OK;
+}
+
+int sar_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host) {
+    SAR_TRY(enqueue_colorize_format(cfg, rt, format, out_host));
     HIP_TRY(hipStreamSynchronize(rt->stream));
+    return SAR_OK;
+}
+
+int sar_colorize_format_async(const sar_config* cfg, sar_runtime* rt, int format, void* out_host, uint64_t* ticket_out) {
+    if (!ticket_out) { set_error("sar_colorize_format_async: NULL ticket"); return SAR_ERR_INVALID; }
+    SAR_TRY(enqueue_colorize_format(cfg, rt, format, out_host));
+    hipEvent_t& ev = rt->img_events[rt->img_next % 8];
+    if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev, rt->stream));
+    *ticket_out = rt->img_next++;
+    return SAR_OK;
+}
+
+int sar_runtime_wait_image(sar_runtime* rt, uint64_t ticket) {
+    if (!rt || ticket >= rt->img_next) { set_error("sar_runtime_wait_image: no such ticket"); return SAR_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(rt->device));
+    HIP_TRY(hipEventSynchronize(rt->img_events[ticket % 8]));
+    return SAR_OK;
+}
+
+int sar_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) { set_error("sar_host_alloc: NULL output or zero size"); return SAR_ERR_INVALID; }
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return SAR_OK;
+}
+
+int sar_host_free(void* p) {
+    if (p) HIP_TRY(hipHostFree(p));
     return SAR_OK;
 }
 

@@ -79,6 +79,8 @@ struct sar_runtime {
         bool range_measured = false;
     } pf;
     uint32_t prefetch_used = 0;      // statistic: render calls that found their warm-up done
+    hipEvent_t img_events[8] = {};   // sar_colorize_format_async tickets (ticket t is event t % 8: a later recording on the
+    uint64_t img_next = 0;           // same stream completes no earlier, so waiting for it is always sufficient)
     char last_launch[256] = {0};     // sar_runtime_describe_last_launch
     uint32_t last_chunks = 0;
     uint32_t* d_seg_any = nullptr;   // [npix / 2048 + 1] 2048-pixel segments with a count in the current launch (k_fold_resolve skips the rest)

@@ -67,43 +67,88 @@ def frame_seed(seed: int, k: int) -> int:
 def render_sequence(config: "api.Config", start: float, end: float, step: float, *, units: int = 0,
                     jobs_per_thread: int = 12, seed: int = 0, rank: int = 0, world: int = 1, device: int = 0,
                     file_name: str = "attractor", image_format: int | None = None,
-                    sink: Callable[[int, str, np.ndarray], None] | None = None) -> list[tuple[int, str, np.ndarray]]:
+                    sink: Callable[[int, str, np.ndarray], object] | None = None,
+                    ring: int = 0, lanes: int = 2) -> list[tuple[int, str, np.ndarray]]:
     """Renders this rank's frames of the sweep (frame k belongs to rank k % world; no collective is needed).
     Returns [(frame index, file name, image)] unless `sink` consumes the frames. The image is RGBA16, or — with
-    `image_format` (SAR_FMT_*) — the CLI's converted format, converted on the device before the read-back."""
+    `image_format` (SAR_FMT_*) — the CLI's converted format, converted on the device before the read-back.
+
+    The loop is the reference CLI's (src/bin/main.rs:493-517: frame k goes to the writer threads, the renderer goes on
+    with frame k+1) moved one step down: everything of frame k is only ENQUEUED — reset, start points, iterate, colorize,
+    conversion, the copy into one of `ring` page-locked host images — on the stream of one of `lanes` runtimes, used in
+    turn, and the frame `lanes` back is handed to `sink` while the GPU works on the later ones. Frames are independent
+    (each has its own Runtime state, :950-951 resets it), so with two lanes the GPU fills one frame's latency-bound parts
+    (the 1000-iteration warm-up of a few waves per SIMD, the kernel tails, the read-back on the copy engine) with the other
+    frame's arithmetic. The array a sink receives is a view of a host image: it stays valid until `ring - lanes` further
+    frames have been delivered, or — when the sink returns an object with `.result()` (a Future of its consumer) — until
+    that has returned, which the loop waits for before it reuses the image. ring 0 = lanes + 2."""
     todo = [(k, a, f) for (k, a, f) in frames(start, end, step, file_name) if k % world == rank]
     out = []
     if not todo:
         return out
+    if lanes < 1:
+        raise ValueError("lanes must be at least 1")
+    ring = ring or lanes + 2
+    if ring < lanes + 1:
+        raise ValueError("ring must be at least lanes + 1")
+    from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     renderer = api.ParallelRenderer(device=device, units=units, seed=seed)
     T = renderer.num_threads()
     total_jobs = T * jobs_per_thread
     per_job = config.iterations // T // jobs_per_thread          # src/lib.rs:1058
-    rt = None
+    fmt = api._abi.SAR_FMT_RGBA16 if image_format is None else image_format
+    rts: list = []
+    images: list = []
+    busy: list = []                                               # per host image: what its last consumer returned
     # the next frame's start points (~1 ms of host time per 2e5 jobs: as long as a frame renders) are drawn on a helper
     # thread while the GPU works on the current frame (the ctypes call releases the GIL)
     pool = ThreadPoolExecutor(max_workers=1)
     draw = lambda k: api.start_points(frame_seed(seed, k), 0, total_jobs)  # noqa: E731
     pending = pool.submit(draw, todo[0][0])
+
+    def deliver(rt, slot: int, ticket: int, k: int, name: str):
+        api.wait_image(rt, ticket)
+        if sink is not None:
+            busy[slot] = sink(k, name, images[slot].array)
+        else:
+            out.append((k, name, np.array(images[slot].array)))
+
     try:
+        in_flight = deque()
         for n, (k, angle, name) in enumerate(todo):
             cfg = config.replace(angle=angle, jobs_total=total_jobs, iterations=per_job * total_jobs, seed=seed)
-            if rt is None:
-                rt = api.Runtime(cfg, device=device)
+            if not images:
+                images = [api.HostImage(cfg.c.width, cfg.c.height, fmt) for _ in range(ring)]
+                busy = [None] * ring
+            if len(rts) < min(lanes, len(todo)):
+                rts.append(api.Runtime(cfg, device=device))
+            rt = rts[n % len(rts)]
+            slot = n % ring
+            if hasattr(busy[slot], "result"):                     # the consumer of the frame that last used this image
+                busy[slot].result()
+            busy[slot] = None
             rt.reset()                                            # :950-951
             starts = pending.result()
             if n + 1 < len(todo):
                 pending = pool.submit(draw, todo[n + 1][0])
             api.render_jobs(cfg, rt, starts)
-            img = api.colorize(cfg, rt) if image_format is None else api.colorize_format(cfg, rt, image_format)  # :1080
-            if sink is not None:
-                sink(k, name, img)
-            else:
-                out.append((k, name, img))
+            ticket = api.colorize_format_async(cfg, rt, images[slot])  # :1080
+            in_flight.append((rt, slot, ticket, k, name))
+            if len(in_flight) > lanes:
+                deliver(*in_flight.popleft())                     # frame n-lanes, while the GPU is busy with the later ones
+        while in_flight:
+            deliver(*in_flight.popleft())
+        for b in busy:
+            if hasattr(b, "result"):
+                b.result()
     finally:
         pool.shutdown(wait=True)
-        if rt is not None:
+        for rt in rts:
+            rt.synchronize()
+        for im in images:
+            im.close()
+        for rt in rts:
             rt.close()
         renderer.shutdown()
     return out
@@ -128,7 +173,10 @@ def render_sequence_to_files(config: "api.Config", start: float, end: float, ste
 
     with ThreadPoolExecutor(max_workers=max(1, encoders)) as pool:
         def sink(k: int, name: str, img: np.ndarray):  # img is already in the file's format (converted on the device)
-            pending.append(pool.submit(encode, img, os.path.splitext(name)[0] + "." + kind))
+            f = pool.submit(encode, img, os.path.splitext(name)[0] + "." + kind)
+            pending.append(f)
+            return f                                  # the page-locked image is reused only after its file is written
 
+        kw.setdefault("ring", max(1, encoders) + kw.get("lanes", 2) + 1)
         render_sequence(config, start, end, step, file_name=file_name, image_format=fmt, sink=sink, **kw)
         return [f.result() for f in pending]

@@ -62,6 +62,37 @@ def test_sequence_frames_match_oracle_and_do_not_depend_on_world_size(sar, oracl
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lanes,ring", [(1, 2), (1, 3), (2, 3), (2, 0), (3, 4)])
+def test_sequence_sink_receives_every_frame_while_the_next_one_renders(sar, gpu, lanes, ring):
+    """The read-back of frame k overlaps frame k+1 (sar_colorize_format_async into `ring` page-locked images): a sink sees
+    the frames in order, each equal to the frame of the list-returning call, also when it holds the image back through a
+    Future (the loop must not reuse a page-locked image before its consumer is done), and whatever the number of runtimes
+    (`lanes`) the frames are rendered on in turn."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    from strange_attractor_renderer_amd.sequence import render_sequence
+    cfg = sar.Config.solar_sail(iterations=300_000, width=160, height=120, scale=1.0, transparent=0)
+    kw = dict(units=64, jobs_per_thread=2, seed=3, image_format=sar.SAR_FMT_RGB8)
+    want = render_sequence(cfg, 0.0, 7.0, 1.0, lanes=1, **kw)
+    assert len(want) == 7 and want[0][2].shape == (120, 160, 3) and want[0][2].dtype == np.uint8
+    assert any(not np.array_equal(want[0][2], w[2]) for w in want[1:])
+    got = []
+
+    def slow_copy(k, img):
+        time.sleep(0.02)                                     # the image must still be frame k's after the loop moved on
+        got.append((k, np.array(img)))
+
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        render_sequence(cfg, 0.0, 7.0, 1.0, sink=lambda k, name, img: pool.submit(slow_copy, k, img), ring=ring, lanes=lanes,
+                        **kw)
+    assert [k for k, _ in got] == list(range(7))
+    for (k, img), (_, _, w) in zip(got, want):
+        np.testing.assert_array_equal(img, w)
+    with pytest.raises(ValueError):
+        render_sequence(cfg, 0.0, 2.0, 1.0, ring=lanes, lanes=lanes, **kw)
+
+
+@pytest.mark.gpu
 def test_sequence_to_files_overlapped_encoding(sar, oracle, gpu, tmp_path):
     """render_sequence_to_files: frames rendered, converted and encoded on writer threads; every file decodes to the
     oracle's frame (start points continue across frames, runtime reset per frame)."""
