@@ -237,23 +237,27 @@ def main():
         # BASELINE configs[4]: `sequence --start 0 --end 360 --step 1` (src/bin/main.rs:107-176, 493-517), frame k -> rank k mod N.
         # A step is one frame: reset, render_parallel's job split with a fresh start-point stream per frame, colorize, RGB16
         # conversion on the device, read-back into host memory. The PNG encoder (the CLI runs it on other threads) is excluded.
-        from strange_attractor_renderer_amd.sequence import render_sequence
+        from strange_attractor_renderer_amd.sequence import SequenceRenderer, frames as sequence_frames
         frame_jobs = 65536 if a.jobs == DEFAULT_JOBS else a.jobs
         units, jpt = frame_jobs // 4, 4
         scfg = S.Config.solar_sail(iterations=100_000_000, width=1800, height=2000, scale=1.0, transparent=0)
         per_job = scfg.iterations // units // jpt
         done = [0]
+        # the runtimes and the page-locked images live as long as the CLI's sweep does: made once, outside the timed frames
+        seq = SequenceRenderer(scfg, units=units, jobs_per_thread=jpt, seed=4, device=local_rank, image_format=S.SAR_FMT_RGB16,
+                               lanes=a.lanes)
 
         def sink(k, name, img):
             done[0] += 1
 
         def sweep(frames_per_rank):
             done[0] = 0
-            render_sequence(scfg, 0.0, float(frames_per_rank * world), 1.0, units=units, jobs_per_thread=jpt, rank=rank, world=world,
-                            device=local_rank, seed=4, sink=sink, image_format=S.SAR_FMT_RGB16, lanes=a.lanes)
+            todo = [f for f in sequence_frames(0.0, float(frames_per_rank * world), 1.0) if f[0] % world == rank]
+            seq.run(todo, sink)
             torch.cuda.synchronize()
+            assert done[0] == frames_per_rank
 
-        sweep(max(a.warmup, 1))
+        sweep(max(a.warmup, a.lanes))
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
@@ -265,6 +269,7 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        seq.close()
         if rank == 0:
             frames = a.steps * world
             print(json.dumps({

@@ -64,6 +64,121 @@ def frame_seed(seed: int, k: int) -> int:
     return (seed + 0x9E3779B97F4A7C15 * (k + 1)) & 0xFFFFFFFFFFFFFFFF
 
 
+SETTLE = 1  # stream synchronisations a new runtime's first frames are waited for with (SequenceRenderer.run)
+
+
+class SequenceRenderer:
+    """What a `sequence` sweep keeps between frames: the job split of one ParallelRenderer, `lanes` runtimes (each with its
+    own stream) used in turn, and a ring of page-locked host images the converted frames are read back into. One object
+    can render several sweeps (`run`); `close` frees the device and page-locked memory."""
+
+    def __init__(self, config: "api.Config", *, units: int = 0, jobs_per_thread: int = 12, seed: int = 0, device: int = 0,
+                 image_format: int | None = None, ring: int = 0, lanes: int = 2):
+        if lanes < 1:
+            raise ValueError("lanes must be at least 1")
+        ring = ring or lanes + 2
+        if ring < lanes + 1:
+            raise ValueError("ring must be at least lanes + 1")
+        self.config, self.seed, self.device, self.lanes, self.ring = config, seed, device, lanes, ring
+        self.fmt = api._abi.SAR_FMT_RGBA16 if image_format is None else image_format
+        renderer = api.ParallelRenderer(device=device, units=units, seed=seed)
+        try:
+            T = renderer.num_threads()
+        finally:
+            renderer.shutdown()
+        self.total_jobs = T * jobs_per_thread
+        self.per_job = config.iterations // T // jobs_per_thread   # src/lib.rs:1058
+        self.rts: list = []
+        self.settle: dict = {}                                     # stream synchronisations done per runtime (see run)
+        self.images: list = []
+        self.busy: list = []                                       # per host image: what its last consumer returned
+
+    def frame_config(self, angle: float) -> "api.Config":
+        return self.config.replace(angle=angle, jobs_total=self.total_jobs, iterations=self.per_job * self.total_jobs,
+                                   seed=self.seed)
+
+    def run(self, todo: list[tuple[int, float, str]],
+            sink: Callable[[int, str, np.ndarray], object] | None = None) -> list[tuple[int, str, np.ndarray]]:
+        """Renders the frames [(index, angle, name)] in order; returns them unless `sink` consumes them."""
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        out: list = []
+        if not todo:
+            return out
+        images, busy, rts, ring, lanes = self.images, self.busy, self.rts, self.ring, self.lanes
+        # the next frame's start points (~1 ms of host time per 2e5 jobs: as long as a frame renders) are drawn on a helper
+        # thread while the GPU works on the current frame (the ctypes call releases the GIL)
+        pool = ThreadPoolExecutor(max_workers=1)
+        draw = lambda k: api.start_points(frame_seed(self.seed, k), 0, self.total_jobs)  # noqa: E731
+        pending = pool.submit(draw, todo[0][0])
+
+        def deliver(rt, slot: int, ticket: int, k: int, name: str):
+            if self.settle.get(id(rt), 0) < SETTLE:
+                # Measured on ROCm 7.2, in a process that uses nothing but this library: the kernels of two freshly created
+                # streams do not overlap — as if they shared a hardware queue — until one of them has been synchronised
+                # ONCE while the other was busy (1.7 ms per frame for the first ~70 frames per runtime, 1.2 after; an event
+                # wait does not do it, a synchronise of the idle streams neither; with three streams two of them stay
+                # coupled until ~70 frames per runtime whatever is synchronised). So the first frame of every runtime is
+                # waited for with a stream synchronise: one bubble of a frame or two at the start of a sweep.
+                rt.synchronize()
+                self.settle[id(rt)] = self.settle.get(id(rt), 0) + 1
+            api.wait_image(rt, ticket)
+            if sink is not None:
+                busy[slot] = sink(k, name, images[slot].array)
+            else:
+                out.append((k, name, np.array(images[slot].array)))
+
+        try:
+            in_flight = deque()
+            for n, (k, angle, name) in enumerate(todo):
+                cfg = self.frame_config(angle)
+                if not images:
+                    images.extend(api.HostImage(cfg.c.width, cfg.c.height, self.fmt) for _ in range(ring))
+                    busy.extend([None] * ring)
+                if len(rts) < min(lanes, len(todo)):
+                    rts.append(api.Runtime(cfg, device=self.device))
+                rt = rts[n % len(rts)]
+                slot = n % ring
+                if hasattr(busy[slot], "result"):                 # the consumer of the frame that last used this image
+                    busy[slot].result()
+                busy[slot] = None
+                rt.reset()                                        # :950-951
+                starts = pending.result()
+                if n + 1 < len(todo):
+                    pending = pool.submit(draw, todo[n + 1][0])
+                api.render_jobs(cfg, rt, starts)
+                ticket = api.colorize_format_async(cfg, rt, images[slot])  # :1080
+                in_flight.append((rt, slot, ticket, k, name))
+                if len(in_flight) > lanes:
+                    deliver(*in_flight.popleft())                 # frame n-lanes, while the GPU is busy with the later ones
+            while in_flight:
+                deliver(*in_flight.popleft())
+            for i, b in enumerate(busy):
+                if hasattr(b, "result"):
+                    b.result()
+                busy[i] = None
+        finally:
+            pool.shutdown(wait=True)
+            for rt in rts:                                        # also after an error: nothing may still write the images
+                rt.synchronize()
+        return out
+
+    def close(self):
+        for rt in self.rts:
+            rt.synchronize()
+        for im in self.images:
+            im.close()
+        for rt in self.rts:
+            rt.close()
+        self.rts, self.images, self.busy, self.settle = [], [], [], {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def render_sequence(config: "api.Config", start: float, end: float, step: float, *, units: int = 0,
                     jobs_per_thread: int = 12, seed: int = 0, rank: int = 0, world: int = 1, device: int = 0,
                     file_name: str = "attractor", image_format: int | None = None,
@@ -83,75 +198,11 @@ def render_sequence(config: "api.Config", start: float, end: float, step: float,
     frames have been delivered, or — when the sink returns an object with `.result()` (a Future of its consumer) — until
     that has returned, which the loop waits for before it reuses the image. ring 0 = lanes + 2."""
     todo = [(k, a, f) for (k, a, f) in frames(start, end, step, file_name) if k % world == rank]
-    out = []
     if not todo:
-        return out
-    if lanes < 1:
-        raise ValueError("lanes must be at least 1")
-    ring = ring or lanes + 2
-    if ring < lanes + 1:
-        raise ValueError("ring must be at least lanes + 1")
-    from collections import deque
-    from concurrent.futures import ThreadPoolExecutor
-    renderer = api.ParallelRenderer(device=device, units=units, seed=seed)
-    T = renderer.num_threads()
-    total_jobs = T * jobs_per_thread
-    per_job = config.iterations // T // jobs_per_thread          # src/lib.rs:1058
-    fmt = api._abi.SAR_FMT_RGBA16 if image_format is None else image_format
-    rts: list = []
-    images: list = []
-    busy: list = []                                               # per host image: what its last consumer returned
-    # the next frame's start points (~1 ms of host time per 2e5 jobs: as long as a frame renders) are drawn on a helper
-    # thread while the GPU works on the current frame (the ctypes call releases the GIL)
-    pool = ThreadPoolExecutor(max_workers=1)
-    draw = lambda k: api.start_points(frame_seed(seed, k), 0, total_jobs)  # noqa: E731
-    pending = pool.submit(draw, todo[0][0])
-
-    def deliver(rt, slot: int, ticket: int, k: int, name: str):
-        api.wait_image(rt, ticket)
-        if sink is not None:
-            busy[slot] = sink(k, name, images[slot].array)
-        else:
-            out.append((k, name, np.array(images[slot].array)))
-
-    try:
-        in_flight = deque()
-        for n, (k, angle, name) in enumerate(todo):
-            cfg = config.replace(angle=angle, jobs_total=total_jobs, iterations=per_job * total_jobs, seed=seed)
-            if not images:
-                images = [api.HostImage(cfg.c.width, cfg.c.height, fmt) for _ in range(ring)]
-                busy = [None] * ring
-            if len(rts) < min(lanes, len(todo)):
-                rts.append(api.Runtime(cfg, device=device))
-            rt = rts[n % len(rts)]
-            slot = n % ring
-            if hasattr(busy[slot], "result"):                     # the consumer of the frame that last used this image
-                busy[slot].result()
-            busy[slot] = None
-            rt.reset()                                            # :950-951
-            starts = pending.result()
-            if n + 1 < len(todo):
-                pending = pool.submit(draw, todo[n + 1][0])
-            api.render_jobs(cfg, rt, starts)
-            ticket = api.colorize_format_async(cfg, rt, images[slot])  # :1080
-            in_flight.append((rt, slot, ticket, k, name))
-            if len(in_flight) > lanes:
-                deliver(*in_flight.popleft())                     # frame n-lanes, while the GPU is busy with the later ones
-        while in_flight:
-            deliver(*in_flight.popleft())
-        for b in busy:
-            if hasattr(b, "result"):
-                b.result()
-    finally:
-        pool.shutdown(wait=True)
-        for rt in rts:
-            rt.synchronize()
-        for im in images:
-            im.close()
-        for rt in rts:
-            rt.close()
-        renderer.shutdown()
-    return out
+        return []
+    with SequenceRenderer(config, units=units, jobs_per_thread=jobs_per_thread, seed=seed, device=device,
+                          image_format=image_format, ring=ring, lanes=lanes) as seq:
+        return seq.run(todo, sink)
 
 
 def render_sequence_to_files(config: "api.Config", start: float, end: float, step: float, *, file_name: str = "attractor.png",

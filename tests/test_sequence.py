@@ -90,6 +90,14 @@ def test_sequence_sink_receives_every_frame_while_the_next_one_renders(sar, gpu,
         np.testing.assert_array_equal(img, w)
     with pytest.raises(ValueError):
         render_sequence(cfg, 0.0, 2.0, 1.0, ring=lanes, lanes=lanes, **kw)
+    # one SequenceRenderer, several sweeps (what bench.py --config c5 does): the runtimes and host images are reused
+    from strange_attractor_renderer_amd.sequence import SequenceRenderer, frames
+    with SequenceRenderer(cfg, units=64, jobs_per_thread=2, seed=3, image_format=sar.SAR_FMT_RGB8, lanes=lanes, ring=ring) as seq:
+        todo = frames(0.0, 7.0, 1.0)
+        first = seq.run(todo[:3])
+        again = seq.run(todo)
+    for (k, _, img), (_, _, w) in zip(first + again, want[:3] + want):
+        np.testing.assert_array_equal(img, w)
 
 
 @pytest.mark.gpu

@@ -13,7 +13,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 900 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err; tail -c 300 $OUT/bench_n1.json; echo
 timeout 900 python bench.py --config c4 --steps 5 --warmup 1 > $OUT/bench_c4_n1.json 2> $OUT/bench_c4_n1.err; tail -c 300 $OUT/bench_c4_n1.json; echo
 timeout 900 python bench.py --config c4 --jobs 524288 --steps 5 --warmup 1 > $OUT/bench_c4_n1_524288_jobs.json 2> $OUT/bench_c4_n1_524288.err
-timeout 900 python bench.py --config c5 --steps 45 --warmup 3 > $OUT/bench_c5_n1.json 2> $OUT/bench_c5_n1.err; tail -c 300 $OUT/bench_c5_n1.json; echo
+timeout 900 python bench.py --config c5 --steps 360 --warmup 4 > $OUT/bench_c5_n1.json 2> $OUT/bench_c5_n1.err; tail -c 300 $OUT/bench_c5_n1.json; echo
 timeout 1200 python bench.py --gpus 2 --steps 5 --warmup 2 --check > $OUT/bench_n2_gloo_one_gpu.json 2> $OUT/bench_n2_gloo.err; tail -c 400 $OUT/bench_n2_gloo_one_gpu.json; echo
 timeout 900 python bench.py --native --gpus 2 --config c2 --steps 5 --warmup 1 > $OUT/bench_native_2shards_c2.json 2> $OUT/native.err
 timeout 900 python bench.py --native --gpus 8 --config c2 --steps 3 --warmup 1 > $OUT/bench_native_8shards_c2.json 2>> $OUT/native.err
