@@ -6,37 +6,74 @@
 #include <vector>
 #include <map>
 #include <algorithm>
-__global__ void __launch_bounds__(128) k(uint32_t* out, int spin) {
+#ifndef WAVES   // waves per workgroup: -DWAVES=3 -DVREG=77 is the shape of the three-wave experiment (80 VGPRs, six waves per SIMD)
+#define WAVES 2
+#endif
+#ifndef VREG
+#define VREG 107
+#endif
+#define STR_(x) #x
+#define STR(x) STR_(x)
+__global__ void __launch_bounds__(64 * WAVES, WAVES == 3 ? 6 : 4) k(uint32_t* out, int spin, unsigned long long* alive) {
+    asm volatile("v_mov_b32 v" STR(VREG) ", 0" ::: "v" STR(VREG));  // the register footprint of the real kernel
+#ifdef SREG
+    asm volatile("s_mov_b32 s" STR(SREG) ", 0" ::: "s" STR(SREG));
+#endif
     extern __shared__ uint32_t lds[];
     lds[threadIdx.x] = threadIdx.x;
     __syncthreads();
+    if (threadIdx.x == 0) {  // alive[0] now, [1] the most at once, [2] ended, [3] started after another had ended
+        atomicMax(alive + 1, atomicAdd(alive, 1ull) + 1ull);
+        if (atomicAdd(alive + 2, 0ull) != 0ull) atomicAdd(alive + 3, 1ull);
+    }
     uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID, all 32 bits
     uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
     // keep the workgroup resident for a while so that the whole grid is placed together
     long long t0 = clock64();
     while (clock64() - t0 < spin) { }
+    if (threadIdx.x == 0) { atomicAdd(alive, ~0ull); atomicAdd(alive + 2, 1ull); }
     if ((threadIdx.x & 63) == 0) {
-        uint32_t w = blockIdx.x * 2 + (threadIdx.x >> 6);
+        uint32_t w = blockIdx.x * WAVES + (threadIdx.x >> 6);
         out[2 * w] = hw;
-        out[2 * w + 1] = xcc | (lds[threadIdx.x] << 8);
+        out[2 * w + 1] = xcc | (lds[threadIdx.x] << 8) | ((uint32_t)(t0 >> 12) << 12);  // bits 12..: start time / 4096
     }
+}
+__global__ void __launch_bounds__(256) k_before(double* x, int n) {  // something like k_warmup right in front
+    double a = x[threadIdx.x & 7], b = 1.0000001;
+    for (int i = 0; i < n; ++i) a = a * b + 1e-9;
+    if (a == 12345.678) x[0] = a;
 }
 int main(int argc, char** argv) {
     int grid = argc > 1 ? atoi(argv[1]) : 2048;
     int ldsb = argc > 2 ? atoi(argv[2]) : 20352;
     uint32_t* d;
-    hipMalloc(&d, grid * 2 * 2 * sizeof(uint32_t));
+    hipMalloc(&d, grid * WAVES * 2 * sizeof(uint32_t));
+    hipMemset(d, 0xFF, grid * WAVES * 2 * sizeof(uint32_t));
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(128), ldsb, 0, d, 2000000);
+    unsigned long long* alive;
+    hipMalloc(&alive, 32);
+    hipMemset(alive, 0, 32);
+    if (argc > 3) { double* x; hipMalloc(&x, 64); hipMemset(x, 0, 64); hipLaunchKernelGGL(k_before, dim3(atoi(argv[3])), dim3(256), 0, 0, x, 20000); }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WAVES), ldsb, 0, d, 2000000, alive);
     hipDeviceSynchronize();
-    std::vector<uint32_t> h(grid * 4);
+    unsigned long long ha[4];
+    hipMemcpy(ha, alive, 32, hipMemcpyDeviceToHost);
+    printf("most workgroups alive at once %llu of %d; started after another had ended: %llu\n", ha[1], grid, ha[3]);
+    std::vector<uint32_t> h(grid * WAVES * 2);
     hipMemcpy(h.data(), d, h.size() * 4, hipMemcpyDeviceToHost);
     // gfx9 HW_ID: wave_id [3:0], simd_id [5:4], pipe [7:6], cu_id [11:8], sh_id [12], se_id [15:13] (gfx94x: se_id [14:13])
     std::map<uint32_t, std::vector<std::pair<uint32_t, uint32_t>>> by_cu;  // key (xcc, se, sh, cu) -> (simd<<8|slot, wave index)
-    for (int w = 0; w < grid * 2; ++w) {
+    for (int w = 0; w < grid * WAVES; ++w) {
         uint32_t hw = h[2 * w], xcc = h[2 * w + 1] & 7u;
         uint32_t slot = hw & 15u, simd = (hw >> 4) & 3u, cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
         by_cu[(xcc << 16) | (se << 8) | (sh << 4) | cu].push_back({(simd << 8) | slot, (uint32_t)w});
+    }
+    {   // a workgroup that started well after the first ones waited for a free slot: the grid was not resident at once
+        uint32_t tmin = 0xFFFFFFFFu;
+        for (int w = 0; w < grid * WAVES; ++w) tmin = std::min(tmin, h[2 * w + 1] >> 12);
+        int late = 0;
+        for (int w = 0; w < grid * WAVES; w += WAVES) late += ((h[2 * w + 1] >> 12) - tmin) > 200u;
+        printf("workgroups of %d waves: %d, of which started late (second round): %d\n", WAVES, grid, late);
     }
     printf("CUs seen: %zu\n", by_cu.size());
     int shown = 0;
@@ -45,11 +82,11 @@ int main(int argc, char** argv) {
         auto v = kv.second;
         std::sort(v.begin(), v.end());
         int per_simd_w0[4] = {0, 0, 0, 0}, per_simd[4] = {0, 0, 0, 0};
-        for (auto& p : v) { per_simd[p.first >> 8]++; if ((p.second & 1) == 0) per_simd_w0[p.first >> 8]++; }
+        for (auto& p : v) { per_simd[p.first >> 8]++; if ((p.second % WAVES) == 0) per_simd_w0[p.first >> 8]++; }
         for (int s = 0; s < 4; ++s) prod_hist[s][std::min(per_simd_w0[s], 8)]++;
         if (shown++ < 3) {
             printf("xcc %u se %u sh %u cu %u: %zu waves\n", kv.first >> 16, (kv.first >> 8) & 255, (kv.first >> 4) & 15, kv.first & 15, v.size());
-            for (auto& p : v) printf("   simd %u slot %u : wg %u wave %u\n", p.first >> 8, p.first & 255, p.second >> 1, p.second & 1);
+            for (auto& p : v) printf("   simd %u slot %u : wg %u wave %u\n", p.first >> 8, p.first & 255, p.second / WAVES, p.second % WAVES);
         }
     }
     for (int s = 0; s < 4; ++s) {
