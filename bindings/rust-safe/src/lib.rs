@@ -19,7 +19,7 @@
 //! the library's message.
 
 use std::ffi::CStr;
-use std::os::raw::c_int;
+use std::os::raw::{c_int, c_void};
 
 use image::ImageBuffer;
 use sar_sys as sys;
@@ -221,6 +221,68 @@ pub fn colorize<T: Mi355xTransform>(config: &Config<PolynomialSprott2Degree, T>,
     check(unsafe { sys::sar_colorize(&abi, runtime.raw, buf.as_mut_ptr()) });
     // FinalImage = ImageBuffer<Rgba<u16>, Vec<u16>> (:625)
     ImageBuffer::from_raw(config.width, config.height, buf).expect("buffer has width*height*4 samples")
+}
+
+/// A page-locked host image in one of the CLI's export formats (`sar_image_format`): the target of an asynchronous
+/// read-back, what the `sequence` loop (src/bin/main.rs:493-517) hands to its writer threads.
+pub struct PinnedImage {
+    ptr: *mut c_void,
+    bytes: usize,
+    format: c_int,
+}
+unsafe impl Send for PinnedImage {}
+
+impl PinnedImage {
+    pub fn new(format: c_int, width: u32, height: u32) -> Self {
+        let bytes = unsafe { sys::sar_image_bytes(format, width, height) };
+        assert!(bytes > 0, "unknown image format");
+        let mut ptr = std::ptr::null_mut();
+        check(unsafe { sys::sar_host_alloc(bytes, &mut ptr) });
+        Self { ptr, bytes, format }
+    }
+    /// The samples (host-endian, `format`'s layout). Only reachable while no read-back into the image is pending: a
+    /// `PendingImage` holds the exclusive borrow until it has been waited for.
+    pub fn bytes(&self) -> &[u8] {
+        unsafe { std::slice::from_raw_parts(self.ptr as *const u8, self.bytes) }
+    }
+}
+impl Drop for PinnedImage {
+    fn drop(&mut self) {
+        unsafe { sys::sar_host_free(self.ptr) };
+    }
+}
+
+/// A read-back in flight: borrows the runtime's stream order and the image until `wait` (or drop) has seen it land.
+pub struct PendingImage<'a> {
+    runtime: *mut sys::SarRuntime,
+    ticket: u64,
+    image: &'a mut PinnedImage,
+}
+impl<'a> PendingImage<'a> {
+    /// Blocks until the frame is in the image and gives the image back.
+    pub fn wait(self) -> &'a PinnedImage {
+        check(unsafe { sys::sar_runtime_wait_image(self.runtime, self.ticket) });
+        let this = std::mem::ManuallyDrop::new(self);
+        // SAFETY: `this` is never dropped, so the exclusive borrow it held is handed on exactly once
+        unsafe { &*(this.image as *const PinnedImage) }
+    }
+}
+impl Drop for PendingImage<'_> {
+    fn drop(&mut self) {
+        // the copy must not outlive the borrow of the image
+        unsafe { sys::sar_runtime_wait_image(self.runtime, self.ticket) };
+    }
+}
+
+/// `colorize` + the CLI's format conversion, only ENQUEUED (`sar_colorize_format_async`). The handle borrows the runtime
+/// (shared) and the image (exclusive) until the frame has landed: a `sequence` loop keeps the GPU busy by rendering frame
+/// k+1 on a SECOND runtime meanwhile (the C ABI would also allow resetting this one — the borrow is the safe subset).
+pub fn colorize_format_async<'a, T: Mi355xTransform>(config: &Config<PolynomialSprott2Degree, T>, runtime: &'a GpuRuntime,
+                                                     image: &'a mut PinnedImage) -> PendingImage<'a> {
+    let abi = to_abi(config, &runtime.opts);
+    let mut ticket = 0u64;
+    check(unsafe { sys::sar_colorize_format_async(&abi, runtime.raw, image.format, image.ptr, &mut ticket) });
+    PendingImage { runtime: runtime.raw, ticket, image }
 }
 
 /// `ParallelRenderer` (:908-915): owns the execution units the job split divides by — here the lanes of one or
