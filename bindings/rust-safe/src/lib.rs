@@ -262,9 +262,10 @@ impl<'a> PendingImage<'a> {
     /// Blocks until the frame is in the image and gives the image back.
     pub fn wait(self) -> &'a PinnedImage {
         check(unsafe { sys::sar_runtime_wait_image(self.runtime, self.ticket) });
-        let this = std::mem::ManuallyDrop::new(self);
-        // SAFETY: `this` is never dropped, so the exclusive borrow it held is handed on exactly once
-        unsafe { &*(this.image as *const PinnedImage) }
+        let image: *const PinnedImage = &*self.image;
+        std::mem::forget(self);  // no second wait in Drop
+        // SAFETY: the exclusive borrow `self` held for 'a is handed on, as a shared one, exactly once
+        unsafe { &*image }
     }
 }
 impl Drop for PendingImage<'_> {
