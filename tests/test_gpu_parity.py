@@ -544,6 +544,48 @@ def test_random_configurations_bit_exact(sar, oracle, gpu, seed):
     np.testing.assert_array_equal(sar.colorize_format(cfg, rt, fmt), oracle.convert(fmt, want))
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_custom_attractors_views_and_transforms_bit_exact(sar, oracle, gpu, seed):
+    """The reference's Config is generic data, not two presets (src/lib.rs:253-308): any 30 coefficients
+    (PolynomialSprott2Degree, :575-580), any View (center_camera, un-normalised axis, rotation, scale: :291-308), either
+    colour transform with its own offset / factor (:507-516) or the other preset's, a palette of 1..8 entries (:406-473).
+    Perturbed coefficients leave the attractor bounded, let it collapse to a point or blow up to inf / NaN within the
+    frame — every one of those has to give the oracle's bits, dead jobs and all."""
+    rng = np.random.default_rng(77_000 + seed)
+    preset = ["poisson_saturne", "solar_sail"][seed % 2]
+    base = _cfg(sar, preset)
+    rel = [0.0, 1e-6, 1e-3, 3e-2, 0.3][int(rng.integers(5))]       # how far from the preset's map
+    co = {k: np.array(getattr(base.c, k)[:]) * (1.0 + rel * rng.standard_normal(10)) for k in ("coeff_x", "coeff_y", "coeff_z")}
+    if seed % 5 == 0:
+        co["coeff_y"][int(rng.integers(10))] = -0.0                  # a signed zero among the coefficients
+    w, h = int(rng.integers(8, 900)), int(rng.integers(8, 700))
+    jobs, n = int(rng.integers(1, 1500)), int(rng.integers(1, 1200))
+    kw = dict(iterations=jobs * n, width=w, height=h, jobs_total=jobs, render_kind=int(rng.integers(2)),
+              transparent=int(rng.integers(2)), angle=float(rng.uniform(-7, 7)), scale=float(rng.uniform(0.2, 3.0)),
+              center_camera=rng.uniform(-0.6, 0.6, 3), rotation_axis=rng.uniform(-1.5, 1.5, 3),
+              rotation_angle=float(rng.uniform(-4, 4)), color_transform=int(rng.integers(2)),
+              ct_offset=float(rng.uniform(-1, 1)), ct_factor=float(rng.uniform(-2, 2)),
+              palette_rgb=rng.uniform(0, 1, (int(rng.integers(1, 9)), 3)), brightness_offset=float(rng.uniform(-0.5, 0.2)),
+              brightness_factor=float(rng.uniform(0.5, 3.0)), **co)
+    cfg = base.replace(**kw)
+    cfg.validate()
+    st = sar.start_points(int(rng.integers(1 << 30)), 0, jobs)
+    rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
+    sar.render_jobs(cfg, rt, st)
+    oracle.render_jobs(cfg.c, ort, st, n)
+    assert_state_equal(rt, ort, f"seed {seed}: {preset} rel={rel} {w}x{h} jobs={jobs} n={n}")
+    np.testing.assert_array_equal(sar.colorize(cfg, rt), oracle.colorize(cfg.c, ort))
+    # the same configuration through the job split of render_parallel (:1051-1082)
+    units, jpt = 8, 3
+    pr = sar.ParallelRenderer(units=units, seed=5)
+    c2 = cfg.replace(iterations=units * jpt * 257)
+    img = sar.render_parallel(pr, c2, jpt)
+    ort2 = oracle.Runtime(w, h)
+    oracle.render_jobs(c2.replace(jobs_total=units * jpt).c, ort2, sar.start_points(5, 0, units * jpt), 257)
+    np.testing.assert_array_equal(img, oracle.colorize(c2.c, ort2))
+    pr.shutdown()
+
+
 def test_device_resident_start_points_give_the_same_bits(sar, oracle, gpu):
     """sar_render_job_range_device: start points handed over in device memory (across several launch chunks)."""
     import torch
