@@ -1,0 +1,50 @@
+"""Offline differential fuzz: the two seeded random-configuration parity tests of tests/test_gpu_parity.py over many more
+seeds than the suite runs. python tools/fuzz_parity.py FIRST LAST   (needs a GPU; prints the seeds that differ)"""
+import sys, os, traceback
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+import strange_attractor_renderer_amd as sar
+import oracle_lib as oracle
+import test_gpu_parity as T
+oracle.lib()
+
+first, last = int(sys.argv[1]), int(sys.argv[2])
+bad = []
+for seed in ([] if len(sys.argv) > 3 else range(first, last)):
+    for fn in (T.test_random_configurations_bit_exact, T.test_custom_attractors_views_and_transforms_bit_exact):
+        try:
+            getattr(fn, "__wrapped__", fn)(sar, oracle, None, seed)
+        except Exception as e:  # noqa: BLE001
+            bad.append((fn.__name__, seed))
+            print("MISMATCH", fn.__name__, seed, repr(e)[:300], flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "big":
+    # larger shapes than the suite's: images up to 5000 x 5000 (bins of 65 536 pixels, narrow hints, shared hint array),
+    # up to 150 000 jobs, ~5e7 iterations per case; both presets, both kinds, either hint width / stager / kernel form
+    for seed in range(first, last):
+        rng = np.random.default_rng(555_000 + seed)
+        preset = ["poisson_saturne", "solar_sail"][int(rng.integers(2))]
+        w, h = int(rng.integers(500, 5000)), int(rng.integers(500, 5000))
+        jobs = int(rng.integers(1000, 150000))
+        n = max(1, 50_000_000 // jobs)
+        kw = dict(iterations=jobs * n, width=w, height=h, jobs_total=jobs, render_kind=int(rng.integers(2)),
+                  angle=float(rng.uniform(0, 6.3)), scale=float(rng.uniform(0.5, 2.0)))
+        cfg = getattr(sar.Config, preset)(**kw)
+        st = sar.start_points(int(rng.integers(1 << 30)), 0, jobs)
+        rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
+        opts = {}
+        if rng.integers(3) == 0: opts["hint_bits"] = [16, 32][int(rng.integers(2))]
+        if rng.integers(3) == 0: opts["split_waves"] = [1, 2][int(rng.integers(2))]
+        if rng.integers(4) == 0: opts["hint_shared"] = [1, 2][int(rng.integers(2))]
+        if rng.integers(4) == 0: opts["debug_chunk_jobs"] = int(rng.integers(2000, 40000))
+        for k, v in opts.items(): rt.set_option(k, v)
+        try:
+            sar.render_jobs(cfg, rt, st)
+            oracle.render_jobs(cfg.c, ort, st, n)
+            T.assert_state_equal(rt, ort, f"big seed {seed}")
+            np.testing.assert_array_equal(sar.colorize(cfg, rt), oracle.colorize(cfg.c, ort))
+            print("ok", seed, preset, f"{w}x{h}", jobs, n, opts, rt.describe_last_launch()[:60], flush=True)
+        except Exception as e:  # noqa: BLE001
+            bad.append(("big", seed)); print("MISMATCH big", seed, preset, w, h, jobs, n, opts, repr(e)[:300], flush=True)
+        rt.close()
+cases = (last - first) * (1 if len(sys.argv) > 3 else 2)
+print(f"seeds {first}..{last - 1}: {cases - len(bad)} of {cases} cases bit-exact, {len(bad)} differ: {bad}")
