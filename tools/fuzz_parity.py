@@ -46,5 +46,31 @@ if len(sys.argv) > 3 and sys.argv[3] == "big":
         except Exception as e:  # noqa: BLE001
             bad.append(("big", seed)); print("MISMATCH big", seed, preset, w, h, jobs, n, opts, repr(e)[:300], flush=True)
         rt.close()
+if len(sys.argv) > 3 and sys.argv[3] == "shards":
+    # the native multi-device renderer over 1..8 shards of device 0, two frames each (the start-point stream runs on)
+    for seed in range(first, last):
+        rng = np.random.default_rng(888_000 + seed)
+        preset = ["poisson_saturne", "solar_sail"][int(rng.integers(2))]
+        k = int(rng.integers(1, 9))
+        w, h = int(rng.integers(30, 3000)), int(rng.integers(30, 2500))
+        units, jpu = int(rng.integers(1, 4000)), int(rng.integers(1, 6))
+        n = max(1, 20_000_000 // (units * jpu))
+        cfg = getattr(sar.Config, preset)(iterations=units * jpu * n + int(rng.integers(units * jpu)), width=w, height=h,
+                                          render_kind=int(rng.integers(2)), transparent=int(rng.integers(2)),
+                                          angle=float(rng.uniform(0, 6.3)), scale=float(rng.uniform(0.5, 2.0)))
+        sd = int(rng.integers(1 << 30))
+        try:
+            pr = sar.ParallelRenderer(devices=[0] * k, units=units, seed=sd)
+            for frame in range(2):
+                c = cfg.replace(angle=cfg.angle + 0.3 * frame)
+                img = sar.render_parallel(pr, c, jpu)
+                ort = oracle.Runtime(w, h)
+                oracle.render_jobs(c.replace(jobs_total=units * jpu).c, ort, sar.start_points(sd, frame * units * jpu, units * jpu), n)
+                np.testing.assert_array_equal(img, oracle.colorize(c.c, ort))
+            T.assert_state_equal(pr.runtime(), ort, f"shards seed {seed}")
+            pr.shutdown()
+            print("ok", seed, preset, f"{w}x{h}", "shards", k, "units", units, "jpu", jpu, "n", n, flush=True)
+        except Exception as e:  # noqa: BLE001
+            bad.append(("shards", seed)); print("MISMATCH shards", seed, preset, w, h, k, units, jpu, n, repr(e)[:300], flush=True)
 cases = (last - first) * (1 if len(sys.argv) > 3 else 2)
 print(f"seeds {first}..{last - 1}: {cases - len(bad)} of {cases} cases bit-exact, {len(bad)} differ: {bad}")
