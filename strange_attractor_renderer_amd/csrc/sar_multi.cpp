@@ -60,6 +60,20 @@ struct Shard {
     hipEvent_t packed = nullptr, merged = nullptr, begin = nullptr, end = nullptr;
     // job slice of the current frame
     uint32_t first_job = 0, n_jobs = 0;
+    // the NEXT frame's slice of start points, uploaded and announced (sar_runtime_prefetch_device) while this frame renders:
+    // its warm-up then runs under this frame's accumulate / fold / colorize
+    // (two buffers in turn: the frame in flight still reads the one announced a frame ago — the start points of its later
+    // launch chunks are converted on its own stream — while the next frame's points are uploaded)
+    double* d_next_buf[2] = {nullptr, nullptr};
+    size_t next_cap[2] = {0, 0};  // jobs
+    uint32_t next_slot = 0;       // the buffer the NEXT upload goes to
+    hipEvent_t next_read[2] = {nullptr, nullptr};  // recorded behind the frame that read buffer [i] (a caller that passes no
+    bool next_read_rec[2] = {false, false};        // host image is not waited for by sar_render_parallel itself)
+    double* d_next = nullptr;     // the buffer that holds the announced points
+    hipStream_t up = nullptr;
+    bool next_valid = false;
+    uint32_t next_first = 0, next_n = 0;
+    uint64_t next_iters = 0;
     int status = SAR_OK;
     char error[512] = {0};
 };
@@ -138,14 +152,23 @@ int ensure_shard(sar_renderer* r, Shard& sh, const sar_config* cfg, uint32_t S) 
 }
 
 // what one reference worker thread does with its share of the jobs (:950-988), for a whole GPU
-void render_shard(sar_renderer* r, Shard* sh, const sar_config* cfg, uint64_t per_job, const double* starts, uint32_t S) {
+void render_shard(sar_renderer* r, Shard* sh, const sar_config* cfg, uint64_t per_job, const double* starts, uint32_t S, bool use_next) {
     const uint32_t G = static_cast<uint32_t>(r->shards.size());
     auto run = [&]() -> int {
         HIP_TRY(hipSetDevice(sh->device));
         sar_runtime* rt = sh->rt;
         if (G > 1) HIP_TRY(hipEventRecord(sh->begin, rt->stream));
         SAR_TRY(sar_runtime_reset(rt));  // :951
-        SAR_TRY(render_chunked(cfg, rt, sh->n_jobs, per_job, starts + 3 * static_cast<size_t>(sh->first_job)));
+        if (use_next && sh->next_valid && sh->next_first == sh->first_job && sh->next_n == sh->n_jobs && sh->next_iters == per_job) {
+            SAR_TRY(render_chunked(cfg, rt, sh->n_jobs, per_job, sh->d_next, true));  // the points uploaded during the previous frame
+            const uint32_t slot = sh->d_next == sh->d_next_buf[0] ? 0u : 1u;
+            if (!sh->next_read[slot]) HIP_TRY(hipEventCreateWithFlags(&sh->next_read[slot], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(sh->next_read[slot], rt->stream));
+            sh->next_read_rec[slot] = true;
+        } else {
+            SAR_TRY(render_chunked(cfg, rt, sh->n_jobs, per_job, starts + 3 * static_cast<size_t>(sh->first_job)));
+        }
+        sh->next_valid = false;
         if (G > 1) {
             launch_exch_pack(rt->d_count, rt->d_key, rt->d_steps, rt->npix, S, G, sh->d_pack, rt->stream);
             HIP_TRY(hipGetLastError());
@@ -262,7 +285,12 @@ int sar_renderer_shutdown(sar_renderer* r) {
         if (sh.rt) hipStreamSynchronize(sh.rt->stream);
     }
     for (Shard& sh : r->shards) {
+        if (sh.rt) sar_runtime_free(sh.rt);  // first: an announced warm-up may still read d_next on the runtime's side stream
+        sh.rt = nullptr;
         free_shard_buffers(sh);
+        for (double* q : sh.d_next_buf) if (q) hipFree(q);
+        for (hipEvent_t ev : sh.next_read) if (ev) hipEventDestroy(ev);
+        if (sh.up) hipStreamDestroy(sh.up);
         if (sh.d_sc) hipFree(sh.d_sc);
         if (sh.h_sc) hipHostFree(sh.h_sc);
         for (hipStream_t st : sh.pull_streams) if (st) hipStreamDestroy(st);
@@ -271,7 +299,6 @@ int sar_renderer_shutdown(sar_renderer* r) {
         if (sh.merged) hipEventDestroy(sh.merged);
         if (sh.begin) hipEventDestroy(sh.begin);
         if (sh.end) hipEventDestroy(sh.end);
-        if (sh.rt) sar_runtime_free(sh.rt);
     }
     delete r;
     return SAR_OK;
@@ -315,8 +342,10 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
     // per-thread RNGs as they pick jobs up, :748; here the stream is one and the job -> point map is deterministic)
     const Rng rng_before = r->ahead_jobs ? r->rng_mark : r->rng;  // the stream as the PREVIOUS frame left it
     std::vector<double> starts;
+    bool from_ahead = false;                // the shards may hold their slices of these points already (announce_next)
     if (r->ahead_jobs == total_jobs && !r->ahead.empty()) {
         starts.swap(r->ahead);              // drawn during the previous frame
+        from_ahead = true;
     } else {
         if (r->ahead_jobs) r->rng = r->rng_mark;  // a different job count: un-draw what was drawn ahead
         starts.resize(static_cast<size_t>(total_jobs) * 3);
@@ -328,6 +357,54 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
         r->ahead.resize(static_cast<size_t>(total_jobs) * 3);
         for (uint64_t k = 0; k < total_jobs; ++k) r->rng.start_point(&r->ahead[3 * static_cast<size_t>(k)]);
         r->ahead_jobs = total_jobs;
+    };
+    // ... and once they are drawn: every device gets its slice of them and is told (sar_runtime_prefetch_device), so that
+    // the next frame's 1000 warm-up iterations per job run under THIS frame's accumulate / fold / colorize. The warm-up is
+    // the map alone: the next frame may turn the view (a sweep does). Best effort — a failure here only costs the overlap.
+    auto announce_next = [&]() {
+        const uint64_t base = total_jobs / G, rem = total_jobs % G;
+        uint64_t first = 0;
+        for (uint32_t d = 0; d < G; ++d) {
+            Shard& sh = r->shards[d];
+            const uint32_t nj = static_cast<uint32_t>(base + (d < rem ? 1u : 0u));
+            const uint32_t fj = static_cast<uint32_t>(first);
+            first += nj;
+            sh.next_valid = false;
+            // a device listed several times (tests; a box with fewer GPUs than shards) runs one warm-up ahead, its first
+            // shard's: the chip is busy with the other shards' frames anyway, and eight warm-ups piled onto one GPU only delay
+            // the exchange they run under
+            bool first_on_device = true;
+            for (uint32_t e = 0; e < d; ++e) first_on_device = first_on_device && r->shards[e].device != sh.device;
+            if (!first_on_device) continue;
+            if (nj == 0 || per_job == 0 || hipSetDevice(sh.device) != hipSuccess) continue;
+            bool ok = true;
+            if (!sh.up) ok = hipStreamCreateWithFlags(&sh.up, hipStreamNonBlocking) == hipSuccess;
+            // the previous announcement's copy of these buffers (the side stream's kernel) is long done; make it certain
+            if (ok && sh.rt->side) ok = hipStreamSynchronize(sh.rt->side) == hipSuccess;
+            const uint32_t slot = sh.next_slot;
+            if (ok && sh.next_read_rec[slot]) {  // the frame that read this buffer: two frames back, done unless nobody waited
+                ok = hipEventSynchronize(sh.next_read[slot]) == hipSuccess;
+                sh.next_read_rec[slot] = false;
+            }
+            if (ok && nj > sh.next_cap[slot]) {
+                if (sh.d_next_buf[slot]) hipFree(sh.d_next_buf[slot]);  // last read two frames ago
+                sh.d_next_buf[slot] = nullptr;
+                sh.next_cap[slot] = 0;
+                ok = hipMalloc(&sh.d_next_buf[slot], static_cast<size_t>(nj) * 3 * sizeof(double)) == hipSuccess;
+                if (ok) sh.next_cap[slot] = nj;
+            }
+            sh.d_next = sh.d_next_buf[slot];
+            ok = ok && hipMemcpyAsync(sh.d_next, &r->ahead[3 * static_cast<size_t>(fj)], static_cast<size_t>(nj) * 3 * sizeof(double),
+                                      hipMemcpyHostToDevice, sh.up) == hipSuccess &&
+                 hipStreamSynchronize(sh.up) == hipSuccess &&
+                 sar_runtime_prefetch_device(cfg, sh.rt, nj, per_job, sh.d_next) == SAR_OK;
+            if (!ok) { (void)hipGetLastError(); continue; }
+            sh.next_valid = true;
+            sh.next_slot = slot ^ 1u;
+            sh.next_first = fj;
+            sh.next_n = nj;
+            sh.next_iters = per_job;
+        }
     };
     // A frame that fails leaves the renderer as it found it: the start-point stream is wound back (the next frame draws
     // the points this one would have used), nothing drawn ahead survives, every device has finished what it was given,
@@ -345,6 +422,7 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
         r->rng = rng_before;
         r->ahead_jobs = 0;
         r->ahead.clear();
+        for (Shard& sh : r->shards) sh.next_valid = false;
         r->scattered = false;
         set_error("%s", keep);
         return status;
@@ -363,10 +441,11 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
 
     if (G == 1) {
         Shard& sh = r->shards[0];
-        render_shard(r, &sh, cfg, per_job, starts.data(), S);
+        render_shard(r, &sh, cfg, per_job, starts.data(), S, from_ahead);
         if (sh.status != SAR_OK) { set_error("%s", sh.error); return failed(sh.status); }
         int st = SAR_OK;
         draw_ahead();
+        announce_next();
         if (rgba_out_host) st = sar_colorize(cfg, sh.rt, rgba_out_host);  // :1080
         r->timing.total_ms = static_cast<float>(now_ms() - t0);
         return st == SAR_OK ? st : failed(st);
@@ -376,12 +455,13 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
     {
         std::vector<std::thread> workers;
         workers.reserve(G);
-        for (uint32_t d = 0; d < G; ++d) workers.emplace_back(render_shard, r, &r->shards[d], cfg, per_job, starts.data(), S);
+        for (uint32_t d = 0; d < G; ++d) workers.emplace_back(render_shard, r, &r->shards[d], cfg, per_job, starts.data(), S, from_ahead);
         for (auto& w : workers) w.join();
     }
     for (Shard& sh : r->shards)
         if (sh.status != SAR_OK) { set_error("device %d: %s", sh.device, sh.error); return failed(sh.status); }
     draw_ahead();
+    announce_next();
 
     const size_t blk = static_cast<size_t>(S) * 16u;
     // Is the caller's image pinned memory (then every device copies its slice straight into it), or pageable (an async copy

@@ -575,8 +575,12 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     ba.warm_out = carry ? rt->d_warm : nullptr;
     span_begin(rt, rt->warm_spans, rt->warm_used);
     const sar_runtime::Prefetch& pf = rt->pf;
-    const bool ahead = first && !carry && use_prefetch && pf.valid && pf.m == m && pf.iters == ia.iters && pf.width == ia.width &&
-                       std::memcmp(&pf.p, &ia.p, sizeof(ia.p)) == 0;
+    // The warm-up is the MAP alone (:750-752): an announcement stands for every call with the same 30 coefficients, start
+    // points and job shape — a sweep's next frame has another angle, the same warm-up. (The depth range a warm-up measured
+    // for the narrow hints under the announcing view only sets their quantiser: any range gives the same image.)
+    const bool same_map = std::memcmp(pf.p.cx, ia.p.cx, sizeof(ia.p.cx)) == 0 && std::memcmp(pf.p.cy, ia.p.cy, sizeof(ia.p.cy)) == 0 &&
+                          std::memcmp(pf.p.cz, ia.p.cz, sizeof(ia.p.cz)) == 0;
+    const bool ahead = first && !carry && use_prefetch && pf.valid && pf.m == m && pf.iters == ia.iters && pf.width == ia.width && same_map;
     if (ahead) {
         // this chunk's warm-up ran ahead (sar_runtime_prefetch_device): its buffers become the current ones
         HIP_TRY(hipStreamWaitEvent(rt->stream, rt->pf_done, 0));

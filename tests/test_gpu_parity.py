@@ -665,6 +665,33 @@ def test_announced_frames_with_narrow_hints_and_launch_chunks(sar, oracle, gpu):
         rt.close()
 
 
+@pytest.mark.parametrize("hint_bits", [32, 16])
+def test_an_announcement_stands_for_another_view_but_not_another_map(sar, oracle, gpu, hint_bits):
+    """The warm-up is the map alone (src/lib.rs:750-752): a frame announced under one view is found done by a call that
+    renders the same jobs under ANOTHER angle / scale / kind (a sweep's next frame; render_parallel announces its next
+    frame under the current view) — with the narrow hints too, whose quantiser then spans a depth range measured under the
+    announcing view —, and is dropped when a coefficient differs."""
+    import torch
+    jobs, n, w, h = 6144, 260, 520, 410
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=w, height=h, jobs_total=jobs)
+    st = sar.start_points(91, 0, jobs)
+    dev = torch.from_numpy(st).cuda()
+    torch.cuda.synchronize()
+    rt = sar.Runtime(cfg)
+    rt.set_option("hint_bits", hint_bits)
+    turned = cfg.replace(angle=2.2, scale=1.7, render_kind=sar.SAR_RENDER_DEPTH)
+    other_map = cfg.replace(coeff_z=np.array(cfg.c.coeff_z[:]) * (1 + 1e-9))
+    for announced, rendered, found in ((cfg, turned, 1), (cfg, other_map, 1), (turned, cfg, 2)):  # warm-ups found done so far
+        rt.reset()
+        sar.prefetch_device(announced, rt, jobs, n, dev.data_ptr())
+        sar.render_job_range_device(rendered, rt, jobs, n, dev.data_ptr())
+        ort = oracle.Runtime(w, h)
+        oracle.render_jobs(rendered.c, ort, st, n)
+        assert_state_equal(rt, ort, f"hint_bits {hint_bits}, announcements found so far {found}")
+        assert f"warmup_ahead={found}" in rt.describe_last_launch(), rt.describe_last_launch()
+        np.testing.assert_array_equal(sar.colorize(rendered, rt), oracle.colorize(rendered.c, ort))
+
+
 def test_every_job_diverging_in_the_warm_up(sar, oracle, gpu):
     """No trajectory survives the warm-up (start points far outside the basin): the hot kernel has nothing to do, every
     counted iteration lands on pixel (0,0) (reference src/lib.rs:789, 800-802) and the depth buffer stays empty."""
