@@ -173,11 +173,13 @@ int sar_render_job_range(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs
 int sar_render_job_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
                                 uint64_t iters_per_job, const double* starts_xyz_dev);
 
-/* Announces the NEXT sar_render_job_range_device call on this runtime — exactly these arguments — so that the 1000 uncounted
+/* Announces the NEXT sar_render_job_range_device call on this runtime — these start points, job count and iterations per
+ * job, and the attractor's 30 coefficients; the view, render kind and colours of cfg may differ in the announced call (the
+ * warm-up is the map alone: a sweep's next frame only turns the view) — so that the 1000 uncounted
  * warm-up iterations of its jobs (src/lib.rs:750-752) can run ahead, on a second stream, under the accumulate / fold /
  * colorize tail of the frame in flight (the CLI's frame loop, src/bin/main.rs:493-517, knows the next frame while it
- * renders this one). Results do not depend on it: a call that does not match the announcement simply runs its own
- * warm-up. The start points must be in place in device memory when this is called and stay unchanged until the announced
+ * renders this one; sar_render_parallel announces its own next frame this way). Results do not depend on it: a call that
+ * does not match the announcement simply runs its own warm-up. The start points must be in place in device memory when this is called and stay unchanged until the announced
  * call; a reset in between is fine. Enqueues only. */
 int sar_runtime_prefetch_device(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
                                 uint64_t iters_per_job, const double* starts_xyz_dev);
