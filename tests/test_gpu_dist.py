@@ -273,6 +273,24 @@ def _nccl_single_rank(port, W, H, jobs, n, seed, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("devices,units,jpu", [([0], 1516, 5), ([0, 0, 0], 1516, 5), ([0, 0], 4000, 3)])
+def test_frames_announced_by_render_parallel_without_anybody_waiting(sar, oracle, gpu, devices, units, jpu):
+    """sar_render_parallel uploads the next frame's start points (two device buffers in turn) and announces them while the
+    current frame renders. Frames rendered WITHOUT a host image are not waited for by the call, so the host runs ahead of
+    the GPU: the sixth frame (view turned every frame, several launch chunks per shard) must still be the oracle's."""
+    n, w, h, frames = 400, 600, 400, 6
+    cfg = sar.Config.poisson_saturne(iterations=units * jpu * n, width=w, height=h)
+    pr = sar.ParallelRenderer(devices=devices, units=units, seed=9)
+    for f in range(frames - 1):
+        sar.render_parallel_into(pr, cfg.replace(angle=0.2 * f), jpu, 0)
+    c = cfg.replace(angle=0.2 * (frames - 1))
+    img = sar.render_parallel(pr, c, jpu)
+    ort = oracle.Runtime(w, h)
+    oracle.render_jobs(c.replace(jobs_total=units * jpu).c, ort, sar.start_points(9, (frames - 1) * units * jpu, units * jpu), n)
+    np.testing.assert_array_equal(img, oracle.colorize(c.c, ort))
+    pr.shutdown()
+
+
 @pytest.mark.timeout(300)
 def test_exchange_runs_over_rccl_itself_with_one_rank(sar, gpu):
     """A 1-GPU box cannot hold two RCCL ranks, but it can hold one: the device-native branch of distributed.py
