@@ -358,6 +358,8 @@ int sar_runtime_describe_last_launch(const sar_runtime* rt, char* out, size_t ca
  *   "hint_shared"        1: one array of depth hints per XCD, 2: one array for the whole chip (each XCD's L2 then sees the
  *                        others' updates late — more visits pass the filter, none wrongly); 0 = per XCD unless the eight
  *                        copies exceed 200 MB (then they would not fit the Infinity Cache)
+ *   "chunk_ahead"        a render call of several launch chunks runs its next chunk's warm-up ahead, under the current chunk's
+ *                        accumulate and fold (0 / 1, the default); 2 = not (A/B)
  *   "depth_pipe"         visits between a depth-hint (or depth-key) load and its use in the iterate kernel: 1 or 2 (default 2)
  *   "acc_threads"        threads per block of the record-accumulate kernel (256, 512, 1024)
  *   "acc_lists"          (bin, wave) record lists a lane group of that kernel walks at the same time: 1, 2, 4 or 8

@@ -675,6 +675,51 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
 // replaces a depth winner with a strictly greater z, exactly like a later render call.
 }  // namespace
 
+// The warm-up of the first `m` jobs of a coming launch, on the side stream, into the second set of warm-up buffers: behind
+// the iterate kernel in flight (its accumulate / fold / colorize are what this runs under) or, with nothing in flight, at
+// once. `starts` is [m][3] in device memory, or (soa) the kernel's x[m] y[m] z[m] block. Leaves rt->pf describing it.
+static int warmup_ahead(sar_runtime* rt, const sar::MapParams& p, const double* starts, bool soa, uint32_t m, uint64_t iters,
+                        bool measure_range) {
+    rt->pf.valid = false;
+    if (!rt->side) {
+        HIP_TRY(hipStreamCreateWithFlags(&rt->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&rt->iter_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&rt->pf_done, hipEventDisableTiming));
+    }
+    if (m > rt->warm_alt_cap) {
+        // nothing reads the second set while no announced call is pending; what wrote it last ran on this side stream
+        HIP_TRY(hipStreamSynchronize(rt->side));
+        for (void* q : {static_cast<void*>(rt->d_warm_alt), static_cast<void*>(rt->d_joblist_alt), static_cast<void*>(rt->d_starts_alt)})
+            if (q) hipFree(q);
+        rt->d_warm_alt = nullptr; rt->d_joblist_alt = nullptr; rt->d_starts_alt = nullptr;
+        rt->warm_alt_cap = 0;
+        HIP_TRY(hipMalloc(&rt->d_warm_alt, static_cast<size_t>(m) * 3 * sizeof(double)));
+        HIP_TRY(hipMalloc(&rt->d_joblist_alt, static_cast<size_t>(m) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&rt->d_starts_alt, static_cast<size_t>(m) * 3 * sizeof(double)));
+        rt->warm_alt_cap = m;
+    }
+    if (!rt->d_active_alt) HIP_TRY(hipMalloc(&rt->d_active_alt, 4 * sizeof(uint32_t)));
+    if (!rt->d_hint_range_alt) HIP_TRY(hipMalloc(&rt->d_hint_range_alt, 2 * sizeof(uint32_t)));
+    sar_runtime::Prefetch& pf = rt->pf;
+    pf.p = p;
+    pf.n_jobs = m;
+    pf.m = m;
+    pf.width = rt->W;
+    pf.iters = iters;
+    pf.starts = nullptr;
+    pf.range_measured = measure_range;
+    if (rt->iter_done_recorded) HIP_TRY(hipStreamWaitEvent(rt->side, rt->iter_done, 0));
+    if (!soa) launch_starts_soa(starts, rt->d_starts_alt, m, rt->side);
+    HIP_TRY(hipMemsetAsync(rt->d_active_alt, 0, 4 * sizeof(uint32_t), rt->side));
+    if (measure_range) HIP_TRY(hipMemsetAsync(rt->d_hint_range_alt, 0, 2 * sizeof(uint32_t), rt->side));
+    launch_warmup(pf.p, soa ? starts : rt->d_starts_alt, m, iters, rt->d_warm_alt, rt->d_joblist_alt, rt->d_active_alt,
+                  reinterpret_cast<unsigned long long*>(rt->d_active_alt + 2), rt->W, measure_range ? rt->d_hint_range_alt : nullptr, rt->side);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(rt->pf_done, rt->side));
+    pf.valid = true;
+    return SAR_OK;
+}
+
 int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, const double* starts,
                         bool starts_on_device) {
     if (!rt->timing_accumulate) {
@@ -732,6 +777,12 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
     fa.scalars = rt->d_scalars;
 
     const int mode = rt->measure_mode == 0 ? 2 : (rt->measure_mode == 1 ? 1 : 0);
+    bool chunk_ahead = false;
+    if (pl.binned && n_seg == 1 && n_jobs > pl.chunk_jobs && !rt->side) {  // so that the first chunk's iterate kernel is already marked
+        HIP_TRY(hipStreamCreateWithFlags(&rt->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&rt->iter_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&rt->pf_done, hipEventDisableTiming));
+    }
     for (uint64_t off = 0; off < n_jobs; off += pl.chunk_jobs) {
         const uint32_t m = static_cast<uint32_t>((n_jobs - off < pl.chunk_jobs) ? n_jobs - off : pl.chunk_jobs);
         ia.n_jobs = m;
@@ -745,7 +796,16 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
             if (pl.binned) {
                 // the announced call: same start points, same job count; the first chunk's warm-up may already be done
                 const bool announced = off == 0 && starts_on_device && rt->pf.valid && rt->pf.starts == starts && rt->pf.n_jobs == n_jobs;
-                SAR_TRY(launch_binned_chunk(rt, pl, ia, fa, mode, first, carry, announced));
+                SAR_TRY(launch_binned_chunk(rt, pl, ia, fa, mode, first, carry, announced || chunk_ahead));
+                chunk_ahead = false;
+                // a call of several launch chunks (configs[3] on one GPU: three) announces its own next chunk: that chunk's
+                // warm-up runs under this chunk's accumulate and fold (its start points are staged already)
+                const uint64_t next = off + pl.chunk_jobs;
+                if (n_seg == 1 && next < n_jobs && mode == 2 && rt->chunk_ahead != 2) {
+                    const uint32_t m_next = static_cast<uint32_t>((n_jobs - next < pl.chunk_jobs) ? n_jobs - next : pl.chunk_jobs);
+                    SAR_TRY(warmup_ahead(rt, ia.p, rt->d_starts + next * 3, true, m_next, it, false));
+                    chunk_ahead = true;
+                }
             } else {
                 ia.resume = first ? 0u : 1u;
                 ia.state_out = carry ? rt->d_starts + off * 3 : nullptr;
@@ -1033,44 +1093,11 @@ int sar_runtime_prefetch_device(const sar_config* cfg, sar_runtime* rt, uint32_t
     SAR_TRY(plan_launch(cfg, rt, n_jobs, iters_per_job, pl));
     if (!pl.binned) return SAR_OK;
     const uint32_t m = static_cast<uint32_t>(n_jobs < pl.chunk_jobs ? n_jobs : pl.chunk_jobs);
-    if (!rt->side) {
-        HIP_TRY(hipStreamCreateWithFlags(&rt->side, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&rt->iter_done, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&rt->pf_done, hipEventDisableTiming));
-    }
-    if (m > rt->warm_alt_cap) {
-        // nothing reads the second set while no announced call is pending; what wrote it last ran on this side stream
-        HIP_TRY(hipStreamSynchronize(rt->side));
-        for (void* q : {static_cast<void*>(rt->d_warm_alt), static_cast<void*>(rt->d_joblist_alt), static_cast<void*>(rt->d_starts_alt)})
-            if (q) hipFree(q);
-        rt->d_warm_alt = nullptr; rt->d_joblist_alt = nullptr; rt->d_starts_alt = nullptr;
-        rt->warm_alt_cap = 0;
-        HIP_TRY(hipMalloc(&rt->d_warm_alt, static_cast<size_t>(m) * 3 * sizeof(double)));
-        HIP_TRY(hipMalloc(&rt->d_joblist_alt, static_cast<size_t>(m) * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&rt->d_starts_alt, static_cast<size_t>(m) * 3 * sizeof(double)));
-        rt->warm_alt_cap = m;
-    }
-    if (!rt->d_active_alt) HIP_TRY(hipMalloc(&rt->d_active_alt, 4 * sizeof(uint32_t)));
-    if (!rt->d_hint_range_alt) HIP_TRY(hipMalloc(&rt->d_hint_range_alt, 2 * sizeof(uint32_t)));
-    sar_runtime::Prefetch& pf = rt->pf;
-    fill_map_params(*cfg, pf.p);
-    pf.n_jobs = n_jobs;
-    pf.m = m;
-    pf.width = rt->W;
-    pf.iters = iters_per_job;
-    pf.starts = starts_xyz_dev;
-    pf.range_measured = pl.hint_bytes == 2;
-    // after the iterate kernel of the frame in flight (its accumulate / fold / colorize are what this runs under); with no
-    // frame in flight, at once
-    if (rt->iter_done_recorded) HIP_TRY(hipStreamWaitEvent(rt->side, rt->iter_done, 0));
-    launch_starts_soa(starts_xyz_dev, rt->d_starts_alt, m, rt->side);
-    HIP_TRY(hipMemsetAsync(rt->d_active_alt, 0, 4 * sizeof(uint32_t), rt->side));
-    if (pf.range_measured) HIP_TRY(hipMemsetAsync(rt->d_hint_range_alt, 0, 2 * sizeof(uint32_t), rt->side));
-    launch_warmup(pf.p, rt->d_starts_alt, m, iters_per_job, rt->d_warm_alt, rt->d_joblist_alt, rt->d_active_alt,
-                  reinterpret_cast<unsigned long long*>(rt->d_active_alt + 2), rt->W, pf.range_measured ? rt->d_hint_range_alt : nullptr, rt->side);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(rt->pf_done, rt->side));
-    pf.valid = true;
+    MapParams p;
+    fill_map_params(*cfg, p);
+    SAR_TRY(warmup_ahead(rt, p, starts_xyz_dev, false, m, iters_per_job, pl.hint_bytes == 2));
+    rt->pf.n_jobs = n_jobs;
+    rt->pf.starts = starts_xyz_dev;
     return SAR_OK;
 }
 
@@ -1450,6 +1477,9 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "hint_shared")) {
         if (v > 2) { set_error("hint_shared must be 0, 1 or 2"); return SAR_ERR_INVALID; }
         rt->hint_shared = v;
+    } else if (!std::strcmp(name, "chunk_ahead")) {
+        if (v > 2) { set_error("chunk_ahead must be 0, 1 or 2"); return SAR_ERR_INVALID; }
+        rt->chunk_ahead = v;
     } else if (!std::strcmp(name, "acc_halves")) {
         rt->acc_halves = v ? 1u : 0u;
     } else if (!std::strcmp(name, "acc_threads")) {

@@ -78,7 +78,8 @@ struct sar_runtime {
         const double* starts = nullptr;
         bool range_measured = false;
     } pf;
-    uint32_t prefetch_used = 0;      // statistic: render calls that found their warm-up done
+    uint32_t prefetch_used = 0;      // statistic: launches that found their warm-up done
+    uint32_t chunk_ahead = 0;        // option: 2 = a call of several launch chunks does not run its next chunk's warm-up ahead (A/B)
     hipEvent_t img_events[8] = {};   // sar_colorize_format_async tickets (ticket t is event t % 8: a later recording on the
     uint64_t img_next = 0;           // same stream completes no earlier, so waiting for it is always sufficient)
     char last_launch[256] = {0};     // sar_runtime_describe_last_launch
