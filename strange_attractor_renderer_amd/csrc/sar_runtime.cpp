@@ -687,16 +687,26 @@ static int warmup_ahead(sar_runtime* rt, const sar::MapParams& p, const double* 
         HIP_TRY(hipEventCreateWithFlags(&rt->pf_done, hipEventDisableTiming));
     }
     if (m > rt->warm_alt_cap) {
-        // nothing reads the second set while no announced call is pending; what wrote it last ran on this side stream
+        // what wrote the second set last ran on this side stream; what read it last — it was the current set before the last
+        // swap — may be an iterate kernel still in flight on the launch stream (a rare path: only while the sets grow)
         HIP_TRY(hipStreamSynchronize(rt->side));
-        for (void* q : {static_cast<void*>(rt->d_warm_alt), static_cast<void*>(rt->d_joblist_alt), static_cast<void*>(rt->d_starts_alt)})
+        HIP_TRY(hipStreamSynchronize(rt->stream));
+        for (void* q : {static_cast<void*>(rt->d_warm_alt), static_cast<void*>(rt->d_joblist_alt)})
             if (q) hipFree(q);
-        rt->d_warm_alt = nullptr; rt->d_joblist_alt = nullptr; rt->d_starts_alt = nullptr;
+        rt->d_warm_alt = nullptr; rt->d_joblist_alt = nullptr;
         rt->warm_alt_cap = 0;
         HIP_TRY(hipMalloc(&rt->d_warm_alt, static_cast<size_t>(m) * 3 * sizeof(double)));
         HIP_TRY(hipMalloc(&rt->d_joblist_alt, static_cast<size_t>(m) * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&rt->d_starts_alt, static_cast<size_t>(m) * 3 * sizeof(double)));
         rt->warm_alt_cap = m;
+    }
+    // the converted start points of an announced call: NOT one of the two sets that swap (its capacity is its own)
+    if (!soa && m > rt->starts_alt_cap) {
+        HIP_TRY(hipStreamSynchronize(rt->side));
+        if (rt->d_starts_alt) hipFree(rt->d_starts_alt);
+        rt->d_starts_alt = nullptr;
+        rt->starts_alt_cap = 0;
+        HIP_TRY(hipMalloc(&rt->d_starts_alt, static_cast<size_t>(m) * 3 * sizeof(double)));
+        rt->starts_alt_cap = m;
     }
     if (!rt->d_active_alt) HIP_TRY(hipMalloc(&rt->d_active_alt, 4 * sizeof(uint32_t)));
     if (!rt->d_hint_range_alt) HIP_TRY(hipMalloc(&rt->d_hint_range_alt, 2 * sizeof(uint32_t)));

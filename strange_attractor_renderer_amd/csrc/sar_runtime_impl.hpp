@@ -66,7 +66,8 @@ struct sar_runtime {
     uint32_t* d_active_alt = nullptr;
     uint32_t* d_hint_range_alt = nullptr;
     double* d_starts_alt = nullptr;
-    size_t warm_alt_cap = 0;         // jobs
+    size_t warm_alt_cap = 0;         // jobs (of d_warm_alt / d_joblist_alt: the two sets swap, capacities included)
+    size_t starts_alt_cap = 0;       // jobs (of d_starts_alt, which does not swap)
     hipStream_t side = nullptr;
     hipEvent_t iter_done = nullptr, pf_done = nullptr;
     bool iter_done_recorded = false;

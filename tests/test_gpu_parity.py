@@ -694,6 +694,29 @@ def test_an_announcement_stands_for_another_view_but_not_another_map(sar, oracle
         np.testing.assert_array_equal(sar.colorize(rendered, rt), oracle.colorize(rendered.c, ort))
 
 
+def test_announced_calls_of_growing_and_shrinking_size(sar, oracle, gpu):
+    """The two sets of warm-up buffers swap when an announced call is consumed, capacities included, while the converted
+    start points of an announcement live in a buffer of their own: a small announced call followed by larger ones (and a
+    call of several launch chunks, which announces its own next chunk) must not write past any of them."""
+    import torch
+    w, h, n = 300, 200, 120
+    rt = None
+    for k, jobs in enumerate((300, 9000, 700, 20000, 20000, 64)):
+        cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=w, height=h, jobs_total=jobs)
+        st = sar.start_points(500 + k, 0, jobs)
+        dev = torch.from_numpy(st).cuda()
+        torch.cuda.synchronize()
+        if rt is None:
+            rt = sar.Runtime(cfg)
+            rt.set_option("debug_chunk_jobs", 6000)              # 9000 and 20000 jobs run as 2 and 4 launch chunks
+        rt.reset()
+        sar.prefetch_device(cfg, rt, jobs, n, dev.data_ptr())
+        sar.render_job_range_device(cfg, rt, jobs, n, dev.data_ptr())
+        ort = oracle.Runtime(w, h)
+        oracle.render_jobs(cfg.c, ort, st, n)
+        assert_state_equal(rt, ort, f"call {k}: {jobs} jobs")
+
+
 def test_every_job_diverging_in_the_warm_up(sar, oracle, gpu):
     """No trajectory survives the warm-up (start points far outside the basin): the hot kernel has nothing to do, every
     counted iteration lands on pixel (0,0) (reference src/lib.rs:789, 800-802) and the depth buffer stays empty."""
