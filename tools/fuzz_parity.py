@@ -72,5 +72,40 @@ if len(sys.argv) > 3 and sys.argv[3] == "shards":
             print("ok", seed, preset, f"{w}x{h}", "shards", k, "units", units, "jpu", jpu, "n", n, flush=True)
         except Exception as e:  # noqa: BLE001
             bad.append(("shards", seed)); print("MISMATCH shards", seed, preset, w, h, k, units, jpu, n, repr(e)[:300], flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "announce":
+    # one runtime, a random series of calls: sizes up and down, one or several launch chunks, announced / announced with
+    # other points / not announced, with and without a reset in between (an un-reset runtime accumulates, :742-744)
+    import torch
+    for seed in range(first, last):
+        rng = np.random.default_rng(333_000 + seed)
+        preset = ["poisson_saturne", "solar_sail"][int(rng.integers(2))]
+        w, h = int(rng.integers(40, 1500)), int(rng.integers(40, 1200))
+        base = getattr(sar.Config, preset)(width=w, height=h, render_kind=int(rng.integers(2)))
+        rt, ort = sar.Runtime(base), oracle.Runtime(w, h)
+        if rng.integers(2): rt.set_option("hint_bits", [16, 32][int(rng.integers(2))])
+        log = []
+        try:
+            keep = []
+            for call in range(8):
+                jobs, n = int(rng.integers(1, 30000)), int(rng.integers(1, 400))
+                cfg = base.replace(iterations=jobs * n, jobs_total=jobs, angle=float(rng.uniform(0, 6.3)))
+                if rng.integers(3) == 0: rt.set_option("debug_chunk_jobs", int(rng.integers(300, 20000)))
+                st = sar.start_points(int(rng.integers(1 << 30)), 0, jobs)
+                dev = torch.from_numpy(st).cuda(); keep.append(dev)
+                torch.cuda.synchronize()
+                mode = int(rng.integers(4))       # 0 not announced, 1 announced, 2 announced under another view, 3 announced with other points
+                if rng.integers(3) > 0:
+                    rt.reset(); ort.reset()
+                if mode == 1: sar.prefetch_device(cfg, rt, jobs, n, dev.data_ptr())
+                if mode == 2: sar.prefetch_device(cfg.replace(angle=1.0, scale=1.3), rt, jobs, n, dev.data_ptr())
+                if mode == 3 and keep[:-1]: sar.prefetch_device(cfg, rt, min(jobs, keep[0].shape[0]), n, keep[0].data_ptr())
+                sar.render_job_range_device(cfg, rt, jobs, n, dev.data_ptr())
+                oracle.render_jobs(cfg.c, ort, st, n)
+                log.append((jobs, n, mode))
+                T.assert_state_equal(rt, ort, f"announce seed {seed} call {call} {log}")
+            print("ok", seed, preset, f"{w}x{h}", log, flush=True)
+        except Exception as e:  # noqa: BLE001
+            bad.append(("announce", seed)); print("MISMATCH announce", seed, preset, w, h, log, repr(e)[:300], flush=True)
+        rt.close()
 cases = (last - first) * (1 if len(sys.argv) > 3 else 2)
 print(f"seeds {first}..{last - 1}: {cases - len(bad)} of {cases} cases bit-exact, {len(bad)} differ: {bad}")
