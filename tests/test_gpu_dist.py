@@ -228,16 +228,18 @@ def test_multi_device_renderer_on_distinct_gpus(sar, oracle, gpu):
         pytest.skip(f"{ndev} GPU visible: the cross-device exchange needs at least two")
     W, H, units, jpu = 1024, 768, 2048, 3
     cfg = sar.Config.poisson_saturne(iterations=units * jpu * 2000, width=W, height=H, transparent=0)
+    frames = [cfg.replace(angle=0.4 * f) for f in range(3)]     # from the second on, every device finds its slice announced
     single = sar.ParallelRenderer(device=0, units=units, seed=11)
-    want = sar.render_parallel(single, cfg, jpu)
+    want = [sar.render_parallel(single, c, jpu) for c in frames]
     want_count = single.runtime().count().copy()
     single.shutdown()
+    assert not np.array_equal(want[0], want[2])
     for devices in (list(range(ndev)), list(range(ndev)) * 2):
         multi = sar.ParallelRenderer(devices=devices, units=units, seed=11)
-        got = sar.render_parallel(multi, cfg, jpu)
-        assert np.array_equal(got, want), devices
+        for c, w in zip(frames, want):
+            assert np.array_equal(sar.render_parallel(multi, c, jpu), w), devices
+            assert multi.last_timing()["peer_access_failures"] == 0
         assert np.array_equal(multi.runtime().count(), want_count), devices
-        assert multi.last_timing()["peer_access_failures"] == 0
         multi.shutdown()
 
 
