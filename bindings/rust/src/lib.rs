@@ -69,6 +69,7 @@ pub struct SarTiming {
     pub warmup_ms: f32,
     pub iterations_counted: u64,
     pub depth_atomics: u64,
+    pub depth_candidates: u64,
 }
 
 #[repr(C)]

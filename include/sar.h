@@ -104,6 +104,7 @@ typedef struct sar_timing {
     float    warmup_ms;     /* sum over launch chunks of the warm-up + packing kernel (was padding before ABI 2) */
     uint64_t iterations_counted; /* jobs * iterations-per-job executed by the last render call */
     uint64_t depth_atomics;      /* binned path: global depth atomics issued since the last query (statistic) */
+    uint64_t depth_candidates;   /* binned path: visits that passed the depth-hint filter (one chip-wide key load each) since the last query */
 } sar_timing;
 
 /* ---- misc ---------------------------------------------------------------------------------- */

@@ -85,6 +85,7 @@ class SarTiming(C.Structure):
         ("warmup_ms", C.c_float),
         ("iterations_counted", C.c_uint64),
         ("depth_atomics", C.c_uint64),
+        ("depth_candidates", C.c_uint64),
     ]
 
 

@@ -134,6 +134,7 @@ class Timing:
     iterations_counted: int
     depth_atomics: int = 0
     warmup_ms: float = 0.0
+    depth_candidates: int = 0
 
 
 class Runtime:
@@ -229,7 +230,7 @@ class Runtime:
         t = SarTiming()
         _check(_lib().sar_runtime_last_timing(self._h, C.byref(t)), "sar_runtime_last_timing")
         return Timing(t.iterate_ms, t.resolve_ms, t.colorize_ms, t.merge_ms, t.iterate_launches,
-                      t.iterations_counted, t.depth_atomics, t.warmup_ms)
+                      t.iterations_counted, t.depth_atomics, t.warmup_ms, t.depth_candidates)
 
     def set_option(self, name: str, value: int):
         _check(_lib().sar_runtime_set_option(self._h, name.encode(), int(value)), f"sar_runtime_set_option({name})")

@@ -176,24 +176,31 @@ struct DepthPipe {
     unsigned long long* key;
     uint32_t lo_base;
     HintQuant hq;         // narrow hints: the quantiser (wave-uniform)
+    HintTile ht;          // narrow hints: their layout (wave-uniform)
     // Stage-1 slot of a visit that waits for its hint. Per visit only what the filter itself needs is computed: the wide
     // hint is the f32 depth itself and stage 1 is ONE float compare (the hints start at the largest float below -1.0, so
     // `z >= hint` is the reference's strict `z > -1.0` while nobody has been there, and NaN fails); the sortable key, the
     // visit ordinal and the -0.0 fix are only formed for the ~1 % that pass. (Round 2 formed all of them for every visit:
     // six vector instructions on the consumer wave of k_iterate_split, which is that kernel's critical path.)
     bool pv[U];           // wide hints: the visit exists; narrow hints: it is a candidate (z > -1)
-    uint32_t p_idx[U], p_zf[U], p_hint[U], p_q[U], n_sent;
+    uint32_t p_idx[U], p_zf[U], p_hint[U], p_q[U], n_sent, n_pass;
     uint32_t p_t[U];      // wave-uniform: the visit's iteration
     bool gv[U];           // stage-2 candidate, waiting for the chip-wide key
     uint32_t g_idx[U], g_q[U];
     unsigned long long g_mine[U], g_cur[U];
 
-    __device__ __forceinline__ void depth_init(H* zhint_, unsigned long long* key_, uint32_t lo_base_, const uint32_t* hint_range_) {
+    // where pixel idx keeps its narrow hint (HintTile): four full-rate instructions, the identity for mask2 = 0
+    __device__ __forceinline__ uint32_t hint_index(uint32_t idx) const {
+        if (kWide) return idx;
+        return bfi(ht.mask2, bfi(ht.mask1, idx >> ht.shift1, idx << 3), idx);
+    }
+    __device__ __forceinline__ void depth_init(H* zhint_, unsigned long long* key_, uint32_t lo_base_, const uint32_t* hint_range_, const HintTile& tile_) {
+        ht = tile_;
         zhint = zhint_;
         key = key_;
         lo_base = lo_base_;
         hq = hint_quant(kWide ? nullptr : hint_range_);
-        n_sent = 0;
+        n_sent = n_pass = 0;
 #pragma unroll
         for (uint32_t k = 0; k < U; ++k) {
             pv[k] = gv[k] = false;
@@ -224,7 +231,7 @@ struct DepthPipe {
                 const uint32_t qs = seen ? depth_q16(sortable_f32(seen), hq) : 0u;
                 learnt = qs > g_q[k] ? qs : g_q[k];
             }
-            zhint[g_idx[k]] = (H)learnt;
+            zhint[hint_index(g_idx[k])] = (H)learnt;
         }
         // p_hint is the raw dword holding this pixel's hint and its neighbour's: it is unpacked only HERE, U visits
         // after the load was issued. (Unpacking next to the load makes the compiler wait for the load right there.)
@@ -235,6 +242,7 @@ struct DepthPipe {
             gv[k] = pv[k] && p_q[k] >= hint;
         }
         if (gv[k]) {
+            ++n_pass;  // statistic: visits that passed stage 1 (one key load each)
             const float zc = __uint_as_float(p_zf[k]) + 0.0f;  // -0.0 -> +0.0: integer order == float order
             g_idx[k] = p_idx[k];
             g_q[k] = kWide ? __float_as_uint(zc) : p_q[k];
@@ -269,7 +277,8 @@ struct DepthPipe {
     __device__ __forceinline__ void depth_request(uint32_t k, bool cand, uint32_t idx) {
         // every lane loads (the others from entry 0): a load under the candidates' exec mask instead costs 8 % at 4096^2,
         // where the hints miss the L2 — the partial register write makes the previous load of that register a dependency
-        if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (idx & ~1u)) : 0u));
+        // (the tiling leaves bit 0 of the index alone: the pixel's hint is the half of the dword its own parity names)
+        if (DEPTH) p_hint[k] = *(const uint32_t*)(zhint + (cand ? (kWide ? idx : (hint_index(idx) & ~1u)) : 0u));
     }
 
     // After the last visit: settle what is in flight.
@@ -282,9 +291,13 @@ struct DepthPipe {
         }
 #pragma unroll
         for (uint32_t k = 0; k < U; ++k) settle_depth(k);  // settles it
-        uint32_t tot = n_sent;  // statistics: depth atomics issued by this wave
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
+        uint32_t tot = n_sent, pas = n_pass;  // statistics: depth atomics issued / stage-1 passers of this wave
+        for (int off = 32; off > 0; off >>= 1) {
+            tot += __shfl_down(tot, off);
+            pas += __shfl_down(pas, off);
+        }
         if (lane == 0 && tot) atomicAdd(stats + 1, (unsigned long long)tot);
+        if (lane == 0 && pas) atomicAdd(stats + 14, (unsigned long long)pas);
     }
 };
 
@@ -325,7 +338,7 @@ struct Stager : DepthPipe<DEPTH, U, H> {
     uint2 fpend[R / 4u];
 
     __device__ __forceinline__ void init(char* wbase, uint32_t bins, uint32_t lane_, uint4* arena_, H* zhint_,
-                                         unsigned long long* key_, const BinMap& map_, uint32_t lo_base_, const uint32_t* hint_range_) {
+                                         unsigned long long* key_, const BinMap& map_, uint32_t lo_base_, const uint32_t* hint_range_, const HintTile& tile_) {
         n_bins = bins;
         lane = lane_;
         rec = (unsigned short*)wbase;
@@ -337,7 +350,7 @@ struct Stager : DepthPipe<DEPTH, U, H> {
         dummy = bins + lane;
         arena = arena_;
         cursor = 0;
-        depth_init(zhint_, key_, lo_base_, hint_range_);
+        depth_init(zhint_, key_, lo_base_, hint_range_, tile_);
         map = map_;
         bin_bits_v = map_.bin_bits;
         asm volatile("" : "+v"(bin_bits_v));  // stays in a VGPR: v_bfe_u32 takes one scalar operand, the field offset
@@ -536,7 +549,7 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
     static __device__ __forceinline__ char* lds_ptr(uint32_t a) { return (char*)(__attribute__((address_space(3))) char*)(uintptr_t)a; }
 
     __device__ __forceinline__ void init(char* wbase, uint32_t bins, uint32_t lane_, uint4* arena_, H* zhint_,
-                                         unsigned long long* key_, const BinMap& map_, uint32_t lo_base_, const uint32_t* hint_range_) {
+                                         unsigned long long* key_, const BinMap& map_, uint32_t lo_base_, const uint32_t* hint_range_, const HintTile& tile_) {
         n_bins = bins;
         lane = lane_;
         // layout: buffers (bins + P) * CB | ctl bins | ring P (lanes without a visit are masked off, not redirected)
@@ -551,7 +564,7 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         if (lane < P) ring[lane] = pool0 + (bins + lane) * CB;
         arena = arena_;
         cursor = drained = 0;
-        depth_init(zhint_, key_, lo_base_, hint_range_);
+        depth_init(zhint_, key_, lo_base_, hint_range_, tile_);
         map = map_;
         bin_bits_v = map_.bin_bits;
         asm volatile("" : "+v"(bin_bits_v));  // stays in a VGPR: v_bfe_u32 takes one scalar operand, the field offset
@@ -771,7 +784,7 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     // low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie
     st.init((char*)smem + (threadIdx.x >> 6) * (POOL ? kPoolWaveLds(a.n_bins, R) : kLeanWaveLds(a.n_bins, R)), a.n_bins, lane,
             (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkStride(R),
-            (H*)a.zhint + (size_t)(xcc_id() & a.hint_copy_mask) * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n, a.hint_range);
+            (H*)a.zhint + (size_t)(xcc_id() & a.hint_copy_mask) * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n, a.hint_range, a.tile);
 
     MapParams p = a.it.p;
     pin_map_params(p);
@@ -975,7 +988,7 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
     } else {
         PoolStager<DEPTH, R, U, H> st;
         st.init((char*)smem, a.n_bins, lane, (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkStride(R),
-                (H*)a.zhint + (size_t)(xcc_id() & a.hint_copy_mask) * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n, a.hint_range);
+                (H*)a.zhint + (size_t)(xcc_id() & a.hint_copy_mask) * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n, a.hint_range, a.tile);
         uint32_t t = 0, phase = 0;
 #ifdef SAR_EXPERIMENT_PROF  // wave-cycles of the consumer: [0] barrier, [1] hand-over read, [2] place_visit, [3] depth, [4] requests
         st.prof_last = __builtin_readcyclecounter();

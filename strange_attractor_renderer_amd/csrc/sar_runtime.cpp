@@ -572,6 +572,16 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     // that size sharing costs: 2048^2 5.90 -> 6.05 ms).
     const bool share = rt->hint_shared == 2 || (rt->hint_shared == 0 && static_cast<uint64_t>(rt->npix) * pl.hint_bytes * 8u > (200ull << 20));
     ba.hint_copy_mask = share ? 0u : 7u;
+    // narrow hints of an image whose width is a power of two: 8 x 8 tiles per 128-byte line (HintTile); the permutation stays
+    // inside blocks of eight rows, so the height must be a multiple of eight
+    const bool pow2w = (rt->W & (rt->W - 1u)) == 0u && rt->W >= 8u && rt->H % 8u == 0u;
+    if (pl.hint_bytes == 2 && pow2w && rt->hint_tile != 1u) {
+        uint32_t b = 0;
+        while ((1u << b) < rt->W) ++b;
+        ba.tile.shift1 = b - 3u;
+        ba.tile.mask1 = 0x38u;
+        ba.tile.mask2 = ((1u << (b + 3u)) - 1u) & ~7u;
+    }
     ba.warm_out = carry ? rt->d_warm : nullptr;
     span_begin(rt, rt->warm_spans, rt->warm_used);
     const sar_runtime::Prefetch& pf = rt->pf;
@@ -1413,9 +1423,12 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
     if (rt->merge_timed && hipEventElapsedTime(&ms, rt->merge_span.a, rt->merge_span.b) == hipSuccess) out->merge_ms = ms;
     out->iterate_launches = static_cast<uint32_t>(rt->iter_used);
     if (rt->d_nan_count) {  // cumulative statistic of the binned path; cleared by reading
-        unsigned long long sent = 0;
+        unsigned long long sent = 0, passed = 0;
         HIP_TRY(hipMemcpy(&sent, rt->d_nan_count + 1, sizeof(sent), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(rt->d_nan_count + 1, 0, sizeof(sent)));
+        HIP_TRY(hipMemcpy(&passed, rt->d_nan_count + 14, sizeof(passed), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(rt->d_nan_count + 14, 0, sizeof(passed)));
+        out->depth_candidates = passed;
 #ifdef SAR_EXPERIMENT_PROF
         unsigned long long seg[11];
         HIP_TRY(hipMemcpy(seg, rt->d_nan_count + 2, sizeof(seg), hipMemcpyDeviceToHost));
@@ -1481,6 +1494,10 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "split_waves")) {
         if (v > 2) { set_error("split_waves must be 0, 1 or 2"); return SAR_ERR_INVALID; }
         rt->split_waves = v;
+    } else if (!std::strcmp(name, "hint_tile")) {
+        if (v > 1) { set_error("hint_tile must be 0 (automatic) or 1 (row-major hints)"); return SAR_ERR_INVALID; }
+        if (rt->hint_tile != v && rt->d_zhint) { HIP_TRY(hipSetDevice(rt->device)); SAR_TRY(clear_hints(rt)); }  // another layout: the old hints mean nothing
+        rt->hint_tile = v;
     } else if (!std::strcmp(name, "acc_lists")) {
         if (v && v != 1 && v != 2 && v != 4 && v != 8) { set_error("acc_lists must be 1, 2, 4 or 8"); return SAR_ERR_INVALID; }
         rt->acc_lists = v;

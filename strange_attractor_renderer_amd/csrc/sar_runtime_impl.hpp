@@ -48,6 +48,7 @@ struct sar_runtime {
     void* d_zhint = nullptr;
     uint32_t zhint_bytes = 0;        // bytes per hint of the current allocation (2 or 4)
     uint32_t hint_bits = 0;          // option: 0 = by image size, 16, 32
+    uint32_t hint_tile = 0;          // option: 0 = narrow hints of power-of-two-wide images in 8 x 8 tiles, 1 = always row-major
     uint32_t hint_shared = 0;        // option: 0 = automatic, 1 = one hint array per XCD, 2 = one array for the whole chip
     unsigned long long* d_nan_count = nullptr;
     uint32_t* d_hint_range = nullptr;   // {~sortable(min z), sortable(max z)}: what the narrow depth hints quantise (HintQuant)

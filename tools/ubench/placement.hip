@@ -14,8 +14,16 @@
 #endif
 #define STR_(x) #x
 #define STR(x) STR_(x)
-__global__ void __launch_bounds__(64 * WAVES, WAVES == 3 ? 6 : 4) k(uint32_t* out, int spin, unsigned long long* alive) {
+#ifndef OCC     // waves per SIMD the register budget is compiled for: -DOCC=6 -DVREG=72 is k_iterate_split6
+#define OCC (WAVES == 3 ? 6 : 4)
+#endif
+__global__ void __launch_bounds__(64 * WAVES, OCC) k(uint32_t* out, int spin, unsigned long long* alive) {
     asm volatile("v_mov_b32 v" STR(VREG) ", 0" ::: "v" STR(VREG));  // the register footprint of the real kernel
+#ifdef SCRATCH  // a private segment of SCRATCH dwords per lane (the real kernel's frame of spilled scalars enables one)
+    volatile uint32_t priv[SCRATCH];
+    for (int i = 0; i < SCRATCH; ++i) priv[i] = i + spin;
+    if (priv[spin & (SCRATCH - 1)] == 0xdeadbeefu) out[0] = 1;
+#endif
 #ifdef SREG
     asm volatile("s_mov_b32 s" STR(SREG) ", 0" ::: "s" STR(SREG));
 #endif
