@@ -168,7 +168,7 @@ def main():
                     "With N > 1 and no --config: c2 as `value`, then c4 under `strong_c4` and both through the C ABI under `native`")
     ap.add_argument("--native", action="store_true", help="only the C-ABI multi-device renderer (sar_renderer_new_multi) over "
                     "--gpus devices in ONE process (device ordinals wrap around on a box with fewer GPUs)")
-    ap.add_argument("--extras-seconds", type=float, default=420.0, help="N > 1 without --config: time the strong_c4 + native "
+    ap.add_argument("--extras-seconds", type=float, default=240.0, help="N > 1 without --config: time the strong_c4 + native "
                     "extras may take before the line is printed without them")
     ap.add_argument("--sustained-seconds", type=float, default=3.0, help="N=1: length of the extra sustained-rate loop (0 = skip)")
     ap.add_argument("--exchange", default="sliced", choices=["sliced", "rooted"], help="N>1: all-to-all of image slices + "
@@ -575,6 +575,10 @@ def main():
             sys.stdout.flush()
             os._exit(0)
 
+        # ... and the line as it stands goes to stderr at once (flushed), so that even a kill from outside during the extras
+        # leaves the configs[1] measurement on record; stdout keeps its ONE line, printed last.
+        if rank == 0:
+            print("[bench] weak-scaling line before the extras: " + json.dumps(out), file=sys.stderr, flush=True)
         dog = threading.Timer(a.extras_seconds, give_up)
         dog.daemon = True
         dist.barrier()

@@ -241,7 +241,7 @@ impl PinnedImage {
         Self { ptr, bytes, format }
     }
     /// The samples (host-endian, `format`'s layout). Only reachable while no read-back into the image is pending: a
-    /// `PendingImage` holds the exclusive borrow until it has been waited for.
+    /// `PendingImage` owns the image until it has been waited for.
     pub fn bytes(&self) -> &[u8] {
         unsafe { std::slice::from_raw_parts(self.ptr as *const u8, self.bytes) }
     }
@@ -252,38 +252,39 @@ impl Drop for PinnedImage {
     }
 }
 
-/// A read-back in flight: borrows the runtime's stream order and the image until `wait` (or drop) has seen it land.
+/// A read-back in flight. It OWNS the image until `wait` hands it back: `std::mem::forget` of a handle that merely
+/// borrowed the image would end the borrow without waiting (the image could then be read, or freed, under the DMA);
+/// forgetting an owning handle only leaks the page-locked memory, which nobody can touch any more.
 pub struct PendingImage<'a> {
-    runtime: *mut sys::SarRuntime,
+    runtime: &'a GpuRuntime,
     ticket: u64,
-    image: &'a mut PinnedImage,
+    image: Option<PinnedImage>,
 }
 impl<'a> PendingImage<'a> {
     /// Blocks until the frame is in the image and gives the image back.
-    pub fn wait(self) -> &'a PinnedImage {
-        check(unsafe { sys::sar_runtime_wait_image(self.runtime, self.ticket) });
-        let image: *const PinnedImage = &*self.image;
-        std::mem::forget(self);  // no second wait in Drop
-        // SAFETY: the exclusive borrow `self` held for 'a is handed on, as a shared one, exactly once
-        unsafe { &*image }
+    pub fn wait(mut self) -> PinnedImage {
+        check(unsafe { sys::sar_runtime_wait_image(self.runtime.raw, self.ticket) });
+        self.image.take().expect("a pending image holds its image until it is waited for")
     }
 }
 impl Drop for PendingImage<'_> {
     fn drop(&mut self) {
-        // the copy must not outlive the borrow of the image
-        unsafe { sys::sar_runtime_wait_image(self.runtime, self.ticket) };
+        if self.image.is_some() {
+            // dropped without `wait`: the copy must have landed before the image is freed (PinnedImage::drop runs next)
+            unsafe { sys::sar_runtime_wait_image(self.runtime.raw, self.ticket) };
+        }
     }
 }
 
 /// `colorize` + the CLI's format conversion, only ENQUEUED (`sar_colorize_format_async`). The handle borrows the runtime
-/// (shared) and the image (exclusive) until the frame has landed: a `sequence` loop keeps the GPU busy by rendering frame
-/// k+1 on a SECOND runtime meanwhile (the C ABI would also allow resetting this one — the borrow is the safe subset).
+/// (shared) and takes the image until the frame has landed: a `sequence` loop keeps the GPU busy by rendering frame k+1
+/// on a SECOND runtime meanwhile (the C ABI would also allow resetting this one — the borrow is the safe subset).
 pub fn colorize_format_async<'a, T: Mi355xTransform>(config: &Config<PolynomialSprott2Degree, T>, runtime: &'a GpuRuntime,
-                                                     image: &'a mut PinnedImage) -> PendingImage<'a> {
+                                                     image: PinnedImage) -> PendingImage<'a> {
     let abi = to_abi(config, &runtime.opts);
     let mut ticket = 0u64;
     check(unsafe { sys::sar_colorize_format_async(&abi, runtime.raw, image.format, image.ptr, &mut ticket) });
-    PendingImage { runtime: runtime.raw, ticket, image }
+    PendingImage { runtime, ticket, image: Some(image) }
 }
 
 /// `ParallelRenderer` (:908-915): owns the execution units the job split divides by — here the lanes of one or

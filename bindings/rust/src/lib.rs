@@ -82,6 +82,10 @@ pub struct SarParallelTiming {
     pub n_devices: u32,
     pub peer_access_failures: u32,
     pub exchange_bytes_per_device: u64,
+    pub host_ms_before_exchange: f32,
+    pub host_ms_enqueue: f32,
+    pub draw_ahead_ms: f32,
+    pub _pad: f32,
 }
 
 #[repr(C)]

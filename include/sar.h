@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SAR_ABI_VERSION 3
+#define SAR_ABI_VERSION 4  /* 4: start-point stream in blocks of 4096 jobs (jump); sar_timing.depth_candidates; sar_parallel_timing.host_ms_before_exchange */
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -125,10 +125,14 @@ int sar_config_validate(const sar_config* cfg);
 /* EulerAxisRotation::to_rotation_matrix, release semantics (:176-196). m is row-major 3x3. */
 int sar_rotation_matrix(const sar_config* cfg, double m_out[9]);
 /*
- * The start-point stream the reference leaves to OS entropy (:656, :748): SplitMix64(seed) seeds
- * xoshiro256++; every f64 is (next_u64 >> 11) * 2^-53; job k takes draws 3k..3k+2 as x,y,z, each
- * multiplied by 0.1 (`rng.random::<Vec3>() * 0.1`). Writes n_jobs*3 doubles for jobs
- * [first_job, first_job+n_jobs).
+ * The start-point stream the reference leaves to OS entropy (:656, :748). SplitMix64(seed) seeds xoshiro256++ (four outputs
+ * = the state: what rand 0.9 documents for SmallRng::seed_from_u64 on 64-bit targets); every f64 is (next_u64 >> 11) * 2^-53,
+ * multiplied by 0.1 (`rng.random::<Vec3>() * 0.1`). Jobs come in BLOCKS of 4096: block b draws from the generator after b
+ * applications of xoshiro256's published jump() (2^128 steps each), and job k takes draws 3i..3i+2 of block k / 4096 as
+ * x, y, z, with i = k % 4096 — so the first 4096 jobs are the plain stream, and any job's point is found without drawing
+ * its predecessors' (a multi-device render_parallel draws every device's job slice on its own host thread). Writes n_jobs*3
+ * doubles for jobs [first_job, first_job+n_jobs). The published vectors of both generators and the jump polynomial are
+ * held by tests/test_oracle_kat.py.
  */
 int sar_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double* xyz_out_host);
 
@@ -323,6 +327,12 @@ typedef struct sar_parallel_timing {
                                        no, or hipDeviceEnablePeerAccess failed; sar_last_error keeps the last reason): their
                                        copies are staged through host memory by the HIP runtime */
     uint64_t exchange_bytes_per_device;  /* bytes every device pulls over xGMI per frame */
+    float    host_ms_before_exchange;    /* host time between the last device's render being enqueued and the first pull of the
+                                            exchange being enqueued (one device: entry to render enqueued) — the next frame's
+                                            start points are drawn on helper threads meanwhile, off this path */
+    float    host_ms_enqueue;            /* host time from entry until the whole frame (render, exchange, colorize, copies) is enqueued */
+    float    draw_ahead_ms;              /* a helper thread's time to draw one device's slice of the next frame's start points */
+    float    _pad;
 } sar_parallel_timing;
 int sar_renderer_last_timing(const sar_renderer* r, sar_parallel_timing* out);
 

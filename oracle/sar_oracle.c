@@ -362,33 +362,86 @@ void sar_oracle_colorize(const sar_config* cfg, const sar_oracle_runtime* rt, ui
 }
 
 /* ---- start-point stream (this project's definition; the reference uses OS entropy, :656) ------ */
+/* SplitMix64 (Vigna's splitmix64.c) seeds xoshiro256++ 1.0 (Blackman & Vigna, xoshiro256plusplus.c): the algorithm rand 0.9
+ * documents for SmallRng::seed_from_u64 on 64-bit targets (Cargo.toml:16; unpinned, no lockfile: SURVEY 8c). Jobs are drawn
+ * in BLOCKS of 4096: block b uses the generator after b applications of the published jump() (2^128 steps each), job k of
+ * the stream takes draws 3i..3i+2 (x, y, z) of block k / 4096 with i = k % 4096. The raw entries below exist for the tests
+ * that hold the three pieces to their published vectors (tests/test_oracle_kat.py). */
 static inline uint64_t rotl64(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
 
-void sar_oracle_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double* xyz) {
-    uint64_t s[4];
-    uint64_t sm = seed;
-    for (int k = 0; k < 4; ++k) { /* SplitMix64 */
-        sm += 0x9e3779b97f4a7c15ULL;
-        uint64_t z = sm;
-        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
-        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
-        s[k] = z ^ (z >> 31);
-    }
-    const uint64_t skip = first_job * 3u;
-    const uint64_t total = skip + (uint64_t)n_jobs * 3u;
-    for (uint64_t d = 0; d < total; ++d) { /* xoshiro256++ */
-        const uint64_t r = rotl64(s[0] + s[3], 23) + s[0];
-        const uint64_t t = s[1] << 17;
-        s[2] ^= s[0];
-        s[3] ^= s[1];
-        s[1] ^= s[2];
-        s[0] ^= s[3];
-        s[2] ^= t;
-        s[3] = rotl64(s[3], 45);
-        if (d >= skip) {
-            const double u = (double)(r >> 11) * 0x1.0p-53; /* [0,1) */
-            xyz[d - skip] = u * 0.1;                         /* `random::<Vec3>() * 0.1`, :748 */
+static uint64_t splitmix64_next(uint64_t* state) {
+    uint64_t z = (*state += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+
+static uint64_t xoshiro256pp_next(uint64_t s[4]) {
+    const uint64_t result = rotl64(s[0] + s[3], 23) + s[0];
+    const uint64_t t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return result;
+}
+
+static void xoshiro256_jump(uint64_t s[4]) {
+    static const uint64_t JUMP[] = {0x180ec6d33cfd0abaULL, 0xd5a61266f0c9392cULL, 0xa9582618e03fc9aaULL, 0x39abdc4529b1661cULL};
+    uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (unsigned i = 0; i < sizeof JUMP / sizeof *JUMP; i++)
+        for (int b = 0; b < 64; b++) {
+            if (JUMP[i] & (UINT64_C(1) << b)) {
+                s0 ^= s[0];
+                s1 ^= s[1];
+                s2 ^= s[2];
+                s3 ^= s[3];
+            }
+            (void)xoshiro256pp_next(s);
         }
+    s[0] = s0;
+    s[1] = s1;
+    s[2] = s2;
+    s[3] = s3;
+}
+
+void sar_oracle_splitmix64(uint64_t seed, uint32_t n, uint64_t* out) {
+    for (uint32_t k = 0; k < n; ++k) out[k] = splitmix64_next(&seed);
+}
+void sar_oracle_xoshiro256pp(uint64_t state[4], uint32_t n, uint64_t* out) {
+    for (uint32_t k = 0; k < n; ++k) out[k] = xoshiro256pp_next(state);
+}
+void sar_oracle_xoshiro256_jump(uint64_t state[4]) { xoshiro256_jump(state); }
+double sar_oracle_unit_f64(uint64_t raw) { return (double)(raw >> 11) * 0x1.0p-53; } /* [0,1): rand's StandardUniform for f64 */
+
+void sar_oracle_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double* xyz) {
+    uint64_t block_state[4], s[4] = {0, 0, 0, 0};
+    uint64_t sm = seed;
+    for (int k = 0; k < 4; ++k) block_state[k] = splitmix64_next(&sm);
+    uint64_t block = 0;     /* the block block_state belongs to */
+    uint64_t drawn = 4096;  /* jobs already drawn from s; 4096 = s is not set up */
+    uint64_t s_block = ~0ULL;
+    for (uint64_t job = first_job; job < first_job + n_jobs; ++job) {
+        const uint64_t b = job / 4096u, i = job % 4096u;
+        while (block < b) {
+            xoshiro256_jump(block_state);
+            ++block;
+        }
+        if (s_block != b || drawn > i) {
+            for (int k = 0; k < 4; ++k) s[k] = block_state[k];
+            s_block = b;
+            drawn = 0;
+        }
+        for (; drawn < i; ++drawn) {
+            (void)xoshiro256pp_next(s);
+            (void)xoshiro256pp_next(s);
+            (void)xoshiro256pp_next(s);
+        }
+        for (int c = 0; c < 3; ++c) /* `random::<Vec3>() * 0.1`, :748: x then y then z (:161-166) */
+            xyz[3 * (job - first_job) + c] = sar_oracle_unit_f64(xoshiro256pp_next(s)) * 0.1;
+        ++drawn;
     }
 }
 

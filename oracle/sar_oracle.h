@@ -79,6 +79,11 @@ void sar_oracle_convert(int format, uint64_t npix, const uint16_t* rgba16, void*
 
 /* Start-point stream (defined by this project, see include/sar.h sar_start_points). */
 void sar_oracle_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double* xyz);
+/* the stream's pieces, for the tests that hold them to their published vectors */
+void sar_oracle_splitmix64(uint64_t seed, uint32_t n, uint64_t* out);          /* n outputs of SplitMix64 from state `seed` */
+void sar_oracle_xoshiro256pp(uint64_t state[4], uint32_t n, uint64_t* out);    /* n outputs of xoshiro256++; state advanced */
+void sar_oracle_xoshiro256_jump(uint64_t state[4]);                            /* the published jump(): 2^128 steps */
+double sar_oracle_unit_f64(uint64_t raw);                                      /* (raw >> 11) * 2^-53 */
 
 /* FNV-1a 64 over raw bytes (fixture hashing). */
 uint64_t sar_oracle_fnv1a64(const void* data, uint64_t nbytes);

@@ -72,6 +72,10 @@ class SarParallelTiming(C.Structure):
         ("n_devices", C.c_uint32),
         ("peer_access_failures", C.c_uint32),
         ("exchange_bytes_per_device", C.c_uint64),
+        ("host_ms_before_exchange", C.c_float),
+        ("host_ms_enqueue", C.c_float),
+        ("draw_ahead_ms", C.c_float),
+        ("_pad", C.c_float),
     ]
 
 

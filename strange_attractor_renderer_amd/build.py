@@ -103,7 +103,9 @@ def build_library(force: bool = False, verbose: bool = False, out: str | None = 
 if __name__ == "__main__":
     if "--variant" in sys.argv:  # python -m ...build --variant NAME  (flags from SAR_EXTRA_FLAGS / SAR_KERNEL_FLAGS)
         name = sys.argv[sys.argv.index("--variant") + 1]
+        import tempfile
+        scratch = os.environ.get("SAR_VARIANT_BUILD_DIR") or os.path.join(tempfile.gettempdir(), "sar_build")
         print(build_library(force=True, verbose=True, out=os.path.join(PKG, f"libsar_hip_{name}.so"),
-                            build_dir=os.path.join("/tmp", "sar_build", f"sar_hip_{name}")))
+                            build_dir=os.path.join(scratch, f"sar_hip_{name}")))
     else:
         print(build_library(force="--force" in sys.argv, verbose=True))

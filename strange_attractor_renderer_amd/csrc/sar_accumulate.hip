@@ -16,9 +16,13 @@ namespace sar {
 // Bins of 65536 pixels (the most a 16-bit record addresses — 4096^2 in 256 bins) do not fit 32-bit counters into the LDS:
 //   MODE 2, PACKED (default): two 16-bit counters per LDS word, 128 KiB for the whole bin, ONE workgroup reads the lists
 //     once. A counter is 15 bits plus a guard bit: the lane whose (returning) add sets the guard bit takes 32768 out again
-//     and notes the pixel in a short event list; every event is worth 32768 hits when the histogram is written out. No
-//     carry ever reaches the neighbouring counter: between the add that sets the guard bit and the subtraction by the same
-//     lane at most 16 waves x 15 outstanding LDS operations x 64 lanes = 15360 more adds can land on that counter.
+//     and notes the pixel in a short event list; every event is worth 32768 hits when the histogram is written out. A
+//     carry into the neighbouring counter would need 32768 FURTHER adds on this counter between the add that sets the guard
+//     bit and the same lane's subtraction, which follows it by a few instructions. That is a timing argument, not an
+//     enforced bound (the other fifteen waves keep issuing meanwhile): adds to one LDS address are serialised by the
+//     atomic unit at one per clock, so 32768 of them are ~16 us against a sub-microsecond window; the tests drive one pixel
+//     through 9000 guard events, and a build with -DSAR_ACC_GUARD_CHECK traps on an add that finds the guard bit set with the
+//     counter already above 0x4000 (the parity suite runs through it without one). `acc_halves` = 1 (MODE 1) is the fallback without this argument.
 //   MODE 1, HALF (round 2; `acc_halves` 1 selects it for A/B runs and tests): two workgroups per (bin, split), each reads the
 //     lists and counts the records of its half of the bin (record bit 15) in a 32768-entry histogram of 32-bit counters —
 //     every list is read twice: 4.35 ms per launch of configs[3] on one GPU against 2.82 ms (which is the rate of isolated
@@ -97,6 +101,9 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
                     const uint32_t inc = __umul24(rec & 1u, 0xFFFFu) + 1u;
                     const uint32_t full = __umul24(inc, 0x7FFFu);
                     const uint32_t old = atomicAdd(&hist[rec >> 1], inc);
+#ifdef SAR_ACC_GUARD_CHECK  // debug builds: an add that finds the guard bit set AND the counter far on its way again
+                    if ((old & (inc << 15)) && (old & full) >= __umul24(inc, 0x4000u)) __builtin_trap();
+#endif
                     if (__builtin_expect((old & full) == full, 0)) {
                         atomicSub(&hist[rec >> 1], inc << 15);
                         const uint32_t e = atomicAdd(&ev_ctl[0], 1u);

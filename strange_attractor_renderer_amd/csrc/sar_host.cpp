@@ -44,7 +44,10 @@ static void config_defaults(sar_config* c) {
     c->jobs_total = 1;
 }
 
-// xoshiro256++ seeded through SplitMix64 (definition in include/sar.h, sar_start_points)
+// xoshiro256++ seeded through SplitMix64 (definition in include/sar.h, sar_start_points): SplitMix64 as published by
+// Steele, Lea & Flood / Vigna (splitmix64.c), xoshiro256++ 1.0 as published by Blackman & Vigna (xoshiro256plusplus.c) —
+// what rand 0.9 documents for `SmallRng::seed_from_u64` on 64-bit targets. tests/test_oracle_kat.py holds both to their
+// published vectors and proves the jump polynomial (T^(2^128) over GF(2)).
 void Rng::seed(uint64_t seed) {
     uint64_t sm = seed;
     for (int k = 0; k < 4; ++k) {
@@ -54,26 +57,73 @@ void Rng::seed(uint64_t seed) {
         z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
         s[k] = z ^ (z >> 31);
     }
+    for (int k = 0; k < 4; ++k) base[k] = s[k];
+    in_block = 0;
 }
 
+static inline uint64_t rotl64(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
+
 uint64_t Rng::next_u64() {
-    auto rotl = [](uint64_t v, int k) { return (v << k) | (v >> (64 - k)); };
-    const uint64_t r = rotl(s[0] + s[3], 23) + s[0];
+    const uint64_t r = rotl64(s[0] + s[3], 23) + s[0];
     const uint64_t t = s[1] << 17;
     s[2] ^= s[0];
     s[3] ^= s[1];
     s[1] ^= s[2];
     s[0] ^= s[3];
     s[2] ^= t;
-    s[3] = rotl(s[3], 45);
+    s[3] = rotl64(s[3], 45);
     return r;
+}
+
+// xoshiro256's jump(): equivalent to 2^128 calls of next_u64 (the polynomial is the published JUMP constant)
+void Rng::jump(uint64_t st[4]) {
+    static const uint64_t kJump[4] = {0x180ec6d33cfd0abaull, 0xd5a61266f0c9392cull, 0xa9582618e03fc9aaull, 0x39abdc4529b1661cull};
+    uint64_t acc[4] = {0, 0, 0, 0};
+    for (int w = 0; w < 4; ++w)
+        for (int b = 0; b < 64; ++b) {
+            if (kJump[w] & (1ull << b))
+                for (int k = 0; k < 4; ++k) acc[k] ^= st[k];
+            const uint64_t t = st[1] << 17;  // one step of the linear engine (next_u64 without its output)
+            st[2] ^= st[0];
+            st[3] ^= st[1];
+            st[1] ^= st[2];
+            st[0] ^= st[3];
+            st[2] ^= t;
+            st[3] = rotl64(st[3], 45);
+        }
+    for (int k = 0; k < 4; ++k) st[k] = acc[k];
 }
 
 // `rng.random::<Vec3>() * 0.1` (src/lib.rs:748, :161-166): x, y, z drawn in that order
 void Rng::start_point(double out[3]) {
+    if (in_block == kStartBlockJobs) {  // the next block: the generator 2^128 steps on from this block's start
+        jump(base);
+        for (int k = 0; k < 4; ++k) s[k] = base[k];
+        in_block = 0;
+    }
     for (int k = 0; k < 3; ++k) {
         const double u = static_cast<double>(next_u64() >> 11) * 0x1.0p-53;
         out[k] = u * 0.1;
+    }
+    ++in_block;
+}
+
+void Rng::skip_points(uint64_t n_jobs) {
+    while (n_jobs) {
+        if (in_block == kStartBlockJobs) {
+            jump(base);
+            for (int k = 0; k < 4; ++k) s[k] = base[k];
+            in_block = 0;
+        }
+        const uint64_t room = kStartBlockJobs - in_block;
+        if (n_jobs >= room) {  // the rest of this block: nothing to draw, the next block starts from jump(base)
+            in_block = kStartBlockJobs;
+            n_jobs -= room;
+        } else {
+            for (uint64_t d = 0; d < 3 * n_jobs; ++d) (void)next_u64();
+            in_block += static_cast<uint32_t>(n_jobs);
+            n_jobs = 0;
+        }
     }
 }
 
@@ -190,8 +240,7 @@ int sar_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double*
     if (!xyz_out_host && n_jobs) return SAR_ERR_INVALID;
     sar::Rng rng;
     rng.seed(seed);
-    double tmp[3];
-    for (uint64_t k = 0; k < first_job; ++k) rng.start_point(tmp);
+    rng.skip_points(first_job);
     for (uint32_t k = 0; k < n_jobs; ++k) rng.start_point(xyz_out_host + 3 * static_cast<size_t>(k));
     return SAR_OK;
 }

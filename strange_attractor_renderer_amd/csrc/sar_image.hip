@@ -270,6 +270,21 @@ __global__ void k_exch_scalars_export(const uint32_t* scalars, long long* out4) 
     out4[1] = scalars[SC_WRAP];
     out4[2] = scalars[SC_ZMAX];
     out4[3] = (long long)(~scalars[SC_ZMIN]);
+    __threadfence_system();  // out4 may be host memory that other devices read (the native renderer's board)
+}
+// the native multi-device renderer: every device's quad sits on a board in page-locked host memory (written by
+// k_exch_scalars_export, one slot per device); each device reduces the G quads itself — no host round trip
+__global__ void k_exch_scalars_reduce(uint32_t* scalars, const volatile long long* board, uint32_t G) {
+    long long m[4] = {0, 0, 0, 0};
+    for (uint32_t d = 0; d < G; ++d)
+        for (int k = 0; k < 4; ++k) {
+            const long long v = board[4 * d + k];
+            m[k] = v > m[k] ? v : m[k];
+        }
+    scalars[SC_MAX] = (uint32_t)m[0];
+    scalars[SC_WRAP] = (uint32_t)m[1];
+    scalars[SC_ZMAX] = (uint32_t)m[2];
+    scalars[SC_ZMIN] = ~(uint32_t)m[3];
 }
 __global__ void k_exch_scalars_import(uint32_t* scalars, const long long* in4) {
     scalars[SC_MAX] = (uint32_t)in4[0];
@@ -397,6 +412,9 @@ void launch_exch_merge_slices(uint32_t* count, unsigned long long* key, double* 
 
 void launch_exch_scalars_export(const uint32_t* scalars, void* out4, hipStream_t s) {
     hipLaunchKernelGGL(k_exch_scalars_export, dim3(1), dim3(1), 0, s, scalars, (long long*)out4);
+}
+void launch_exch_scalars_reduce(uint32_t* scalars, const void* board, uint32_t G, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_scalars_reduce, dim3(1), dim3(1), 0, s, scalars, (const volatile long long*)board, G);
 }
 void launch_exch_scalars_import(uint32_t* scalars, const void* in4, hipStream_t s) {
     hipLaunchKernelGGL(k_exch_scalars_import, dim3(1), dim3(1), 0, s, scalars, (const long long*)in4);

@@ -12,12 +12,20 @@ namespace sar {
 extern thread_local char g_last_error[512];
 void set_error(const char* fmt, ...);
 
-// Start-point stream (include/sar.h: sar_start_points).
+// Start-point stream (include/sar.h: sar_start_points): xoshiro256++ seeded through SplitMix64, in BLOCKS of
+// kStartBlockJobs jobs — block b draws from the generator after b applications of xoshiro256's published jump()
+// (2^128 steps each), so that any job's point is found without drawing its predecessors' (a multi-GPU frame draws
+// its job slices on one host thread per device).
+constexpr uint32_t kStartBlockJobs = 4096;
 struct Rng {
-    uint64_t s[4];
+    uint64_t s[4];        // the generator the current block draws from
+    uint64_t base[4];     // its state at the start of the current block
+    uint32_t in_block;    // jobs drawn from the current block
     void seed(uint64_t seed);
-    uint64_t next_u64();
-    void start_point(double out[3]);
+    uint64_t next_u64();                  // one raw xoshiro256++ output (no block logic)
+    void start_point(double out[3]);      // the next job's point
+    void skip_points(uint64_t n_jobs);    // as if n_jobs points had been drawn: whole blocks by jump(), the rest by drawing
+    static void jump(uint64_t st[4]);     // xoshiro256's jump(): 2^128 steps
 };
 
 void rotation_matrix(const sar_config& cfg, double m[9]);

@@ -178,7 +178,7 @@ struct DepthPipe {
     HintQuant hq;         // narrow hints: the quantiser (wave-uniform)
     HintTile ht;          // narrow hints: their layout (wave-uniform)
     // Stage-1 slot of a visit that waits for its hint. Per visit only what the filter itself needs is computed: the wide
-    // hint is the f32 depth itself and stage 1 is ONE float compare (the hints start at the largest float below -1.0, so
+    // hint is the f32 depth itself and stage 1 is ONE float compare (the hints start at the smallest float above -1.0 (nextafter(-1, +inf) = 0xBF7FFFFF), so
     // `z >= hint` is the reference's strict `z > -1.0` while nobody has been there, and NaN fails); the sortable key, the
     // visit ordinal and the -0.0 fix are only formed for the ~1 % that pass. (Round 2 formed all of them for every visit:
     // six vector instructions on the consumer wave of k_iterate_split, which is that kernel's critical path.)
@@ -709,6 +709,7 @@ __global__ void __launch_bounds__(256) k_warmup(const MapParams pin, const doubl
     MapParams p = pin;
     pin_map_params(p);
     double x = 0., y = 0., z = 0.;
+    float zlo = __builtin_inff(), zhi = -__builtin_inff();  // depth range of this lane's candidates (neutral for lanes without a job)
     if (valid) {
         x = starts[job];
         y = starts[n_jobs + job];
@@ -719,7 +720,6 @@ __global__ void __launch_bounds__(256) k_warmup(const MapParams pin, const doubl
             // the same 1000 iterations; the last ones also project the point and note the depth of every visit that could
             // win a depth test (in bounds, z > -1): the range the narrow depth hints quantise (HintQuant)
             for (int w = 0; w < 1000 - kWarmupRangeIters; ++w) next_point(p, x, y, z);
-            float zlo = __builtin_inff(), zhi = -__builtin_inff();
             for (int w = 0; w < kWarmupRangeIters; ++w) {
                 bool inb;
                 uint32_t idx;
@@ -730,14 +730,16 @@ __global__ void __launch_bounds__(256) k_warmup(const MapParams pin, const doubl
                     zhi = fmaxf(zhi, zf);
                 }
             }
-            for (int off = 32; off > 0; off >>= 1) {
-                zlo = fminf(zlo, __shfl_down(zlo, off));
-                zhi = fmaxf(zhi, __shfl_down(zhi, off));
-            }
-            if ((threadIdx.x & 63u) == 0u && zhi >= zlo) {
-                atomicMax(hint_range, ~f32_sortable(zlo + 0.0f));
-                atomicMax(hint_range + 1, f32_sortable(zhi + 0.0f));
-            }
+        }
+    }
+    if (hint_range) {  // (kernel-uniform) the wave's range: every lane takes part in the shuffles, the job-less ones with +-inf
+        for (int off = 32; off > 0; off >>= 1) {
+            zlo = fminf(zlo, __shfl_down(zlo, off));
+            zhi = fmaxf(zhi, __shfl_down(zhi, off));
+        }
+        if ((threadIdx.x & 63u) == 0u && zhi >= zlo) {
+            atomicMax(hint_range, ~f32_sortable(zlo + 0.0f));
+            atomicMax(hint_range + 1, f32_sortable(zhi + 0.0f));
         }
     }
     const bool live = valid && x == x;

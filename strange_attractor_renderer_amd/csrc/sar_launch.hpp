@@ -42,6 +42,7 @@ void launch_exch_merge_slices(uint32_t* count, unsigned long long* key, double* 
                               uint32_t G, const void* in, uint32_t* scalars, bool keep_max, hipStream_t s);
 void launch_exch_scalars_export(const uint32_t* scalars, void* out4, hipStream_t s);
 void launch_exch_scalars_import(uint32_t* scalars, const void* in4, hipStream_t s);
+void launch_exch_scalars_reduce(uint32_t* scalars, const void* board, uint32_t G, hipStream_t s);  // board: [G][4] int64 quads
 int launch_convert(const void* rgba16, int format, void* out, uint32_t npix, hipStream_t s);
 // returns the number of blocks = 12-double partial results written to `out`
 uint32_t launch_extent(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* out, hipStream_t s);

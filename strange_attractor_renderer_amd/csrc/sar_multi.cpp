@@ -13,10 +13,16 @@
 //      ran one after the other, each at single-link speed: round 2) — and fold them with Runtime::merge in device order
 //      (k_exch_merge_slices: device 0 is the accumulator, the earlier device wins depth ties, the running max sees every
 //      intermediate sum);
-//   3. four scalars (max, wrap flag, depth range) are combined on the host, every device colorizes ITS slice and copies
-//      it into the caller's host image over its own PCIe link (through a pinned staging buffer if that image is pageable).
+//   3. four scalars (max, wrap flag, depth range): every device writes its quad onto a small board in page-locked host
+//      memory, waits (on its stream, through the other devices' events) until all quads are there and reduces them itself —
+//      no host round trip —, colorizes ITS slice and copies it into the caller's host image over its own PCIe link (through
+//      a pinned staging buffer if that image is pageable).
+// The host only enqueues: the NEXT frame's start points are drawn on one helper thread per device while the GPUs work (the
+// stream is addressable in blocks of 4096 jobs, sar_start_points), uploaded from page-locked memory and announced
+// (sar_runtime_prefetch_device) once the exchange is enqueued.
 // With one device steps 2-3 collapse to a plain colorize.
 #include <chrono>
+#include <functional>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -51,8 +57,6 @@ struct Shard {
     void* d_pack = nullptr;   // [G][S*16] this device's partial buffers, one block per owner
     void* d_recv = nullptr;   // [G][S*16] every device's block of the slice this device owns
     void* d_rgba = nullptr;   // [S*8] colorized slice
-    void* d_sc = nullptr;     // int64[4] scalars in / out
-    long long* h_sc = nullptr;  // pinned int64[4]
     uint16_t* h_rgba = nullptr;  // pinned [S*4]: the colorized slice on its way into a pageable host image
     std::vector<hipStream_t> pull_streams;  // one per source device: this owner's pulls run side by side
     std::vector<hipEvent_t> pulled;         // ... and are joined to the owner's stream through these
@@ -66,10 +70,14 @@ struct Shard {
     // launch chunks are converted on its own stream — while the next frame's points are uploaded)
     double* d_next_buf[2] = {nullptr, nullptr};
     size_t next_cap[2] = {0, 0};  // jobs
-    uint32_t next_slot = 0;       // the buffer the NEXT upload goes to
+    uint32_t next_slot = 0;       // the buffer the NEXT frame's points are drawn into / uploaded to
+    uint32_t cur_slot = 0;        // the buffer that holds THIS frame's points (host side)
     hipEvent_t next_read[2] = {nullptr, nullptr};  // recorded behind the frame that read buffer [i] (a caller that passes no
     bool next_read_rec[2] = {false, false};        // host image is not waited for by sar_render_parallel itself)
     double* d_next = nullptr;     // the buffer that holds the announced points
+    double* h_next[2] = {nullptr, nullptr};  // page-locked: the slice's points as the helper thread drew them (upload source)
+    size_t h_next_cap[2] = {0, 0};           // jobs
+    hipEvent_t uploaded = nullptr;           // the upload of the announced points (the announced warm-up waits for it)
     hipStream_t up = nullptr;
     bool next_valid = false;
     uint32_t next_first = 0, next_n = 0;
@@ -83,13 +91,13 @@ struct Shard {
 struct sar_renderer {
     uint32_t units = 0;
     uint64_t seed = 0;
-    Rng rng;                      // the renderer's start-point stream: job k of a frame takes the next three draws
-    // start points of the NEXT frame, drawn while the GPUs work on the current one (a frame's job list costs ~1 ms of
-    // host time at 2e5 jobs — as much as a whole configs[4] frame renders in): valid for `ahead_jobs` jobs; `rng_mark` is
-    // the stream's state before they were drawn, restored if the next frame asks for another job count
-    std::vector<double> ahead;
+    Rng rng;                      // the renderer's start-point stream, at the first job of the next frame to render
+    // The NEXT frame's start points are drawn while the GPUs work on the current one, every device's slice on its own helper
+    // thread into page-locked memory (Shard::h_next): `ahead_jobs` jobs from `rng_next` on (the stream behind the current
+    // frame) are there. A next frame with another job count simply does not use them.
     uint64_t ahead_jobs = 0;
-    Rng rng_mark;
+    Rng rng_next;
+    long long* h_board = nullptr; // page-locked, visible to every device: [64][4] scalar quads of the exchange (step 3)
     std::vector<Shard> shards;    // one per device, in fold order
     bool scattered = false;       // shard runtimes hold only their own merged slice (gather before handing one out)
     uint32_t peer_access_failures = 0;  // ordered device pairs whose copies cannot go peer to peer
@@ -130,8 +138,6 @@ int ensure_shard(sar_renderer* r, Shard& sh, const sar_config* cfg, uint32_t S) 
         HIP_TRY(hipEventCreate(&sh.merged));
         HIP_TRY(hipEventCreate(&sh.begin));
         HIP_TRY(hipEventCreate(&sh.end));
-        HIP_TRY(hipMalloc(&sh.d_sc, 4 * sizeof(long long)));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sh.h_sc), 4 * sizeof(long long), hipHostMallocDefault));
         sh.pull_streams.assign(G, nullptr);
         sh.pulled.assign(G, nullptr);
         for (uint32_t k = 0; k < G; ++k) {
@@ -152,7 +158,7 @@ int ensure_shard(sar_renderer* r, Shard& sh, const sar_config* cfg, uint32_t S) 
 }
 
 // what one reference worker thread does with its share of the jobs (:950-988), for a whole GPU
-void render_shard(sar_renderer* r, Shard* sh, const sar_config* cfg, uint64_t per_job, const double* starts, uint32_t S, bool use_next) {
+void render_shard(sar_renderer* r, Shard* sh, const sar_config* cfg, uint64_t per_job, uint32_t S, bool use_next) {
     const uint32_t G = static_cast<uint32_t>(r->shards.size());
     auto run = [&]() -> int {
         HIP_TRY(hipSetDevice(sh->device));
@@ -166,7 +172,7 @@ void render_shard(sar_renderer* r, Shard* sh, const sar_config* cfg, uint64_t pe
             HIP_TRY(hipEventRecord(sh->next_read[slot], rt->stream));
             sh->next_read_rec[slot] = true;
         } else {
-            SAR_TRY(render_chunked(cfg, rt, sh->n_jobs, per_job, starts + 3 * static_cast<size_t>(sh->first_job)));
+            SAR_TRY(render_chunked(cfg, rt, sh->n_jobs, per_job, sh->h_next[sh->cur_slot]));  // this slice's points as drawn (page-locked host memory)
         }
         sh->next_valid = false;
         if (G > 1) {
@@ -289,10 +295,10 @@ int sar_renderer_shutdown(sar_renderer* r) {
         sh.rt = nullptr;
         free_shard_buffers(sh);
         for (double* q : sh.d_next_buf) if (q) hipFree(q);
+        for (double* q : sh.h_next) if (q) hipHostFree(q);
+        if (sh.uploaded) hipEventDestroy(sh.uploaded);
         for (hipEvent_t ev : sh.next_read) if (ev) hipEventDestroy(ev);
         if (sh.up) hipStreamDestroy(sh.up);
-        if (sh.d_sc) hipFree(sh.d_sc);
-        if (sh.h_sc) hipHostFree(sh.h_sc);
         for (hipStream_t st : sh.pull_streams) if (st) hipStreamDestroy(st);
         for (hipEvent_t ev : sh.pulled) if (ev) hipEventDestroy(ev);
         if (sh.packed) hipEventDestroy(sh.packed);
@@ -300,6 +306,7 @@ int sar_renderer_shutdown(sar_renderer* r) {
         if (sh.begin) hipEventDestroy(sh.begin);
         if (sh.end) hipEventDestroy(sh.end);
     }
+    if (r->h_board) hipHostFree(r->h_board);
     delete r;
     return SAR_OK;
 }
@@ -337,96 +344,8 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
     r->scattered = false;
 
     for (Shard& sh : r->shards) SAR_TRY(ensure_shard(r, sh, cfg, S));
-
-    // fresh start points for every job, in job order, from the renderer's stream (the reference's workers draw from
-    // per-thread RNGs as they pick jobs up, :748; here the stream is one and the job -> point map is deterministic)
-    const Rng rng_before = r->ahead_jobs ? r->rng_mark : r->rng;  // the stream as the PREVIOUS frame left it
-    std::vector<double> starts;
-    bool from_ahead = false;                // the shards may hold their slices of these points already (announce_next)
-    if (r->ahead_jobs == total_jobs && !r->ahead.empty()) {
-        starts.swap(r->ahead);              // drawn during the previous frame
-        from_ahead = true;
-    } else {
-        if (r->ahead_jobs) r->rng = r->rng_mark;  // a different job count: un-draw what was drawn ahead
-        starts.resize(static_cast<size_t>(total_jobs) * 3);
-        for (uint64_t k = 0; k < total_jobs; ++k) r->rng.start_point(&starts[3 * static_cast<size_t>(k)]);
-    }
-    r->ahead_jobs = 0;
-    auto draw_ahead = [&]() {               // called once the GPUs have their work: the host has nothing else to do
-        r->rng_mark = r->rng;
-        r->ahead.resize(static_cast<size_t>(total_jobs) * 3);
-        for (uint64_t k = 0; k < total_jobs; ++k) r->rng.start_point(&r->ahead[3 * static_cast<size_t>(k)]);
-        r->ahead_jobs = total_jobs;
-    };
-    // ... and once they are drawn: every device gets its slice of them and is told (sar_runtime_prefetch_device), so that
-    // the next frame's 1000 warm-up iterations per job run under THIS frame's accumulate / fold / colorize. The warm-up is
-    // the map alone: the next frame may turn the view (a sweep does). Best effort — a failure here only costs the overlap.
-    auto announce_next = [&]() {
-        const uint64_t base = total_jobs / G, rem = total_jobs % G;
-        uint64_t first = 0;
-        for (uint32_t d = 0; d < G; ++d) {
-            Shard& sh = r->shards[d];
-            const uint32_t nj = static_cast<uint32_t>(base + (d < rem ? 1u : 0u));
-            const uint32_t fj = static_cast<uint32_t>(first);
-            first += nj;
-            sh.next_valid = false;
-            // a device listed several times (tests; a box with fewer GPUs than shards) runs one warm-up ahead, its first
-            // shard's: the chip is busy with the other shards' frames anyway, and eight warm-ups piled onto one GPU only delay
-            // the exchange they run under
-            bool first_on_device = true;
-            for (uint32_t e = 0; e < d; ++e) first_on_device = first_on_device && r->shards[e].device != sh.device;
-            if (!first_on_device) continue;
-            if (nj == 0 || per_job == 0 || hipSetDevice(sh.device) != hipSuccess) continue;
-            bool ok = true;
-            if (!sh.up) ok = hipStreamCreateWithFlags(&sh.up, hipStreamNonBlocking) == hipSuccess;
-            // the previous announcement's copy of these buffers (the side stream's kernel) is long done; make it certain
-            if (ok && sh.rt->side) ok = hipStreamSynchronize(sh.rt->side) == hipSuccess;
-            const uint32_t slot = sh.next_slot;
-            if (ok && sh.next_read_rec[slot]) {  // the frame that read this buffer: two frames back, done unless nobody waited
-                ok = hipEventSynchronize(sh.next_read[slot]) == hipSuccess;
-                sh.next_read_rec[slot] = false;
-            }
-            if (ok && nj > sh.next_cap[slot]) {
-                if (sh.d_next_buf[slot]) hipFree(sh.d_next_buf[slot]);  // last read two frames ago
-                sh.d_next_buf[slot] = nullptr;
-                sh.next_cap[slot] = 0;
-                ok = hipMalloc(&sh.d_next_buf[slot], static_cast<size_t>(nj) * 3 * sizeof(double)) == hipSuccess;
-                if (ok) sh.next_cap[slot] = nj;
-            }
-            sh.d_next = sh.d_next_buf[slot];
-            ok = ok && hipMemcpyAsync(sh.d_next, &r->ahead[3 * static_cast<size_t>(fj)], static_cast<size_t>(nj) * 3 * sizeof(double),
-                                      hipMemcpyHostToDevice, sh.up) == hipSuccess &&
-                 hipStreamSynchronize(sh.up) == hipSuccess &&
-                 sar_runtime_prefetch_device(cfg, sh.rt, nj, per_job, sh.d_next) == SAR_OK;
-            if (!ok) { (void)hipGetLastError(); continue; }
-            sh.next_valid = true;
-            sh.next_slot = slot ^ 1u;
-            sh.next_first = fj;
-            sh.next_n = nj;
-            sh.next_iters = per_job;
-        }
-    };
-    // A frame that fails leaves the renderer as it found it: the start-point stream is wound back (the next frame draws
-    // the points this one would have used), nothing drawn ahead survives, every device has finished what it was given,
-    // and no shard claims to hold merged slices.
-    auto failed = [&](int status) {
-        char keep[512];
-        std::snprintf(keep, sizeof(keep), "%s", sar_last_error());
-        for (Shard& sh : r->shards) {
-            if (!sh.rt) continue;
-            hipSetDevice(sh.device);
-            hipStreamSynchronize(sh.rt->stream);
-            for (hipStream_t st : sh.pull_streams) if (st) hipStreamSynchronize(st);
-        }
-        (void)hipGetLastError();
-        r->rng = rng_before;
-        r->ahead_jobs = 0;
-        r->ahead.clear();
-        for (Shard& sh : r->shards) sh.next_valid = false;
-        r->scattered = false;
-        set_error("%s", keep);
-        return status;
-    };
+    if (G > 1 && !r->h_board)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r->h_board), 64 * 4 * sizeof(long long), hipHostMallocPortable | hipHostMallocMapped));
 
     // contiguous job slices, sizes differ by at most one (the same partition as distributed.shard_jobs)
     {
@@ -439,29 +358,184 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
         }
     }
 
+    // Fresh start points for every job, in job order, from the renderer's stream (the reference's workers draw from
+    // per-thread RNGs as they pick jobs up, :748; here the stream is one and the job -> point map is deterministic). Every
+    // device's slice is drawn on its own host thread into page-locked memory: the stream is addressable in blocks of 4096 jobs.
+    const Rng frame_rng = r->rng;                                  // the stream at this frame's first job
+    const bool from_ahead = r->ahead_jobs == total_jobs;           // drawn (and, where possible, uploaded + announced) during the previous frame
+    r->ahead_jobs = 0;
+    auto pinned_slice = [](Shard& sh, uint32_t slot, uint32_t jobs) -> int {   // on the shard's device
+        if (jobs <= sh.h_next_cap[slot]) return SAR_OK;
+        if (sh.uploaded) HIP_TRY(hipEventSynchronize(sh.uploaded));            // the last upload out of this memory
+        if (sh.h_next[slot]) hipHostFree(sh.h_next[slot]);
+        sh.h_next[slot] = nullptr;
+        sh.h_next_cap[slot] = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sh.h_next[slot]), static_cast<size_t>(jobs) * 3 * sizeof(double), hipHostMallocDefault));
+        sh.h_next_cap[slot] = jobs;
+        return SAR_OK;
+    };
+    auto draw_slice = [](const Rng& from, uint64_t skip, uint32_t jobs, double* out) {
+        Rng g = from;
+        g.skip_points(skip);
+        for (uint32_t k = 0; k < jobs; ++k) g.start_point(out + 3 * static_cast<size_t>(k));
+    };
+    if (!from_ahead) {  // the first frame, or another job count than the previous one: draw now, all slices at the same time
+        std::vector<std::thread> drawers;
+        for (uint32_t d = 0; d < G; ++d) {
+            Shard& sh = r->shards[d];
+            HIP_TRY(hipSetDevice(sh.device));
+            sh.next_valid = false;
+            sh.cur_slot = sh.next_slot;
+            SAR_TRY(pinned_slice(sh, sh.cur_slot, sh.n_jobs));
+            sh.next_slot ^= 1u;
+        }
+        for (uint32_t d = 0; d < G; ++d) {
+            Shard& sh = r->shards[d];
+            drawers.emplace_back(draw_slice, std::cref(frame_rng), static_cast<uint64_t>(sh.first_job), sh.n_jobs, sh.h_next[sh.cur_slot]);
+        }
+        for (auto& t : drawers) t.join();
+    }
+    // The NEXT frame's points (same job count assumed: a sweep, a sequence): drawn from now on by one helper thread per
+    // device while this thread enqueues the frame; joined once the exchange is enqueued.
+    std::vector<std::thread> helpers;
+    double draw_ms = 0.0;
+    bool ahead_ok = per_job != 0;
+    if (ahead_ok) {
+        for (uint32_t d = 0; d < G && ahead_ok; ++d) {
+            Shard& sh = r->shards[d];
+            ahead_ok = hipSetDevice(sh.device) == hipSuccess && pinned_slice(sh, sh.next_slot, sh.n_jobs) == SAR_OK &&
+                       (!sh.uploaded || hipEventSynchronize(sh.uploaded) == hipSuccess);  // nothing reads that memory any more
+        }
+        if (!ahead_ok) (void)hipGetLastError();
+    }
+    if (ahead_ok) {
+        const double td = now_ms();
+        for (uint32_t d = 0; d < G; ++d) {
+            Shard* sh = &r->shards[d];
+            helpers.emplace_back([=, &frame_rng, &draw_ms]() {
+                Rng nx = frame_rng;
+                nx.skip_points(total_jobs);              // the stream behind this frame
+                if (d == 0) r->rng_next = nx;
+                nx.skip_points(sh->first_job);
+                double* out = sh->h_next[sh->next_slot];
+                for (uint32_t k = 0; k < sh->n_jobs; ++k) nx.start_point(out + 3 * static_cast<size_t>(k));
+                if (d == 0) draw_ms = now_ms() - td;     // (device 0's slice: they are equal)
+            });
+        }
+    }
+    auto join_helpers = [&]() {
+        for (auto& t : helpers) t.join();
+        helpers.clear();
+    };
+    // ... and once they are drawn: every device gets its slice of them and is told (sar_runtime_prefetch_device), so that
+    // the next frame's 1000 warm-up iterations per job run under THIS frame's accumulate / fold / colorize. The warm-up is
+    // the map alone: the next frame may turn the view (a sweep does). Best effort — a failure here only costs the overlap.
+    // Nothing here waits for the GPU: the upload comes out of page-locked memory and the announced warm-up waits for it on
+    // its own stream.
+    auto announce_next = [&]() {
+        for (uint32_t d = 0; d < G; ++d) {
+            Shard& sh = r->shards[d];
+            const uint32_t slot = sh.next_slot;
+            sh.next_valid = false;
+            // a device listed several times (tests; a box with fewer GPUs than shards) runs one warm-up ahead, its first
+            // shard's: the chip is busy with the other shards' frames anyway, and eight warm-ups piled onto one GPU only delay
+            // the exchange they run under
+            bool first_on_device = true;
+            for (uint32_t e = 0; e < d; ++e) first_on_device = first_on_device && r->shards[e].device != sh.device;
+            if (!first_on_device) continue;
+            const uint32_t nj = sh.n_jobs;
+            if (nj == 0 || per_job == 0 || hipSetDevice(sh.device) != hipSuccess) continue;
+            bool ok = true;
+            if (!sh.up) ok = hipStreamCreateWithFlags(&sh.up, hipStreamNonBlocking) == hipSuccess;
+            if (ok && !sh.uploaded) ok = hipEventCreateWithFlags(&sh.uploaded, hipEventDisableTiming) == hipSuccess;
+            if (ok && sh.next_read_rec[slot]) {  // the frame that read this buffer: two frames back, done unless nobody waited
+                ok = hipEventSynchronize(sh.next_read[slot]) == hipSuccess;
+                sh.next_read_rec[slot] = false;
+            }
+            if (ok && nj > sh.next_cap[slot]) {
+                if (sh.d_next_buf[slot]) hipFree(sh.d_next_buf[slot]);  // last read two frames ago
+                sh.d_next_buf[slot] = nullptr;
+                sh.next_cap[slot] = 0;
+                ok = hipMalloc(&sh.d_next_buf[slot], static_cast<size_t>(nj) * 3 * sizeof(double)) == hipSuccess;
+                if (ok) sh.next_cap[slot] = nj;
+            }
+            sh.d_next = sh.d_next_buf[slot];
+            ok = ok && hipMemcpyAsync(sh.d_next, sh.h_next[slot], static_cast<size_t>(nj) * 3 * sizeof(double), hipMemcpyHostToDevice, sh.up) == hipSuccess &&
+                 hipEventRecord(sh.uploaded, sh.up) == hipSuccess;
+            if (ok) {
+                sh.rt->prefetch_after = sh.uploaded;  // the announced warm-up's stream waits for the upload; this thread does not
+                ok = sar_runtime_prefetch_device(cfg, sh.rt, nj, per_job, sh.d_next) == SAR_OK;
+                sh.rt->prefetch_after = nullptr;
+            }
+            if (!ok) { (void)hipGetLastError(); continue; }
+            sh.next_valid = true;
+            sh.next_first = sh.first_job;
+            sh.next_n = nj;
+            sh.next_iters = per_job;
+        }
+    };
+    // the frame is under way: the stream moves behind it, and the points drawn meanwhile belong to the next one
+    auto commit_ahead = [&]() {
+        const bool had = !helpers.empty();
+        join_helpers();
+        r->timing.draw_ahead_ms = static_cast<float>(draw_ms);
+        if (had) {
+            r->rng = r->rng_next;
+            announce_next();
+            for (Shard& sh : r->shards) {
+                sh.cur_slot = sh.next_slot;
+                sh.next_slot ^= 1u;
+            }
+            r->ahead_jobs = total_jobs;
+        } else {
+            r->rng.skip_points(total_jobs);
+        }
+    };
+    // A frame that fails leaves the renderer as it found it: the start-point stream stays at this frame's first job (the
+    // next frame draws the points this one would have used), nothing drawn ahead survives, every device has finished what it
+    // was given, and no shard claims to hold merged slices.
+    auto failed = [&](int status) {
+        char keep[512];
+        std::snprintf(keep, sizeof(keep), "%s", sar_last_error());
+        join_helpers();
+        for (Shard& sh : r->shards) {
+            if (!sh.rt) continue;
+            hipSetDevice(sh.device);
+            hipStreamSynchronize(sh.rt->stream);
+            for (hipStream_t st : sh.pull_streams) if (st) hipStreamSynchronize(st);
+        }
+        (void)hipGetLastError();
+        r->rng = frame_rng;
+        r->ahead_jobs = 0;
+        for (Shard& sh : r->shards) sh.next_valid = false;
+        r->scattered = false;
+        set_error("%s", keep);
+        return status;
+    };
+
     if (G == 1) {
         Shard& sh = r->shards[0];
-        render_shard(r, &sh, cfg, per_job, starts.data(), S, from_ahead);
+        render_shard(r, &sh, cfg, per_job, S, from_ahead);
         if (sh.status != SAR_OK) { set_error("%s", sh.error); return failed(sh.status); }
         int st = SAR_OK;
-        draw_ahead();
-        announce_next();
-        if (rgba_out_host) st = sar_colorize(cfg, sh.rt, rgba_out_host);  // :1080
+        r->timing.host_ms_before_exchange = static_cast<float>(now_ms() - t0);
+        if (rgba_out_host) st = sar_colorize(cfg, sh.rt, rgba_out_host);  // :1080 (waits for the image: the helper drew meanwhile)
+        if (st != SAR_OK) return failed(st);
+        commit_ahead();
         r->timing.total_ms = static_cast<float>(now_ms() - t0);
-        return st == SAR_OK ? st : failed(st);
+        return SAR_OK;
     }
 
     // 1. one host thread per device (as the reference has one per core): stage, render, pack
     {
         std::vector<std::thread> workers;
         workers.reserve(G);
-        for (uint32_t d = 0; d < G; ++d) workers.emplace_back(render_shard, r, &r->shards[d], cfg, per_job, starts.data(), S, from_ahead);
+        for (uint32_t d = 0; d < G; ++d) workers.emplace_back(render_shard, r, &r->shards[d], cfg, per_job, S, from_ahead);
         for (auto& w : workers) w.join();
     }
     for (Shard& sh : r->shards)
         if (sh.status != SAR_OK) { set_error("device %d: %s", sh.device, sh.error); return failed(sh.status); }
-    draw_ahead();
-    announce_next();
+    const double t_rendered = now_ms();
 
     const size_t blk = static_cast<size_t>(S) * 16u;
     // Is the caller's image pinned memory (then every device copies its slice straight into it), or pageable (an async copy
@@ -476,7 +550,7 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
     }
     auto exchange = [&]() -> int {
         // 2. the owners pull their blocks (every pair of devices over its own link, all links at the same time) and fold them
-        // in device order
+        // in device order; every device then posts its slice's four scalars on the board
         for (uint32_t d = 0; d < G; ++d) {
             Shard& dst = r->shards[d];
             HIP_TRY(hipSetDevice(dst.device));
@@ -486,6 +560,7 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
                 Shard& src = r->shards[s];
                 hipStream_t cs = s == d ? st : dst.pull_streams[s];
                 if (s != d) HIP_TRY(hipStreamWaitEvent(cs, src.packed, 0));
+                if (d == 0 && k == 0) r->timing.host_ms_before_exchange = static_cast<float>(now_ms() - t_rendered);
                 HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(dst.d_recv) + s * blk, dst.device,
                                            static_cast<const char*>(src.d_pack) + d * blk, src.device, blk, cs));
                 if (s != d) {
@@ -497,28 +572,21 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
             const uint32_t n = first >= npix ? 0u : static_cast<uint32_t>((npix - first < S) ? npix - first : S);
             launch_exch_merge_slices(dst.rt->d_count, dst.rt->d_key, dst.rt->d_steps, static_cast<uint32_t>(first >= npix ? 0 : first), n, S, G,
                                      dst.d_recv, dst.rt->d_scalars, d == 0, st);
-            launch_exch_scalars_export(dst.rt->d_scalars, dst.d_sc, st);
+            launch_exch_scalars_export(dst.rt->d_scalars, r->h_board + 4 * d, st);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(dst.h_sc, dst.d_sc, 4 * sizeof(long long), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipEventRecord(dst.merged, st));
         }
         r->scattered = true;
 
-        // 3. the four scalars become global on the host; every device colorizes its slice into the caller's image
-        long long red[4] = {0, 0, 0, 0};
-        for (uint32_t d = 0; d < G; ++d) {
-            Shard& sh = r->shards[d];
-            HIP_TRY(hipSetDevice(sh.device));
-            HIP_TRY(hipEventSynchronize(sh.merged));
-            for (int k = 0; k < 4; ++k) red[k] = sh.h_sc[k] > red[k] ? sh.h_sc[k] : red[k];
-        }
+        // 3. every device waits — on its stream — for the other devices' quads, reduces the G of them itself (no host round
+        // trip), colorizes its slice and copies it into the caller's image
         for (uint32_t d = 0; d < G; ++d) {
             Shard& sh = r->shards[d];
             HIP_TRY(hipSetDevice(sh.device));
             hipStream_t st = sh.rt->stream;
-            for (int k = 0; k < 4; ++k) sh.h_sc[k] = red[k];
-            HIP_TRY(hipMemcpyAsync(sh.d_sc, sh.h_sc, 4 * sizeof(long long), hipMemcpyHostToDevice, st));
-            launch_exch_scalars_import(sh.rt->d_scalars, sh.d_sc, st);
+            for (uint32_t e = 0; e < G; ++e)
+                if (e != d) HIP_TRY(hipStreamWaitEvent(st, r->shards[e].merged, 0));
+            launch_exch_scalars_reduce(sh.rt->d_scalars, r->h_board, G, st);
             const uint64_t first = static_cast<uint64_t>(d) * S;
             const uint32_t n = first >= npix ? 0u : static_cast<uint32_t>((npix - first < S) ? npix - first : S);
             if (rgba_out_host && n) {
@@ -528,7 +596,11 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
             }
             HIP_TRY(hipEventRecord(sh.end, st));
         }
-        // wait for every device; a pageable image gets its slices from the staging buffers, one host thread per device
+        r->timing.host_ms_enqueue = static_cast<float>(now_ms() - t0);
+        // everything of this frame is enqueued: the next frame's points (drawn meanwhile) go to the devices
+        commit_ahead();
+        // wait for every device (the pack / receive buffers are reused by the next frame); a pageable image gets its slices
+        // from the staging buffers, one host thread per device
         std::vector<std::thread> movers;
         std::vector<int> sync_status(G, SAR_OK);
         for (uint32_t d = 0; d < G; ++d) {

@@ -173,7 +173,7 @@ BinGeometry bin_geometry(uint32_t npix, uint32_t want_block, uint32_t want_shift
 
 int clear_hints(sar_runtime* rt) {
     // hints are lower bounds of depths already accumulated; anything that can lower zbuf voids them
-    // Wide hints hold the depth itself as f32 and start at the largest float below -1.0: stage 1's `z >= hint` is then the
+    // Wide hints hold the depth itself as f32 and start at the smallest float above -1.0 (nextafter(-1, +inf) = 0xBF7FFFFF): stage 1's `z >= hint` is then the
     // reference's strict `z > -1.0` (:693, :821) for a pixel nobody has reached. Narrow hints are 16-bit fixed point from 0.
     if (rt->d_zhint && rt->zhint_bytes == 4)
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(rt->d_zhint), static_cast<int>(0xBF7FFFFFu), (static_cast<size_t>(rt->npix) + 2u) * 8u, rt->stream));
@@ -729,6 +729,7 @@ static int warmup_ahead(sar_runtime* rt, const sar::MapParams& p, const double* 
     pf.starts = nullptr;
     pf.range_measured = measure_range;
     if (rt->iter_done_recorded) HIP_TRY(hipStreamWaitEvent(rt->side, rt->iter_done, 0));
+    if (rt->prefetch_after) HIP_TRY(hipStreamWaitEvent(rt->side, rt->prefetch_after, 0));  // the points are still on their way
     if (!soa) launch_starts_soa(starts, rt->d_starts_alt, m, rt->side);
     HIP_TRY(hipMemsetAsync(rt->d_active_alt, 0, 4 * sizeof(uint32_t), rt->side));
     if (measure_range) HIP_TRY(hipMemsetAsync(rt->d_hint_range_alt, 0, 2 * sizeof(uint32_t), rt->side));

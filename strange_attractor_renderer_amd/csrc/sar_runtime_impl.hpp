@@ -71,6 +71,8 @@ struct sar_runtime {
     size_t starts_alt_cap = 0;       // jobs (of d_starts_alt, which does not swap)
     hipStream_t side = nullptr;
     hipEvent_t iter_done = nullptr, pf_done = nullptr;
+    hipEvent_t prefetch_after = nullptr;  // set around sar_runtime_prefetch_device by the multi-device renderer: the side stream
+                                          // waits for it (the upload of the announced points) instead of the host
     bool iter_done_recorded = false;
     struct Prefetch {
         bool valid = false;

@@ -98,8 +98,9 @@ class SequenceRenderer:
                                    seed=self.seed)
 
     def run(self, todo: list[tuple[int, float, str]],
-            sink: Callable[[int, str, np.ndarray], object] | None = None) -> list[tuple[int, str, np.ndarray]]:
-        """Renders the frames [(index, angle, name)] in order; returns them unless `sink` consumes them."""
+            sink: Callable[[int, str, np.ndarray], object] | None = None, zero_copy: bool = False) -> list[tuple[int, str, np.ndarray]]:
+        """Renders the frames [(index, angle, name)] in order; returns them unless `sink` consumes them. A sink receives its
+        own copy of the frame unless `zero_copy` asks for the view of the recycled page-locked image (see render_sequence)."""
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         out: list = []
@@ -124,7 +125,7 @@ class SequenceRenderer:
                 self.settle[id(rt)] = self.settle.get(id(rt), 0) + 1
             api.wait_image(rt, ticket)
             if sink is not None:
-                busy[slot] = sink(k, name, images[slot].array)
+                busy[slot] = sink(k, name, images[slot].array if zero_copy else np.array(images[slot].array))
             else:
                 out.append((k, name, np.array(images[slot].array)))
 
@@ -183,7 +184,7 @@ def render_sequence(config: "api.Config", start: float, end: float, step: float,
                     jobs_per_thread: int = 12, seed: int = 0, rank: int = 0, world: int = 1, device: int = 0,
                     file_name: str = "attractor", image_format: int | None = None,
                     sink: Callable[[int, str, np.ndarray], object] | None = None,
-                    ring: int = 0, lanes: int = 2) -> list[tuple[int, str, np.ndarray]]:
+                    ring: int = 0, lanes: int = 2, zero_copy: bool = False) -> list[tuple[int, str, np.ndarray]]:
     """Renders this rank's frames of the sweep (frame k belongs to rank k % world; no collective is needed).
     Returns [(frame index, file name, image)] unless `sink` consumes the frames. The image is RGBA16, or — with
     `image_format` (SAR_FMT_*) — the CLI's converted format, converted on the device before the read-back.
@@ -194,15 +195,17 @@ def render_sequence(config: "api.Config", start: float, end: float, step: float,
     turn, and the frame `lanes` back is handed to `sink` while the GPU works on the later ones. Frames are independent
     (each has its own Runtime state, :950-951 resets it), so with two lanes the GPU fills one frame's latency-bound parts
     (the 1000-iteration warm-up of a few waves per SIMD, the kernel tails, the read-back on the copy engine) with the other
-    frame's arithmetic. The array a sink receives is a view of a host image: it stays valid until `ring - lanes` further
-    frames have been delivered, or — when the sink returns an object with `.result()` (a Future of its consumer) — until
-    that has returned, which the loop waits for before it reuses the image. ring 0 = lanes + 2."""
+    frame's arithmetic. A sink receives its own copy of the frame (as every frame was a fresh array before the images were
+    recycled). With `zero_copy` it receives a VIEW of one of the `ring` page-locked images instead: frame k + ring's
+    read-back is enqueued before frame k + ring - lanes is delivered, so the view stays valid for `ring - lanes - 1` further
+    deliveries (ONE with the default ring of lanes + 2) — or, when the sink returns an object with `.result()` (a Future of
+    its consumer), until that has returned, which the loop waits for before it reuses the image. ring 0 = lanes + 2."""
     todo = [(k, a, f) for (k, a, f) in frames(start, end, step, file_name) if k % world == rank]
     if not todo:
         return []
     with SequenceRenderer(config, units=units, jobs_per_thread=jobs_per_thread, seed=seed, device=device,
                           image_format=image_format, ring=ring, lanes=lanes) as seq:
-        return seq.run(todo, sink)
+        return seq.run(todo, sink, zero_copy)
 
 
 def render_sequence_to_files(config: "api.Config", start: float, end: float, step: float, *, file_name: str = "attractor.png",
@@ -229,5 +232,5 @@ def render_sequence_to_files(config: "api.Config", start: float, end: float, ste
             return f                                  # the page-locked image is reused only after its file is written
 
         kw.setdefault("ring", max(1, encoders) + kw.get("lanes", 2) + 1)
-        render_sequence(config, start, end, step, file_name=file_name, image_format=fmt, sink=sink, **kw)
+        render_sequence(config, start, end, step, file_name=file_name, image_format=fmt, sink=sink, zero_copy=True, **kw)  # the encoder's Future guards the view
         return [f.result() for f in pending]

@@ -86,6 +86,15 @@ def lib():
     L.sar_oracle_convert.restype = None
     L.sar_oracle_start_points.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, dp]
     L.sar_oracle_start_points.restype = None
+    u64p = C.POINTER(C.c_uint64)
+    L.sar_oracle_splitmix64.argtypes = [C.c_uint64, C.c_uint32, u64p]
+    L.sar_oracle_splitmix64.restype = None
+    L.sar_oracle_xoshiro256pp.argtypes = [u64p, C.c_uint32, u64p]
+    L.sar_oracle_xoshiro256pp.restype = None
+    L.sar_oracle_xoshiro256_jump.argtypes = [u64p]
+    L.sar_oracle_xoshiro256_jump.restype = None
+    L.sar_oracle_unit_f64.argtypes = [C.c_uint64]
+    L.sar_oracle_unit_f64.restype = C.c_double
     L.sar_oracle_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
     L.sar_oracle_fnv1a64.restype = C.c_uint64
     L.sar_oracle_render_parallel.argtypes = [
@@ -220,6 +229,31 @@ def start_points(seed: int, first_job: int, n_jobs: int) -> np.ndarray:
     return out
 
 
+# the start-point stream's pieces (tests/test_oracle_kat.py holds them to their published vectors)
+def splitmix64(seed: int, n: int) -> list:
+    out = (C.c_uint64 * n)()
+    lib().sar_oracle_splitmix64(seed, n, out)
+    return list(out)
+
+
+def xoshiro256pp(state, n: int):
+    """n outputs from `state` (four u64); returns (outputs, state afterwards)."""
+    st = (C.c_uint64 * 4)(*state)
+    out = (C.c_uint64 * n)()
+    lib().sar_oracle_xoshiro256pp(st, n, out)
+    return list(out), list(st)
+
+
+def xoshiro256_jump(state) -> list:
+    st = (C.c_uint64 * 4)(*state)
+    lib().sar_oracle_xoshiro256_jump(st)
+    return list(st)
+
+
+def unit_f64(raw: int) -> float:
+    return lib().sar_oracle_unit_f64(raw)
+
+
 def render(cfg: SarConfig, rt: Runtime, p0, iterations: int):
     p = np.ascontiguousarray(p0, dtype=np.float64)
     lib().sar_oracle_render(C.byref(cfg), rt.ptr, _dptr(p), iterations)
@@ -303,7 +337,7 @@ def render_parallel(cfg: SarConfig, threads: int, jobs_per_thread: int, seed: in
 
 
 __all__ = [
-    "lib", "build_oracle", "poisson_saturne", "solar_sail", "copy_config", "Runtime", "start_points",
+    "lib", "build_oracle", "poisson_saturne", "solar_sail", "copy_config", "Runtime", "start_points", "splitmix64", "xoshiro256pp", "xoshiro256_jump", "unit_f64",
     "render", "render_jobs", "render_jobs_mt", "host_threads", "iterate", "rotation_matrix", "colorize", "merge", "fnv1a64",
     "render_parallel", "SAR_RENDER_GAS", "SAR_RENDER_DEPTH",
 ]

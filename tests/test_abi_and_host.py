@@ -76,8 +76,11 @@ def test_setup_math_matches_oracle_bit_for_bit(sar, oracle):
         a = mk_s().rotation_matrix()
         b = oracle.rotation_matrix(mk_o())
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
-    for seed, first, n in ((0, 0, 7), (1, 5, 2), (2**63 + 12345, 1000, 33)):
-        assert np.array_equal(sar.start_points(seed, first, n), oracle.start_points(seed, first, n))
+    # the start-point stream: blocks of 4096 jobs, block b = the generator jumped b times (also across block boundaries,
+    # from inside a block, and far into the stream)
+    for seed, first, n in ((0, 0, 7), (1, 5, 2), (2**63 + 12345, 1000, 33), (7, 0, 3 * 4096 + 5), (7, 4090, 12), (7, 4096, 1),
+                           (7, 8191, 4100), (2**64 - 1, 1_048_576 - 3, 10), (3, 5 * 131072, 4096)):
+        assert np.array_equal(sar.start_points(seed, first, n), oracle.start_points(seed, first, n)), (seed, first, n)
 
 
 def test_validation_and_error_reporting(sar):

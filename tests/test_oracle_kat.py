@@ -79,6 +79,87 @@ def test_start_point_stream(oracle):
     assert a.min() >= 0.0 and a.max() < 0.1
 
 
+# ---- the start-point stream against the PUBLISHED vectors of its algorithms (the only part of the third-party
+# arithmetic on this path that can be pinned; rand 0.9 documents SplitMix64 -> xoshiro256++ for SmallRng::seed_from_u64) ----
+def test_splitmix64_published_vector(oracle):
+    # Vigna's splitmix64.c from state 1234567: the first five outputs as listed by Rosetta Code's "Pseudo-random
+    # numbers/Splitmix64" task (seed 1234567), which reproduces the reference C implementation
+    assert oracle.splitmix64(1234567, 5) == [6457827717110365317, 3203168211198807973, 9817491932198370423,
+                                             4593380528125082431, 16408922859458223821]
+
+
+def test_xoshiro256pp_published_vector(oracle):
+    # xoshiro256plusplus.c (Blackman & Vigna) from s = {1, 2, 3, 4}: the vector rand_xoshiro's own test `reference` holds for
+    # Xoshiro256PlusPlus ("These values were produced with the reference implementation")
+    out, _ = oracle.xoshiro256pp([1, 2, 3, 4], 10)
+    assert out == [41943041, 58720359, 3588806011781223, 3591011842654386, 9228616714210784205, 9973669472204895162,
+                   14011001112246962877, 12406186145184390807, 15849039046786891736, 10450023813501588000]
+
+
+def test_unit_f64_conversion_on_the_extremes(oracle):
+    # rand's StandardUniform for f64: the top 53 bits times 2^-53 — in [0, 1), never 1.0
+    assert oracle.unit_f64(0) == 0.0
+    assert oracle.unit_f64((1 << 11) - 1) == 0.0                     # the low 11 bits are dropped
+    assert oracle.unit_f64(1 << 11) == 2.0 ** -53
+    assert oracle.unit_f64((1 << 64) - 1) == 1.0 - 2.0 ** -53        # the largest value: one ulp below 1
+    assert oracle.unit_f64(1 << 63) == 0.5
+    st = oracle.start_points(12345, 0, 4096)
+    assert st.min() >= 0.0 and st.max() < 0.1
+
+
+def _gf2_step_matrix():
+    """256 x 256 matrix over GF(2) of one step of xoshiro256's linear engine (column j = step of unit state e_j)."""
+    M = (1 << 64) - 1
+    def rotl(x, k):
+        return ((x << k) | (x >> (64 - k))) & M
+    def step(s):
+        s = list(s)
+        t = (s[1] << 17) & M
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45)
+        return s
+    T = np.zeros((256, 256), dtype=np.int64)
+    for j in range(256):
+        e = [0, 0, 0, 0]
+        e[j >> 6] = 1 << (j & 63)
+        out = step(e)
+        for i in range(256):
+            T[i, j] = (out[i >> 6] >> (i & 63)) & 1
+    return T
+
+
+def test_jump_is_2_to_the_128_steps(oracle):
+    """The published JUMP polynomial, PROVEN: T^(2^128) by 128 squarings of the engine's GF(2) transition matrix gives the
+    same state as the oracle's jump() for random states (the host library's jump is held to the oracle's by
+    test_abi_and_host.py through sar_start_points across block boundaries)."""
+    P = _gf2_step_matrix()
+    for _ in range(128):
+        P = (P @ P) & 1
+    rng = np.random.default_rng(5)
+    for _ in range(4):
+        s = [int(x) for x in rng.integers(0, 1 << 63, size=4)] 
+        s[0] |= 1 << 63
+        bits = np.array([(s[i >> 6] >> (i & 63)) & 1 for i in range(256)], dtype=np.int64)
+        want_bits = (P @ bits) & 1
+        want = [sum(int(want_bits[64 * w + b]) << b for b in range(64)) for w in range(4)]
+        assert oracle.xoshiro256_jump(s) == want
+
+
+def test_start_points_are_the_published_generators_in_blocks_of_4096(oracle):
+    """Job k = draws 3i..3i+2 (i = k % 4096) of xoshiro256++ seeded by four SplitMix64 outputs and jumped k // 4096 times."""
+    seed = 20240928
+    state = oracle.splitmix64(seed, 4)
+    for block in range(3):
+        raw, _ = oracle.xoshiro256pp(state, 3 * 4096)
+        want = np.array([oracle.unit_f64(r) * 0.1 for r in raw]).reshape(4096, 3)
+        got = oracle.start_points(seed, 4096 * block, 4096)
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), block
+        state = oracle.xoshiro256_jump(state)
+    # any slice equals the same rows of the whole list, across block boundaries
+    whole = oracle.start_points(seed, 0, 3 * 4096)
+    for first, n in ((4090, 12), (4095, 1), (4096, 1), (8191, 2), (100, 9000)):
+        assert np.array_equal(oracle.start_points(seed, first, n), whole[first:first + n])
+
+
 def test_palette(oracle):
     import ctypes as C
     ps = oracle.poisson_saturne()
