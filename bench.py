@@ -112,8 +112,8 @@ def cpu_baseline(seconds_hint: float):
 def native_measure(S, torch, devices, config, steps, warmup):
     """The same frame through the C ABI alone: sar_renderer_new_multi over `devices` (one host thread + one stream per
     device, slices exchanged with hipMemcpyPeerAsync, colorized per slice into a pinned host image). A step is one
-    sar_render_parallel call: start points drawn on the host (the next frame's while the GPUs work), uploaded, reset,
-    render, exchange, colorize, image in host memory."""
+    sar_render_parallel call: reset, render, exchange, colorize, image in host memory — the next frame's start points are
+    drawn meanwhile on one helper thread per device, uploaded from page-locked memory and announced."""
     g = len(devices)
     if config == "c4":
         width, total_jobs, iters = C4_SIZE, C4_JOBS, C4_ITERS
@@ -125,7 +125,8 @@ def native_measure(S, torch, devices, config, steps, warmup):
     cfg = S.Config.poisson_saturne(iterations=iters, width=width, height=width, transparent=0, seed=1)
     r = S.ParallelRenderer(devices=devices, units=units, seed=1)
     img = torch.empty((width, width, 4), dtype=torch.int16).pin_memory()
-    phases = {"render_ms": 0.0, "exchange_ms": 0.0, "colorize_ms": 0.0}
+    phases = {"render_ms": 0.0, "exchange_ms": 0.0, "colorize_ms": 0.0, "host_ms_before_exchange": 0.0, "host_ms_enqueue": 0.0,
+              "draw_ahead_ms": 0.0}
     for _ in range(warmup):
         S.render_parallel_into(r, cfg, jpu, img.data_ptr())
     t0 = time.perf_counter()
@@ -140,7 +141,10 @@ def native_measure(S, torch, devices, config, steps, warmup):
     return {"value": n * total_jobs * steps / el, "unit": "iterations/s", "ms_per_step": el / steps * 1e3, "steps": steps,
             "scaling": "strong" if config == "c4" else "weak", "devices": list(devices), "jobs_total": total_jobs,
             "iterations_per_job": n, "image": f"{width}x{width}",
-            "phase_ms_per_step_slowest_device": {k: v / steps for k, v in phases.items()},
+            "phase_ms_per_step_slowest_device": {k: v / steps for k, v in phases.items() if k.endswith("_ms") and not k.startswith(("host", "draw"))},
+            "host_ms_per_step": {"between_render_and_exchange_enqueue": phases["host_ms_before_exchange"] / steps,
+                                 "until_the_frame_is_enqueued": phases["host_ms_enqueue"] / steps,
+                                 "next_frame_points_drawn_on_helper_threads": phases["draw_ahead_ms"] / steps},
             "exchange_bytes_per_device": int(t["exchange_bytes_per_device"]), "peer_access_failures": int(t["peer_access_failures"]),
             "note": "sar_render_parallel end to end, image in pinned host memory (PCIe and the host-side job list included)"}
 

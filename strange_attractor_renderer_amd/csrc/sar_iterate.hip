@@ -216,7 +216,18 @@ struct DepthPipe {
     //   stage 2  the chip-wide 64-bit key itself, read at device scope U visits after stage 1 passed: the atomic is sent
     //            only if this visit beats what ANY XCD has sent — and the private hint learns the chip-wide depth on the way.
     // k is a compile-time constant after unrolling.
+#ifdef SAR_EXPERIMENT_PROF  // wave-cycles of settle_depth: [0] stage 2 (key wait, atomic, hint store), [1] stage 1 (hint wait, compare, key load)
+    unsigned long long dprof[2] = {0, 0};
+#define SAR_DMARK(i, t0) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long n_ = __builtin_readcyclecounter(); dprof[i] += n_ - t0; t0 = n_; } while (0)
+#else
+#define SAR_DMARK(i, t0)
+#endif
     __device__ __forceinline__ void settle_depth(uint32_t k) {
+#ifdef SAR_EXPERIMENT_PROF
+        // (this build measures how long the memory takes, not how well the pipeline hides it: first everything in flight is
+        // waited for under [1]'s clock — the hint and key loads of U steps ago —, then each stage's own work is timed)
+        unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
         if (gv[k]) {
             if (g_mine[k] > g_cur[k]) {
                 atomicMax(key + g_idx[k], g_mine[k]);
@@ -233,6 +244,7 @@ struct DepthPipe {
             }
             zhint[hint_index(g_idx[k])] = (H)learnt;
         }
+        SAR_DMARK(0, t0_);
         // p_hint is the raw dword holding this pixel's hint and its neighbour's: it is unpacked only HERE, U visits
         // after the load was issued. (Unpacking next to the load makes the compiler wait for the load right there.)
         if (kWide) {
@@ -250,6 +262,7 @@ struct DepthPipe {
             g_mine[k] = ((unsigned long long)f32_sortable(zc) << 32) | (unsigned long long)(lo_base - p_t[k]);
             g_cur[k] = __hip_atomic_load(key + p_idx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        SAR_DMARK(1, t0_);
     }
 
     // Settles the candidate of visit t - U (its hint was requested U whole steps ago) and files this visit's. Returns
@@ -1030,8 +1043,11 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
                 ++phase;
             }
 #ifdef SAR_EXPERIMENT_PROF
-        if (lane == 0)
+        if (lane == 0) {
             for (int i = 0; i < 5; ++i) atomicAdd(a.nan_count + 8 + i, st.prof[i]);
+            atomicAdd(a.nan_count + 13, st.dprof[0]);
+            atomicAdd(a.nan_count + 15, st.dprof[1]);
+        }
 #endif
         st.finish(a.heads, a.n_waves, wave, a.nan_count);
     }

@@ -1446,6 +1446,13 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
                                  "place_visit %.1f%%  depth settle %.1f%%  slot+hint request %.1f%% (total %.4g)\n",
                          100. * seg[4] / ptot, 100. * seg[5] / ptot, ptot, 100. * seg[6] / ctot, 100. * seg[7] / ctot, 100. * seg[8] / ctot,
                          100. * seg[9] / ctot, 100. * seg[10] / ctot, ctot);
+        unsigned long long dp[3];
+        HIP_TRY(hipMemcpy(dp, rt->d_nan_count + 13, sizeof(dp), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(rt->d_nan_count + 13, 0, sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(rt->d_nan_count + 15, 0, sizeof(unsigned long long)));
+        if (ctot > 0)
+            std::fprintf(stderr, "[prof-depth] of the consumer's time (memory drained at each mark): stage 2 (key wait, atomic, hint store, drain) %.1f%%  "
+                                 "stage 1 (compare, key load, drain) %.1f%%\n", 100. * dp[0] / ctot, 100. * dp[2] / ctot);
 #endif
         out->depth_atomics = sent;
     }
