@@ -96,7 +96,7 @@ typedef struct sar_renderer sar_renderer;   /* opaque; ParallelRenderer, src/lib
 
 /* Per-call device timings (HIP events on the runtime's stream), filled when timing is enabled. */
 typedef struct sar_timing {
-    float    iterate_ms;    /* sum over launch chunks of the iterate kernel (k_iterate_lean) alone */
+    float    iterate_ms;    /* sum over launch chunks of the iterate kernel (k_iterate_split / k_iterate_lean) alone */
     float    resolve_ms;    /* depth-winner payload resolve + max reduction */
     float    colorize_ms;   /* last colorize */
     float    merge_ms;      /* last merge */
@@ -348,37 +348,31 @@ int sar_runtime_describe_last_launch(const sar_runtime* rt, char* out, size_t ca
 /* Tuning / test options by name (value 0 restores the default unless noted):
  *   "block_threads"      lanes per workgroup of the iterate kernel (64, 128, 192, 256)
  *   "checkpoint_stride"  iterations between trajectory checkpoints used by the payload resolve
- *   "path"               accumulate path: 0 default (= 3 when the image fits), 1 one global atomic per
- *                        visit at agent scope, 2 the same into one scratch copy per XCD, 3 LDS-binned records
+ *   "path"               accumulate path: 0 default (= 3 when the image fits, up to 64 Mpx), 1 one global atomic per
+ *                        visit, 3 LDS-binned records (an error where they do not fit)
  *   "bin_shift"          log2(pixels per bin) of the binned path (12..16; 16: the accumulate kernel packs two 16-bit counters
- *                        into an LDS word, see "acc_halves")
+ *                        with a guard bit into an LDS word)
  *   "bin_interleave"     which pixels form a bin: 1 consecutive pixels, 2 every B-th 2048-pixel segment of the image
  *                        (B bins, a power of two: every bin carries the same share of the visits whatever the attractor
  *                        covers); 0 = 2 when the power-of-two bin count costs at most a third more bins, else 1
  *   "splits"             workgroups per bin in the record-accumulate kernel (1..16)
- *   "chunk_records"      u16 records per chunk: 12, 20, 28 or 60 (32/48/64/128-byte chunks; fewer = less LDS per wave;
- *                        60: pool stager only)
- *   "stager"             how the iterate kernel copies full staging buffers out: 1 the lane that filled one copies it,
- *                        2 full buffers are swapped against spares and the whole wave copies them out in batches
- *                        (needs slightly more LDS); 0 = 2 where it keeps the waves per CU, else 1
+ *   "chunk_records"      u16 records per chunk: 12, 20, 28 or 60 (32/48/64/128-byte chunks; fewer = less LDS per wave)
  *   "split_waves"        the iterate kernel as producer / consumer wave pairs (one wave runs the map, its partner stages the
- *                        visits): 1 never, 2 wherever the kernel exists (pool stager, 64- or 128-byte chunks); 0 = 2 for
+ *                        visits): 1 never, 2 wherever the kernel exists (64- or 128-byte chunks); 0 = 2 for
  *                        launches whose jobs are all resident at once (512 per CU), 1 for larger ones
  *   "hint_bits"          per-XCD depth hints of the iterate kernel: 16 (fixed point over the depth range the warm-up saw) or
  *                        32 (the depth itself as f32); 0 = by image size
  *   "hint_shared"        1: one array of depth hints per XCD, 2: one array for the whole chip (each XCD's L2 then sees the
  *                        others' updates late — more visits pass the filter, none wrongly); 0 = per XCD unless the eight
  *                        copies exceed 200 MB (then they would not fit the Infinity Cache)
+ *   "hint_tile"          1: 16-bit hints always in row-major order; 0 = in 8 x 8 tiles (one 128-byte line each) where the
+ *                        image width is a power of two and the height a multiple of eight
  *   "chunk_ahead"        a render call of several launch chunks runs its next chunk's warm-up ahead, under the current chunk's
  *                        accumulate and fold (0 / 1, the default); 2 = not (A/B)
- *   "depth_pipe"         visits between a depth-hint (or depth-key) load and its use in the iterate kernel: 1 or 2 (default 2)
  *   "acc_threads"        threads per block of the record-accumulate kernel (256, 512, 1024)
- *   "acc_lists"          (bin, wave) record lists a lane group of that kernel walks at the same time: 1, 2, 4 or 8
- *   "acc_halves"         bins of 65536 pixels: 1 = two workgroups per bin count one half each with 32-bit counters (every
- *                        list is read twice; round 2), 0 = one workgroup, 16-bit counters with a guard bit (default)
+ *   "acc_lists"          (bin, wave) record lists a lane group of that kernel walks at the same time: 1 or 4
  *   "timing_accumulate"  1: the spans of successive render calls add up (sar_timing sums, iterate_launches counts
  *                        them) until sar_runtime_last_timing reads and clears them; 0: last render call only
- *   "measure"            measurement-only kernels: 1 count only, 2 arithmetic only (results are NOT the render)
  *   "debug_chunk_jobs"   test hook: cap on jobs per launch chunk
  *   "debug_max_ordinals" test hook: visits one launch may order (default 2^32-2); jobs with more iterations run as segments
  *

@@ -148,9 +148,9 @@ class Runtime:
             h = C.c_void_p()
             _check(_lib().sar_runtime_new(C.byref(config.c), device, C.byref(h)), "sar_runtime_new")
             self._h = h
-            # A/B and whole-suite test hook of THIS harness (the library itself reads no environment): SAR_STAGER=1|2 and
-            # SAR_SPLIT=1|2 force one stager / the whole or the split iterate kernel on every runtime created through it
-            for env, opt in (("SAR_STAGER", "stager"), ("SAR_SPLIT", "split_waves")):
+            # A/B and whole-suite test hook of THIS harness (the library itself reads no environment): SAR_SPLIT=1|2 forces
+            # the whole or the split iterate kernel on every runtime created through it
+            for env, opt in (("SAR_SPLIT", "split_waves"),):
                 if os.environ.get(env, "") in ("1", "2"):
                     _check(_lib().sar_runtime_set_option(self._h, opt.encode(), int(os.environ[env])), "sar_runtime_set_option")
         self.device = device
@@ -236,11 +236,11 @@ class Runtime:
         _check(_lib().sar_runtime_set_option(self._h, name.encode(), int(value)), f"sar_runtime_set_option({name})")
 
     def set_tuning(self, block_threads: int = 0, checkpoint_stride: int = 0, variant: int = 0, **more):
-        """Convenience over set_option. variant: bits 0-3 path, bits 4-7 measure, bits 8+ debug_chunk_jobs."""
+        """Convenience over set_option. variant: bits 0-3 path (0 automatic, 1 one atomic per visit, 3 binned), bits 8+
+        debug_chunk_jobs."""
         self.set_option("block_threads", block_threads)
         self.set_option("checkpoint_stride", checkpoint_stride)
         self.set_option("path", variant & 0xF)
-        self.set_option("measure", (variant >> 4) & 0xF)
         self.set_option("debug_chunk_jobs", variant >> 8)
         for k, v in more.items():
             self.set_option(k, v)

@@ -18,8 +18,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libsar_hip.so")
 BUILD_DIR = os.path.join(os.path.dirname(PKG), "build", "sar_hip")
-SOURCES = ["sar_host.cpp", "sar_export.cpp", "sar_runtime.cpp", "sar_multi.cpp", "sar_iterate.hip", "sar_accumulate.hip", "sar_image.hip"]
-HEADERS = ["sar_internal.hpp", "sar_launch.hpp", "sar_device.hpp", "sar_runtime_impl.hpp", os.path.join("..", "..", "include", "sar.h")]
+SOURCES = ["sar_host.cpp", "sar_export.cpp", "sar_plan.cpp", "sar_render.cpp", "sar_runtime.cpp", "sar_multi.cpp", "sar_iterate.hip", "sar_accumulate.hip",
+           "sar_image.hip"]
+HEADERS = ["sar_internal.hpp", "sar_launch.hpp", "sar_device.hpp", "sar_runtime_impl.hpp", "sar_plan.hpp", os.path.join("..", "..", "include", "sar.h")]
 ARCH = "gfx950"
 FOLD_FUSED_OPS = 6   # v_fma_f64 in k_fold_resolve: the sqrt + div expansions of color_transform, nothing else
 

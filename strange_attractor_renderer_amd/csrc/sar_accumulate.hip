@@ -14,7 +14,7 @@ namespace sar {
 // bin's LDS histogram with LDS atomics; the histogram is then written — plainly, fully — as copy s of
 // the scratch count bins, which k_fold_resolve sums into Runtime::count.
 // Bins of 65536 pixels (the most a 16-bit record addresses — 4096^2 in 256 bins) do not fit 32-bit counters into the LDS:
-//   MODE 2, PACKED (default): two 16-bit counters per LDS word, 128 KiB for the whole bin, ONE workgroup reads the lists
+//   PACKED: two 16-bit counters per LDS word, 128 KiB for the whole bin, ONE workgroup reads the lists
 //     once. A counter is 15 bits plus a guard bit: the lane whose (returning) add sets the guard bit takes 32768 out again
 //     and notes the pixel in a short event list; every event is worth 32768 hits when the histogram is written out. A
 //     carry into the neighbouring counter would need 32768 FURTHER adds on this counter between the add that sets the guard
@@ -22,15 +22,12 @@ namespace sar {
 //     enforced bound (the other fifteen waves keep issuing meanwhile): adds to one LDS address are serialised by the
 //     atomic unit at one per clock, so 32768 of them are ~16 us against a sub-microsecond window; the tests drive one pixel
 //     through 9000 guard events, and a build with -DSAR_ACC_GUARD_CHECK traps on an add that finds the guard bit set with the
-//     counter already above 0x4000 (the parity suite runs through it without one). `acc_halves` = 1 (MODE 1) is the fallback without this argument.
-//   MODE 1, HALF (round 2; `acc_halves` 1 selects it for A/B runs and tests): two workgroups per (bin, split), each reads the
-//     lists and counts the records of its half of the bin (record bit 15) in a 32768-entry histogram of 32-bit counters —
-//     every list is read twice: 4.35 ms per launch of configs[3] on one GPU against 2.82 ms (which is the rate of isolated
-//     64-byte reads, 2.7 of the 3.4 TB/s MI355X serves).
+//     counter already above 0x4000 (the parity suite runs through it without one). (Round 2 counted such a bin in two halves,
+//     two workgroups reading every list: 4.35 ms per launch of configs[3] on one GPU against 2.82 ms, which is the rate of
+//     isolated 64-byte reads, 2.7 of the 3.4 TB/s MI355X serves; that form left the tree in round 4.)
 constexpr uint32_t kAccEvents = 2040u;  // event list of the PACKED mode (u16 records), next to two counters
-template <uint32_t R, uint32_t K, uint32_t MODE>
+template <uint32_t R, uint32_t K, bool PACKED>
 __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
-    constexpr bool HALF = MODE == 1u, PACKED = MODE == 2u;
     constexpr uint32_t Q = kChunkQuads(R);       // 16-byte quads per chunk
     constexpr uint32_t G = kChunkLanes(R);       // lanes that share one list: lane q of a group reads quad q
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
@@ -38,13 +35,9 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     uint32_t* const ev_ctl = hist + 32768u;
     unsigned short* const ev = (unsigned short*)(ev_ctl + 2);
     uint32_t* const out = a.scratch_count + (size_t)blockIdx.y * a.npix;
-    // HALF: the two workgroups of a bin read the same lists — give them block numbers 8 apart, so that they run on the same
-    // XCD (workgroups go to the XCDs round-robin) at the same time and the second reader finds the chunks in that L2
-    const bool swz = HALF && (a.n_bins & 7u) == 0u;
-    const uint32_t b = !HALF ? blockIdx.x : (swz ? ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7u) : blockIdx.x >> 1);
+    const uint32_t b = blockIdx.x;
     const uint32_t s = blockIdx.y;
-    const uint32_t half_base = !HALF ? 0u : (swz ? (blockIdx.x >> 3) & 1u : blockIdx.x & 1u) << 15;
-    const uint32_t hist_px = HALF ? 32768u : 1u << a.bin_shift;
+    const uint32_t hist_px = 1u << a.bin_shift;
     const uint32_t hist_words = PACKED ? hist_px / 2u : hist_px;
     auto pixel_of = [&](uint32_t rec) {  // (bin, record) -> image position (BinMap)
         return (rec & a.map.low_mask) | (b << a.map.seg_shift) | ((rec & ~a.map.low_mask) << a.map.hi_shift);
@@ -134,8 +127,6 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
                 auto count = [&](bool valid, uint32_t rec) {  // rec: 16 bits
                     if (PACKED) {
                         if (valid) packed_add(rec);
-                    } else if (HALF) {
-                        if (valid && (rec & 0x8000u) == half_base) atomicAdd(&hist[rec & 0x7FFFu], 1u);
                     } else if (valid) {
                         atomicAdd(&hist[rec], 1u);
                     }
@@ -163,8 +154,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     if (direct) __threadfence();
     for (uint32_t k = threadIdx.x; k < hist_px; k += blockDim.x) {
         uint32_t v = PACKED ? (hist[k >> 1] >> ((k & 1u) << 4)) & 0xFFFFu : hist[k];
-        const uint32_t rec = k | half_base;
-        const uint32_t px = pixel_of(rec);
+        const uint32_t px = pixel_of(k);
         if (direct && px < a.npix) v += __hip_atomic_load(&out[px], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool live = v != 0u && px < a.npix;
         if (live) out[px] = v;
@@ -306,50 +296,35 @@ __global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) {
     }
 }
 
-int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, uint32_t lists, bool halves, hipStream_t s) {
-    const bool half = a.bin_shift == 16u && halves, packed = a.bin_shift == 16u && !halves;
-    const size_t lds = packed ? (size_t)(32768u + 2u) * 4u + kAccEvents * 2u : (size_t)4u << (half ? 15u : a.bin_shift);
+// lists: (bin, wave) lists a lane group walks at the same time — 4 with the 128 KiB histograms (one workgroup per CU: four
+// loads in flight per lane make up for the missing second workgroup), 1 otherwise
+#define SAR_FOR_EACH_ACC(X) X(12u, 1u) X(12u, 4u) X(20u, 1u) X(20u, 4u) X(28u, 1u) X(28u, 4u) X(60u, 1u) X(60u, 4u)
+int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, uint32_t lists, hipStream_t s) {
+    const bool packed = a.bin_shift == 16u;
+    const size_t lds = packed ? (size_t)(32768u + 2u) * 4u + kAccEvents * 2u : (size_t)4u << a.bin_shift;
     // a list takes a group of 2, 4 or 8 lanes: 1024 threads walk 128..512 lists per block, `lists` per group at a time
     if (threads == 0) threads = 1024u;
-    const dim3 grid(half ? 2u * a.n_bins : a.n_bins, a.splits);
-#define SAR_ACC(RR, KK)                                                                                     \
-    if (half) hipLaunchKernelGGL((k_bin_accumulate<RR, KK, 1u>), grid, dim3(threads), lds, s, a);           \
-    else if (packed) hipLaunchKernelGGL((k_bin_accumulate<RR, KK, 2u>), grid, dim3(threads), lds, s, a);    \
-    else hipLaunchKernelGGL((k_bin_accumulate<RR, KK, 0u>), grid, dim3(threads), lds, s, a)
-#define SAR_ACC_R(RR)                     \
-    switch (lists) {                      \
-        case 1: { SAR_ACC(RR, 1u); } break; \
-        case 2: { SAR_ACC(RR, 2u); } break; \
-        case 4: { SAR_ACC(RR, 4u); } break; \
-        case 8: { SAR_ACC(RR, 8u); } break; \
-        default: return 1;                \
+    const dim3 grid(a.n_bins, a.splits);
+    bool launched = false;
+#define SAR_ACC(RR, KK)                                                                                         \
+    if (!launched && records == RR && lists == KK) {                                                             \
+        if (packed) hipLaunchKernelGGL((k_bin_accumulate<RR, KK, true>), grid, dim3(threads), lds, s, a);        \
+        else hipLaunchKernelGGL((k_bin_accumulate<RR, KK, false>), grid, dim3(threads), lds, s, a);              \
+        launched = true;                                                                                        \
     }
-    switch (records) {
-        case 12: SAR_ACC_R(12u); break;
-        case 20: SAR_ACC_R(20u); break;
-        case 28: SAR_ACC_R(28u); break;
-        case 60: SAR_ACC_R(60u); break;
-        default: return 1;
-    }
-#undef SAR_ACC_R
+    SAR_FOR_EACH_ACC(SAR_ACC)
 #undef SAR_ACC
-    return 0;
+    return launched ? 0 : 1;
 }
 
 int accumulate_kernel_attributes() {
     // a bin's histogram needs more dynamic LDS than the 64 KiB default window when the bin has 32768 pixels
     hipError_t e = hipSuccess;
-#define SAR_ATTR1(RR, KK) \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK, 0u>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK, 2u>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)
-#define SAR_ATTR(RR) SAR_ATTR1(RR, 1u); SAR_ATTR1(RR, 2u); SAR_ATTR1(RR, 4u); SAR_ATTR1(RR, 8u)
-    SAR_ATTR(12u);
-    SAR_ATTR(20u);
-    SAR_ATTR(28u);
-    SAR_ATTR(60u);
+#define SAR_ATTR(RR, KK) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    SAR_FOR_EACH_ACC(SAR_ATTR)
 #undef SAR_ATTR
-#undef SAR_ATTR1
     return (int)e;
 }
 

@@ -1,36 +1,16 @@
-// sar_iterate.hip — gfx950 (MI355X) kernels that run the map: k_warmup, k_iterate_lean (the hot loop), k_iterate (one
-// global atomic per visit: fallback and A/B reference), k_extent, k_starts_soa. DESIGN.md section 3 has the measurements
+// sar_iterate.hip — gfx950 (MI355X) kernels that run the map: k_warmup, k_iterate_split / k_iterate_lean (the hot loop as
+// wave pairs / whole), k_iterate (one global atomic per visit: the fallback beyond 64 Mpx), k_extent, k_starts_soa. DESIGN.md section 3 has the measurements
 // behind every choice; sar_device.hpp states the bit-exactness contract.
 #include "sar_device.hpp"
 #include "sar_launch.hpp"
 
-#include <type_traits>
-
 namespace sar {
 
 // ---------------------------------------------------------------------------------------------------
-// k_iterate — the hot loop (render, src/lib.rs:747-838)
+// k_iterate — render's loop (src/lib.rs:747-838) with ONE global atomic per visit: the fallback for images beyond
+// 64 Mpx (more bins than the LDS staging holds) and for single jobs whose record arena would not fit. The chip retires
+// ~2.1e10 scattered atomics per second: 45 ms per 1e9 visits, an order of magnitude behind the binned path.
 // ---------------------------------------------------------------------------------------------------
-template <bool XCD_LOCAL>
-__device__ __forceinline__ void bin_count(uint32_t* addr, uint32_t v) {
-    if (XCD_LOCAL) {
-        // this scratch copy is only ever touched by CUs of ONE XCD (copy index = hardware XCC id),
-        // so the XCD's own L2 is a sufficient coherence point: workgroup scope keeps the atomic in L2.
-        __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-        __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-template <bool XCD_LOCAL>
-__device__ __forceinline__ void bin_key(unsigned long long* addr, unsigned long long v) {
-    if (XCD_LOCAL) {
-        __hip_atomic_fetch_max(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-        __hip_atomic_fetch_max(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-template <bool XCD_LOCAL, int MODE>
 __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
     const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
     if (job >= a.n_jobs) return;
@@ -60,9 +40,6 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
     if (!a.resume)
         for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);
 
-    uint32_t* const count = a.scratch_count + (XCD_LOCAL ? (size_t)xcc_id() * a.npix : 0);
-    unsigned long long* const key = a.scratch_key + (XCD_LOCAL ? (size_t)xcc_id() * a.npix : 0);
-
     const uint32_t n = (uint32_t)a.iters;
     // visit ordinal = job*n + t (job-major, iteration-minor == the sequential order of the reference);
     // the key's low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie.
@@ -88,7 +65,7 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
                 // passes the bounds test (:789, all comparisons false), casts to pixel (0,0)
                 // (:800-802) and never wins the depth test. Add them in one go instead of hammering
                 // one address n-t times.
-                if (MODE != 0) bin_count<XCD_LOCAL>(count, n - t);
+                __hip_atomic_fetch_add(a.scratch_count, n - t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ended = true;
                 break;
             }
@@ -104,16 +81,14 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
             const uint32_t i = (fi == fi) ? (uint32_t)fi : 0u;  // Rust `as u32`: NaN -> 0
             const uint32_t j = (fj == fj) ? (uint32_t)fj : 0u;
             const uint32_t idx = j * a.width + i;
-            if (MODE != 0) bin_count<XCD_LOCAL>(count + idx, 1u);  // :807-812
-            if (MODE == 2) {
-                float zf = (float)z2;  // `z2 as f32`
-                // strict `>` against an initial -1.0 (:693, :821): z <= -1 and NaN can never win
-                if (zf > -1.0f) {
-                    zf = zf + 0.0f;  // -0.0 -> +0.0 so the integer order agrees with the float order
-                    const unsigned long long k =
-                        ((unsigned long long)f32_sortable(zf) << 32) | (unsigned long long)(lo_base - t);
-                    bin_key<XCD_LOCAL>(key + idx, k);
-                }
+            __hip_atomic_fetch_add(a.scratch_count + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // :807-812
+            float zf = (float)z2;  // `z2 as f32`
+            // strict `>` against an initial -1.0 (:693, :821): z <= -1 and NaN can never win
+            if (zf > -1.0f) {
+                zf = zf + 0.0f;  // -0.0 -> +0.0 so the integer order agrees with the float order
+                const unsigned long long k =
+                    ((unsigned long long)f32_sortable(zf) << 32) | (unsigned long long)(lo_base - t);
+                __hip_atomic_fetch_max(a.scratch_key + idx, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -121,9 +96,6 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
         a.state_out[job] = x;
         a.state_out[a.n_jobs + job] = y;
         a.state_out[2u * a.n_jobs + job] = z;
-    }
-    if (MODE == 0) {  // measurement-only variant: keep the arithmetic alive
-        if (x + y + z == 12345.678) a.scratch_count[0] = 1;
     }
 }
 
@@ -134,34 +106,31 @@ __global__ void __launch_bounds__(256) k_iterate(const IterArgs a) {
 // scope or width, while the fp64 arithmetic of this loop alone runs at ~3.3e11 iterations/s. So a
 // visit must not cost a global atomic. Here every visit becomes a 2-byte RECORD instead:
 //
-//   * the image is cut into B bins of 2^bin_shift consecutive pixels; a record is the pixel's offset
-//     inside its bin (u16);
-//   * each WAVE owns B staging buffers of R records in LDS (2R + 8 bytes per bin: records, counter, link);
-//     a visit takes a slot with one LDS atomic (ds_add_rtn) and writes its u16 there one iteration later;
-//   * the lane that takes the last slot copies the R records + {link to the previous chunk of this
-//     (wave, bin), count} as ONE chunk to the wave's private arena in HBM — position from a
-//     wave-local cursor, so no global atomic and nothing to wait for — and resets the buffer;
+//   * the image is cut into B bins (BinMap: 2^bin_shift pixels each, dealt round-robin in 2048-pixel segments); a record
+//     is the pixel's position inside its bin (u16);
+//   * each WAVE owns B staging buffers of R records in LDS; a visit takes a slot with one LDS atomic (ds_add_rtn) and writes
+//     its u16 there one iteration later;
+//   * a full buffer leaves the LDS as ONE chunk {link to the previous chunk of this (wave, bin), count, records} into the
+//     wave's private arena in HBM — position from a wave-local cursor, so no global atomic and nothing to wait for;
 //   * k_bin_accumulate later walks the per-(bin, wave) chunk lists and histograms them in LDS.
 //
 // Depth: see DepthPipe::settle_depth — two filters (this XCD's hint, then the chip-wide key) in front of the
 // 64-bit atomic max, as a software pipeline U visits deep. A stale or lost hint only costs an extra atomic,
 // never a wrong result.
 //
-// Control flow: the per-visit operations are issued unconditionally with a select on the ADDRESS instead
-// of a branch (every `if` around an LDS or memory operation costs s_and_saveexec / s_cbranch_execz / s_or):
-//   * a lane without a visit requests its slot from a private dummy counter and writes its record to
-//     a private scratch slot (cnt[B + lane], rec[B*R + lane]);
-//   * the hint of a lane without a depth candidate is loaded from element 0;
-//   * only the rare-per-lane events keep a wave-level branch: "some lane filled a buffer" (copy-out,
-//     which also places the records that overflowed into the next buffer generation), "some lane passed
-//     a depth filter". A trajectory that ended in NaN is looked for once per checkpoint, not per iteration: until then
-//     its iterations land on pixel (0,0) through the ordinary record path, exactly where the reference counts them.
+// Control flow: lanes without a visit are masked off for the slot request and the record write (two scalar instructions each:
+// vector issue is the scarcer resource), the hint of a lane without a depth candidate is loaded from element 0 (a load under
+// the candidates' exec mask costs 8 % at 4096^2), and only the rare-per-lane events keep a wave-level branch: "some lane
+// filled a buffer", "some lane passed a depth filter". A trajectory that ended in NaN is looked for once per checkpoint,
+// not per iteration: until then its iterations land on pixel (0,0) through the ordinary record path, exactly where the
+// reference counts them.
 //
-// A stager (Stager or PoolStager below) is everything a wave needs to turn a stream of visits into staged records +
-// depth candidates. One visit per lane per step(); all per-visit state lives in registers, the staging buffers in the
-// wave's LDS slice (Stager: B buffers of R records + B counters + B links + 64 scratch records + 64 dummy counters).
+// PoolStager below is everything a wave needs to turn a stream of visits into staged records + depth candidates: one visit
+// per lane per step(); all per-visit state lives in registers, the staging buffers in the wave's LDS slice. (Rounds 1-2
+// also had a stager whose filling lane copied its buffer out by itself — ~30 instructions that 90 % of a wave's iterations
+// ran with 2-3 lanes active; it left the tree in round 4, see profiles/dead_ends.md.)
 
-// The depth path shared by both stagers: two filters (this XCD's hint, then the chip-wide key) in front of the 64-bit
+// The depth path: two filters (this XCD's hint, then the chip-wide key) in front of the 64-bit
 // atomic max, as a software pipeline U visits deep — visit t uses slot t % U, whose previous occupant (visit t - U) is
 // settled first. A hint or key load therefore has U whole iterations to arrive, and because the loop is unrolled U times
 // every slot is a fixed set of registers: no copies that would have to wait for a load. A stale or lost hint only costs
@@ -314,205 +283,11 @@ struct DepthPipe {
     }
 };
 
-template <bool DEPTH, uint32_t R, uint32_t U, typename H>
-struct Stager : DepthPipe<DEPTH, U, H> {
-    using DepthPipe<DEPTH, U, H>::depth_init;
-    using DepthPipe<DEPTH, U, H>::depth_candidate;
-    using DepthPipe<DEPTH, U, H>::depth_request;
-    using DepthPipe<DEPTH, U, H>::depth_drain;
-    static constexpr uint32_t Q = kChunkQuads(R);  // 16-byte quads per chunk
-    unsigned short* rec;  // [B][R] staged records + 64 scratch slots
-    uint32_t* cnt;        // [B] fill counters + 64 dummy counters
-    uint32_t* prv;        // [B] previous chunk of this (wave, bin) list
-    uint32_t trash, dummy, lane, n_bins;
-    uint4* arena;         // this wave's chunk arena
-    uint32_t cursor;      // wave-uniform: next free chunk
-    BinMap map;
-    uint32_t bin_bits_v;  // map.bin_bits, held in a vector register
-    bool b_have;          // previous visit, waiting for its LDS slot
-    uint32_t b_bin, b_slot, b_local;
-#ifdef SAR_EXPERIMENT_PROF
-    // timing experiment: wave-cycles per segment of the loop body (s_memtime; every mark drains lgkmcnt, so the LDS
-    // round trips that normally overlap the next segment are charged to the segment that issued them)
-    unsigned long long prof[4] = {0, 0, 0, 0}, prof_last = 0;
-    __device__ __forceinline__ void mark(int i) {
-        asm volatile("" ::: "memory");
-        const unsigned long long now = __builtin_readcyclecounter();
-        asm volatile("" ::: "memory");
-        prof[i] += now - prof_last;
-        prof_last = now;
-    }
-#define SAR_MARK(i) this->mark(i)
-#else
-#define SAR_MARK(i)
-#endif
-    bool f_on;            // a filled buffer whose 2R bytes sit in registers, waiting to be stored
-    uint32_t f_chunk, f_prev;
-    uint2 fpend[R / 4u];
-
-    __device__ __forceinline__ void init(char* wbase, uint32_t bins, uint32_t lane_, uint4* arena_, H* zhint_,
-                                         unsigned long long* key_, const BinMap& map_, uint32_t lo_base_, const uint32_t* hint_range_, const HintTile& tile_) {
-        n_bins = bins;
-        lane = lane_;
-        rec = (unsigned short*)wbase;
-        cnt = (uint32_t*)(wbase + bins * 2u * R + 128u);
-        prv = cnt + bins + 64u;
-        for (uint32_t b = lane; b < bins + 64u; b += 64u) cnt[b] = 0u;
-        for (uint32_t b = lane; b < bins; b += 64u) prv[b] = kNoChunk;
-        trash = bins * R + lane;
-        dummy = bins + lane;
-        arena = arena_;
-        cursor = 0;
-        depth_init(zhint_, key_, lo_base_, hint_range_, tile_);
-        map = map_;
-        bin_bits_v = map_.bin_bits;
-        asm volatile("" : "+v"(bin_bits_v));  // stays in a VGPR: v_bfe_u32 takes one scalar operand, the field offset
-        b_have = f_on = false;
-        b_bin = b_slot = b_local = 0;
-        f_chunk = f_prev = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < R / 4u; ++k) fpend[k] = make_uint2(0u, 0u);
-    }
-
-    // one chunk: {previous chunk of this (wave, bin), record count, records}
-    __device__ __forceinline__ void store_chunk(uint32_t chunk, uint32_t prev, uint32_t count, const uint2 (&f)[R / 4u]) {
-        uint32_t w[4u * Q];
-        w[0] = prev;
-        w[1] = count;
-#pragma unroll
-        for (uint32_t k = 0; k < R / 4u; ++k) {
-            w[2u + 2u * k] = f[k].x;
-            w[3u + 2u * k] = f[k].y;
-        }
-        u32x4* dst = (u32x4*)(arena + (size_t)chunk * kChunkStride(R));
-#pragma unroll
-        for (uint32_t q = 0; q < Q; ++q)  // streamed once, read once: keep them out of the L2 the hints live in
-            __builtin_nontemporal_store((u32x4){w[4u * q], w[4u * q + 1u], w[4u * q + 2u], w[4u * q + 3u]}, dst + q);
-    }
-    // immediate copy-out (rare path)
-    __device__ __forceinline__ void flush_full(uint32_t bin, uint32_t chunk) {
-        const uint2* r = (const uint2*)(rec + mul24(bin, R));  // 2R bytes, 8-byte aligned
-        uint2 f[R / 4u];
-#pragma unroll
-        for (uint32_t k = 0; k < R / 4u; ++k) f[k] = r[k];
-        store_chunk(chunk, prv[bin], R, f);
-        prv[bin] = chunk;
-        __hip_atomic_fetch_sub(&cnt[bin], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    // The common copy-out is split: the lane that filled a buffer ISSUES the LDS reads (and frees the buffer:
-    // LDS executes a wave's operations in order, so later writes cannot overtake them); the global stores go
-    // out later in the step, when the reads have long returned.
-    __device__ __forceinline__ void flush_store_pending() {
-        if (f_on) store_chunk(f_chunk, f_prev, R, fpend);
-        f_on = false;
-    }
-
-    // Places the pending record. slot = R*gen + pos: slots are handed out consecutively per bin, so the
-    // quotient says which refill generation of the R-record buffer a record belongs to. The generation-0
-    // write is unconditional (scratch slot for lanes without one); everything else only exists when some lane
-    // filled a buffer in the same slot request.
-    __device__ __forceinline__ void place_visit() {
-        // slot < R + 64 (a counter is below R whenever a slot request finds it), so slot / R is exact through a
-        // 24-bit multiply: full-rate v_mul_u32_u24 / v_mad_u32_u24 instead of the quarter-rate 32-bit multiplies
-        constexpr uint32_t kInvR = (65536u + R - 1u) / R;
-        const uint32_t gen = mul24(b_slot, kInvR) >> 16;
-        const uint32_t pos = b_slot - mul24(gen, R);
-        const uint32_t base = mul24(b_bin, R);
-        const uint32_t at = base + pos;
-        const bool w0 = b_have && gen == 0u;
-        rec[w0 ? at : trash] = (unsigned short)b_local;
-        const bool fl = w0 && pos == R - 1u;
-        const unsigned long long fb = wave_ballot(fl);
-        if (fb) {
-            if (fl) {
-                const uint2* r = (const uint2*)(rec + base);
-#pragma unroll
-                for (uint32_t k = 0; k < R / 4u; ++k) fpend[k] = r[k];
-                f_chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
-                f_prev = prv[b_bin];
-                f_on = true;
-                prv[b_bin] = f_chunk;
-                __hip_atomic_fetch_sub(&cnt[b_bin], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            cursor += (uint32_t)__popcll(fb);
-            // records that overflowed into the next generation of a buffer that was just emptied
-            const bool e1 = b_have && gen == 1u && pos < R - 1u;
-            rec[e1 ? at : trash] = (unsigned short)b_local;
-            bool pend = b_have && gen >= 1u && !e1;  // a later generation's last slot, or generation >= 2: rare
-            for (uint32_t g = 1; wave_ballot(pend); ++g) {
-                const bool mine = pend && gen == g;
-                if (mine) rec[at] = (unsigned short)b_local;
-                const bool fl2 = mine && pos == R - 1u;
-                const unsigned long long fb2 = wave_ballot(fl2);
-                if (fb2) {
-                    if (fl2) flush_full(b_bin, cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb2 >> 32),
-                                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)fb2, 0u)));
-                    cursor += (uint32_t)__popcll(fb2);
-                }
-                const bool early = pend && gen == g + 1u && pos < R - 1u;
-                if (early) rec[at] = (unsigned short)b_local;
-                pend = pend && !(mine || early);
-            }
-        }
-    }
-
-    // One visit of this lane: inb = the iteration landed inside the image at pixel idx with depth zf
-    // (reference src/lib.rs:807-834); t = iteration number (for the visit ordinal); k = t % U, a compile-time
-    // constant after unrolling.
-    __device__ __forceinline__ void step(uint32_t k, bool inb, uint32_t idx, float zf, uint32_t t) {
-        // the staging phase is a chain of short dependent steps with memory round trips at its end: let it win the
-        // SIMD's issue arbitration against the other waves' long arithmetic phase, so that its loads start early
-        __builtin_amdgcn_s_setprio(3);
-        // the previous visit's record first: pure LDS work
-        place_visit();
-        SAR_MARK(1);
-        const bool cand = depth_candidate(k, inb, idx, zf, t);
-        SAR_MARK(2);
-        // chunk stores of a buffer that filled up (their LDS reads were issued by place_visit above), then this
-        // visit's slot request
-        flush_store_pending();
-        b_have = inb;
-        b_bin = __builtin_amdgcn_ubfe(idx, map.seg_shift, bin_bits_v);
-        b_local = bfi(map.low_mask, idx, idx >> map.hi_shift);
-        b_slot = atomicAdd(&cnt[inb ? b_bin : dummy], 1u);  // ds_add_rtn_u32
-        depth_request(k, cand, idx);
-        __builtin_amdgcn_s_setprio(0);
-        SAR_MARK(3);
-    }
-
-    // After the last visit: settle what is in flight, flush the partly filled buffers, publish the list heads.
-    __device__ __forceinline__ void finish(uint32_t* heads, uint32_t n_waves, uint32_t wave, unsigned long long* stats) {
-        place_visit();
-        flush_store_pending();
-        depth_drain(lane, stats);
-        for (uint32_t b0 = 0; b0 < n_bins; b0 += 64u) {
-            const uint32_t b = b0 + lane;
-            const uint32_t have = (b < n_bins) ? cnt[b] : 0u;
-            const bool flusher = have != 0u;
-            const unsigned long long fb = wave_ballot(flusher);
-            uint32_t head = (b < n_bins) ? prv[b] : kNoChunk;
-            if (flusher) {
-                const uint32_t chunk = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32),
-                                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
-                const uint2* r = (const uint2*)(rec + b * R);
-                uint2 f[R / 4u];
-#pragma unroll
-                for (uint32_t k = 0; k < R / 4u; ++k) f[k] = r[k];
-                store_chunk(chunk, head, have, f);
-                head = chunk;
-            }
-            cursor += (uint32_t)__popcll(fb);
-            if (b < n_bins) heads[(size_t)b * n_waves + wave] = head;
-        }
-    }
-};
-
 // ---------------------------------------------------------------------------------------------------
-// PoolStager — the same staging with the copy-out taken off the per-iteration path
+// PoolStager — the staging, with the copy-out taken off the per-iteration path
 // ---------------------------------------------------------------------------------------------------
-// In Stager the lane that fills a buffer copies it out by itself: 2R bytes of LDS reads, four 16-byte stores, list
-// bookkeeping — ~30 instructions that 90 % of a wave's iterations execute with 2-3 of 64 lanes active (a wave fills
-// 64 / R buffers per iteration). Here a full buffer is only SWAPPED against a spare one:
+// A wave fills 64 / R buffers per iteration, so whatever a filling lane does runs in most iterations with 2-3 of 64 lanes
+// active. Here a full buffer is only SWAPPED against a spare one:
 //   * the staged chunk already has its final form in LDS: {previous chunk of this (wave, bin), n, R x u16};
 //   * ctl[bin] = (LDS address of the bin's current buffer << 7) | fill: one ds_add_rtn hands out the slot AND names the
 //     buffer, so swapping a buffer is one more atomic add on that word;
@@ -524,7 +299,7 @@ struct Stager : DepthPipe<DEPTH, U, H> {
 //     of pending chunk l / 4 — one 16-byte LDS read and one 16-byte store per lane for 16 chunks, to consecutive
 //     addresses of the wave's arena (1 KiB runs) — and the buffers are free again where they stand in the ring.
 // Records that overflow a buffer within one slot request (several lanes, same bin, across the R boundary) are placed
-// in the new buffer by a generation loop, as in Stager (rare).
+// in the new buffer by a generation loop (rare).
 template <bool DEPTH, uint32_t R, uint32_t U, typename H>
 struct PoolStager : DepthPipe<DEPTH, U, H> {
     using DepthPipe<DEPTH, U, H>::depth_init;
@@ -547,7 +322,8 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
     bool b_have;          // previous visit, waiting for its LDS slot
     uint32_t b_bin, b_old, b_local;
 #ifdef SAR_EXPERIMENT_PROF
-    // timing experiment (k_iterate_split's consumer wave): wave-cycles per segment, see Stager::mark
+    // timing experiment: wave-cycles per segment of the loop body (s_memtime; every mark drains lgkmcnt, so the LDS round
+    // trips that normally overlap the next segment are charged to the segment that issued them)
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0;
     __device__ __forceinline__ void mark(int i) {
         asm volatile("" ::: "memory");
@@ -556,6 +332,9 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         prof[i] += now - prof_last;
         prof_last = now;
     }
+#define SAR_MARK(i) this->mark(i)
+#else
+#define SAR_MARK(i)
 #endif
 
     static __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
@@ -662,7 +441,9 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
     }
 
     __device__ __forceinline__ void step(uint32_t k, bool inb, uint32_t idx, float zf, uint32_t t) {
-        __builtin_amdgcn_s_setprio(3);  // as in Stager::step
+        // the staging phase is a chain of short dependent steps with memory round trips at its end: let it win the SIMD's
+        // issue arbitration against the other waves' long arithmetic phase, so that its loads start early
+        __builtin_amdgcn_s_setprio(3);
         place_visit();
         SAR_MARK(2);
         const bool cand = depth_candidate(k, inb, idx, zf, t);
@@ -773,7 +554,7 @@ __global__ void __launch_bounds__(256) k_warmup(const MapParams pin, const doubl
     }
 }
 
-template <bool DEPTH, uint32_t R, uint32_t U, typename H, bool POOL>
+template <bool DEPTH, uint32_t R, uint32_t U, typename H>
 __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -794,19 +575,17 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     const uint32_t job = alive ? a.joblist[slot] : 0u;
     const uint32_t n = (uint32_t)a.it.iters;
 
-    typename std::conditional<POOL, PoolStager<DEPTH, R, U, H>, Stager<DEPTH, R, U, H>>::type st;
+    PoolStager<DEPTH, R, U, H> st;
     // visit ordinal = job*n + t (job-major, iteration-minor == the sequential order of the reference); the key's
     // low word is 0xFFFFFFFF - ordinal so that the EARLIEST visit wins a depth tie
-    st.init((char*)smem + (threadIdx.x >> 6) * (POOL ? kPoolWaveLds(a.n_bins, R) : kLeanWaveLds(a.n_bins, R)), a.n_bins, lane,
+    st.init((char*)smem + (threadIdx.x >> 6) * kPoolWaveLds(a.n_bins, R), a.n_bins, lane,
             (uint4*)a.arena + (size_t)wave * a.chunks_per_wave * kChunkStride(R),
             (H*)a.zhint + (size_t)(xcc_id() & a.hint_copy_mask) * kHintStride(a.it.npix), a.it.scratch_key, a.map, 0xFFFFFFFFu - job * n, a.hint_range, a.tile);
 
     MapParams p = a.it.p;
     pin_map_params(p);
-    if (POOL) {  // fewer VGPRs than Stager: room to keep the y coefficients out of the (spilling) scalar file as well
 #pragma unroll
-        for (int k = 0; k < 10; ++k) p.cy[k] = vgpr_pin(p.cy[k]);
-    }
+    for (int k = 0; k < 10; ++k) p.cy[k] = vgpr_pin(p.cy[k]);  // room enough: the y coefficients stay out of the (spilling) scalar file as well
     double x = 0., y = 0., z = 0.;
     if (alive) {  // the point after the warm-up (:750-752), from k_warmup
         x = a.warm[slot];
@@ -874,7 +653,7 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
     }
 #ifdef SAR_EXPERIMENT_PROF
     if (lane == 0)
-        for (int i = 0; i < 4; ++i) atomicAdd(a.nan_count + 2 + i, st.prof[(POOL && i) ? i + 1 : i]);  // PoolStager marks 0, 2, 3, 4
+        for (int i = 0; i < 4; ++i) atomicAdd(a.nan_count + 2 + i, st.prof[i ? i + 1 : i]);  // PoolStager marks 0, 2, 3, 4
 #endif
     if (a.warm_out && slot < active) {  // the next segment of a > 2^32-2-iteration job starts here (a NaN state stays NaN
         a.warm_out[slot] = x;           // and is found again by that segment's first checkpoint)
@@ -1122,100 +901,60 @@ __global__ void __launch_bounds__(256) k_starts_soa(const double* __restrict__ a
     }
 }
 
-void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode, hipStream_t s) {
-    const uint32_t grid = (a.n_jobs + block - 1) / block;
-    if (xcd_local) {
-        if (mode == 2) hipLaunchKernelGGL((k_iterate<true, 2>), dim3(grid), dim3(block), 0, s, a);
-        else if (mode == 1) hipLaunchKernelGGL((k_iterate<true, 1>), dim3(grid), dim3(block), 0, s, a);
-        else hipLaunchKernelGGL((k_iterate<true, 0>), dim3(grid), dim3(block), 0, s, a);
-    } else {
-        if (mode == 2) hipLaunchKernelGGL((k_iterate<false, 2>), dim3(grid), dim3(block), 0, s, a);
-        else if (mode == 1) hipLaunchKernelGGL((k_iterate<false, 1>), dim3(grid), dim3(block), 0, s, a);
-        else hipLaunchKernelGGL((k_iterate<false, 0>), dim3(grid), dim3(block), 0, s, a);
-    }
+void launch_iterate(const IterArgs& a, uint32_t block, hipStream_t s) {
+    hipLaunchKernelGGL(k_iterate, dim3((a.n_jobs + block - 1) / block), dim3(block), 0, s, a);
 }
 
-uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records, bool pool) { return pool ? kPoolWaveLds(bins, records) : kLeanWaveLds(bins, records); }
+uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records) { return kPoolWaveLds(bins, records); }
 uint32_t chunk_bytes(uint32_t records) { return kChunkStride(records) * 16u; }
 
+// The instantiations of the hot kernel are exactly the shapes the host's planning can pick (sar_plan.cpp): chunk size
+// (records per chunk: 12 / 20 / 28 / 60 = 32- / 48-on-64- / 64- / 128-byte chunks) x hint type, depth pipeline of two visits;
+// the wave-pair form for 64- and 128-byte chunks, with one or two iterations per barrier phase.
+#define SAR_FOR_EACH_LEAN(X)                                                                                         \
+    X(12u, unsigned short) X(20u, unsigned short) X(28u, unsigned short) X(60u, unsigned short)                       \
+    X(12u, uint32_t) X(20u, uint32_t) X(28u, uint32_t) X(60u, uint32_t)
+#define SAR_FOR_EACH_SPLIT(X)                                                                                        \
+    X(28u, unsigned short, 1u) X(28u, unsigned short, 2u) X(28u, uint32_t, 1u) X(28u, uint32_t, 2u)                   \
+    X(60u, unsigned short, 1u) X(60u, unsigned short, 2u) X(60u, uint32_t, 1u) X(60u, uint32_t, 2u)
 
-// the instantiations of the hot kernel: chunk size x depth-pipeline length x hint type (count-only kernels have neither)
-#ifdef SAR_FEW_KERNELS  // variant builds for timing experiments: only the shapes the sweeps use
-#define SAR_FOR_EACH_LEAN(X) X(true, 20u, 2u, uint32_t) X(true, 28u, 2u, uint32_t) X(true, 12u, 2u, unsigned short) X(false, 28u, 1u, unsigned short)
-#else
-#define SAR_FOR_EACH_LEAN(X)                                                                                          \
-    X(true, 12u, 1u, unsigned short) X(true, 12u, 2u, unsigned short) X(true, 20u, 1u, unsigned short)                \
-    X(true, 20u, 2u, unsigned short) X(true, 28u, 1u, unsigned short) X(true, 28u, 2u, unsigned short)                \
-    X(true, 12u, 1u, uint32_t) X(true, 12u, 2u, uint32_t) X(true, 20u, 1u, uint32_t) X(true, 20u, 2u, uint32_t)         \
-    X(true, 28u, 1u, uint32_t) X(true, 28u, 2u, uint32_t)                                                              \
-    X(false, 12u, 1u, unsigned short) X(false, 20u, 1u, unsigned short) X(false, 28u, 1u, unsigned short)
-#endif
-// 128-byte chunks: pool stager only (the classic stager would hold a chunk's 120 bytes in registers)
-#define SAR_FOR_EACH_LEAN_POOL(X)                                                                                     \
-    X(true, 60u, 1u, unsigned short) X(true, 60u, 2u, unsigned short) X(true, 60u, 1u, uint32_t) X(true, 60u, 2u, uint32_t) \
-    X(false, 60u, 1u, unsigned short)
-
-int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
-                        bool pool, bool split, hipStream_t s) {
+int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t hint_bytes, bool split, hipStream_t s) {
+    const uint32_t stage = lean_wave_lds_bytes(a.n_bins, records);
+    bool launched = false;
     if (split) {  // producer / consumer wave pairs: one workgroup of 128 threads per launched wave (a.n_waves of them)
-        if (!pool || !depth || pipe != 2u) return 1;
-        const uint32_t stage = lean_wave_lds_bytes(a.n_bins, records, true);
         const uint32_t ph = (stage + 2048u) * 8u <= 160u * 1024u ? 2u : 1u;  // visits in flight: two iterations if they fit
         const size_t lds2 = stage + ph * 1024u;
-#define SAR_SPLIT(RR, HH, PP) hipLaunchKernelGGL((k_iterate_split<true, RR, 2u, HH, PP>), dim3(a.n_waves), dim3(128), lds2, s, a)
-#define SAR_SPLIT_R(RR)                                                                                        \
-    if (hint_bytes == 4 && ph == 2) SAR_SPLIT(RR, uint32_t, 2u);                                               \
-    else if (hint_bytes == 4) SAR_SPLIT(RR, uint32_t, 1u);                                                     \
-    else if (ph == 2) SAR_SPLIT(RR, unsigned short, 2u);                                                       \
-    else SAR_SPLIT(RR, unsigned short, 1u)
-        if (records == 60u) { SAR_SPLIT_R(60u); }
-        else if (records == 28u) { SAR_SPLIT_R(28u); }
-        else return 1;
-#undef SAR_SPLIT_R
-#undef SAR_SPLIT
-        return 0;
+#define SAR_LAUNCH_SPLIT(RR, HH, PP)                                                                                  \
+    if (!launched && records == RR && hint_bytes == sizeof(HH) && ph == PP) {                                          \
+        hipLaunchKernelGGL((k_iterate_split<true, RR, 2u, HH, PP>), dim3(a.n_waves), dim3(128), lds2, s, a);           \
+        launched = true;                                                                                              \
+    }
+        SAR_FOR_EACH_SPLIT(SAR_LAUNCH_SPLIT)
+#undef SAR_LAUNCH_SPLIT
+        return launched ? 0 : 1;
     }
     const uint32_t grid = (a.it.n_jobs + block - 1) / block;
-    const size_t lds = (size_t)(block / 64u) * lean_wave_lds_bytes(a.n_bins, records, pool);
-    if (!depth) {
-        pipe = 1;
-        hint_bytes = 2;
-    }
-    bool launched = false;
-#define SAR_LAUNCH_LEAN(DD, RR, UU, HH)                                                                    \
-    if (!launched && depth == DD && records == RR && pipe == UU && hint_bytes == sizeof(HH)) {             \
-        if (pool) hipLaunchKernelGGL((k_iterate_lean<DD, RR, UU, HH, true>), dim3(grid), dim3(block), lds, s, a);   \
-        else hipLaunchKernelGGL((k_iterate_lean<DD, RR, UU, HH, false>), dim3(grid), dim3(block), lds, s, a);       \
-        launched = true;                                                                                   \
+    const size_t lds = (size_t)(block / 64u) * stage;
+#define SAR_LAUNCH_LEAN(RR, HH)                                                                                       \
+    if (!launched && records == RR && hint_bytes == sizeof(HH)) {                                                      \
+        hipLaunchKernelGGL((k_iterate_lean<true, RR, 2u, HH>), dim3(grid), dim3(block), lds, s, a);                    \
+        launched = true;                                                                                              \
     }
     SAR_FOR_EACH_LEAN(SAR_LAUNCH_LEAN)
 #undef SAR_LAUNCH_LEAN
-#define SAR_LAUNCH_LEAN_POOL(DD, RR, UU, HH)                                                               \
-    if (!launched && pool && depth == DD && records == RR && pipe == UU && hint_bytes == sizeof(HH)) {     \
-        hipLaunchKernelGGL((k_iterate_lean<DD, RR, UU, HH, true>), dim3(grid), dim3(block), lds, s, a);    \
-        launched = true;                                                                                   \
-    }
-    SAR_FOR_EACH_LEAN_POOL(SAR_LAUNCH_LEAN_POOL)
-#undef SAR_LAUNCH_LEAN_POOL
     return launched ? 0 : 1;
 }
 
 int iterate_kernel_attributes() {
     // the staging buffers need more dynamic LDS than the 64 KiB default window
     hipError_t e = hipSuccess;
-#define SAR_ATTR_LEAN(DD, RR, UU, HH) \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU, HH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU, HH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define SAR_ATTR_LEAN(RR, HH) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<true, RR, 2u, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SAR_FOR_EACH_LEAN(SAR_ATTR_LEAN)
 #undef SAR_ATTR_LEAN
-#define SAR_ATTR_LEAN_POOL(DD, RR, UU, HH) \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_lean<DD, RR, UU, HH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    SAR_FOR_EACH_LEAN_POOL(SAR_ATTR_LEAN_POOL)
-#undef SAR_ATTR_LEAN_POOL
 #define SAR_ATTR_SPLIT(RR, HH, PP) \
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_split<true, RR, 2u, HH, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    SAR_ATTR_SPLIT(60u, uint32_t, 2u) SAR_ATTR_SPLIT(60u, uint32_t, 1u) SAR_ATTR_SPLIT(60u, unsigned short, 2u) SAR_ATTR_SPLIT(60u, unsigned short, 1u)
-    SAR_ATTR_SPLIT(28u, uint32_t, 2u) SAR_ATTR_SPLIT(28u, uint32_t, 1u) SAR_ATTR_SPLIT(28u, unsigned short, 2u) SAR_ATTR_SPLIT(28u, unsigned short, 1u)
+    SAR_FOR_EACH_SPLIT(SAR_ATTR_SPLIT)
 #undef SAR_ATTR_SPLIT
     return (int)e;
 }

@@ -7,17 +7,15 @@
 
 namespace sar {
 
-// mode: 2 = full path (count + depth key); 1 = count only, 0 = arithmetic only (measurement variants)
-void launch_iterate(const IterArgs& a, uint32_t block, bool xcd_local, int mode, hipStream_t s);
-uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records, bool pool);
+// the one-atomic-per-visit fallback (images beyond 64 Mpx, single jobs whose record arena would not fit)
+void launch_iterate(const IterArgs& a, uint32_t block, hipStream_t s);
+uint32_t lean_wave_lds_bytes(uint32_t bins, uint32_t records);  // LDS staging of one wave (or wave pair) of the binned path
 uint32_t chunk_bytes(uint32_t records);
-// records: 12 / 20 / 28 per chunk; pipe: 1 / 2 visits of depth pipeline
-// hint_bytes: 2 (16-bit fixed-point hints) or 4 (sortable f32 hints)
-// pool: PoolStager (full buffers swapped against spares, cooperative copy-out) instead of Stager
-int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t pipe, uint32_t hint_bytes, bool depth,
-                        bool pool, bool split, hipStream_t s);
-// halves: bins of 65536 pixels counted by two workgroups with 32-bit counters (round 2) instead of one with packed 16-bit ones
-int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, uint32_t lists, bool halves, hipStream_t s);
+// records: 12 / 20 / 28 / 60 per chunk; hint_bytes: 2 (16-bit fixed-point hints) or 4 (the depth itself as f32);
+// split: producer / consumer wave pairs (k_iterate_split: 28 or 60 records) instead of the whole kernel (k_iterate_lean)
+int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, uint32_t hint_bytes, bool split, hipStream_t s);
+// lists: 1 or 4 (bin, wave) lists per lane group at a time; bins of 65536 pixels are counted with packed 16-bit counters
+int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t records, uint32_t lists, hipStream_t s);
 int iterate_kernel_attributes();     // sar_iterate.hip
 int accumulate_kernel_attributes();  // sar_accumulate.hip
 int binned_kernel_attributes();      // both

@@ -33,21 +33,6 @@
 
 using namespace sar;
 
-#define HIP_TRY(expr)                                                                 \
-    do {                                                                              \
-        hipError_t e_ = (expr);                                                       \
-        if (e_ != hipSuccess) {                                                       \
-            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return (e_ == hipErrorOutOfMemory) ? SAR_ERR_OOM : SAR_ERR_HIP;           \
-        }                                                                             \
-    } while (0)
-
-#define SAR_TRY(expr)                    \
-    do {                                 \
-        int s_ = (expr);                 \
-        if (s_ != SAR_OK) return s_;     \
-    } while (0)
-
 namespace {
 
 struct Shard {

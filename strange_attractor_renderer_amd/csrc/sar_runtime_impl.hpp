@@ -36,7 +36,6 @@ struct sar_runtime {
 
     // scratch bins the iterate kernel accumulates into (zero between launches)
     uint32_t copies = 0;      // scratch_count copies
-    uint32_t key_copies = 0;  // scratch_key copies
     uint32_t* d_scratch_count = nullptr;
     unsigned long long* d_scratch_key = nullptr;
 
@@ -111,10 +110,7 @@ struct sar_runtime {
     // tuning
     uint32_t block_threads = sar::kDefaultBlock;
     uint32_t ckpt_stride = sar::kDefaultCkptStride;
-    uint32_t bins_mode = 0;     // 0 default (binned when eligible), 1 one copy + agent-scope atomics,
-                                // 2 one copy per XCD + L2-local atomics, 3 LDS-binned records
-    uint32_t measure_mode = 0;  // 0 full path, 1 count only, 2 arithmetic only
-    uint32_t depth_pipe = 0;         // visits of depth pipeline in the iterate kernel (0 = default)
+    uint32_t bins_mode = 0;     // 0 default (binned when eligible), 1 one global atomic per visit, 3 LDS-binned records or an error
     bool timing_accumulate = false;  // spans of successive render calls add up until sar_runtime_last_timing reads them
     uint32_t debug_chunk_jobs = 0;  // test hook: cap on jobs per launch chunk (0 = none)
     uint64_t max_ordinals = 0;      // test hook: visits one launch may order (0 = 2^32-2); longer jobs run as segments
@@ -122,11 +118,9 @@ struct sar_runtime {
     uint32_t bin_interleave = 0;    // 0 = automatic, 1 = bins of consecutive pixels, 2 = interleaved bins (BinMap)
     uint32_t splits = 0;            // 0 = automatic
     uint32_t acc_threads = 0;       // threads per k_bin_accumulate block (0 = automatic)
-    uint32_t acc_halves = 0;        // 1: bins of 65536 pixels are counted in two halves (32-bit counters, lists read twice) instead of packed
     uint32_t split_waves = 0;       // 2: the iterate kernel as producer / consumer wave pairs (k_iterate_split) where it applies
-    uint32_t acc_lists = 0;         // (bin, wave) lists a lane group of k_bin_accumulate walks at the same time: 1, 2, 4 (0 = automatic)
-    uint32_t stager = 0;            // 0 automatic, 1 Stager (the filling lane copies its buffer out), 2 PoolStager (sar_iterate.hip)
-    uint32_t chunk_records = 0;     // records per chunk (0 = default 28; 12 / 20 shrink the LDS staging per wave)
+    uint32_t acc_lists = 0;         // (bin, wave) lists a lane group of k_bin_accumulate walks at the same time: 1, 4 (0 = automatic)
+    uint32_t chunk_records = 0;     // records per chunk: 12 / 20 / 28 / 60 (0 = automatic)
 
     // timing
     bool timing = false;
@@ -138,7 +132,44 @@ struct sar_runtime {
 };
 
 
+#define HIP_TRY(expr)                                                                 \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            sar::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorOutOfMemory) ? SAR_ERR_OOM : SAR_ERR_HIP;           \
+        }                                                                             \
+    } while (0)
+
+#define SAR_TRY(expr)                    \
+    do {                                 \
+        int s_ = (expr);                 \
+        if (s_ != SAR_OK) return s_;     \
+    } while (0)
+
 namespace sar {
+
+// Grows a device buffer (contents are not preserved). cap and need in elements of T.
+template <typename T>
+int grow_device(T*& ptr, size_t& cap, size_t need) {
+    if (need <= cap) return SAR_OK;
+    if (ptr) hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ptr), need * sizeof(T)));
+    cap = need;
+    return SAR_OK;
+}
+
+// sar_runtime.cpp
+int clear_hints(sar_runtime* rt);  // hints are lower bounds of depths already accumulated; anything that can lower zbuf voids them
+void span_begin(sar_runtime* rt, std::vector<Span>& spans, size_t& used);
+void span_end(sar_runtime* rt, std::vector<Span>& spans, size_t& used);
+void single_begin(sar_runtime* rt, Span& s);
+void single_end(sar_runtime* rt, Span& s, bool& flag);
+// sar_render.cpp
+void fill_map_params(const sar_config& cfg, MapParams& p);      // render's hoisted constants (:755-764)
+void fill_ct_params(const sar_config& cfg, ColorTransformParams& ct);
 
 // Runs n_jobs trajectories of `iters` counted iterations each into rt (sequential job-major semantics); `starts` is
 // [n_jobs][3] in host memory, or in device memory with starts_on_device. Enqueues only.

@@ -48,7 +48,7 @@ def test_c1_single_trajectory_matches_golden_and_oracle(sar, oracle, gpu):
         np.testing.assert_array_equal(sar.colorize(c2, rt), oracle.colorize(c2.c, ort))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 3])
 @pytest.mark.parametrize("block", [64, 256])
 def test_many_jobs_bit_exact(sar, oracle, gpu, variant, block):
     """Thousands of short trajectories: exercises depth ties, the checkpoint resolve and both bin layouts."""
@@ -322,33 +322,28 @@ def test_bin_maps_small_and_odd_shapes(sar, oracle, gpu, size, interleave, bin_s
     cfg = _cfg(sar, "solar_sail", iterations=jobs * n, width=w, height=h, jobs_total=jobs, scale=0.9)
     st = sar.start_points(29, 0, 2 * jobs)
     rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
-    rt.set_tuning(variant=3, bin_shift=bin_shift, bin_interleave=interleave, chunk_records=60 if bin_shift >= 15 else 0,
-                  stager=2 if bin_shift >= 15 else 0)
+    rt.set_tuning(variant=3, bin_shift=bin_shift, bin_interleave=interleave, chunk_records=60 if bin_shift >= 15 else 0)
     for part in (st[:jobs], st[jobs:]):
         sar.render_jobs(cfg, rt, part)
         oracle.render_jobs(cfg.c, ort, part, n)
     assert_state_equal(rt, ort, f"{w}x{h} bin_shift={bin_shift} bin_interleave={interleave}")
 
 
-@pytest.mark.parametrize("halves", [0, 1])
-@pytest.mark.parametrize("stager", [1, 2])
-@pytest.mark.parametrize("records", [12, 20, 28])
+@pytest.mark.parametrize("records", [12, 20, 28, 60])
 @pytest.mark.parametrize("acc_lists", [1, 4])
-def test_two_half_accumulate_with_every_chunk_size(sar, oracle, gpu, records, stager, acc_lists, halves):
-    """Bins of 65536 pixels — k_bin_accumulate counts them with packed 16-bit counters (halves=0, the default) or in two
-    halves by the records' top bit (halves=1) — under both stagers and the small chunk sizes, on an image of 5 such bins
-    whose last one is ragged, interleaved (8 bins) and not."""
+def test_packed_counters_with_every_chunk_size(sar, oracle, gpu, records, acc_lists):
+    """Bins of 65536 pixels — k_bin_accumulate counts them with packed 16-bit counters — under every chunk size, on an image
+    of 5 such bins whose last one is ragged, interleaved (8 bins) and not."""
     w, h = 640, 480
     jobs, n = 1500, 500
     cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=w, height=h, jobs_total=jobs)
     st = sar.start_points(37, 0, jobs)
     for interleave in (1, 2):
         rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
-        rt.set_tuning(variant=3, bin_shift=16, chunk_records=records, stager=stager, acc_lists=acc_lists, bin_interleave=interleave,
-                      acc_halves=halves)
+        rt.set_tuning(variant=3, bin_shift=16, chunk_records=records, acc_lists=acc_lists, bin_interleave=interleave)
         sar.render_jobs(cfg, rt, st)
         oracle.render_jobs(cfg.c, ort, st, n)
-        assert_state_equal(rt, ort, f"records={records} stager={stager} acc_lists={acc_lists} bin_interleave={interleave} halves={halves}")
+        assert_state_equal(rt, ort, f"records={records} acc_lists={acc_lists} bin_interleave={interleave}")
 
 
 def _fixed_point_config(sar, **kw):
@@ -374,19 +369,18 @@ def _expect_hot_pixel(sar, oracle, cfg, w, h, total):
     return ort, (int(ys[0]), int(xs[0]))
 
 
-@pytest.mark.parametrize("halves", [0, 1])
-def test_hot_pixel_through_the_packed_counters(sar, oracle, gpu, halves):
+def test_hot_pixel_through_the_packed_counters(sar, oracle, gpu):
     """3e8 visits of ONE pixel through bins of 65536 pixels: with one workgroup per bin the packed 16-bit counter of that
     pixel overflows ~9000 times — more events than the workgroup's list holds, so both the event list and the
-    straight-to-memory path of k_bin_accumulate's PACKED mode carry hits. (halves=1: the 32-bit counters of round 2.)"""
+    straight-to-memory path of k_bin_accumulate's PACKED mode carry hits."""
     w = h = 1024
     jobs, n = 65536, 4578
     cfg = _fixed_point_config(sar, iterations=jobs * n, width=w, height=h, jobs_total=jobs)
     rt = sar.Runtime(cfg)
-    rt.set_tuning(variant=3, bin_shift=16, splits=1, acc_halves=halves)
+    rt.set_tuning(variant=3, bin_shift=16, splits=1)
     sar.render_jobs(cfg, rt, sar.start_points(5, 0, jobs))
     ort, _ = _expect_hot_pixel(sar, oracle, cfg, w, h, jobs * n)
-    assert_state_equal(rt, ort, f"hot pixel, halves={halves}")
+    assert_state_equal(rt, ort, "hot pixel")
 
 
 def test_hot_pixel_past_u32_through_the_binned_path(sar, oracle, gpu):
@@ -494,31 +488,48 @@ def test_attractor_extent_bit_exact(sar, oracle, gpu, preset):
     np.testing.assert_array_equal(_bits(sar.attractor_extent(cfg, rt, jobs, n)), _bits(want))
 
 
-@pytest.mark.parametrize("stager", [1, 2])
 @pytest.mark.parametrize("records", [12, 20, 28, 60])
-@pytest.mark.parametrize("splits,acc_threads,pipe,hint_bits,interleave,acc_lists,split_waves",
-                         [(0, 0, 0, 0, 0, 0, 0), (1, 256, 1, 16, 1, 2, 1), (5, 512, 2, 16, 2, 4, 2), (16, 1024, 1, 32, 1, 1, 2),
-                          (3, 1024, 2, 32, 2, 2, 1), (2, 1024, 2, 32, 2, 4, 2)])
-def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, splits, acc_threads, pipe, hint_bits, interleave, acc_lists,
-                                                     split_waves, stager):
+@pytest.mark.parametrize("splits,acc_threads,hint_bits,interleave,acc_lists,split_waves",
+                         [(0, 0, 0, 0, 0, 0), (1, 256, 16, 1, 1, 1), (5, 512, 16, 2, 4, 2), (16, 1024, 32, 1, 1, 2),
+                          (3, 1024, 32, 2, 4, 1), (2, 1024, 32, 2, 4, 2)])
+def test_chunk_sizes_and_accumulate_shapes_bit_exact(sar, oracle, gpu, records, splits, acc_threads, hint_bits, interleave, acc_lists,
+                                                     split_waves):
     """Every chunk size of the binned path (32 / 48-on-64 / 64 / 128-byte chunks: different lane-group shapes in
-    k_bin_accumulate; the 128-byte chunk exists for the pool stager only), the iterate kernel whole (split_waves 1) and as
-    producer / consumer wave pairs (2: 64- and 128-byte chunks of the pool stager), with several accumulate grids, against the
-    oracle; enough records per (bin, wave) list to chain many chunks and to overflow staging buffers within one slot
-    request (all trajectories start close together)."""
-    if records == 60 and stager == 1:
-        pytest.skip("128-byte chunks: pool stager only")
+    k_bin_accumulate), the iterate kernel whole (split_waves 1) and as producer / consumer wave pairs (2: 64- and 128-byte
+    chunks), both hint types, with several accumulate grids, against the oracle; enough records per (bin, wave) list to chain
+    many chunks and to overflow staging buffers within one slot request (all trajectories start close together)."""
     jobs, n = 2048 + 64, 1201  # odd: the depth pipeline's pass of 2 leaves a last single iteration
     cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=256, height=192, jobs_total=jobs)
     st = sar.start_points(23, 0, jobs)
     st[:512] = st[0] + np.arange(512)[:, None] * 1e-13  # near-identical trajectories: many lanes hit one bin at once
     rt, ort = sar.Runtime(cfg), oracle.Runtime(256, 192)
-    rt.set_tuning(variant=3, chunk_records=records, splits=splits, acc_threads=acc_threads, depth_pipe=pipe, hint_bits=hint_bits,
-                  stager=stager, bin_interleave=interleave, acc_lists=acc_lists, split_waves=split_waves)
+    rt.set_tuning(variant=3, chunk_records=records, splits=splits, acc_threads=acc_threads, hint_bits=hint_bits,
+                  bin_interleave=interleave, acc_lists=acc_lists, split_waves=split_waves)
     sar.render_jobs(cfg, rt, st)
     oracle.render_jobs(cfg.c, ort, st, n)
-    assert_state_equal(rt, ort, f"records={records} splits={splits} acc_threads={acc_threads} depth_pipe={pipe} hint_bits={hint_bits} stager={stager} "
+    assert_state_equal(rt, ort, f"records={records} splits={splits} acc_threads={acc_threads} hint_bits={hint_bits} "
                                f"bin_interleave={interleave} acc_lists={acc_lists} split_waves={split_waves}")
+
+
+@pytest.mark.parametrize("size", [(256, 64), (4096, 8), (64, 24), (1024, 1024)])
+def test_tiled_narrow_hints_on_power_of_two_widths(sar, oracle, gpu, size):
+    """16-bit depth hints of images whose width is a power of two (and whose height is a multiple of eight) live in 8 x 8
+    tiles (HintTile); "hint_tile" 1 keeps them row-major. Both layouts, two render calls into one runtime (the hints of the
+    first call filter the second), against the oracle; switching the layout in between clears the hints."""
+    w, h = size
+    jobs, n = 1024, 600
+    cfg = _cfg(sar, "poisson_saturne", iterations=jobs * n, width=w, height=h, jobs_total=jobs, scale=0.8)
+    st = sar.start_points(61, 0, 2 * jobs)
+    for tile in (0, 1):
+        rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
+        rt.set_tuning(variant=3, hint_bits=16, hint_tile=tile)
+        for part, flip in ((st[:jobs], False), (st[jobs:], tile == 0)):
+            if flip:
+                rt.set_option("hint_tile", 1)   # another layout mid-way: the old hints must not be read under it
+            sar.render_jobs(cfg, rt, part)
+            oracle.render_jobs(cfg.c, ort, part, n)
+        assert_state_equal(rt, ort, f"{w}x{h} hint_tile={tile}")
+        assert "q16" in rt.describe_last_launch()
 
 
 @pytest.mark.parametrize("seed", range(32))

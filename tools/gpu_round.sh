@@ -1,16 +1,19 @@
 #!/bin/bash
-# One GPU-box visit of a round: the -m gpu suite, the default bench line, the multi-rank paths on one GPU (gloo), the C4
-# frame. Usage (through gpurun, from the repo root): tools/gpu_round.sh <tag>
-set -u
-TAG=${1:-x}
-OUT=gpurun_out/$TAG
-mkdir -p $OUT
-rocminfo | grep -E "Marketing|Compute Unit" | head -4 > $OUT/box.txt 2>&1
-nproc >> $OUT/box.txt
-timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
-tail -5 $OUT/pytest_gpu.log
-timeout 600 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err; tail -c 600 $OUT/bench_n1.json
-timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --check > $OUT/bench_n2_gloo.json 2> $OUT/bench_n2_gloo.err; tail -c 900 $OUT/bench_n2_gloo.json; tail -3 $OUT/bench_n2_gloo.err
-timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --exchange rooted --check > $OUT/bench_n2_gloo_rooted.json 2> $OUT/bench_n2_gloo_rooted.err; tail -3 $OUT/bench_n2_gloo_rooted.err
-timeout 600 python bench.py --config c4 --steps 3 --warmup 1 > $OUT/bench_c4_n1.json 2> $OUT/bench_c4_n1.err; tail -c 900 $OUT/bench_c4_n1.json
-timeout 600 python bench.py --config c4 --gpus 2 --steps 2 --warmup 1 --check > $OUT/bench_c4_n2_gloo.json 2> $OUT/bench_c4_n2_gloo.err; tail -c 600 $OUT/bench_c4_n2_gloo.json; tail -3 $OUT/bench_c4_n2_gloo.err
+# One closing-style GPU-box visit: the whole -m gpu suite, the parity suite with the whole / the split iterate kernel forced
+# and through a build with a ring of two spare buffers, smoke(), the default bench line, the config table.
+#   tools/gpu_round.sh <tag> [fast]      (fast: skip the variant suites)
+tag=${1:-r}; fast=${2:-}
+cd $GRAFT_REPO_ROOT
+out=gpurun_out/$tag; mkdir -p $out
+timeout 1500 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; echo "rc=$?" >> $out/pytest_gpu.log; tail -4 $out/pytest_gpu.log
+if [ -z "$fast" ]; then
+  for v in 1 2; do SAR_SPLIT=$v timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q > $out/pytest_split$v.log 2>&1; echo "SAR_SPLIT=$v: $(tail -1 $out/pytest_split$v.log)"; done
+  SAR_LIBRARY=$GRAFT_REPO_ROOT/strange_attractor_renderer_amd/libsar_hip_spare2.so timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q > $out/pytest_spare2.log 2>&1; echo "spare2: $(tail -1 $out/pytest_spare2.log)"
+fi
+python __graft_entry__.py --smoke 2>&1 | tail -1
+python bench.py > $out/bench_n1.json 2> $out/bench_n1.err; python - <<PY
+import json
+d=json.loads(open("$out/bench_n1.json").read().strip().splitlines()[-1])
+print("bench: value %.4g  ms/step %.3f  kernel_ms %.3f  frac %.3f  sustained median %.3f  cpu %s" % (d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d.get("sustained",{}).get("ms_per_frame",{}).get("median",0), d.get("cpu_baseline",{}).get("value")))
+PY
+python tools/config_table.py --reps 4 --out $out/config_table.jsonl 2>/dev/null | cut -c1-330
