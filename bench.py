@@ -49,10 +49,11 @@ FP64_PEAK_OPS = 78.6e12 / 2      # MI355X vector fp64 78.6 TFLOP/s counts an FMA
 
 
 def pmc_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r*_pmc.json):
-    (2*FETCH_SIZE + WRITE_SIZE) * 1024, the guide's gfx950 correction (FETCH_SIZE reads 1/2 of a coalesced stream)."""
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of the headline workload
+    (profiles/rNN_pmc.json): (2*FETCH_SIZE + WRITE_SIZE) * 1024 — the fallback when the run cannot measure them itself."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")) if re.fullmatch(r"r\d+_pmc\.json", os.path.basename(f)))
     if not files:
         return None, None
     try:
@@ -61,6 +62,47 @@ def pmc_traffic_bytes():
         return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
+
+
+def measure_traffic_live(kernel: str, timeout_s: float = 150.0):
+    """HBM bytes per launch of `kernel`, MEASURED by this run the way MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE
+    and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (they do not fit one pass; --kernel-trace only, no other trace domain),
+    each over a short child run of this very bench (3 timed steps), unit KiB, FETCH_SIZE doubled (on gfx950 it tallies the
+    128-byte fabric requests at 64 B). Returns (bytes per launch, description) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="sar_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pipeline", "--sustained-seconds", "0",
+                   "--no-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            got = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kernel in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                        got.append(float(r["Counter_Value"]))
+            if not got:
+                return None, f"no {counter} rows for {kernel}"
+            vals[counter] = sum(got) / len(got)
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (
+            f"measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in two separate passes over a 3-step child run, "
+            f"mean per launch of {kernel}, (2*FETCH_SIZE + WRITE_SIZE)*1024 with the guide's gfx950 read correction "
+            f"(FETCH_SIZE {vals['FETCH_SIZE'] * 1024 / 1e9:.3f} GB uncorrected — an upper estimate for this kernel's scattered 4-byte reads — "
+            f"+ WRITE_SIZE {vals['WRITE_SIZE'] * 1024 / 1e9:.3f} GB)")
+    except Exception as e:  # a missing tool, a time-out, a changed csv: the committed passes stand in
+        return None, f"live PMC passes failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_baseline(seconds_hint: float):
@@ -179,6 +221,8 @@ def main():
                     "sharded colorize (default) or all-reduce MAX + reduce SUM onto rank 0")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false", help="do not announce the next frame "
                     "(sar_runtime_prefetch_device): every frame runs its warm-up inside its own render call")
+    ap.add_argument("--no-traffic", dest="traffic", action="store_false", help="skip the two rocprofv3 --pmc child passes that measure "
+                    "roofline.traffic (the child passes themselves run with it)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="skip the two-stream pipelined-throughput "
                     "measurement that is reported next to `value` at N=1")
     ap.add_argument("--variant", type=lambda s: int(s, 0), default=0)
@@ -494,9 +538,15 @@ def main():
             kern_s = iter_ms * 1e-3 / max(launches, 1)             # average duration of one launch of the iterate kernel
             launch_desc = rt.describe_last_launch()                # what the library really launched (not a guess made here)
             iterate_kernel = launch_desc.split(" ")[0]
-            traffic, traffic_src = pmc_traffic_bytes()
-            if not (config == "c2" and int(a.iters) == ITERS_PER_GPU and jobs == DEFAULT_JOBS):
-                traffic, traffic_src = None, None
+            traffic, traffic_src = None, None
+            if config == "c2" and int(a.iters) == ITERS_PER_GPU and jobs == DEFAULT_JOBS and world == 1 and a.traffic:
+                traffic, traffic_src = measure_traffic_live(iterate_kernel)
+                if traffic is None:
+                    why = traffic_src
+                    traffic, traffic_src = pmc_traffic_bytes()
+                    if traffic_src:
+                        traffic_src = (f"{traffic_src}: PMC passes of this workload committed with the round ((2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                                       f"launch), NOT measured by this run ({why})")
             per_launch = n * jobs * steps / max(launches, 1)      # counted iterations one launch processes
             ach = ALG_BYTES_PER_ITER * per_launch / kern_s / 1e9
             out = {
@@ -525,16 +575,15 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach / HBM_PEAK_GBS,
                              "traffic": traffic,
-                             "traffic_source": (f"{traffic_src}: PMC passes of this workload committed with the round "
-                                                "((2*FETCH_SIZE + WRITE_SIZE)*1024 per launch), NOT measured by this run") if traffic_src else None,
+                             "traffic_source": traffic_src,
                              "kernel": iterate_kernel, "launch": launch_desc, "kernel_ms": kern_s * 1e3,
                              "alg_bytes_per_iteration": ALG_BYTES_PER_ITER,
                              "launches_timed": launches,
                              "valu_frac": FP64_OPS_PER_ITER * per_launch / kern_s / FP64_PEAK_OPS,
                              "note": "judged roofline per SURVEY 8(d) is HBM with 12.07 algorithmic B/iteration; the "
                                      "kernel's binding resource is fp64 VALU issue (88 unfused ops/iteration, no FMA "
-                                     "allowed): valu_frac = 88*it/s / 39.3e12 op/s. traffic = PMC bytes/launch "
-                                     "(profiles/), below the algorithmic bytes because the scatter state lives in LDS/L2"},
+                                     "allowed): valu_frac = 88*it/s / 39.3e12 op/s. traffic = HBM-side bytes per launch from the "
+                                     "PMC counters (traffic_source), below the algorithmic bytes because the scatter state lives in LDS/L2"},
                 "sustained": sustained,
                 "kernel_ms_per_step": {"warmup_and_pack": tm.warmup_ms / steps, "iterate": iter_ms / steps,
                                        "accumulate_fold_resolve": fold_ms / steps,

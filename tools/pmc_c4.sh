@@ -13,7 +13,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_c4_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 SHARE="python $GRAFT_REPO_ROOT/tools/config_table.py --only C4/8 --reps 3 --out /tmp/pmc_c4_share.jsonl ${OPTS:+--option $OPTS}"
-FULL="python $GRAFT_REPO_ROOT/bench.py --config c4 --steps 1 --warmup 1 --no-cpu-baseline --no-pipeline --sustained-seconds 0"
+FULL="python $GRAFT_REPO_ROOT/bench.py --config c4 --steps 1 --warmup 1 --no-cpu-baseline --no-pipeline --sustained-seconds 0 --no-traffic"
 run_pmc() { # case name counters...
   local cmd=$1 name=$2; shift 2
   local c="$SHARE"; [ "$cmd" = full ] && c="$FULL"

@@ -7,11 +7,11 @@ set -u
 TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipeline --sustained-seconds 0"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipeline --sustained-seconds 0 --no-traffic"
 cd /tmp && export TMPDIR=/tmp
 # the timing pass runs the bench's default step count, so that the tracer's average per kernel and the bench line's HIP-event
 # average (roofline.kernel_ms) are averages over the same dispatches; the counter passes below need only a few
-BENCH20="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pipeline --sustained-seconds 0"
+BENCH20="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pipeline --sustained-seconds 0 --no-traffic"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH20 > $OUT/trace_bench.json 2> $OUT/trace.err
 run_pmc() { # name counters...
   local name=$1; shift
