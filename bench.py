@@ -301,7 +301,7 @@ def main():
         def sweep(frames_per_rank):
             done[0] = 0
             todo = [f for f in sequence_frames(0.0, float(frames_per_rank * world), 1.0) if f[0] % world == rank]
-            seq.run(todo, sink)
+            seq.run(todo, sink, zero_copy=True)   # the sink only counts: no copy of the page-locked image
             torch.cuda.synchronize()
             assert done[0] == frames_per_rank
 
@@ -640,16 +640,19 @@ def main():
             # the strong-scaling frame on the same ranks: BASELINE configs[3], the same frame at every N
             c4 = run_config("c4", max(2, min(a.steps, 6)), 1, False)
             if rank == 0:
-                ref = None
-                try:
-                    ref = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_c4_n1.json")))
+                ref, ref_file = None, None
+                try:  # the committed N=1 line of the same workload (the newest round's)
+                    import glob
+                    ref_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_c4_n1.json")))[-1]
+                    ref = json.loads(open(ref_file).read().strip().splitlines()[-1])
+                    ref_file = os.path.relpath(ref_file, ROOT)
                 except Exception:
                     pass
                 out["strong_c4"] = {"value": c4["value"], "unit": c4["unit"], "ms_per_step": c4["ms_per_step"], "steps": c4["steps"],
                                     "scaling": "strong", "workload": c4["config"]["workload"], "jobs_total": c4["config"]["jobs_total"],
                                     "exchange_ms_per_step": c4.get("exchange_ms_per_step"), "kernel_ms_per_step": c4["kernel_ms_per_step"],
                                     "launch": c4["roofline"]["kernel"],
-                                    "n1_profile": ({"file": "profiles/r03_bench_c4_n1.json", "value": ref["value"], "ms_per_step": ref["ms_per_step"]}
+                                    "n1_profile": ({"file": ref_file, "value": ref["value"], "ms_per_step": ref["ms_per_step"]}
                                                    if ref else None),
                                     "speedup_vs_n1_profile": (c4["value"] / ref["value"]) if ref else None}
         except Exception as e:

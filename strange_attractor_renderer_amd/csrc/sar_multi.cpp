@@ -502,11 +502,15 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
         Shard& sh = r->shards[0];
         render_shard(r, &sh, cfg, per_job, S, from_ahead);
         if (sh.status != SAR_OK) { set_error("%s", sh.error); return failed(sh.status); }
-        int st = SAR_OK;
         r->timing.host_ms_before_exchange = static_cast<float>(now_ms() - t0);
-        if (rgba_out_host) st = sar_colorize(cfg, sh.rt, rgba_out_host);  // :1080 (waits for the image: the helper drew meanwhile)
-        if (st != SAR_OK) return failed(st);
+        // the next frame's points (the helper has been drawing them since before the render was enqueued) go to the device and
+        // are announced BEFORE this thread waits for the image: the announced warm-up then runs under this frame's tail
         commit_ahead();
+        r->timing.host_ms_enqueue = static_cast<float>(now_ms() - t0);
+        if (rgba_out_host) {
+            const int st = sar_colorize(cfg, sh.rt, rgba_out_host);  // :1080 (waits for the image)
+            if (st != SAR_OK) return failed(st);
+        }
         r->timing.total_ms = static_cast<float>(now_ms() - t0);
         return SAR_OK;
     }
