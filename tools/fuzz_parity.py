@@ -30,12 +30,18 @@ if len(sys.argv) > 3 and sys.argv[3] == "big":
                   angle=float(rng.uniform(0, 6.3)), scale=float(rng.uniform(0.5, 2.0)))
         cfg = getattr(sar.Config, preset)(**kw)
         st = sar.start_points(int(rng.integers(1 << 30)), 0, jobs)
-        rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
         opts = {}
         if rng.integers(3) == 0: opts["hint_bits"] = [16, 32][int(rng.integers(2))]
         if rng.integers(3) == 0: opts["split_waves"] = [1, 2][int(rng.integers(2))]
         if rng.integers(4) == 0: opts["hint_shared"] = [1, 2][int(rng.integers(2))]
         if rng.integers(4) == 0: opts["debug_chunk_jobs"] = int(rng.integers(2000, 40000))
+        if rng.integers(4) == 0:  # a power-of-two width (and a height that is a multiple of eight): the narrow hints then live in 8 x 8 tiles
+            w, h = 1 << int(rng.integers(9, 13)), 8 * int(rng.integers(60, 600))
+            kw.update(width=w, height=h)
+            cfg = getattr(sar.Config, preset)(**kw)
+            opts["hint_bits"] = 16
+            if rng.integers(3) == 0: opts["hint_tile"] = 1
+        rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
         for k, v in opts.items(): rt.set_option(k, v)
         try:
             sar.render_jobs(cfg, rt, st)
