@@ -347,7 +347,7 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
 int sar_runtime_describe_last_launch(const sar_runtime* rt, char* out, size_t cap);
 /* Tuning / test options by name (value 0 restores the default unless noted):
  *   "block_threads"      lanes per workgroup of the iterate kernel (64, 128, 192, 256)
- *   "checkpoint_stride"  iterations between trajectory checkpoints used by the payload resolve
+ *   "checkpoint_stride"  iterations between trajectory checkpoints used by the payload resolve (default 32)
  *   "path"               accumulate path: 0 default (= 3 when the image fits, up to 64 Mpx), 1 one global atomic per
  *                        visit, 3 LDS-binned records (an error where they do not fit)
  *   "bin_shift"          log2(pixels per bin) of the binned path (12..16; 16: the accumulate kernel packs two 16-bit counters
