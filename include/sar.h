@@ -131,8 +131,8 @@ int sar_rotation_matrix(const sar_config* cfg, double m_out[9]);
  * applications of xoshiro256's published jump() (2^128 steps each), and job k takes draws 3i..3i+2 of block k / 4096 as
  * x, y, z, with i = k % 4096 — so the first 4096 jobs are the plain stream, and any job's point is found without drawing
  * its predecessors' (a multi-device render_parallel draws every device's job slice on its own host thread). Writes n_jobs*3
- * doubles for jobs [first_job, first_job+n_jobs). The published vectors of both generators and the jump polynomial are
- * held by tests/test_oracle_kat.py.
+ * doubles for jobs [first_job, first_job+n_jobs) (first_job <= 2^36: reaching a job costs first_job / 4096 jumps of about a
+ * microsecond each). The published vectors of both generators and the jump polynomial are held by tests/test_oracle_kat.py.
  */
 int sar_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double* xyz_out_host);
 

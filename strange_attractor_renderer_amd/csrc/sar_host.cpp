@@ -238,6 +238,8 @@ int sar_rotation_matrix(const sar_config* cfg, double m_out[9]) {
 
 int sar_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double* xyz_out_host) {
     if (!xyz_out_host && n_jobs) return SAR_ERR_INVALID;
+    // reaching job k takes k / 4096 jumps of ~1 us each: 2^36 jobs (seconds) is far beyond any frame list and still bounded
+    if (first_job > (1ull << 36)) { sar::set_error("sar_start_points: first_job beyond 2^36"); return SAR_ERR_RANGE; }
     sar::Rng rng;
     rng.seed(seed);
     rng.skip_points(first_job);

@@ -85,6 +85,9 @@ def test_setup_math_matches_oracle_bit_for_bit(sar, oracle):
 
 def test_validation_and_error_reporting(sar):
     lib = sar.load_library()
+    with pytest.raises(sar.SarError) as e:   # a start point 2^40 jobs into the stream: refused, not computed for minutes
+        sar.start_points(1, 1 << 40, 1)
+    assert e.value.status == 6
     for bad in (dict(width=0), dict(height=0), dict(render_kind=7), dict(color_transform=5), dict(palette_len=0),
                 dict(palette_len=16), dict(attractor_kind=3), dict(width=65536, height=65536)):
         with pytest.raises(sar.SarError) as e:
