@@ -83,6 +83,7 @@ struct sar_renderer {
     uint64_t ahead_jobs = 0;
     Rng rng_next;
     long long* h_board = nullptr; // page-locked, visible to every device: [64][4] scalar quads of the exchange (step 3)
+    long long* d_board = nullptr; // ... as the devices address it
     std::vector<Shard> shards;    // one per device, in fold order
     bool scattered = false;       // shard runtimes hold only their own merged slice (gather before handing one out)
     uint32_t peer_access_failures = 0;  // ordered device pairs whose copies cannot go peer to peer
@@ -329,8 +330,12 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
     r->scattered = false;
 
     for (Shard& sh : r->shards) SAR_TRY(ensure_shard(r, sh, cfg, S));
-    if (G > 1 && !r->h_board)
+    if (G > 1 && !r->h_board) {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r->h_board), 64 * 4 * sizeof(long long), hipHostMallocPortable | hipHostMallocMapped));
+        void* dev_view = nullptr;  // what the kernels use (the same address under unified addressing; asked for, not assumed)
+        HIP_TRY(hipHostGetDevicePointer(&dev_view, r->h_board, 0));
+        r->d_board = static_cast<long long*>(dev_view);
+    }
 
     // contiguous job slices, sizes differ by at most one (the same partition as distributed.shard_jobs)
     {
@@ -561,7 +566,7 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
             const uint32_t n = first >= npix ? 0u : static_cast<uint32_t>((npix - first < S) ? npix - first : S);
             launch_exch_merge_slices(dst.rt->d_count, dst.rt->d_key, dst.rt->d_steps, static_cast<uint32_t>(first >= npix ? 0 : first), n, S, G,
                                      dst.d_recv, dst.rt->d_scalars, d == 0, st);
-            launch_exch_scalars_export(dst.rt->d_scalars, r->h_board + 4 * d, st);
+            launch_exch_scalars_export(dst.rt->d_scalars, r->d_board + 4 * d, st);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(dst.merged, st));
         }
@@ -575,7 +580,7 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
             hipStream_t st = sh.rt->stream;
             for (uint32_t e = 0; e < G; ++e)
                 if (e != d) HIP_TRY(hipStreamWaitEvent(st, r->shards[e].merged, 0));
-            launch_exch_scalars_reduce(sh.rt->d_scalars, r->h_board, G, st);
+            launch_exch_scalars_reduce(sh.rt->d_scalars, r->d_board, G, st);
             const uint64_t first = static_cast<uint64_t>(d) * S;
             const uint32_t n = first >= npix ? 0u : static_cast<uint32_t>((npix - first < S) ? npix - first : S);
             if (rgba_out_host && n) {
