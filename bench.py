@@ -64,7 +64,7 @@ def pmc_traffic_bytes():
         return None, None
 
 
-def measure_traffic_live(kernel: str, timeout_s: float = 150.0):
+def measure_traffic_live(kernel: str, timeout_s: float = 90.0):
     """HBM bytes per launch of `kernel`, MEASURED by this run the way MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE
     and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (they do not fit one pass; --kernel-trace only, no other trace domain),
     each over a short child run of this very bench (3 timed steps), unit KiB, FETCH_SIZE doubled (on gfx950 it tallies the
