@@ -173,11 +173,11 @@ static inline uint32_t f32_sortable_host(float f) {
 constexpr uint32_t kLnLutEntries = 1u << 20;  // ln(k+1), k < 2^20, host libm (exact parity with the oracle)
 constexpr uint64_t kMaxChunkOrdinals = 0xFFFFFFFEull;
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
-constexpr uint32_t kDefaultChunkRecords = 28;
+constexpr uint32_t kDefaultChunkRecords = 28;  // u16 records per chunk (8-byte header): 12 / 20 / 28 / 60 -> 32 / 48-on-64 / 64 / 128-byte chunks
 constexpr double kWideHintMaxSpan2 = 11.0e6;  // (width * scale)^2 up to which 32-bit depth hints are used
-constexpr uint32_t kDefaultDepthPipe = 2;   // visits between a depth-hint load and its use in the iterate kernel  // u16 records per chunk (8-byte header): 12, 20 or 28 -> 32/48/64-byte chunks
+constexpr uint32_t kDefaultDepthPipe = 2;   // visits between a depth-hint load and its use in the iterate kernel
 constexpr uint32_t kMaxBins = 1024;      // LDS staging is 64 B per bin per wave
-constexpr uint32_t kMaxBinPx = 65536;    // a record is 16 bits; k_bin_accumulate counts a bin of 65536 pixels in two halves
+constexpr uint32_t kMaxBinPx = 65536;    // a record is 16 bits; k_bin_accumulate counts a bin of 65536 pixels with packed 16-bit counters
 constexpr uint32_t kMaxHistPx = 32768;   // its LDS histogram: 4 B per pixel, 128 KiB
 
 }  // namespace sar
