@@ -196,7 +196,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--jobs", type=int, default=DEFAULT_JOBS, help="trajectories per GPU")
+    ap.add_argument("--jobs", type=int, default=None, help=f"trajectories per GPU (c2: {DEFAULT_JOBS}; c4: the frame's total, {C4_JOBS}; c5: per frame, 65536)")
     ap.add_argument("--iters", type=float, default=ITERS_PER_GPU, help="counted iterations per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--stride", type=int, default=0)
     a = ap.parse_args()
+    jobs_given = a.jobs is not None
+    a.jobs = a.jobs if jobs_given else DEFAULT_JOBS
     both_curves = a.config is None and not a.native  # the driver's SCALE command: N > 1 and nothing else said
     a.config = a.config or "c2"
 
@@ -286,7 +288,7 @@ def main():
         # A step is one frame: reset, render_parallel's job split with a fresh start-point stream per frame, colorize, RGB16
         # conversion on the device, read-back into host memory. The PNG encoder (the CLI runs it on other threads) is excluded.
         from strange_attractor_renderer_amd.sequence import SequenceRenderer, frames as sequence_frames
-        frame_jobs = 65536 if a.jobs == DEFAULT_JOBS else a.jobs
+        frame_jobs = a.jobs if jobs_given else 65536
         units, jpt = frame_jobs // 4, 4
         scfg = S.Config.solar_sail(iterations=100_000_000, width=1800, height=2000, scale=1.0, transparent=0)
         per_job = scfg.iterations // units // jpt
@@ -343,7 +345,7 @@ def main():
             # STRONG scaling: the frame (1e10 iterations, 524 288 jobs, 4096^2) is the same at every N; rank r renders the
             # contiguous job slice shard_jobs gives it (src/lib.rs:1056-1062 split)
             width = height = C4_SIZE
-            total_jobs = C4_JOBS if a.jobs == DEFAULT_JOBS else a.jobs
+            total_jobs = a.jobs if jobs_given else C4_JOBS
             n = int(a.iters if a.iters != ITERS_PER_GPU else C4_ITERS) // total_jobs
             first_job, jobs = shard_jobs(total_jobs, world, rank)
         else:

@@ -71,7 +71,7 @@ if __name__ == "__main__":
                     wall = (time.perf_counter() - t0) * 1e3
                     t = rt.last_timing()
                     rec = dict(config=name, jobs=jobs, iters=jobs * n, wall_ms=round(wall, 3), iterate_ms=round(t.iterate_ms, 3),
-                               fold_ms=round(t.resolve_ms, 3), colorize_ms=round(t.colorize_ms, 3), launches=t.iterate_launches,
+                               fold_ms=round(t.resolve_ms, 3), colorize_ms=round(t.colorize_ms, 3), warmup_ms=round(t.warmup_ms, 3), launches=t.iterate_launches,
                                depth_atomics=t.depth_atomics, depth_candidates=t.depth_candidates, git_per_s=round(jobs * n / wall / 1e6, 2), launch=rt.describe_last_launch().split(" | ")[0], **opts)
                     if best is None or rec["wall_ms"] < best["wall_ms"]:
                         best = rec
