@@ -1,3 +1,6 @@
+"""One GPU's eighth of BASELINE configs[3] (4096^2, 131 072 jobs x 9536 iterations = rank 5's slice of the job list) as
+back-to-back frames, with and without the next frame announced: the per-GPU render time behind DESIGN.md section 7's
+strong-scaling prediction. python tools/share_loop.py (needs a GPU)."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
 import strange_attractor_renderer_amd as S
