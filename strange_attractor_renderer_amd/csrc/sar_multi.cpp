@@ -152,6 +152,7 @@ void render_shard(sar_renderer* r, Shard* sh, const sar_config* cfg, uint64_t pe
         if (G > 1) HIP_TRY(hipEventRecord(sh->begin, rt->stream));
         SAR_TRY(sar_runtime_reset(rt));  // :951
         if (use_next && sh->next_valid && sh->next_first == sh->first_job && sh->next_n == sh->n_jobs && sh->next_iters == per_job) {
+            HIP_TRY(hipStreamWaitEvent(rt->stream, sh->uploaded, 0));  // (long done: the announced warm-up waited for it too)
             SAR_TRY(render_chunked(cfg, rt, sh->n_jobs, per_job, sh->d_next, true));  // the points uploaded during the previous frame
             const uint32_t slot = sh->d_next == sh->d_next_buf[0] ? 0u : 1u;
             if (!sh->next_read[slot]) HIP_TRY(hipEventCreateWithFlags(&sh->next_read[slot], hipEventDisableTiming));
@@ -275,6 +276,7 @@ int sar_renderer_shutdown(sar_renderer* r) {
     for (Shard& sh : r->shards) {
         hipSetDevice(sh.device);
         if (sh.rt) hipStreamSynchronize(sh.rt->stream);
+        if (sh.up) hipStreamSynchronize(sh.up);
     }
     for (Shard& sh : r->shards) {
         if (sh.rt) sar_runtime_free(sh.rt);  // first: an announced warm-up may still read d_next on the runtime's side stream
@@ -376,6 +378,7 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
             HIP_TRY(hipSetDevice(sh.device));
             sh.next_valid = false;
             sh.cur_slot = sh.next_slot;
+            if (sh.uploaded) HIP_TRY(hipEventSynchronize(sh.uploaded));  // an earlier frame's upload out of this memory
             SAR_TRY(pinned_slice(sh, sh.cur_slot, sh.n_jobs));
             sh.next_slot ^= 1u;
         }
