@@ -206,7 +206,11 @@ def main():
                     "the per-rank buffers (debug; not timed)")
     ap.add_argument("--host-starts", action="store_true", help="hand the start points over from host memory every step "
                     "(PCIe-inclusive rate; the default keeps them resident in HBM)")
-    ap.add_argument("--lanes", type=int, default=2, help="--config c5: runtimes (streams) per GPU the frames are rendered on in turn")
+    ap.add_argument("--lanes", type=int, default=2, help="--config c5: groups of runtimes (streams) per GPU the frames are rendered on in turn")
+    ap.add_argument("--batch", type=int, default=0, help="--config c5: frames per set of launches (sar_render_jobs_batch); 0 = as many "
+                    "as fill the chip (the library's advice, at most --max-batch), 1 = a frame per launch")
+    ap.add_argument("--max-batch", type=int, default=4)
+    ap.add_argument("--c5-only", default=None, choices=["readback", "hbm"], help="--config c5: only one of the two sweeps (profiling)")
     ap.add_argument("--config", default=None, choices=["c2", "c4", "c5"], help="c2: BASELINE configs[1], weak scaling (default); "
                     "c4: BASELINE configs[3] (1e10 iterations, 4096^2, 1048576 jobs sharded over the ranks), strong scaling. "
                     "c5: BASELINE configs[4], the solar-sail `sequence` sweep, 1e8 iterations per frame at 1800x2000, frame k on "
@@ -293,45 +297,68 @@ def main():
         scfg = S.Config.solar_sail(iterations=100_000_000, width=1800, height=2000, scale=1.0, transparent=0)
         per_job = scfg.iterations // units // jpt
         done = [0]
-        # the runtimes and the page-locked images live as long as the CLI's sweep does: made once, outside the timed frames
-        seq = SequenceRenderer(scfg, units=units, jobs_per_thread=jpt, seed=4, device=local_rank, image_format=S.SAR_FMT_RGB16,
-                               lanes=a.lanes)
 
         def sink(k, name, img):
             done[0] += 1
 
-        def sweep(frames_per_rank):
-            done[0] = 0
-            todo = [f for f in sequence_frames(0.0, float(frames_per_rank * world), 1.0) if f[0] % world == rank]
-            seq.run(todo, sink, zero_copy=True)   # the sink only counts: no copy of the page-locked image
-            torch.cuda.synchronize()
-            assert done[0] == frames_per_rank
+        def measure(seq):
+            """--steps frames per rank through `seq`, after an untimed sweep; the slowest rank's wall time."""
+            def sweep(frames_per_rank):
+                done[0] = 0
+                todo = [f for f in sequence_frames(0.0, float(frames_per_rank * world), 1.0) if f[0] % world == rank]
+                seq.run(todo, sink, zero_copy=True)   # the sink only counts: no copy of the page-locked image
+                torch.cuda.synchronize()
+                assert done[0] == frames_per_rank
+            sweep(max(a.warmup, a.lanes * seq.max_batch * 2))
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            sweep(a.steps)
+            if world > 1:
+                dist.barrier()
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            sizes = list(seq.frames_per_launch)
+            launch = seq.groups[0][0].describe_last_launch() if seq.groups and seq.groups[0] else ""
+            seq.close()
+            return el, sizes, launch
 
-        sweep(max(a.warmup, a.lanes))
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        sweep(a.steps)
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        seq.close()
+        # the runtimes and the page-locked images live as long as the CLI's sweep does: made once, outside the timed frames
+        common = dict(units=units, jobs_per_thread=jpt, seed=4, device=local_rank, lanes=a.lanes, batch=a.batch, max_batch=a.max_batch)
+        if a.c5_only == "hbm":
+            elapsed, sizes, launch = float("nan"), [], ""
+        else:
+            elapsed, sizes, launch = measure(SequenceRenderer(scfg, image_format=S.SAR_FMT_RGB16, **common))
+        # ... and the same sweep to what SURVEY 8(d)'s metric ends with: the colorized frame as RGBA16 in device memory
+        slots = (a.lanes + 1) * max(a.batch, a.max_batch) + 1
+        hbm = [torch.empty(1800 * 2000 * 4, dtype=torch.int16, device="cuda") for _ in range(slots)]
+        if a.c5_only == "readback":
+            el_hbm, sizes_hbm = float("nan"), []
+        else:
+            el_hbm, sizes_hbm, launch_hbm = measure(SequenceRenderer(scfg, device_ring=[t.data_ptr() for t in hbm], ring=slots, **common))
+            launch = launch or launch_hbm
         if rank == 0:
             frames = a.steps * world
+            counted = per_job * units * jpt * frames
             print(json.dumps({
                 "metric": "attractor iterations/sec over the solar-sail sequence sweep (1e8 iterations per frame, 1800x2000), one frame per GPU",
-                "value": per_job * units * jpt * frames / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "value": counted / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": elapsed / a.steps * 1e3, "ms_per_frame_per_gpu": elapsed / a.steps * 1e3, "frames_per_second": frames / elapsed,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "rgba16_in_hbm": {"value": counted / el_hbm, "unit": "iterations/s", "ms_per_frame_per_gpu": el_hbm / a.steps * 1e3,
+                                  "frames_per_second": frames / el_hbm,
+                                  "note": "the same sweep with every frame left as RGBA16 in device memory (colorize, no conversion, "
+                                          "no read-back): what SURVEY 8(d)'s metric ends with"},
                 "config": {"workload": "BASELINE configs[4]: sequence --start 0 --end 360 --step 1 (the first steps*N frames), solar-sail, "
                                        "1e8 iterations per frame, 1800x2000, scale 1, frame k on rank k mod N; RGB16 conversion on the "
                                        "device + read-back included, PNG encoder excluded",
                            "jobs_per_frame": units * jpt, "iterations_per_job": per_job, "frames": frames,
-                           "frames_in_flight_per_gpu": a.lanes,
+                           "lanes_per_gpu": a.lanes, "frames_per_launch": {str(f): sizes.count(f) for f in sorted(set(sizes))},
+                           "frames_per_launch_in_hbm": {str(f): sizes_hbm.count(f) for f in sorted(set(sizes_hbm))},
+                           "launch": launch,
                            "counted_over_executed_iterations": round(per_job / (per_job + 1000.0), 4),
                            "parallelism": f"{world} replica(s), no collective"}}), flush=True)
         if world > 1:

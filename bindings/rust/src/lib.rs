@@ -129,6 +129,10 @@ extern "C" {
                                        starts_xyz_dev: *const f64) -> c_int;
     pub fn sar_runtime_prefetch_device(cfg: *const SarConfig, rt: *mut SarRuntime, n_jobs: u32, iters_per_job: u64,
                                        starts_xyz_dev: *const f64) -> c_int;
+    /// F frames of a sweep (src/bin/main.rs:493-517) through one set of launches: frame i == sar_render_jobs(cfgs[i], rts[i], starts[i]).
+    pub fn sar_render_jobs_batch(n_frames: u32, cfgs: *const *const SarConfig, rts: *const *mut SarRuntime,
+                                 starts_xyz_host: *const *const f64) -> c_int;
+    pub fn sar_runtime_batch_frames(cfg: *const SarConfig, rt: *mut SarRuntime, out_frames: *mut u32) -> c_int;
     pub fn sar_colorize_device(cfg: *const SarConfig, rt: *mut SarRuntime, rgba_out_dev: *mut c_void) -> c_int;
     pub fn sar_runtime_describe_last_launch(rt: *const SarRuntime, out: *mut c_char, cap: usize) -> c_int;
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SAR_ABI_VERSION 4  /* 4: start-point stream in blocks of 4096 jobs (jump); sar_timing.depth_candidates; sar_parallel_timing.host_ms_before_exchange */
+#define SAR_ABI_VERSION 5  /* 5: sar_render_jobs_batch, sar_runtime_batch_frames */
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -177,6 +177,25 @@ int sar_render_job_range(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs
  * runtime's device; read in stream order): nothing crosses PCIe, the call only enqueues. */
 int sar_render_job_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
                                 uint64_t iters_per_job, const double* starts_xyz_dev);
+
+/*
+ * F frames of a sweep in ONE set of launches — F iterations of the CLI's frame loop (src/bin/main.rs:493-517: every frame is a
+ * reset, src/lib.rs:950-951, and a render_parallel of fresh jobs) at a time. Frame i is sar_render_jobs(cfgs[i], rts[i],
+ * starts_xyz_host[i]) and the result is exactly that, bit for bit; what changes is how the chip is filled: a frame of 65 536
+ * jobs occupies a third of an MI355X (a quarter once solar-sail has lost 38 % of its start points in the warm-up), so the frames'
+ * workgroups share ONE launch of each kernel (workgroup -> frame -> that frame's argument block and buffers). The batched
+ * launch applies to runtimes on one device with one image size, configs with the same jobs_total, iterations per job and scale
+ * whose jobs are resident at once (the wave-pair form of the iterate kernel, one launch chunk, at most 4 Mpx); anything else —
+ * and n_frames == 1 — runs the frames one after the other, same result. The runtimes must be distinct; the work is enqueued
+ * on rts[0]'s stream, and a runtime with another stream is ordered with it through events (give the runtimes of a batch one
+ * stream, sar_runtime_set_stream, and nothing needs ordering). starts_xyz_host[i] == NULL (or starts_xyz_host == NULL)
+ * draws frame i's points from rts[i]'s own stream. The launch options (sar_runtime_set_option) are rts[0]'s.
+ */
+int sar_render_jobs_batch(uint32_t n_frames, const sar_config* const* cfgs, sar_runtime* const* rts,
+                          const double* const* starts_xyz_host);
+/* How many frames like cfg fill the chip (eight wave pairs per CU; a frame takes one per 64 jobs that survive the warm-up,
+ * from the survivor share of this runtime's last launch): the n_frames to call sar_render_jobs_batch with. 1..16. */
+int sar_runtime_batch_frames(const sar_config* cfg, sar_runtime* rt, uint32_t* out_frames);
 
 /* Announces the NEXT sar_render_job_range_device call on this runtime — these start points, job count and iterations per
  * job, and the attractor's 30 coefficients; the view, render kind and colours of cfg may differ in the announced call (the

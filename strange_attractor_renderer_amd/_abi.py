@@ -122,6 +122,8 @@ PROTOTYPES = {
     "sar_render_jobs": (C.c_int, [_cfg_p, _vp, _P(C.c_double)]),
     "sar_render_job_range": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _P(C.c_double)]),
     "sar_render_job_range_device": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _vp]),
+    "sar_render_jobs_batch": (C.c_int, [C.c_uint32, _P(_cfg_p), _P(_vp), _P(_P(C.c_double))]),
+    "sar_runtime_batch_frames": (C.c_int, [_cfg_p, _vp, _P(C.c_uint32)]),
     "sar_runtime_prefetch_device": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _vp]),
     "sar_runtime_describe_last_launch": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "sar_colorize": (C.c_int, [_cfg_p, _vp, _P(C.c_uint16)]),

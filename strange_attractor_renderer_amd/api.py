@@ -333,6 +333,33 @@ def render_jobs(config: Config, runtime: Runtime, starts=None):
     del keep
 
 
+def render_jobs_batch(configs, runtimes, starts=None):
+    """F frames of a sweep through ONE set of launches (sar_render_jobs_batch): frame i is ``render_jobs(configs[i],
+    runtimes[i], starts[i])``, bit for bit — the frames share the chip instead of following each other."""
+    n = len(configs)
+    if len(runtimes) != n or (starts is not None and len(starts) != n):
+        raise ValueError("configs, runtimes and starts must have the same length")
+    cfgs = (C.POINTER(SarConfig) * n)(*[C.pointer(c.c) for c in configs])
+    rts = (C.c_void_p * n)(*[r.handle for r in runtimes])
+    keep, ptrs = [], None
+    if starts is not None:
+        ptrs = (C.POINTER(C.c_double) * n)()
+        for i, (c, s) in enumerate(zip(configs, starts)):
+            k, p = _starts_ptr(s, c.c.jobs_total)
+            keep.append(k)
+            if p is not None:
+                ptrs[i] = p
+    _check(_lib().sar_render_jobs_batch(n, cfgs, rts, ptrs), "sar_render_jobs_batch")
+    del keep
+
+
+def batch_frames(config: Config, runtime: Runtime) -> int:
+    """How many frames like `config` fill the chip (sar_runtime_batch_frames): the length to call render_jobs_batch with."""
+    n = C.c_uint32()
+    _check(_lib().sar_runtime_batch_frames(C.byref(config.c), runtime.handle, C.byref(n)), "sar_runtime_batch_frames")
+    return int(n.value)
+
+
 def render_job_range(config: Config, runtime: Runtime, iters_per_job: int, starts):
     """A shard: the given jobs (explicit start points) with iters_per_job iterations each."""
     s = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 3)

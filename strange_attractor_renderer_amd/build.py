@@ -18,7 +18,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libsar_hip.so")
 BUILD_DIR = os.path.join(os.path.dirname(PKG), "build", "sar_hip")
-SOURCES = ["sar_host.cpp", "sar_export.cpp", "sar_plan.cpp", "sar_render.cpp", "sar_runtime.cpp", "sar_multi.cpp", "sar_iterate.hip", "sar_accumulate.hip",
+SOURCES = ["sar_host.cpp", "sar_export.cpp", "sar_plan.cpp", "sar_render.cpp", "sar_runtime.cpp", "sar_batch.cpp", "sar_multi.cpp", "sar_iterate.hip", "sar_accumulate.hip",
            "sar_image.hip"]
 HEADERS = ["sar_internal.hpp", "sar_launch.hpp", "sar_device.hpp", "sar_runtime_impl.hpp", "sar_plan.hpp", os.path.join("..", "..", "include", "sar.h")]
 ARCH = "gfx950"
@@ -64,8 +64,8 @@ def audit_no_fma(asm_paths) -> dict:
     # k_fold_resolve replays next_point / screen_space from the checkpoints for the bit-exact `steps` payload, next to a
     # sqrt and a division whose correctly-rounded expansions legitimately use fused ops: exactly FOLD_FUSED_OPS of them
     # (sqrt 4, div 2... as emitted by ROCm 7.2's device libs). One more means the replay was contracted.
-    fold = [v for k, v in counts.items() if "k_fold_resolve" in k]
-    if fold != [FOLD_FUSED_OPS]:
+    fold = [v for k, v in counts.items() if "k_fold_resolve" in k]   # the single-frame kernel and its batched twin
+    if fold != [FOLD_FUSED_OPS] * 2:
         raise RuntimeError(f"k_fold_resolve holds {fold} fused fp64 ops, expected [{FOLD_FUSED_OPS}] (sqrt/div expansion only): "
                            "either the payload replay was contracted or the device libs changed — inspect the assembly")
     return counts

@@ -27,10 +27,9 @@ namespace sar {
 //     isolated 64-byte reads, 2.7 of the 3.4 TB/s MI355X serves; that form left the tree in round 4.)
 constexpr uint32_t kAccEvents = 2040u;  // event list of the PACKED mode (u16 records), next to two counters
 template <uint32_t R, uint32_t K, bool PACKED>
-__global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
+__device__ __forceinline__ void bin_accumulate_body(const BinAccArgs& a, uint32_t* hist) {
     constexpr uint32_t Q = kChunkQuads(R);       // 16-byte quads per chunk
     constexpr uint32_t G = kChunkLanes(R);       // lanes that share one list: lane q of a group reads quad q
-    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     // PACKED: behind the 32768 words of counters: [0] events noted, [1] "an event went straight to memory", then the events
     uint32_t* const ev_ctl = hist + 32768u;
     unsigned short* const ev = (unsigned short*)(ev_ctl + 2);
@@ -172,6 +171,19 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
     }
 }
 
+template <uint32_t R, uint32_t K, bool PACKED>
+__global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    bin_accumulate_body<R, K, PACKED>(a, hist);
+}
+// F frames in one launch (BatchFrame): the frame is blockIdx.z, (bin, split) stay blockIdx.x / .y
+template <uint32_t R, uint32_t K>
+__global__ void __launch_bounds__(1024) k_bin_accumulate_batch(const BatchFrame* frames) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    const BinAccArgs a = load_frame_args(&frames[blockIdx.z].acc);
+    bin_accumulate_body<R, K, false>(a, hist);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // k_fold_resolve — scratch bins -> persistent Runtime buffers, then the payload of new depth winners
 // ---------------------------------------------------------------------------------------------------
@@ -182,7 +194,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const BinAccArgs a) {
 // ordinal in the key names the job and the iteration. No global atomics except one max per block.
 constexpr uint32_t FOLD_PIX = 2048;
 
-__global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) {
+__device__ __forceinline__ void fold_resolve_body(const FoldArgs& a) {
     __shared__ unsigned long long s_key[FOLD_PIX];
     __shared__ uint32_t s_pix[FOLD_PIX];
     __shared__ uint32_t s_n, s_wrap;
@@ -296,6 +308,12 @@ __global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) {
     }
 }
 
+__global__ void __launch_bounds__(256) k_fold_resolve(const FoldArgs a) { fold_resolve_body(a); }
+__global__ void __launch_bounds__(256) k_fold_resolve_batch(const BatchFrame* frames) {
+    const FoldArgs a = load_frame_args(&frames[blockIdx.z].fold);
+    fold_resolve_body(a);
+}
+
 // lists: (bin, wave) lists a lane group walks at the same time — 4 with the 128 KiB histograms (one workgroup per CU: four
 // loads in flight per lane make up for the missing second workgroup), 1 otherwise
 #define SAR_FOR_EACH_ACC(X) X(12u, 1u) X(12u, 4u) X(20u, 1u) X(20u, 4u) X(28u, 1u) X(28u, 4u) X(60u, 1u) X(60u, 4u)
@@ -317,6 +335,28 @@ int launch_bin_accumulate(const BinAccArgs& a, uint32_t threads, uint32_t record
     return launched ? 0 : 1;
 }
 
+// the batched form exists for bins of up to 32768 pixels (32-bit counters)
+int launch_bin_accumulate_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_bins, uint32_t splits, uint32_t bin_shift,
+                                uint32_t threads, uint32_t records, uint32_t lists, hipStream_t s) {
+    if (bin_shift > 15u) return 1;
+    const size_t lds = (size_t)4u << bin_shift;
+    if (threads == 0) threads = 1024u;
+    const dim3 grid(n_bins, splits, n_frames);
+    bool launched = false;
+#define SAR_ACC_BATCH(RR, KK)                                                                                   \
+    if (!launched && records == RR && lists == KK) {                                                             \
+        hipLaunchKernelGGL((k_bin_accumulate_batch<RR, KK>), grid, dim3(threads), lds, s, frames);               \
+        launched = true;                                                                                        \
+    }
+    SAR_FOR_EACH_ACC(SAR_ACC_BATCH)
+#undef SAR_ACC_BATCH
+    return launched ? 0 : 1;
+}
+
+void launch_fold_resolve_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_fold_resolve_batch, dim3((npix + FOLD_PIX - 1) / FOLD_PIX, 1, n_frames), dim3(256), 0, s, frames);
+}
+
 int accumulate_kernel_attributes() {
     // a bin's histogram needs more dynamic LDS than the 64 KiB default window when the bin has 32768 pixels
     hipError_t e = hipSuccess;
@@ -325,6 +365,10 @@ int accumulate_kernel_attributes() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate<RR, KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     SAR_FOR_EACH_ACC(SAR_ATTR)
 #undef SAR_ATTR
+#define SAR_ATTR_BATCH(RR, KK) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bin_accumulate_batch<RR, KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    SAR_FOR_EACH_ACC(SAR_ATTR_BATCH)
+#undef SAR_ATTR_BATCH
     return (int)e;
 }
 

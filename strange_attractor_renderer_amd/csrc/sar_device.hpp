@@ -215,6 +215,20 @@ __device__ __forceinline__ void pin_map_params(MapParams& p) {
 }
 
 
+// The argument block of one frame of a BATCHED launch (BatchFrame, sar_internal.hpp), read from the table in device memory
+// through the CONSTANT address space: the address is wave-uniform and nothing writes the table while a launch runs, so these
+// are scalar loads into SGPRs — what the by-value kernel arguments of the single-frame kernels are.
+template <typename T>
+__device__ __forceinline__ T load_frame_args(const T* p) {
+    static_assert(sizeof(T) % 8 == 0 && alignof(T) == 8, "argument blocks are 8-byte aligned");
+    typedef const __attribute__((address_space(4))) unsigned long long* Src;  // (dword-aligned or better: a scalar load needs it)
+    union U { T v; unsigned long long w[sizeof(T) / 8]; __device__ U() {} } u;
+    Src src = (Src)(uintptr_t)p;
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(T) / 8; ++k) u.w[k] = src[k];
+    return u.v;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // block-level reductions (result valid in thread 0)
 // ---------------------------------------------------------------------------------------------------

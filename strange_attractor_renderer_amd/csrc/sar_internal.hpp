@@ -149,6 +149,34 @@ struct FoldArgs {
     uint32_t* scalars;               // [0] max, [1] wrap flag
 };
 
+// k_warmup (sar_iterate.hip): the 1000 uncounted iterations of `n_jobs` jobs and the packing of the survivors
+struct WarmArgs {
+    MapParams p;
+    const double* starts;        // [3][n_jobs] SoA
+    uint32_t n_jobs;
+    uint32_t width;
+    uint64_t iters;              // counted iterations per job: what a job that dies in the warm-up adds to nan_count
+    double* warm;                // [3][n_jobs] SoA by packed slot
+    uint32_t* joblist;           // [n_jobs]
+    uint32_t* active;            // survivors (zero before the launch)
+    unsigned long long* nan_count;
+    uint32_t* hint_range;        // nullable: the depth range of the view (narrow hints)
+};
+
+// One frame of a BATCHED launch (sar_batch.cpp): F frames of the same shape — a `sequence` sweep's consecutive frames, each with
+// its own Runtime, view angle and start points (src/bin/main.rs:493-517) — go through ONE launch of every kernel of the
+// binned path; a workgroup finds its frame in blockIdx.z and its argument block in a table of these in device memory.
+struct BatchFrame {
+    WarmArgs warm;
+    BinIterArgs it;
+    BinAccArgs acc;
+    FoldArgs fold;
+    uint32_t* seg_any;           // cleared by k_batch_clear before the launch, like `active` and (if measured) `hint_range`
+    uint32_t seg_words;
+    uint32_t clear_hint_range;
+};
+constexpr uint32_t kMaxBatchFrames = 16;
+
 struct PaletteParams {
     uint32_t len;  // user entries; entry len == entry len-1 (Palette::new, src/lib.rs:416-418)
     uint32_t _pad;

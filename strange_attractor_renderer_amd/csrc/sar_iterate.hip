@@ -494,13 +494,15 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
 // do not (the visit ordinal is formed from the job index, which travels in `joblist`).
 // ---------------------------------------------------------------------------------------------------
 constexpr int kWarmupRangeIters = 64;  // the last warm-up iterations whose depths k_warmup looks at for the hint quantiser
-__global__ void __launch_bounds__(256) k_warmup(const MapParams pin, const double* __restrict__ starts, uint32_t n_jobs,
-                                                uint64_t iters, double* __restrict__ warm, uint32_t* __restrict__ joblist,
-                                                uint32_t* active, unsigned long long* nan_count, uint32_t width,
-                                                uint32_t* hint_range) {
+__device__ __forceinline__ void warmup_body(const WarmArgs& a) {
+    const double* __restrict__ starts = a.starts;
+    double* __restrict__ warm = a.warm;
+    uint32_t* __restrict__ joblist = a.joblist;
+    uint32_t* const hint_range = a.hint_range;
+    const uint32_t n_jobs = a.n_jobs;
     const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = job < n_jobs;
-    MapParams p = pin;
+    MapParams p = a.p;
     pin_map_params(p);
     double x = 0., y = 0., z = 0.;
     float zlo = __builtin_inff(), zhi = -__builtin_inff();  // depth range of this lane's candidates (neutral for lanes without a job)
@@ -518,7 +520,7 @@ __global__ void __launch_bounds__(256) k_warmup(const MapParams pin, const doubl
                 bool inb;
                 uint32_t idx;
                 float zf;
-                iterate_once(p, width, x, y, z, inb, idx, zf);
+                iterate_once(p, a.width, x, y, z, inb, idx, zf);
                 if (inb && zf > -1.0f) {
                     zlo = fminf(zlo, zf);
                     zhi = fmaxf(zhi, zf);
@@ -541,8 +543,8 @@ __global__ void __launch_bounds__(256) k_warmup(const MapParams pin, const doubl
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
     uint32_t base = 0;
     if ((threadIdx.x & 63u) == 0u) {
-        if (lm) base = atomicAdd(active, (uint32_t)__popcll(lm));
-        if (dm) atomicAdd(nan_count, iters * (unsigned long long)__popcll(dm));
+        if (lm) base = atomicAdd(a.active, (uint32_t)__popcll(lm));
+        if (dm) atomicAdd(a.nan_count, a.iters * (unsigned long long)__popcll(dm));
     }
     base = __builtin_amdgcn_readfirstlane(base);
     if (live) {
@@ -552,6 +554,28 @@ __global__ void __launch_bounds__(256) k_warmup(const MapParams pin, const doubl
         warm[2u * n_jobs + slot] = z;
         joblist[slot] = job;
     }
+}
+__global__ void __launch_bounds__(256) k_warmup(const WarmArgs a) { warmup_body(a); }
+
+// ---------------------------------------------------------------------------------------------------
+// Batched launches: F frames of one shape through ONE launch of each kernel (BatchFrame, sar_internal.hpp). The frame is
+// blockIdx.z; its argument block is read from a table in device memory through the CONSTANT address space — the address is
+// wave-uniform and nothing writes the table while a launch runs, so these are scalar loads into SGPRs, exactly what the
+// by-value kernel arguments of the single-frame kernels are — and the kernel body is the single-frame body unchanged.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_warmup_batch(const BatchFrame* frames) {
+    const WarmArgs a = load_frame_args(&frames[blockIdx.z].warm);
+    warmup_body(a);
+}
+// what a render call clears before its kernels (three small memsets per frame otherwise): survivor counter and dead-job
+// iterations, the segment flags of k_bin_accumulate, the measured depth range of the narrow hints
+__global__ void __launch_bounds__(256) k_batch_clear(const BatchFrame* frames) {
+    const BatchFrame* f = frames + blockIdx.y;
+    uint32_t* const seg = f->seg_any;
+    const uint32_t n = f->seg_words;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) seg[k] = 0u;
+    if (blockIdx.x == 0u && threadIdx.x < 4u) f->warm.active[threadIdx.x] = 0u;
+    if (blockIdx.x == 0u && threadIdx.x < 2u && f->clear_hint_range) f->warm.hint_range[threadIdx.x] = 0u;
 }
 
 template <bool DEPTH, uint32_t R, uint32_t U, typename H>
@@ -675,15 +699,13 @@ __global__ void __launch_bounds__(256) k_iterate_lean(const BinIterArgs a) {
 // always ready to issue arithmetic. Same arithmetic, same visit order, same records.
 // PH = iterations per barrier phase: U (2 KiB of visits in flight) or 1 (1 KiB, where the staging leaves no more).
 template <bool DEPTH, uint32_t R, uint32_t U, typename H, uint32_t PH>
-__global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
+__device__ __forceinline__ void iterate_split_body(const BinIterArgs& a, uint32_t* smem, const uint32_t wave) {
     static_assert(PH == 1u || PH == U, "a phase is one iteration or one pass of the depth pipeline");
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u;
-    const bool producer = threadIdx.x < 64u;  // wave-uniform
-    const uint32_t wave = blockIdx.x;          // one set of 64 trajectories per workgroup
+    const bool producer = threadIdx.x < 64u;  // wave-uniform; `wave`: one set of 64 trajectories per workgroup
     const uint32_t slot = wave * 64u + lane;
     const uint32_t active = *a.active;
-    if (a.warm_nan && blockIdx.x == 0u && threadIdx.x == 0u) {  // as in k_iterate_lean
+    if (a.warm_nan && wave == 0u && threadIdx.x == 0u) {  // as in k_iterate_lean
         const unsigned long long dead = *a.warm_nan;
         if (dead) atomicAdd(a.nan_count, dead);
     }
@@ -831,6 +853,36 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
         st.finish(a.heads, a.n_waves, wave, a.nan_count);
     }
 }
+template <bool DEPTH, uint32_t R, uint32_t U, typename H, uint32_t PH>
+__global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    iterate_split_body<DEPTH, R, U, H, PH>(a, smem, blockIdx.x);
+}
+// F frames in one launch, a 1-D grid of F x n_waves workgroups. Which (frame, wave pair) a workgroup is follows the XCDs: the
+// dispatcher deals consecutive workgroups to the eight XCDs round-robin, and every frame has its own depth hints and depth
+// keys — F working sets in every XCD's 4 MiB L2 if every frame ran everywhere (three frames of configs[4]: 1.0 us per
+// iteration step against 0.65 alone). With xcd_map the frames are dealt to the XCDs instead: 8 / F XCDs per frame (F = 2, 4,
+// 8), or F / 8 frames per XCD (16): an XCD's L2 sees the hints of its own frames only. Any other F: frame after frame.
+template <bool DEPTH, uint32_t R, uint32_t U, typename H, uint32_t PH>
+__global__ void __launch_bounds__(128) k_iterate_split_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_waves, uint32_t xcd_map) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t lin = blockIdx.x;
+    uint32_t frame, wave;
+    if (xcd_map == 1u) {         // 8 / F XCDs per frame
+        const uint32_t xpf = 8u / n_frames, xcd = lin & 7u, pos = lin >> 3;
+        frame = xcd / xpf;
+        wave = pos * xpf + xcd % xpf;
+    } else if (xcd_map == 2u) {  // F / 8 frames per XCD
+        const uint32_t fpx = n_frames >> 3, xcd = lin & 7u, pos = lin >> 3;
+        frame = xcd * fpx + pos % fpx;
+        wave = pos / fpx;
+    } else {
+        frame = lin / n_waves;
+        wave = lin - frame * n_waves;
+    }
+    const BinIterArgs a = load_frame_args(&frames[frame].it);
+    iterate_split_body<DEPTH, R, U, H, PH>(a, smem, wave);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // k_extent — the "first pass" the reference leaves as a TODO (src/lib.rs:326-333): bounds of the attractor in screen
@@ -945,6 +997,28 @@ int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, 
     return launched ? 0 : 1;
 }
 
+int launch_iterate_split_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_waves, uint32_t n_bins, uint32_t records,
+                               uint32_t hint_bytes, bool xcd_aware, hipStream_t s) {
+    const uint32_t total = n_frames * n_waves;
+    uint32_t xcd_map = 0;
+    if (xcd_aware && total % 8u == 0u) {
+        if (n_frames <= 8u && 8u % n_frames == 0u && n_waves % (8u / n_frames) == 0u) xcd_map = 1;
+        else if (n_frames % 8u == 0u) xcd_map = 2;
+    }
+    const uint32_t stage = lean_wave_lds_bytes(n_bins, records);
+    const uint32_t ph = (stage + 2048u) * 8u <= 160u * 1024u ? 2u : 1u;
+    const size_t lds2 = stage + ph * 1024u;
+    bool launched = false;
+#define SAR_LAUNCH_SPLIT_BATCH(RR, HH, PP)                                                                                        \
+    if (!launched && records == RR && hint_bytes == sizeof(HH) && ph == PP) {                                                      \
+        hipLaunchKernelGGL((k_iterate_split_batch<true, RR, 2u, HH, PP>), dim3(total), dim3(128), lds2, s, frames, n_frames, n_waves, xcd_map); \
+        launched = true;                                                                                                          \
+    }
+    SAR_FOR_EACH_SPLIT(SAR_LAUNCH_SPLIT_BATCH)
+#undef SAR_LAUNCH_SPLIT_BATCH
+    return launched ? 0 : 1;
+}
+
 int iterate_kernel_attributes() {
     // the staging buffers need more dynamic LDS than the 64 KiB default window
     hipError_t e = hipSuccess;
@@ -956,6 +1030,10 @@ int iterate_kernel_attributes() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_split<true, RR, 2u, HH, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SAR_FOR_EACH_SPLIT(SAR_ATTR_SPLIT)
 #undef SAR_ATTR_SPLIT
+#define SAR_ATTR_SPLIT_BATCH(RR, HH, PP) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_iterate_split_batch<true, RR, 2u, HH, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    SAR_FOR_EACH_SPLIT(SAR_ATTR_SPLIT_BATCH)
+#undef SAR_ATTR_SPLIT_BATCH
     return (int)e;
 }
 
@@ -979,10 +1057,14 @@ void launch_dead_jobs(const uint32_t* active, uint32_t n_jobs, uint64_t iters, u
     hipLaunchKernelGGL(k_dead_jobs, dim3(1), dim3(1), 0, s, active, n_jobs, iters, nan_count);
 }
 
-void launch_warmup(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* warm, uint32_t* joblist,
-                   uint32_t* active, unsigned long long* nan_count, uint32_t width, uint32_t* hint_range, hipStream_t s) {
-    hipLaunchKernelGGL(k_warmup, dim3((n_jobs + 255u) / 256u), dim3(256), 0, s, p, starts, n_jobs, iters, warm, joblist, active,
-                       nan_count, width, hint_range);
+void launch_warmup(const WarmArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_warmup, dim3((a.n_jobs + 255u) / 256u), dim3(256), 0, s, a);
+}
+void launch_warmup_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_jobs, hipStream_t s) {
+    hipLaunchKernelGGL(k_warmup_batch, dim3((n_jobs + 255u) / 256u, 1, n_frames), dim3(256), 0, s, frames);
+}
+void launch_batch_clear(const BatchFrame* frames, uint32_t n_frames, uint32_t seg_words, hipStream_t s) {
+    hipLaunchKernelGGL(k_batch_clear, dim3((seg_words + 255u) / 256u, n_frames), dim3(256), 0, s, frames);
 }
 
 }  // namespace sar

@@ -45,8 +45,15 @@ int launch_convert(const void* rgba16, int format, void* out, uint32_t npix, hip
 // returns the number of blocks = 12-double partial results written to `out`
 uint32_t launch_extent(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* out, hipStream_t s);
 void launch_starts_soa(const double* aos, double* soa, uint32_t m, hipStream_t s);
-void launch_warmup(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* warm, uint32_t* joblist,
-                   uint32_t* active, unsigned long long* nan_count, uint32_t width, uint32_t* hint_range, hipStream_t s);
+void launch_warmup(const WarmArgs& a, hipStream_t s);
+// batched launches (sar_batch.cpp): `frames` is a table of n_frames BatchFrame in device memory, the frame is blockIdx.z
+void launch_batch_clear(const BatchFrame* frames, uint32_t n_frames, uint32_t seg_words, hipStream_t s);
+void launch_warmup_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_jobs, hipStream_t s);
+int launch_iterate_split_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_waves, uint32_t n_bins, uint32_t records,
+                               uint32_t hint_bytes, bool xcd_aware, hipStream_t s);
+int launch_bin_accumulate_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_bins, uint32_t splits, uint32_t bin_shift,
+                                uint32_t threads, uint32_t records, uint32_t lists, hipStream_t s);
+void launch_fold_resolve_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t npix, hipStream_t s);
 void launch_dead_jobs(const uint32_t* active, uint32_t n_jobs, uint64_t iters, unsigned long long* nan_count, hipStream_t s);
 void launch_exch_export(const unsigned long long* key, uint32_t rank, void* out, uint32_t npix, hipStream_t s);
 void launch_exch_select(const uint32_t* count, const unsigned long long* key, const double* steps, uint32_t rank,

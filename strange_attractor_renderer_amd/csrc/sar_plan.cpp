@@ -45,7 +45,7 @@ namespace {
 
 // Records per chunk, bin geometry and the form of the iterate kernel. The job count is scaled by the share of jobs that
 // survived the previous launch's warm-up (solar-sail loses 38 % of its start points there).
-uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, uint32_t& shift, uint32_t& interleave, bool& split, uint64_t& resident_jobs) {
+uint32_t choose_chunk_records(sar_runtime* rt, uint64_t n_jobs, bool batched, uint32_t& shift, uint32_t& interleave, bool& split, uint64_t& resident_jobs) {
     shift = rt->bin_shift;
     interleave = rt->bin_interleave;
     if (rt->active_pending && hipEventQuery(rt->active_copied) == hipSuccess) {
@@ -61,7 +61,8 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, uint32_t& shift,
     // jobs are all resident at once (512 per CU). A launch of several rounds of workgroups desynchronises by itself —
     // workgroups of different rounds are in different phases — and the whole kernel is the faster one there (configs[3] on
     // one GPU, 8 rounds: 81.7 against 89.9 ms). Three pairs per SIMD are slower everywhere (profiles/dead_ends.md).
-    split = rt->split_waves == 2 || (rt->split_waves == 0 && busy <= 512u * cus);
+    // (a batched launch exists as wave pairs only; its caller keeps the frames' survivors near what the chip holds)
+    split = batched || rt->split_waves == 2 || (rt->split_waves == 0 && busy <= 512u * cus);
     if (split) want = 8;
     // jobs (dead ones included: they are launched and dropped by the warm-up) whose survivors the chip holds at once
     resident_jobs = static_cast<uint64_t>(64.0 * cus * want / (rt->survivor_fraction > 0.05 ? rt->survivor_fraction : 0.05));
@@ -99,9 +100,11 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint32_t n_jobs, uint32_t& shift,
 
 }  // namespace
 
-int sar::plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, LaunchPlan& pl) {
+int sar::plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, LaunchPlan& pl, uint32_t batch_frames) {
     uint32_t shift = 0, interleave = 0;
-    pl.R = choose_chunk_records(rt, n_jobs, shift, interleave, pl.split, pl.resident_jobs);
+    if (batch_frames == 0) batch_frames = 1;
+    // (a batched launch holds batch_frames x n_jobs jobs at once: that decides between the wave-pair and the whole kernel)
+    pl.R = choose_chunk_records(rt, static_cast<uint64_t>(n_jobs) * batch_frames, batch_frames > 1, shift, interleave, pl.split, pl.resident_jobs);
     pl.geo = bin_geometry(rt->npix, rt->block_threads, shift, rt->splits, pl.R, interleave);
     // which accumulate path: LDS-binned records (default) or one global atomic per visit
     pl.binned = (rt->bins_mode == 0 || rt->bins_mode == 3) && pl.geo.ok;
@@ -164,7 +167,7 @@ int sar::plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, ui
             // 128 KiB histograms: one workgroup per CU is resident, and with interleaved bins all of them carry the same
             // load — two rounds of workgroups over the chip, up to a few lists per lane group (measured, 2048^2: 4
             // workgroups per bin 0.85 ms, 8 or 16 1.2 ms)
-            cover = 512u / pl.geo.bins;
+            cover = (512u + pl.geo.bins * batch_frames - 1u) / (pl.geo.bins * batch_frames);  // (a batch: over all its frames)
             pl.splits = (pl.max_waves + 8u * groups - 1u) / (8u * groups);
         }
         if (pl.splits < cover) pl.splits = cover;

@@ -36,6 +36,19 @@ struct LaunchPlan {
     uint32_t max_waves = 0;             // waves of the largest launch chunk
     uint32_t arena_waves = 0;           // ... of which hold at least one job: only they own a slice of the record arena
 };
-int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, LaunchPlan& pl);
+// batch_frames > 1: the plan of ONE frame of a batched launch (sar_batch.cpp) — the form of the iterate kernel and the accumulate
+// grid are chosen for batch_frames x n_jobs jobs on the chip at once
+int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters, LaunchPlan& pl, uint32_t batch_frames = 1);
+
+// sar_render.cpp: the pieces of a render call that the batched launch (sar_batch.cpp) shares
+int ensure_scratch(sar_runtime* rt, uint32_t copies);
+int stage_starts(sar_runtime* rt, const LaunchPlan& pl, uint32_t n_jobs, const double* starts, bool on_device);
+int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl);
+void fill_iter_fold_args(const sar_config* cfg, sar_runtime* rt, const LaunchPlan& pl, IterArgs& ia, FoldArgs& fa);
+void fill_bin_iter_args(sar_runtime* rt, const sar_runtime* opt, const LaunchPlan& pl, const IterArgs& ia, BinIterArgs& ba, bool* shared_out);
+void fill_bin_acc_args(sar_runtime* rt, const LaunchPlan& pl, const BinIterArgs& ba, BinAccArgs& ca);
+WarmArgs warm_args(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* warm, uint32_t* joblist,
+                   uint32_t* active, uint32_t width, uint32_t* hint_range);
+void describe_launch(sar_runtime* rt, const LaunchPlan& pl, bool share, uint32_t batch_frames);
 
 }  // namespace sar

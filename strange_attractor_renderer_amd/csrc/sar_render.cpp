@@ -45,11 +45,9 @@ void sar::fill_ct_params(const sar_config& cfg, ColorTransformParams& ct) {
 }
 
 
-namespace {
-
 // the scratch the iterate / accumulate kernels write and k_fold_resolve folds (and clears): `copies` partial histograms
 // (one per accumulate workgroup of a bin; one on the atomic path) and one array of depth keys
-int ensure_scratch(sar_runtime* rt, uint32_t copies) {
+int sar::ensure_scratch(sar_runtime* rt, uint32_t copies) {
     if (rt->copies != copies || !rt->d_scratch_count) {
         if (rt->d_scratch_count) hipFree(rt->d_scratch_count);
         rt->d_scratch_count = nullptr;
@@ -68,7 +66,7 @@ int ensure_scratch(sar_runtime* rt, uint32_t copies) {
 
 // Start points into rt->d_starts, laid out as consecutive per-chunk SoA blocks x[m] y[m] z[m]; `starts` is the caller's
 // [n_jobs][3] array in host memory (through one pinned staging buffer) or already in device memory.
-int stage_starts(sar_runtime* rt, const LaunchPlan& pl, uint32_t n_jobs, const double* starts, bool on_device) {
+int sar::stage_starts(sar_runtime* rt, const LaunchPlan& pl, uint32_t n_jobs, const double* starts, bool on_device) {
     const size_t need = static_cast<size_t>(n_jobs) * 3;
     if (rt->starts_pending) {  // the previous call's upload still reads the staging buffer
         HIP_TRY(hipEventSynchronize(rt->starts_copied));
@@ -108,7 +106,7 @@ int stage_starts(sar_runtime* rt, const LaunchPlan& pl, uint32_t n_jobs, const d
 }
 
 // Device buffers of the binned path: record arena, list heads, depth hints, warm-up output, counters.
-int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
+int sar::ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
     {   // hipFuncSetAttribute is per device and function: once for every device a runtime lives on
         static std::mutex attr_mu;
         static bool attr_done[64] = {false};
@@ -168,14 +166,10 @@ int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
     return SAR_OK;
 }
 
-// One launch chunk of the binned path: warm-up + packing, iterate, accumulate, fold.
-// `first`: the first segment of these jobs (warm-up + packing); `carry`: more segments follow (keep the trajectory state).
-int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& ia, const FoldArgs& fa_in, bool first, bool carry,
-                        bool use_prefetch) {
-    FoldArgs fa = fa_in;
-    fa.seg_any = rt->d_seg_any;
+// The argument blocks of one launch of the binned path on `rt` (the launch options — hint sharing, hint tiles — are `opt`'s:
+// rt itself, or the leader of a batch).
+void sar::fill_bin_iter_args(sar_runtime* rt, const sar_runtime* opt, const LaunchPlan& pl, const IterArgs& ia, BinIterArgs& ba, bool* shared_out) {
     const uint32_t m = ia.n_jobs;
-    BinIterArgs ba;
     std::memset(&ba, 0, sizeof(ba));
     ba.it = ia;
     ba.map = pl.geo.map;
@@ -192,18 +186,103 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     // the XCDs share ONE array: an XCD then sees another's updates only when its own L2 drops the line — a stale hint lets
     // more visits through stage 1, never a wrong one — and the misses stay on chip (4096^2 share: 9.15 -> 8.85 ms; below
     // that size sharing costs: 2048^2 5.90 -> 6.05 ms).
-    const bool share = rt->hint_shared == 2 || (rt->hint_shared == 0 && static_cast<uint64_t>(rt->npix) * pl.hint_bytes * 8u > (200ull << 20));
+    const bool share = opt->hint_shared == 2 || (opt->hint_shared == 0 && static_cast<uint64_t>(rt->npix) * pl.hint_bytes * 8u > (200ull << 20));
     ba.hint_copy_mask = share ? 0u : 7u;
+    if (shared_out) *shared_out = share;
     // narrow hints of an image whose width is a power of two: 8 x 8 tiles per 128-byte line (HintTile); the permutation stays
     // inside blocks of eight rows, so the height must be a multiple of eight
     const bool pow2w = (rt->W & (rt->W - 1u)) == 0u && rt->W >= 8u && rt->H % 8u == 0u;
-    if (pl.hint_bytes == 2 && pow2w && rt->hint_tile != 1u) {
+    if (pl.hint_bytes == 2 && pow2w && opt->hint_tile != 1u) {
         uint32_t b = 0;
         while ((1u << b) < rt->W) ++b;
         ba.tile.shift1 = b - 3u;
         ba.tile.mask1 = 0x38u;
         ba.tile.mask2 = ((1u << (b + 3u)) - 1u) & ~7u;
     }
+}
+
+void sar::fill_bin_acc_args(sar_runtime* rt, const LaunchPlan& pl, const BinIterArgs& ba, BinAccArgs& ca) {
+    std::memset(&ca, 0, sizeof(ca));
+    ca.bin_shift = pl.geo.shift;
+    ca.n_bins = pl.geo.bins;
+    ca.chunks_per_wave = ba.chunks_per_wave;
+    ca.n_waves = ba.n_waves;
+    ca.npix = rt->npix;
+    ca.splits = pl.splits;
+    ca.arena = rt->d_arena;
+    ca.heads = rt->d_heads;
+    ca.scratch_count = rt->d_scratch_count;
+    ca.map = pl.geo.map;
+    ca.seg_any = rt->d_seg_any;
+}
+
+void sar::describe_launch(sar_runtime* rt, const LaunchPlan& pl, bool share, uint32_t batch_frames) {
+    char batch[32] = "";
+    if (batch_frames) std::snprintf(batch, sizeof(batch), " | batch of %u frames", batch_frames);
+    std::snprintf(rt->last_launch, sizeof(rt->last_launch),
+                  "%s R=%u bins=%ux%upx %s hints=%s pipe=%u | k_bin_accumulate splits=%u lists=%u counters=%s%s",
+                  pl.split ? "k_iterate_split" : "k_iterate_lean", pl.R, pl.geo.bins, 1u << pl.geo.shift, pl.geo.interleaved ? "interleaved" : "consecutive",
+                  pl.hint_bytes == 4 ? (share ? "f32/chip" : "f32") : (share ? "q16/chip" : "q16"), kDefaultDepthPipe, pl.splits, pl.acc_lists,
+                  pl.geo.shift == 16u ? "u16-packed" : "u32", batch);
+}
+
+// what every launch chunk of a render call on `rt` shares: the map, the image, the scratch and the persistent buffers
+void sar::fill_iter_fold_args(const sar_config* cfg, sar_runtime* rt, const LaunchPlan& pl, IterArgs& ia, FoldArgs& fa) {
+    std::memset(&ia, 0, sizeof(ia));
+    fill_map_params(*cfg, ia.p);
+    ia.width = rt->W;
+    ia.npix = rt->npix;
+    ia.ckpt_stride = pl.C;
+    ia.scratch_count = rt->d_scratch_count;
+    ia.scratch_key = rt->d_scratch_key;
+    ia.ckpt = rt->d_ckpt;
+
+    std::memset(&fa, 0, sizeof(fa));
+    fa.p = ia.p;
+    fill_ct_params(*cfg, fa.ct);
+    fa.npix = rt->npix;
+    fa.ckpt_stride = pl.C;
+    fa.copies = rt->copies;
+    fa.key_copies = 1;
+    fa.nan_count = pl.binned ? rt->d_nan_count : nullptr;
+    fa.count = rt->d_count;
+    fa.key = rt->d_key;
+    fa.steps = rt->d_steps;
+    fa.scratch_count = rt->d_scratch_count;
+    fa.scratch_key = rt->d_scratch_key;
+    fa.ckpt = rt->d_ckpt;
+    fa.scalars = rt->d_scalars;
+}
+
+sar::WarmArgs sar::warm_args(const sar::MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* warm, uint32_t* joblist,
+                             uint32_t* active, uint32_t width, uint32_t* hint_range) {
+    sar::WarmArgs w;
+    std::memset(&w, 0, sizeof(w));
+    w.p = p;
+    w.starts = starts;
+    w.n_jobs = n_jobs;
+    w.width = width;
+    w.iters = iters;
+    w.warm = warm;
+    w.joblist = joblist;
+    w.active = active;
+    w.nan_count = reinterpret_cast<unsigned long long*>(active + 2);
+    w.hint_range = hint_range;
+    return w;
+}
+
+namespace {
+
+// One launch chunk of the binned path: warm-up + packing, iterate, accumulate, fold.
+// `first`: the first segment of these jobs (warm-up + packing); `carry`: more segments follow (keep the trajectory state).
+int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& ia, const FoldArgs& fa_in, bool first, bool carry,
+                        bool use_prefetch) {
+    FoldArgs fa = fa_in;
+    fa.seg_any = rt->d_seg_any;
+    const uint32_t m = ia.n_jobs;
+    BinIterArgs ba;
+    bool share = false;
+    fill_bin_iter_args(rt, rt, pl, ia, ba, &share);
     ba.warm_out = carry ? rt->d_warm : nullptr;
     span_begin(rt, rt->warm_spans, rt->warm_used);
     const sar_runtime::Prefetch& pf = rt->pf;
@@ -239,8 +318,7 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
             measure = rt->d_hint_range;
             rt->hint_range_set = true;
         }
-        launch_warmup(ia.p, ia.starts, m, ia.iters, rt->d_warm, rt->d_joblist, rt->d_active,
-                      reinterpret_cast<unsigned long long*>(rt->d_active + 2), ia.width, measure, rt->stream);
+        launch_warmup(warm_args(ia.p, ia.starts, m, ia.iters, rt->d_warm, rt->d_joblist, rt->d_active, ia.width, measure), rt->stream);
     } else {
         launch_dead_jobs(rt->d_active, m, ia.iters, rt->d_nan_count, rt->stream);
     }
@@ -265,28 +343,13 @@ int launch_binned_chunk(sar_runtime* rt, const LaunchPlan& pl, const IterArgs& i
     HIP_TRY(hipGetLastError());
     span_end(rt, rt->iter_spans, rt->iter_used);
     ++rt->last_chunks;
-    std::snprintf(rt->last_launch, sizeof(rt->last_launch),
-                  "%s R=%u bins=%ux%upx %s hints=%s pipe=%u | k_bin_accumulate splits=%u lists=%u counters=%s",
-                  pl.split ? "k_iterate_split" : "k_iterate_lean", pl.R, pl.geo.bins, 1u << pl.geo.shift, pl.geo.interleaved ? "interleaved" : "consecutive",
-                  pl.hint_bytes == 4 ? (share ? "f32/chip" : "f32") : (share ? "q16/chip" : "q16"), kDefaultDepthPipe, pl.splits, pl.acc_lists,
-                  pl.geo.shift == 16u ? "u16-packed" : "u32");
+    describe_launch(rt, pl, share, 0);
     if (rt->iter_done) {  // an announced call's warm-up starts here, under this launch's accumulate and fold
         HIP_TRY(hipEventRecord(rt->iter_done, rt->stream));
         rt->iter_done_recorded = true;
     }
     BinAccArgs ca;
-    std::memset(&ca, 0, sizeof(ca));
-    ca.bin_shift = pl.geo.shift;
-    ca.n_bins = pl.geo.bins;
-    ca.chunks_per_wave = ba.chunks_per_wave;
-    ca.n_waves = ba.n_waves;
-    ca.npix = rt->npix;
-    ca.splits = pl.splits;
-    ca.arena = rt->d_arena;
-    ca.heads = rt->d_heads;
-    ca.scratch_count = rt->d_scratch_count;
-    ca.map = pl.geo.map;
-    ca.seg_any = rt->d_seg_any;
+    fill_bin_acc_args(rt, pl, ba, ca);
     span_begin(rt, rt->fold_spans, rt->fold_used);
     HIP_TRY(hipMemsetAsync(rt->d_seg_any, 0, (static_cast<size_t>(rt->npix) / 2048u + 1u) * sizeof(uint32_t), rt->stream));
     if (launch_bin_accumulate(ca, rt->acc_threads, pl.R, pl.acc_lists, rt->stream) != 0) {
@@ -350,8 +413,8 @@ int warmup_ahead(sar_runtime* rt, const sar::MapParams& p, const double* starts,
     if (!soa) launch_starts_soa(starts, rt->d_starts_alt, m, rt->side);
     HIP_TRY(hipMemsetAsync(rt->d_active_alt, 0, 4 * sizeof(uint32_t), rt->side));
     if (measure_range) HIP_TRY(hipMemsetAsync(rt->d_hint_range_alt, 0, 2 * sizeof(uint32_t), rt->side));
-    launch_warmup(pf.p, soa ? starts : rt->d_starts_alt, m, iters, rt->d_warm_alt, rt->d_joblist_alt, rt->d_active_alt,
-                  reinterpret_cast<unsigned long long*>(rt->d_active_alt + 2), rt->W, measure_range ? rt->d_hint_range_alt : nullptr, rt->side);
+    launch_warmup(warm_args(pf.p, soa ? starts : rt->d_starts_alt, m, iters, rt->d_warm_alt, rt->d_joblist_alt, rt->d_active_alt, rt->W,
+                            measure_range ? rt->d_hint_range_alt : nullptr), rt->side);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(rt->pf_done, rt->side));
     pf.valid = true;
@@ -390,31 +453,8 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
     if (pl.binned) SAR_TRY(ensure_binned_buffers(rt, pl));
 
     IterArgs ia;
-    std::memset(&ia, 0, sizeof(ia));
-    fill_map_params(*cfg, ia.p);
-    ia.width = rt->W;
-    ia.npix = rt->npix;
-    ia.ckpt_stride = pl.C;
-    ia.scratch_count = rt->d_scratch_count;
-    ia.scratch_key = rt->d_scratch_key;
-    ia.ckpt = rt->d_ckpt;
-
     FoldArgs fa;
-    std::memset(&fa, 0, sizeof(fa));
-    fa.p = ia.p;
-    fill_ct_params(*cfg, fa.ct);
-    fa.npix = rt->npix;
-    fa.ckpt_stride = pl.C;
-    fa.copies = rt->copies;
-    fa.key_copies = 1;
-    fa.nan_count = pl.binned ? rt->d_nan_count : nullptr;
-    fa.count = rt->d_count;
-    fa.key = rt->d_key;
-    fa.steps = rt->d_steps;
-    fa.scratch_count = rt->d_scratch_count;
-    fa.scratch_key = rt->d_scratch_key;
-    fa.ckpt = rt->d_ckpt;
-    fa.scalars = rt->d_scalars;
+    fill_iter_fold_args(cfg, rt, pl, ia, fa);
 
     bool chunk_ahead = false;
     if (pl.binned && n_seg == 1 && n_jobs > pl.chunk_jobs && !rt->side) {  // so that the first chunk's iterate kernel is already marked

@@ -250,6 +250,10 @@ int sar_runtime_free(sar_runtime* rt) {
     if (rt->d_active_alt) hipFree(rt->d_active_alt);
     if (rt->d_hint_range_alt) hipFree(rt->d_hint_range_alt);
     if (rt->d_starts_alt) hipFree(rt->d_starts_alt);
+    if (rt->d_batch) hipFree(rt->d_batch);
+    if (rt->h_batch) hipHostFree(rt->h_batch);
+    for (hipEvent_t e : rt->batch_copied) if (e) hipEventDestroy(e);
+    if (rt->batch_join) hipEventDestroy(rt->batch_join);
     if (rt->d_seg_any) hipFree(rt->d_seg_any);
     if (rt->h_active) hipHostFree(rt->h_active);
     if (rt->active_copied) hipEventDestroy(rt->active_copied);
@@ -710,6 +714,9 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "hint_shared")) {
         if (v > 2) { set_error("hint_shared must be 0, 1 or 2"); return SAR_ERR_INVALID; }
         rt->hint_shared = v;
+    } else if (!std::strcmp(name, "batch_xcd")) {
+        if (v > 1) { set_error("batch_xcd must be 0 (frames dealt to the XCDs) or 1 (every frame on all XCDs)"); return SAR_ERR_INVALID; }
+        rt->batch_xcd = v;
     } else if (!std::strcmp(name, "chunk_ahead")) {
         if (v > 2) { set_error("chunk_ahead must be 0, 1 or 2"); return SAR_ERR_INVALID; }
         rt->chunk_ahead = v;

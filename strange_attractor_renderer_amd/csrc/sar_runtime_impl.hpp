@@ -18,6 +18,7 @@ constexpr uint32_t kDefaultBlock = 256;
 // iterations between trajectory checkpoints: k_fold_resolve replays on average half a stride per new depth winner (32: the 4096^2
 // share -1.3 %, a sequence frame -2 %, 2048^2 -0.5 % against 64; 16 costs the iterate kernel more than the fold saves)
 constexpr uint32_t kDefaultCkptStride = 32;
+constexpr uint32_t kBatchRing = 8;               // page-locked copies of a batch's argument table in flight
 constexpr uint64_t kCkptBytesCap = 24ull << 30;  // checkpoint + record-arena scratch per launch chunk (HBM is 288 GB)
 
 }  // namespace sar
@@ -108,6 +109,17 @@ struct sar_runtime {
     void* d_rgba = nullptr;
     void* d_export = nullptr;  // converted image of sar_colorize_format (<= 6 bytes per pixel)
     float* d_ztmp = nullptr;
+
+    // batched launches (sar_batch.cpp). As the LEADER of a batch: the table of per-frame argument blocks in device memory and
+    // the page-locked ring it is uploaded from (entry k % kBatchRing is free again once batch_copied[k % kBatchRing] has fired).
+    // As any member: the event its own stream and the leader's stream meet through when they differ.
+    sar::BatchFrame* d_batch = nullptr;
+    sar::BatchFrame* h_batch = nullptr;
+    hipEvent_t batch_copied[sar::kBatchRing] = {};
+    uint64_t batch_next = 0;
+    hipEvent_t batch_join = nullptr;
+    uint32_t batches_launched = 0;   // statistic: batched launches this runtime led
+    uint32_t batch_xcd = 0;          // option: 1 = the frames of a batch are NOT dealt to the XCDs (every frame runs on all eight: A/B)
 
     // tuning
     uint32_t block_threads = sar::kDefaultBlock;

@@ -68,17 +68,29 @@ SETTLE = 1  # stream synchronisations a new runtime's first frames are waited fo
 
 
 class SequenceRenderer:
-    """What a `sequence` sweep keeps between frames: the job split of one ParallelRenderer, `lanes` runtimes (each with its
-    own stream) used in turn, and a ring of page-locked host images the converted frames are read back into. One object
-    can render several sweeps (`run`); `close` frees the device and page-locked memory."""
+    """What a `sequence` sweep keeps between frames: the job split of one ParallelRenderer, `lanes` groups of runtimes (each
+    group on its own stream) used in turn, and a ring of page-locked host images the converted frames are read back into.
+    A group renders a BATCH of consecutive frames per turn — `batch` frames through one set of launches
+    (sar_render_jobs_batch): 0 = as many as fill the chip (asked of the library before every batch, at most `max_batch`),
+    1 = a frame per launch. One object can render several sweeps (`run`); `close` frees the device and page-locked memory."""
 
     def __init__(self, config: "api.Config", *, units: int = 0, jobs_per_thread: int = 12, seed: int = 0, device: int = 0,
-                 image_format: int | None = None, ring: int = 0, lanes: int = 2):
+                 image_format: int | None = None, ring: int = 0, lanes: int = 2, batch: int = 0, max_batch: int = 4,
+                 device_ring: list | None = None):
+        """device_ring: device pointers of width*height*8-byte buffers — the frames are then left there as RGBA16 (colorize
+        only, src/lib.rs:841: what SURVEY 8(d)'s metric ends with) instead of being converted and read back; sinks receive None."""
         if lanes < 1:
             raise ValueError("lanes must be at least 1")
-        ring = ring or lanes + 2
+        if batch < 0 or max_batch < 1:
+            raise ValueError("batch must be >= 0 and max_batch >= 1")
+        self.max_batch = batch if batch else max_batch
+        ring = ring or (lanes + 1) * self.max_batch + 1
         if ring < lanes + 1:
             raise ValueError("ring must be at least lanes + 1")
+        # a frame keeps its host image until it is delivered, `lanes` batches after it was enqueued
+        self.max_batch = max(1, min(self.max_batch, ring // (lanes + 1)))
+        self.batch = batch
+        self.device_ring = list(device_ring) if device_ring else None
         self.config, self.seed, self.device, self.lanes, self.ring = config, seed, device, lanes, ring
         self.fmt = api._abi.SAR_FMT_RGBA16 if image_format is None else image_format
         renderer = api.ParallelRenderer(device=device, units=units, seed=seed)
@@ -88,14 +100,36 @@ class SequenceRenderer:
             renderer.shutdown()
         self.total_jobs = T * jobs_per_thread
         self.per_job = config.iterations // T // jobs_per_thread   # src/lib.rs:1058
-        self.rts: list = []
-        self.settle: dict = {}                                     # stream synchronisations done per runtime (see run)
+        self.groups: list = []                                     # per lane: its runtimes (the first one's stream is the group's)
+        self.settle: dict = {}                                     # stream synchronisations done per group (see run)
         self.images: list = []
         self.busy: list = []                                       # per host image: what its last consumer returned
+        self.next_slot = 0
+        self.frames_per_launch: list = []                          # statistic: the batch sizes of the last run
 
     def frame_config(self, angle: float) -> "api.Config":
         return self.config.replace(angle=angle, jobs_total=self.total_jobs, iterations=self.per_job * self.total_jobs,
                                    seed=self.seed)
+
+    def _group(self, g: int, n: int, cfg: "api.Config") -> list:
+        """The first n runtimes of lane g, all on the stream of the lane's first runtime."""
+        while len(self.groups) <= g:
+            self.groups.append([])
+        grp = self.groups[g]
+        while len(grp) < n:
+            rt = api.Runtime(cfg, device=self.device)
+            if grp:
+                rt.set_stream(grp[0].stream())
+            grp.append(rt)
+        return grp[:n]
+
+    def _batch_size(self, g: int, cfg: "api.Config", left: int) -> int:
+        f = self.batch
+        if f == 0:
+            grp = self.groups[g] if len(self.groups) > g and self.groups[g] else None
+            # the library counts the wave pairs the chip holds against the jobs that survived the last launch's warm-up
+            f = api.batch_frames(cfg, grp[0]) if grp else min(2, self.max_batch)
+        return max(1, min(f, self.max_batch, left))
 
     def run(self, todo: list[tuple[int, float, str]],
             sink: Callable[[int, str, np.ndarray], object] | None = None, zero_copy: bool = False) -> list[tuple[int, str, np.ndarray]]:
@@ -104,25 +138,29 @@ class SequenceRenderer:
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         out: list = []
+        self.frames_per_launch = []
         if not todo:
             return out
-        images, busy, rts, ring, lanes = self.images, self.busy, self.rts, self.ring, self.lanes
-        # the next frame's start points (~1 ms of host time per 2e5 jobs: as long as a frame renders) are drawn on a helper
-        # thread while the GPU works on the current frame (the ctypes call releases the GIL)
+        images, busy, ring, lanes = self.images, self.busy, self.ring, self.lanes
+        # the next batch's start points (~1 ms of host time per 2e5 jobs: as long as a frame renders) are drawn on a helper
+        # thread while the GPU works on the current one (the ctypes call releases the GIL)
         pool = ThreadPoolExecutor(max_workers=1)
-        draw = lambda k: api.start_points(frame_seed(self.seed, k), 0, self.total_jobs)  # noqa: E731
-        pending = pool.submit(draw, todo[0][0])
+        draw = lambda ks: [api.start_points(frame_seed(self.seed, k), 0, self.total_jobs) for k in ks]  # noqa: E731
 
-        def deliver(rt, slot: int, ticket: int, k: int, name: str):
-            if self.settle.get(id(rt), 0) < SETTLE:
+        def deliver(g: int, rt, slot: int, ticket: int, k: int, name: str):
+            if self.settle.get(g, 0) < SETTLE:
                 # Measured on ROCm 7.2, in a process that uses nothing but this library: the kernels of two freshly created
                 # streams do not overlap — as if they shared a hardware queue — until one of them has been synchronised
                 # ONCE while the other was busy (1.7 ms per frame for the first ~70 frames per runtime, 1.2 after; an event
                 # wait does not do it, a synchronise of the idle streams neither; with three streams two of them stay
-                # coupled until ~70 frames per runtime whatever is synchronised). So the first frame of every runtime is
+                # coupled until ~70 frames per runtime whatever is synchronised). So the first frame of every lane is
                 # waited for with a stream synchronise: one bubble of a frame or two at the start of a sweep.
                 rt.synchronize()
-                self.settle[id(rt)] = self.settle.get(id(rt), 0) + 1
+                self.settle[g] = self.settle.get(g, 0) + 1
+            if self.device_ring is not None:
+                if sink is not None:
+                    sink(k, name, None)
+                return
             api.wait_image(rt, ticket)
             if sink is not None:
                 busy[slot] = sink(k, name, images[slot].array if zero_copy else np.array(images[slot].array))
@@ -130,48 +168,73 @@ class SequenceRenderer:
                 out.append((k, name, np.array(images[slot].array)))
 
         try:
-            in_flight = deque()
-            for n, (k, angle, name) in enumerate(todo):
-                cfg = self.frame_config(angle)
-                if not images:
-                    images.extend(api.HostImage(cfg.c.width, cfg.c.height, self.fmt) for _ in range(ring))
-                    busy.extend([None] * ring)
-                if len(rts) < min(lanes, len(todo)):
-                    rts.append(api.Runtime(cfg, device=self.device))
-                rt = rts[n % len(rts)]
-                slot = n % ring
-                if hasattr(busy[slot], "result"):                 # the consumer of the frame that last used this image
-                    busy[slot].result()
-                busy[slot] = None
-                rt.reset()                                        # :950-951
+            in_flight = deque()                                   # batches: lists of (lane, runtime, slot, ticket, k, name)
+            pos, turn = 0, 0
+            cfg0 = self.frame_config(todo[0][1])
+            size = self._batch_size(0, cfg0, len(todo))
+            pending = pool.submit(draw, [k for k, _, _ in todo[:size]])
+            while pos < len(todo):
+                g = turn % lanes
+                part = todo[pos:pos + size]
+                pos += len(part)
+                cfgs = [self.frame_config(angle) for _, angle, _ in part]
+                rts = self._group(g, len(part), cfgs[0])
                 starts = pending.result()
-                if n + 1 < len(todo):
-                    pending = pool.submit(draw, todo[n + 1][0])
-                api.render_jobs(cfg, rt, starts)
-                ticket = api.colorize_format_async(cfg, rt, images[slot])  # :1080
-                in_flight.append((rt, slot, ticket, k, name))
-                if len(in_flight) > lanes:
-                    deliver(*in_flight.popleft())                 # frame n-lanes, while the GPU is busy with the later ones
+                if pos < len(todo):                               # the next batch: its size is the next lane's to say
+                    size = self._batch_size((turn + 1) % lanes, cfg0, len(todo) - pos)
+                    pending = pool.submit(draw, [k for k, _, _ in todo[pos:pos + size]])
+                for rt in rts:
+                    rt.reset()                                    # :950-951
+                if len(part) > 1:
+                    api.render_jobs_batch(cfgs, rts, starts)
+                else:
+                    api.render_jobs(cfgs[0], rts[0], starts[0])
+                self.frames_per_launch.append(len(part))
+                batch = []
+                for (k, _, name), cfg, rt in zip(part, cfgs, rts):
+                    slot = self.next_slot % ring
+                    self.next_slot += 1
+                    if self.device_ring is not None:
+                        api.colorize_device(cfg, rt, self.device_ring[slot % len(self.device_ring)])
+                        batch.append((g, rt, slot, 0, k, name))
+                        continue
+                    while len(images) <= slot:
+                        images.append(api.HostImage(cfg.c.width, cfg.c.height, self.fmt))
+                        busy.append(None)
+                    if hasattr(busy[slot], "result"):             # the consumer of the frame that last used this image
+                        busy[slot].result()
+                    busy[slot] = None
+                    ticket = api.colorize_format_async(cfg, rt, images[slot])  # :1080
+                    batch.append((g, rt, slot, ticket, k, name))
+                in_flight.append(batch)
+                turn += 1
+                if len(in_flight) > lanes:                        # the batch `lanes` back, while the GPU is busy with the later ones
+                    for fr in in_flight.popleft():
+                        deliver(*fr)
             while in_flight:
-                deliver(*in_flight.popleft())
+                for fr in in_flight.popleft():
+                    deliver(*fr)
             for i, b in enumerate(busy):
                 if hasattr(b, "result"):
                     b.result()
                 busy[i] = None
         finally:
             pool.shutdown(wait=True)
-            for rt in rts:                                        # also after an error: nothing may still write the images
-                rt.synchronize()
+            for grp in self.groups:                               # also after an error: nothing may still write the images
+                for rt in grp[:1]:
+                    rt.synchronize()
         return out
 
     def close(self):
-        for rt in self.rts:
-            rt.synchronize()
+        for grp in self.groups:
+            for rt in grp[:1]:
+                rt.synchronize()
         for im in self.images:
             im.close()
-        for rt in self.rts:
-            rt.close()
-        self.rts, self.images, self.busy, self.settle = [], [], [], {}
+        for grp in self.groups:
+            for rt in reversed(grp):                              # the group's stream belongs to its first runtime: freed last
+                rt.close()
+        self.groups, self.images, self.busy, self.settle = [], [], [], {}
 
     def __enter__(self):
         return self
@@ -184,7 +247,8 @@ def render_sequence(config: "api.Config", start: float, end: float, step: float,
                     jobs_per_thread: int = 12, seed: int = 0, rank: int = 0, world: int = 1, device: int = 0,
                     file_name: str = "attractor", image_format: int | None = None,
                     sink: Callable[[int, str, np.ndarray], object] | None = None,
-                    ring: int = 0, lanes: int = 2, zero_copy: bool = False) -> list[tuple[int, str, np.ndarray]]:
+                    ring: int = 0, lanes: int = 2, zero_copy: bool = False, batch: int = 0,
+                    max_batch: int = 4) -> list[tuple[int, str, np.ndarray]]:
     """Renders this rank's frames of the sweep (frame k belongs to rank k % world; no collective is needed).
     Returns [(frame index, file name, image)] unless `sink` consumes the frames. The image is RGBA16, or — with
     `image_format` (SAR_FMT_*) — the CLI's converted format, converted on the device before the read-back.
@@ -199,12 +263,15 @@ def render_sequence(config: "api.Config", start: float, end: float, step: float,
     recycled). With `zero_copy` it receives a VIEW of one of the `ring` page-locked images instead: frame k + ring's
     read-back is enqueued before frame k + ring - lanes is delivered, so the view stays valid for `ring - lanes - 1` further
     deliveries (ONE with the default ring of lanes + 2) — or, when the sink returns an object with `.result()` (a Future of
-    its consumer), until that has returned, which the loop waits for before it reuses the image. ring 0 = lanes + 2."""
+    its consumer), until that has returned, which the loop waits for before it reuses the image. `batch` consecutive frames go
+    through ONE set of launches (sar_render_jobs_batch; 0 = as many as fill the chip, at most `max_batch`; 1 = a frame per
+    launch) — a frame of 65 536 jobs fills a third of an MI355X — and a lane's turn is then a batch. ring 0 = (lanes + 1) *
+    max_batch + 1; a smaller ring caps the batch at ring // (lanes + 1)."""
     todo = [(k, a, f) for (k, a, f) in frames(start, end, step, file_name) if k % world == rank]
     if not todo:
         return []
     with SequenceRenderer(config, units=units, jobs_per_thread=jobs_per_thread, seed=seed, device=device,
-                          image_format=image_format, ring=ring, lanes=lanes) as seq:
+                          image_format=image_format, ring=ring, lanes=lanes, batch=batch, max_batch=max_batch) as seq:
         return seq.run(todo, sink, zero_copy)
 
 
@@ -231,6 +298,7 @@ def render_sequence_to_files(config: "api.Config", start: float, end: float, ste
             pending.append(f)
             return f                                  # the page-locked image is reused only after its file is written
 
-        kw.setdefault("ring", max(1, encoders) + kw.get("lanes", 2) + 1)
+        lanes_ = kw.get("lanes", 2)
+        kw.setdefault("ring", max(1, encoders) + (lanes_ + 1) * (kw.get("batch", 0) or kw.get("max_batch", 4)) + 1)
         render_sequence(config, start, end, step, file_name=file_name, image_format=fmt, sink=sink, zero_copy=True, **kw)  # the encoder's Future guards the view
         return [f.result() for f in pending]

@@ -1,0 +1,211 @@
+"""GPU: F frames of a sweep through ONE set of launches (sar_render_jobs_batch, BASELINE configs[4]).
+
+The reference's frame loop (src/bin/main.rs:493-517) resets (src/lib.rs:950-951) and renders frame after frame; the batched
+launch lets F consecutive frames share the chip. Its contract is "frame i == sar_render_jobs(cfgs[i], rts[i], starts[i])":
+every test here holds the batched frames to the per-frame renders AND to the CPU oracle, bit for bit (count, max, zbuf,
+steps, image).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from strange_attractor_renderer_amd.sequence import frame_seed
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view({4: np.uint32, 8: np.uint64}[a.dtype.itemsize])
+
+
+def _frames(sar, preset, kind, n_frames, width, height, jobs, n, seed, first=0):
+    cfgs, starts = [], []
+    for k in range(first, first + n_frames):
+        cfgs.append(getattr(sar.Config, preset)(iterations=jobs * n, width=width, height=height, jobs_total=jobs, render_kind=kind,
+                                                scale=1.0, transparent=0, angle=k * math.pi / 180.0 * 7.0, seed=seed))
+        starts.append(sar.start_points(frame_seed(seed, k), 0, jobs))
+    return cfgs, starts
+
+
+def _state(sar, cfg, rt):
+    return rt.count(), rt.max(), rt.zbuf(), rt.steps(), sar.colorize(cfg, rt)
+
+
+def _assert_same(a, b, what):
+    assert np.array_equal(a[0], b[0]), f"{what}: count differs"
+    assert a[1] == b[1], f"{what}: max differs"
+    assert np.array_equal(_bits(a[2]), _bits(b[2])), f"{what}: zbuf differs"
+    assert np.array_equal(_bits(a[3]), _bits(b[3])), f"{what}: steps differs"
+    assert np.array_equal(a[4], b[4]), f"{what}: image differs"
+
+
+def _oracle_state(oracle, cfg, starts, n, ort=None):
+    ort = ort or oracle.Runtime(cfg.c.width, cfg.c.height)
+    oracle.render_jobs(cfg.c, ort, starts, n)   # (copies: the arrays are views of the oracle runtime's memory)
+    return ort, (ort.count.copy(), ort.max, ort.zbuf.copy(), ort.steps.copy(), oracle.colorize(cfg.c, ort))
+
+
+@pytest.mark.parametrize("preset,kind", [("solar_sail", 0), ("solar_sail", 1), ("poisson_saturne", 0)])
+@pytest.mark.parametrize("shared_stream", [False, True])
+def test_batched_sweep_equals_per_frame_renders_and_oracle(sar, oracle, gpu, preset, kind, shared_stream):
+    F, W, H, jobs, n = 6, 600, 500, 4096, 300
+    cfgs, starts = _frames(sar, preset, kind, F, W, H, jobs, n, seed=11)
+    rts = [sar.Runtime(c) for c in cfgs]
+    if shared_stream:
+        for rt in rts[1:]:
+            rt.set_stream(rts[0].stream())
+    sar.render_jobs_batch(cfgs, rts, starts)
+    assert "batch of 6 frames" in rts[0].describe_last_launch() and "k_iterate_split" in rts[3].describe_last_launch()
+    differ = 0
+    for i, (cfg, rt, st) in enumerate(zip(cfgs, rts, starts)):
+        got = _state(sar, cfg, rt)
+        one = sar.Runtime(cfg)
+        sar.render_jobs(cfg, one, st)
+        assert "batch" not in one.describe_last_launch()
+        _assert_same(got, _state(sar, cfg, one), f"frame {i} vs its own render call")
+        one.close()
+        _, want = _oracle_state(oracle, cfg, st, n)
+        _assert_same(got, want, f"frame {i} vs the oracle")
+        differ += int(i > 0 and not np.array_equal(got[0], first[0]))
+        first = got if i == 0 else first
+    assert differ == F - 1                                   # every frame has its own view and start points
+    for rt in reversed(rts):
+        rt.close()
+
+
+def test_batches_accumulate_on_unreset_runtimes_and_after_reset_with_narrow_hints(sar, oracle, gpu):
+    """`render` continues an un-reset runtime (src/lib.rs:742-744): a second batch on the same runtimes adds to the first; a
+    reset starts over. With 16-bit depth hints the first warm-up after a reset measures the depth range (per frame)."""
+    F, W, H, jobs, n = 3, 512, 512, 2048, 400
+    cfgs, starts = _frames(sar, "poisson_saturne", 0, F, W, H, jobs, n, seed=5)
+    cfgs2, starts2 = _frames(sar, "poisson_saturne", 0, F, W, H, jobs, n, seed=6, first=10)
+    rts = [sar.Runtime(c) for c in cfgs]
+    rts[0].set_option("hint_bits", 16)                      # the launch options are the leader's
+    sar.render_jobs_batch(cfgs, rts, starts)
+    assert "hints=q16" in rts[0].describe_last_launch() and "batch of 3" in rts[2].describe_last_launch()
+    sar.render_jobs_batch(cfgs2, rts, starts2)
+    for i in range(F):
+        ort, _ = _oracle_state(oracle, cfgs[i], starts[i], n)
+        _, want = _oracle_state(oracle, cfgs2[i], starts2[i], n, ort)
+        _assert_same(_state(sar, cfgs2[i], rts[i]), want, f"frame {i}, two batches on an un-reset runtime")
+    for rt in rts:
+        rt.reset()
+    sar.render_jobs_batch(cfgs2, rts, starts2)
+    for i in range(F):
+        _, want = _oracle_state(oracle, cfgs2[i], starts2[i], n)
+        _assert_same(_state(sar, cfgs2[i], rts[i]), want, f"frame {i} after a reset")
+    for rt in reversed(rts):
+        rt.close()
+
+
+def test_frames_that_cannot_share_a_launch_run_one_after_the_other(sar, oracle, gpu):
+    """Another job count, one frame, more frames than a table holds, a frame that needs several launch chunks: same results."""
+    W, H, n = 256, 192, 200
+    cfgs, starts = _frames(sar, "solar_sail", 0, 3, W, H, 1024, n, seed=2)
+    odd = cfgs[1].replace(jobs_total=512, iterations=512 * n)
+    cfgs[1], starts[1] = odd, starts[1][:512]
+    rts = [sar.Runtime(c) for c in cfgs]
+    sar.render_jobs_batch(cfgs, rts, starts)
+    assert "batch" not in rts[0].describe_last_launch()
+    for i in range(3):
+        _, want = _oracle_state(oracle, cfgs[i], starts[i], n)
+        _assert_same(_state(sar, cfgs[i], rts[i]), want, f"mixed frame {i}")
+    rts[0].reset()
+    sar.render_jobs_batch(cfgs[:1], rts[:1], starts[:1])
+    _assert_same(_state(sar, cfgs[0], rts[0]), _oracle_state(oracle, cfgs[0], starts[0], n)[1], "a batch of one")
+    # a frame cut into launch chunks (test hook) is not batched
+    for rt in rts:
+        rt.reset()
+    cfgs, starts = _frames(sar, "solar_sail", 0, 3, W, H, 1024, n, seed=2)
+    rts[0].set_option("debug_chunk_jobs", 256)
+    sar.render_jobs_batch(cfgs, rts, starts)
+    assert "batch" not in rts[0].describe_last_launch()
+    for i in range(3):
+        _assert_same(_state(sar, cfgs[i], rts[i]), _oracle_state(oracle, cfgs[i], starts[i], n)[1], f"chunked frame {i}")
+    for rt in rts:
+        rt.close()
+    # 19 frames: a table of 16 and a table of 3
+    cfgs, starts = _frames(sar, "poisson_saturne", 0, 19, 128, 128, 256, 100, seed=8)
+    rts = [sar.Runtime(c) for c in cfgs]
+    sar.render_jobs_batch(cfgs, rts, starts)
+    assert "batch of 16 frames" in rts[0].describe_last_launch() and "batch of 3 frames" in rts[18].describe_last_launch()
+    for i in (0, 7, 15, 16, 18):
+        _assert_same(_state(sar, cfgs[i], rts[i]), _oracle_state(oracle, cfgs[i], starts[i], 100)[1], f"frame {i} of 19")
+    with pytest.raises(sar.SarError):
+        sar.render_jobs_batch(cfgs[:2], [rts[0], sar.Runtime(cfgs[0].replace(width=64, height=64))], starts[:2])
+    for rt in rts:
+        rt.close()
+
+
+def test_drawn_start_points_follow_each_runtimes_stream(sar, oracle, gpu):
+    """starts == None: frame i draws from rts[i]'s own stream, as sar_render_jobs does (src/lib.rs:748)."""
+    F, jobs, n = 3, 512, 150
+    cfgs = [sar.Config.poisson_saturne(iterations=jobs * n, width=200, height=160, jobs_total=jobs, seed=40 + i, angle=0.1 * i,
+                                       transparent=0) for i in range(F)]
+    rts = [sar.Runtime(c) for c in cfgs]
+    sar.render_jobs_batch(cfgs, rts, None)
+    for i in range(F):
+        _, want = _oracle_state(oracle, cfgs[i], oracle.start_points(40 + i, 0, jobs), n)
+        _assert_same(_state(sar, cfgs[i], rts[i]), want, f"frame {i}, drawn points")
+    for rt in rts:
+        rt.close()
+
+
+def test_c5_frames_36_to_38_batched_at_full_size(sar, oracle, gpu):
+    """BASELINE configs[4] at full size through the batched path: frames 36..38 of the solar-sail sweep in one set of launches;
+    frame 37 is the committed `c5_frame37` case — oracle (threaded, identical bits) and frozen checksums."""
+    import json
+    import os
+    import fullsize_cases as FC
+    ocfg, starts37, n = FC.build_case("c5_frame37", oracle)
+    jobs = starts37.shape[0]
+    cfgs, starts = [], []
+    for k in (36, 37, 38):
+        c = sar.Config(oracle.copy_config(ocfg)).replace(angle=k * math.pi / 180.0)
+        cfgs.append(c)
+        starts.append(sar.start_points(frame_seed(0, k), 0, jobs))
+    assert np.array_equal(starts[1], starts37)
+    rts = [sar.Runtime(c) for c in cfgs]
+    for rt in rts[1:]:
+        rt.set_stream(rts[0].stream())
+    sar.render_jobs_batch(cfgs, rts, starts)
+    assert "batch of 3 frames" in rts[1].describe_last_launch()
+    cnt, mx, z, st, img = _state(sar, cfgs[1], rts[1])
+    ort = oracle.Runtime(ocfg.width, ocfg.height)
+    oracle.render_jobs_mt(ocfg, ort, starts37, n)
+    _assert_same((cnt, mx, z, st, img), (ort.count, ort.max, ort.zbuf, ort.steps, oracle.colorize(ocfg, ort)), "c5 frame 37, batched")
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fullsize_checksums.json")))["c5_frame37"]
+    got = {"max": mx, "count_sum": int(cnt.sum(dtype=np.uint64)), "touched": int((cnt > 0).sum()),
+           "count_fnv": f"{oracle.fnv1a64(cnt):016x}", "zbuf_fnv": f"{oracle.fnv1a64(z):016x}",
+           "steps_fnv": f"{oracle.fnv1a64(st):016x}", "rgba_fnv": f"{oracle.fnv1a64(img):016x}"}
+    assert got == {k: g[k] for k in got}
+    # the neighbours are other frames, and the library's advice for such a frame is more than one
+    assert not np.array_equal(rts[0].count(), cnt) and not np.array_equal(rts[2].count(), cnt)
+    assert 1 <= sar.batch_frames(cfgs[0], rts[0]) <= 16
+    for rt in reversed(rts):
+        rt.close()
+
+
+@pytest.mark.parametrize("batch,lanes", [(0, 2), (3, 1), (2, 2), (1, 2)])
+def test_sequence_sweep_in_batches_equals_frame_per_launch(sar, oracle, gpu, batch, lanes):
+    """render_sequence with batches of frames per lane turn == the frame-per-launch sweep == the oracle, frame by frame."""
+    from strange_attractor_renderer_amd.sequence import SequenceRenderer, frames, render_sequence
+    cfg = sar.Config.solar_sail(iterations=600_000, width=320, height=240, scale=1.0, transparent=0)
+    kw = dict(units=256, jobs_per_thread=4, seed=21)
+    want = render_sequence(cfg, 0.0, 11.0, 1.0, batch=1, lanes=1, **kw)
+    got = render_sequence(cfg, 0.0, 11.0, 1.0, batch=batch, lanes=lanes, **kw)
+    assert [k for k, _, _ in got] == list(range(11))
+    for (k, name, img), (_, wname, w) in zip(got, want):
+        assert name == wname
+        np.testing.assert_array_equal(img, w)
+    n = 600_000 // 256 // 4
+    for k in (0, 5, 10):
+        c = cfg.replace(angle=k * math.pi / 180.0, jobs_total=1024, iterations=n * 1024)
+        _, o = _oracle_state(oracle, c, oracle.start_points(frame_seed(21, k), 0, 1024), n)
+        np.testing.assert_array_equal(got[k][2], o[4])
+    with SequenceRenderer(cfg, lanes=lanes, batch=batch, **kw) as seq:
+        seq.run(frames(0.0, 11.0, 1.0))
+        sizes = seq.frames_per_launch
+    assert sum(sizes) == 11 and (batch == 0 or max(sizes) == batch)
