@@ -209,7 +209,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="--config c5: groups of runtimes (streams) per GPU the frames are rendered on in turn")
     ap.add_argument("--batch", type=int, default=0, help="--config c5: frames per set of launches (sar_render_jobs_batch); 0 = as many "
                     "as fill the chip (the library's advice, at most --max-batch), 1 = a frame per launch")
-    ap.add_argument("--max-batch", type=int, default=4)
+    ap.add_argument("--max-batch", type=int, default=16)
+    ap.add_argument("--rt-opt", action="append", default=[], help="--config c5: name=value runtime option (sar_runtime_set_option) of every runtime (A/B)")
     ap.add_argument("--c5-only", default=None, choices=["readback", "hbm"], help="--config c5: only one of the two sweeps (profiling)")
     ap.add_argument("--config", default=None, choices=["c2", "c4", "c5"], help="c2: BASELINE configs[1], weak scaling (default); "
                     "c4: BASELINE configs[3] (1e10 iterations, 4096^2, 1048576 jobs sharded over the ranks), strong scaling. "
@@ -327,7 +328,8 @@ def main():
             return el, sizes, launch
 
         # the runtimes and the page-locked images live as long as the CLI's sweep does: made once, outside the timed frames
-        common = dict(units=units, jobs_per_thread=jpt, seed=4, device=local_rank, lanes=a.lanes, batch=a.batch, max_batch=a.max_batch)
+        common = dict(units=units, jobs_per_thread=jpt, seed=4, device=local_rank, lanes=a.lanes, batch=a.batch, max_batch=a.max_batch,
+                      options={o.split("=")[0]: int(o.split("=")[1]) for o in a.rt_opt})
         if a.c5_only == "hbm":
             elapsed, sizes, launch = float("nan"), [], ""
         else:

@@ -133,6 +133,8 @@ extern "C" {
     pub fn sar_render_jobs_batch(n_frames: u32, cfgs: *const *const SarConfig, rts: *const *mut SarRuntime,
                                  starts_xyz_host: *const *const f64) -> c_int;
     pub fn sar_runtime_batch_frames(cfg: *const SarConfig, rt: *mut SarRuntime, out_frames: *mut u32) -> c_int;
+    pub fn sar_runtime_get_copy_stream(rt: *mut SarRuntime, hip_stream_out: *mut *mut c_void) -> c_int;
+    pub fn sar_runtime_set_copy_stream(rt: *mut SarRuntime, hip_stream: *mut c_void) -> c_int;
     pub fn sar_colorize_device(cfg: *const SarConfig, rt: *mut SarRuntime, rgba_out_dev: *mut c_void) -> c_int;
     pub fn sar_runtime_describe_last_launch(rt: *const SarRuntime, out: *mut c_char, cap: usize) -> c_int;
 

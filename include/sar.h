@@ -155,6 +155,11 @@ int sar_runtime_dims(const sar_runtime* rt, uint32_t* width, uint32_t* height);
 /* Use an existing hipStream_t (passed as void*) instead of the runtime's own stream. */
 int sar_runtime_set_stream(sar_runtime* rt, void* hip_stream);
 int sar_runtime_get_stream(const sar_runtime* rt, void** hip_stream_out);
+/* The stream the read-backs of sar_colorize_format_async run on (made on first use). Runtimes that share a launch stream —
+ * the frames of a batch — should share this one too (set it on the others; whoever made it must outlive them): a process
+ * has few hardware queues, and every further stream shares one with somebody's kernels. */
+int sar_runtime_get_copy_stream(sar_runtime* rt, void** hip_stream_out);
+int sar_runtime_set_copy_stream(sar_runtime* rt, void* hip_stream);
 
 /* ---- render (src/lib.rs:747-838) ------------------------------------------------------------------ */
 /* Exactly `render`: ONE trajectory of cfg->iterations counted iterations after a start point drawn
@@ -193,8 +198,10 @@ int sar_render_job_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t
  */
 int sar_render_jobs_batch(uint32_t n_frames, const sar_config* const* cfgs, sar_runtime* const* rts,
                           const double* const* starts_xyz_host);
-/* How many frames like cfg fill the chip (eight wave pairs per CU; a frame takes one per 64 jobs that survive the warm-up,
- * from the survivor share of this runtime's last launch): the n_frames to call sar_render_jobs_batch with. 1..16. */
+/* How many frames like cfg to render per batch: a multiple of eight (every XCD then runs its own frames, one after the other;
+ * sar_render_jobs_batch also deals 2 or 4 frames to the XCDs, any other number runs frame after frame on all of them), the
+ * smallest whose last round of equally long wave pairs fills the XCD — eight pairs per CU, a frame takes one per 64 jobs that
+ * survive the warm-up (the survivor share of this runtime's last launch). 8..32. */
 int sar_runtime_batch_frames(const sar_config* cfg, sar_runtime* rt, uint32_t* out_frames);
 
 /* Announces the NEXT sar_render_job_range_device call on this runtime — these start points, job count and iterations per

@@ -118,6 +118,8 @@ PROTOTYPES = {
     "sar_runtime_dims": (C.c_int, [_vp, _P(C.c_uint32), _P(C.c_uint32)]),
     "sar_runtime_set_stream": (C.c_int, [_vp, _vp]),
     "sar_runtime_get_stream": (C.c_int, [_vp, _P(_vp)]),
+    "sar_runtime_get_copy_stream": (C.c_int, [_vp, _P(_vp)]),
+    "sar_runtime_set_copy_stream": (C.c_int, [_vp, _vp]),
     "sar_render": (C.c_int, [_cfg_p, _vp]),
     "sar_render_jobs": (C.c_int, [_cfg_p, _vp, _P(C.c_double)]),
     "sar_render_job_range": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint64, _P(C.c_double)]),

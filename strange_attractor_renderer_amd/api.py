@@ -259,6 +259,19 @@ class Runtime:
     def set_stream(self, stream_ptr: int):
         _check(_lib().sar_runtime_set_stream(self._h, C.c_void_p(stream_ptr)), "sar_runtime_set_stream")
 
+    def copy_stream(self) -> int:
+        s = C.c_void_p()
+        _check(_lib().sar_runtime_get_copy_stream(self._h, C.byref(s)), "sar_runtime_get_copy_stream")
+        return int(s.value or 0)
+
+    def set_copy_stream(self, stream_ptr: int):
+        _check(_lib().sar_runtime_set_copy_stream(self._h, C.c_void_p(stream_ptr)), "sar_runtime_set_copy_stream")
+
+    def share_streams(self, leader: "Runtime"):
+        """This runtime enqueues where `leader` does (launch stream and read-back stream): the frames of one batch."""
+        self.set_stream(leader.stream())
+        self.set_copy_stream(leader.copy_stream())
+
     # ---- multi-GPU exchange over caller-provided device buffers ------------------------------------
     def exchange_export(self, rank: int, key_i64_dev_ptr: int):
         _check(_lib().sar_runtime_exchange_export(self._h, rank, C.c_void_p(key_i64_dev_ptr)),

@@ -6,7 +6,9 @@
 // chip: workgroup -> frame (blockIdx.z) -> that frame's argument block (BatchFrame) in a table in device memory. Every
 // frame's buffers are the ones its Runtime already owns, every kernel body is the single-frame body, so the result is what F
 // sar_render_jobs calls leave, bit for bit. Host logic only.
+#include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "sar_plan.hpp"
@@ -14,6 +16,17 @@
 using namespace sar;
 
 namespace {
+
+// The iterate kernels of the batches of one device run ONE AFTER THE OTHER, whatever streams they are on: a batched launch
+// fills every CU's LDS, so two of them never share a CU anyway — but left to themselves two lanes of batches fall into step
+// (both iterate kernels interleaved workgroup by workgroup, then both tails at once: 0.75 ms per frame of configs[4]) as
+// often as out of step (one lane's accumulate / fold / colorize / reset / warm-up under the other's iterate kernel: 0.6).
+// One event per device, waited for before a batch's iterate kernel and recorded behind it, keeps them out of step.
+struct IterateChain {
+    std::mutex mu;
+    hipEvent_t done = nullptr;
+    bool recorded = false;
+} g_chain[64];
 
 int sequential(uint32_t n_frames, const sar_config* const* cfgs, sar_runtime* const* rts, const double* const* starts) {
     for (uint32_t i = 0; i < n_frames; ++i) SAR_TRY(sar_render_jobs(cfgs[i], rts[i], starts ? starts[i] : nullptr));
@@ -57,6 +70,28 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
         ~Restore() { for (uint32_t i = 0; i < F; ++i) rts[i]->stream = own[i]; }
     } restore{F, rts, own};
     for (uint32_t i = 0; i < F; ++i) rts[i]->stream = lead->stream;
+    // A preset that loses jobs in the warm-up (solar-sail: 38 %, all within the first ~100 iterations) warms up in two phases:
+    // kFirstPhase iterations, the survivors packed, the rest on full waves. (A launch of one frame runs one wave per SIMD and gains
+    // nothing from fewer waves; a batch keeps the vector units busy, and 38 % fewer waves are 33 % less warm-up time.)
+    constexpr uint32_t kFirstPhase = 160;
+    const bool two_phase = lead->batch_warm == 2u || (lead->batch_warm == 0u && lead->survivor_fraction < 0.9);
+    // start points: 0 = read in place by the (one-phase) warm-up kernel — a thousand iterations hide 1.5 MB per frame over PCIe —
+    // or, before a first phase too short for that, fetched by a kernel of a few waves; 1 / 2 = copied on the upload / launch
+    // stream; 3 = in place whatever the warm-up
+    const uint32_t starts_mode = lead->batch_starts;
+    const bool fetch = starts_mode == 0u && two_phase;
+    const bool in_place = (starts_mode == 0u && !two_phase) || starts_mode == 3u;
+    if (starts_mode == 1u) {
+        if (!lead->upload_stream) HIP_TRY(hipStreamCreateWithFlags(&lead->upload_stream, hipStreamNonBlocking));
+        for (uint32_t i = 0; i < F; ++i) {
+            sar_runtime* rt = rts[i];
+            if (!rt->starts_consumed) HIP_TRY(hipEventCreateWithFlags(&rt->starts_consumed, hipEventDisableTiming));
+            if (!rt->starts_consumed_recorded) {  // its last render was not a batch: whatever its stream holds comes first
+                HIP_TRY(hipEventRecord(rt->starts_consumed, own[i]));
+                rt->starts_consumed_recorded = true;
+            }
+        }
+    }
 
     if (!lead->d_batch) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&lead->d_batch), sizeof(BatchFrame) * kMaxBatchFrames));
@@ -67,6 +102,11 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
     if (lead->batch_next >= kBatchRing) HIP_TRY(hipEventSynchronize(lead->batch_copied[ring]));  // (eight batches back: long done)
     BatchFrame* table = lead->h_batch + static_cast<size_t>(ring) * kMaxBatchFrames;
 
+    // how the iterate kernel deals the frames to the XCDs; a frame on one or two XCDs of its own keeps ONE array of depth hints
+    // (a frame on every XCD keeps one per XCD, as a single-frame launch does)
+    const uint32_t n_waves = static_cast<uint32_t>(((n_jobs + pl.block - 1) / pl.block) * (pl.block / 64u));
+    const uint32_t xcd_map = lead->batch_xcd == 1u ? 0u : batch_xcd_map(F, n_waves);
+    const bool one_hint_array = xcd_map == 2u || (xcd_map == 1u && F >= 4u);
     std::vector<double> drawn;
     bool share = false;
     for (uint32_t i = 0; i < F; ++i) {
@@ -84,7 +124,7 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
             st = drawn.data();
         }
         SAR_TRY(ensure_scratch(rt, pl.splits));
-        SAR_TRY(stage_starts(rt, pl, n_jobs, st, false));
+        SAR_TRY(stage_starts(rt, pl, n_jobs, st, false, starts_mode == 1u ? lead->upload_stream : nullptr, in_place || fetch));
         SAR_TRY(grow_device(rt->d_ckpt, rt->ckpt_cap, static_cast<size_t>(pl.n_ckpt) * 3 * pl.chunk_jobs));
         SAR_TRY(ensure_binned_buffers(rt, pl));
 
@@ -94,11 +134,11 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
         fill_iter_fold_args(cfgs[i], rt, pl, ia, f.fold);
         ia.n_jobs = n_jobs;
         ia.iters = iters;
-        ia.starts = rt->d_starts;
+        ia.starts = in_place ? rt->h_starts : rt->d_starts;  // (page-locked host memory is device-visible at its own address)
         f.fold.n_jobs = n_jobs;
         f.fold.iters = iters;
         f.fold.seg_any = rt->d_seg_any;
-        fill_bin_iter_args(rt, lead, pl, ia, f.it, &share);
+        fill_bin_iter_args(rt, lead, pl, ia, f.it, &share, one_hint_array);
         // narrow hints: the first warm-up after the hints were cleared also measures the depth range they quantise
         uint32_t* measure = nullptr;
         if (pl.hint_bytes == 2 && !rt->hint_range_set) {
@@ -107,6 +147,27 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
             f.clear_hint_range = 1u;
         }
         f.warm = warm_args(ia.p, ia.starts, n_jobs, iters, rt->d_warm, rt->d_joblist, rt->d_active, ia.width, measure);
+        if (two_phase) {
+            if (n_jobs > rt->warm_alt_cap) {  // the second set of warm-up buffers (an announced call's otherwise): the first phase's output
+                if (rt->side) HIP_TRY(hipStreamSynchronize(rt->side));
+                HIP_TRY(hipStreamSynchronize(lead->stream));
+                if (rt->d_warm_alt) hipFree(rt->d_warm_alt);
+                if (rt->d_joblist_alt) hipFree(rt->d_joblist_alt);
+                rt->d_warm_alt = nullptr; rt->d_joblist_alt = nullptr;
+                rt->warm_alt_cap = 0;
+                HIP_TRY(hipMalloc(&rt->d_warm_alt, static_cast<size_t>(n_jobs) * 3 * sizeof(double)));
+                HIP_TRY(hipMalloc(&rt->d_joblist_alt, static_cast<size_t>(n_jobs) * sizeof(uint32_t)));
+                rt->warm_alt_cap = n_jobs;
+            }
+            if (!rt->d_active_alt) HIP_TRY(hipMalloc(&rt->d_active_alt, 4 * sizeof(uint32_t)));
+            f.warm_first = warm_args(ia.p, ia.starts, n_jobs, iters, rt->d_warm_alt, rt->d_joblist_alt, rt->d_active_alt, ia.width, nullptr);
+            f.warm_first.n_iter = kFirstPhase;
+            f.warm_first.nan_count = f.warm.nan_count;  // the jobs it drops count where the iterate kernel looks
+            f.warm.starts = rt->d_warm_alt;
+            f.warm.n_iter = 1000u - kFirstPhase;
+            f.warm.in_active = rt->d_active_alt;
+            f.warm.in_joblist = rt->d_joblist_alt;
+        }
         f.it.warm = rt->d_warm;
         f.it.joblist = rt->d_joblist;
         f.it.active = rt->d_active;
@@ -114,6 +175,9 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
         fill_bin_acc_args(rt, pl, f.it, f.acc);
         f.seg_any = rt->d_seg_any;
         f.seg_words = rt->npix / 2048u + 1u;
+        f.starts_host = rt->h_starts;
+        f.starts_dev = rt->d_starts;
+        f.n_start_quads = static_cast<uint32_t>((static_cast<size_t>(n_jobs) * 3 * sizeof(double) + 15u) / 16u);
     }
 
     const BatchFrame* dtab = lead->d_batch;
@@ -121,16 +185,49 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
     HIP_TRY(hipEventRecord(lead->batch_copied[ring], lead->stream));
     ++lead->batch_next;
 
+    if (fetch) {
+        launch_batch_fetch(dtab, F, lead->stream);
+        for (uint32_t i = 0; i < F; ++i) {  // the page-locked buffers may be written again
+            HIP_TRY(hipEventRecord(rts[i]->starts_copied, lead->stream));
+            rts[i]->starts_pending = true;
+        }
+    }
     span_begin(lead, lead->warm_spans, lead->warm_used);
     launch_batch_clear(dtab, F, lead->npix / 2048u + 1u, lead->stream);
-    launch_warmup_batch(dtab, F, n_jobs, lead->stream);
+    if (two_phase) launch_warmup_batch(dtab, F, n_jobs, true, lead->stream);
+    if (two_phase && in_place)  // the start points have been read: the page-locked buffers may be written again
+        for (uint32_t i = 0; i < F; ++i) {
+            HIP_TRY(hipEventRecord(rts[i]->starts_copied, lead->stream));
+            rts[i]->starts_pending = true;
+        }
+    launch_warmup_batch(dtab, F, n_jobs, false, lead->stream);
     span_end(lead, lead->warm_spans, lead->warm_used);
-    span_begin(lead, lead->iter_spans, lead->iter_used);
-    if (launch_iterate_split_batch(dtab, F, table[0].it.n_waves, pl.geo.bins, pl.R, pl.hint_bytes, lead->batch_xcd != 1u, lead->stream) != 0) {
-        set_error("no batched iterate kernel for chunk_records %u / %u-byte hints", pl.R, pl.hint_bytes);
-        return SAR_ERR_INVALID;
+    for (uint32_t i = 0; i < F; ++i) {  // the start points have been read: their buffer may be written again
+        if (starts_mode == 1u) HIP_TRY(hipEventRecord(rts[i]->starts_consumed, lead->stream));
+        if (in_place && !two_phase) {
+            HIP_TRY(hipEventRecord(rts[i]->starts_copied, lead->stream));
+            rts[i]->starts_pending = true;
+        }
     }
-    HIP_TRY(hipGetLastError());
+    span_begin(lead, lead->iter_spans, lead->iter_used);
+    IterateChain* chain = (lead->batch_chain != 1u && lead->device >= 0 && lead->device < 64) ? &g_chain[lead->device] : nullptr;
+    {
+        std::unique_lock<std::mutex> lock;
+        if (chain) {
+            lock = std::unique_lock<std::mutex>(chain->mu);
+            if (!chain->done) HIP_TRY(hipEventCreateWithFlags(&chain->done, hipEventDisableTiming));
+            if (chain->recorded) HIP_TRY(hipStreamWaitEvent(lead->stream, chain->done, 0));
+        }
+        if (launch_iterate_split_batch(dtab, F, n_waves, pl.geo.bins, pl.R, pl.hint_bytes, xcd_map, lead->stream) != 0) {
+            set_error("no batched iterate kernel for chunk_records %u / %u-byte hints", pl.R, pl.hint_bytes);
+            return SAR_ERR_INVALID;
+        }
+        HIP_TRY(hipGetLastError());
+        if (chain) {
+            HIP_TRY(hipEventRecord(chain->done, lead->stream));
+            chain->recorded = true;
+        }
+    }
     span_end(lead, lead->iter_spans, lead->iter_used);
     span_begin(lead, lead->fold_spans, lead->fold_used);
     if (launch_bin_accumulate_batch(dtab, F, pl.geo.bins, pl.splits, pl.geo.shift, lead->acc_threads, pl.R, pl.acc_lists, lead->stream) != 0) {
@@ -201,14 +298,23 @@ int sar_runtime_batch_frames(const sar_config* cfg, sar_runtime* rt, uint32_t* o
         rt->active_pending = false;
         if (rt->active_jobs_launched) rt->survivor_fraction = static_cast<double>(*rt->h_active) / rt->active_jobs_launched;
     }
-    // the chip holds eight wave pairs per CU; a frame occupies one per 64 surviving jobs
+    // A batch of 8k frames gives every XCD k frames, one after the other (k_iterate_split_batch); an XCD holds eight wave pairs per
+    // CU, a frame occupies one per 64 jobs that survive the warm-up, and all pairs run equally long: the XCD works in ROUNDS. The
+    // smallest batch whose last round is at least 95 % full — or the fullest (configs[4]: 635 pairs per frame on 256 slots are
+    // 2.48 rounds for one frame per XCD, 4.96 for two).
     const uint64_t cus = rt->sm_count ? rt->sm_count : 256u;
+    const double slots = static_cast<double>(cus);  // eight pairs per CU on an eighth of the CUs
     const double live = cfg->jobs_total * (rt->survivor_fraction > 0.05 ? rt->survivor_fraction : 0.05);
-    const uint64_t pairs = static_cast<uint64_t>(live / 64.0 + 0.999);
-    uint64_t f = pairs ? (8u * cus) / pairs : 1u;
-    if (f < 1) f = 1;
-    if (f > kMaxBatchFrames) f = kMaxBatchFrames;
-    *out_frames = static_cast<uint32_t>(f);
+    const double pairs = std::ceil(live / 64.0);
+    uint32_t best = 8;
+    double best_fill = 0.0;
+    for (uint32_t k = 1; 8u * k <= kMaxBatchFrames; ++k) {
+        const double rounds = k * pairs / slots;
+        const double fill = rounds / std::ceil(rounds);
+        if (fill > best_fill + 1e-9) { best_fill = fill; best = 8u * k; }
+        if (fill >= 0.95) break;
+    }
+    *out_frames = best;
     return SAR_OK;
 }
 

@@ -123,8 +123,6 @@ __device__ __forceinline__ uint32_t xcc_id() {
 }
 
 
-// per-XCD hint arrays: an even number of entries each, so that the dword holding a 16-bit hint is aligned
-__host__ __device__ constexpr size_t kHintStride(uint32_t npix) { return ((size_t)npix + 1u) & ~(size_t)1u; }
 // PoolStager (sar_iterate.hip): a staged chunk has its final form {prev, n, R x u16}; kPoolSpare spare buffers per wave
 #ifndef SAR_POOL_SPARE
 #define SAR_POOL_SPARE 16u  // a test build shrinks it (SAR_EXTRA_FLAGS=-DSAR_POOL_SPARE=2u) to force the many-fillers rounds

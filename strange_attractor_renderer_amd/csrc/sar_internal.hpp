@@ -152,7 +152,7 @@ struct FoldArgs {
 // k_warmup (sar_iterate.hip): the 1000 uncounted iterations of `n_jobs` jobs and the packing of the survivors
 struct WarmArgs {
     MapParams p;
-    const double* starts;        // [3][n_jobs] SoA
+    const double* starts;        // [3][n_jobs] SoA: the start points — or, for the second phase, the points the first phase packed
     uint32_t n_jobs;
     uint32_t width;
     uint64_t iters;              // counted iterations per job: what a job that dies in the warm-up adds to nan_count
@@ -161,21 +161,34 @@ struct WarmArgs {
     uint32_t* active;            // survivors (zero before the launch)
     unsigned long long* nan_count;
     uint32_t* hint_range;        // nullable: the depth range of the view (narrow hints)
+    // The warm-up in TWO phases (batched launches of a preset that loses jobs): the first phase runs the iterations within
+    // which trajectories diverge and packs the survivors, the second runs the rest on full waves of survivors. Same
+    // iterations per job, in the same order.
+    uint32_t n_iter;             // warm-up iterations this launch runs (1000 in one phase)
+    uint32_t _pad_iter;
+    const uint32_t* in_active;   // nullable: how many input slots hold a job (the first phase's survivor count); else n_jobs
+    const uint32_t* in_joblist;  // nullable: the job index of every input slot; else the slot itself
 };
 
 // One frame of a BATCHED launch (sar_batch.cpp): F frames of the same shape — a `sequence` sweep's consecutive frames, each with
 // its own Runtime, view angle and start points (src/bin/main.rs:493-517) — go through ONE launch of every kernel of the
 // binned path; a workgroup finds its frame in blockIdx.z and its argument block in a table of these in device memory.
 struct BatchFrame {
-    WarmArgs warm;
+    WarmArgs warm;               // the warm-up, or its second phase
+    WarmArgs warm_first;         // its first phase (n_iter == 0: one phase)
     BinIterArgs it;
     BinAccArgs acc;
     FoldArgs fold;
-    uint32_t* seg_any;           // cleared by k_batch_clear before the launch, like `active` and (if measured) `hint_range`
+    uint32_t* seg_any;           // cleared by k_batch_clear before the launch, like `active` (both phases') and (if measured) `hint_range`
     uint32_t seg_words;
     uint32_t clear_hint_range;
+    // k_batch_fetch: the start points from the page-locked staging buffer into device memory (n_start_quads 16-byte pieces)
+    const void* starts_host;
+    void* starts_dev;
+    uint32_t n_start_quads;
+    uint32_t _pad_fetch;
 };
-constexpr uint32_t kMaxBatchFrames = 16;
+constexpr uint32_t kMaxBatchFrames = 32;
 
 struct PaletteParams {
     uint32_t len;  // user entries; entry len == entry len-1 (Palette::new, src/lib.rs:416-418)
@@ -198,6 +211,8 @@ static inline uint32_t f32_sortable_host(float f) {
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// per-XCD hint arrays: an even number of entries each, so that the dword holding a 16-bit hint is aligned (constexpr: host and device)
+constexpr size_t kHintStride(uint32_t npix) { return ((size_t)npix + 1u) & ~(size_t)1u; }
 constexpr uint32_t kLnLutEntries = 1u << 20;  // ln(k+1), k < 2^20, host libm (exact parity with the oracle)
 constexpr uint64_t kMaxChunkOrdinals = 0xFFFFFFFEull;
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;

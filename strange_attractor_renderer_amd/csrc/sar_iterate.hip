@@ -500,23 +500,28 @@ __device__ __forceinline__ void warmup_body(const WarmArgs& a) {
     uint32_t* __restrict__ joblist = a.joblist;
     uint32_t* const hint_range = a.hint_range;
     const uint32_t n_jobs = a.n_jobs;
-    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = job < n_jobs;
+    const uint32_t slot_in = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_in = a.in_active ? *a.in_active : n_jobs;  // (second phase: what the first phase packed)
+    if (blockIdx.x * blockDim.x >= n_in) return;
+    const bool valid = slot_in < n_in;
+    const uint32_t job = (valid && a.in_joblist) ? a.in_joblist[slot_in] : slot_in;
+    const int n_iter = (int)a.n_iter;
     MapParams p = a.p;
     pin_map_params(p);
     double x = 0., y = 0., z = 0.;
     float zlo = __builtin_inff(), zhi = -__builtin_inff();  // depth range of this lane's candidates (neutral for lanes without a job)
     if (valid) {
-        x = starts[job];
-        y = starts[n_jobs + job];
-        z = starts[2u * n_jobs + job];
+        x = starts[slot_in];
+        y = starts[n_jobs + slot_in];
+        z = starts[2u * n_jobs + slot_in];
         if (!hint_range) {
-            for (int w = 0; w < 1000; ++w) next_point(p, x, y, z);
+            for (int w = 0; w < n_iter; ++w) next_point(p, x, y, z);
         } else {
-            // the same 1000 iterations; the last ones also project the point and note the depth of every visit that could
+            // the same iterations; the last ones also project the point and note the depth of every visit that could
             // win a depth test (in bounds, z > -1): the range the narrow depth hints quantise (HintQuant)
-            for (int w = 0; w < 1000 - kWarmupRangeIters; ++w) next_point(p, x, y, z);
-            for (int w = 0; w < kWarmupRangeIters; ++w) {
+            const int n_range = n_iter < kWarmupRangeIters ? n_iter : kWarmupRangeIters;
+            for (int w = 0; w < n_iter - n_range; ++w) next_point(p, x, y, z);
+            for (int w = 0; w < n_range; ++w) {
                 bool inb;
                 uint32_t idx;
                 float zf;
@@ -563,8 +568,8 @@ __global__ void __launch_bounds__(256) k_warmup(const WarmArgs a) { warmup_body(
 // wave-uniform and nothing writes the table while a launch runs, so these are scalar loads into SGPRs, exactly what the
 // by-value kernel arguments of the single-frame kernels are — and the kernel body is the single-frame body unchanged.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_warmup_batch(const BatchFrame* frames) {
-    const WarmArgs a = load_frame_args(&frames[blockIdx.z].warm);
+__global__ void __launch_bounds__(256) k_warmup_batch(const BatchFrame* frames, uint32_t first_phase) {
+    const WarmArgs a = load_frame_args(first_phase ? &frames[blockIdx.z].warm_first : &frames[blockIdx.z].warm);
     warmup_body(a);
 }
 // what a render call clears before its kernels (three small memsets per frame otherwise): survivor counter and dead-job
@@ -575,6 +580,7 @@ __global__ void __launch_bounds__(256) k_batch_clear(const BatchFrame* frames) {
     const uint32_t n = f->seg_words;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) seg[k] = 0u;
     if (blockIdx.x == 0u && threadIdx.x < 4u) f->warm.active[threadIdx.x] = 0u;
+    if (blockIdx.x == 0u && threadIdx.x < 4u && f->warm_first.n_iter) f->warm_first.active[threadIdx.x] = 0u;
     if (blockIdx.x == 0u && threadIdx.x < 2u && f->clear_hint_range) f->warm.hint_range[threadIdx.x] = 0u;
 }
 
@@ -862,7 +868,7 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
 // dispatcher deals consecutive workgroups to the eight XCDs round-robin, and every frame has its own depth hints and depth
 // keys — F working sets in every XCD's 4 MiB L2 if every frame ran everywhere (three frames of configs[4]: 1.0 us per
 // iteration step against 0.65 alone). With xcd_map the frames are dealt to the XCDs instead: 8 / F XCDs per frame (F = 2, 4,
-// 8), or F / 8 frames per XCD (16): an XCD's L2 sees the hints of its own frames only. Any other F: frame after frame.
+// 8), or F / 8 frames per XCD (16, 24, ...): an XCD's L2 sees the hints of its own frames only. Any other F: frame after frame.
 template <bool DEPTH, uint32_t R, uint32_t U, typename H, uint32_t PH>
 __global__ void __launch_bounds__(128) k_iterate_split_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_waves, uint32_t xcd_map) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -872,10 +878,10 @@ __global__ void __launch_bounds__(128) k_iterate_split_batch(const BatchFrame* f
         const uint32_t xpf = 8u / n_frames, xcd = lin & 7u, pos = lin >> 3;
         frame = xcd / xpf;
         wave = pos * xpf + xcd % xpf;
-    } else if (xcd_map == 2u) {  // F / 8 frames per XCD
-        const uint32_t fpx = n_frames >> 3, xcd = lin & 7u, pos = lin >> 3;
-        frame = xcd * fpx + pos % fpx;
-        wave = pos / fpx;
+    } else if (xcd_map == 2u) {  // F / 8 frames per XCD, one after the other: XCD x runs frames x, x + 8, ... — its L2 holds one frame's
+        const uint32_t xcd = lin & 7u, pos = lin >> 3, turn = pos / n_waves;  // hints at a time, and its CUs never wait for a round of
+        frame = xcd + 8u * turn;                                              // equally long workgroups to end before the next frame starts
+        wave = pos - turn * n_waves;
     } else {
         frame = lin / n_waves;
         wave = lin - frame * n_waves;
@@ -997,14 +1003,18 @@ int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, 
     return launched ? 0 : 1;
 }
 
+// how k_iterate_split_batch deals F frames of n_waves wave pairs to the XCDs: 1 = 8 / F XCDs per frame, 2 = F / 8 frames per
+// XCD, 0 = frame after frame (every frame on all XCDs)
+uint32_t batch_xcd_map(uint32_t n_frames, uint32_t n_waves) {
+    if ((n_frames * n_waves) % 8u != 0u) return 0;
+    if (n_frames <= 8u && 8u % n_frames == 0u && n_waves % (8u / n_frames) == 0u) return 1;
+    if (n_frames % 8u == 0u) return 2;
+    return 0;
+}
+
 int launch_iterate_split_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_waves, uint32_t n_bins, uint32_t records,
-                               uint32_t hint_bytes, bool xcd_aware, hipStream_t s) {
+                               uint32_t hint_bytes, uint32_t xcd_map, hipStream_t s) {
     const uint32_t total = n_frames * n_waves;
-    uint32_t xcd_map = 0;
-    if (xcd_aware && total % 8u == 0u) {
-        if (n_frames <= 8u && 8u % n_frames == 0u && n_waves % (8u / n_frames) == 0u) xcd_map = 1;
-        else if (n_frames % 8u == 0u) xcd_map = 2;
-    }
     const uint32_t stage = lean_wave_lds_bytes(n_bins, records);
     const uint32_t ph = (stage + 2048u) * 8u <= 160u * 1024u ? 2u : 1u;
     const size_t lds2 = stage + ph * 1024u;
@@ -1060,8 +1070,22 @@ void launch_dead_jobs(const uint32_t* active, uint32_t n_jobs, uint64_t iters, u
 void launch_warmup(const WarmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_warmup, dim3((a.n_jobs + 255u) / 256u), dim3(256), 0, s, a);
 }
-void launch_warmup_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_jobs, hipStream_t s) {
-    hipLaunchKernelGGL(k_warmup_batch, dim3((n_jobs + 255u) / 256u, 1, n_frames), dim3(256), 0, s, frames);
+void launch_warmup_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_jobs, bool first_phase, hipStream_t s) {
+    hipLaunchKernelGGL(k_warmup_batch, dim3((n_jobs + 255u) / 256u, 1, n_frames), dim3(256), 0, s, frames, first_phase ? 1u : 0u);
+}
+// The start points of a batch, page-locked host memory -> device memory, by a kernel instead of the copy engine (whose queue
+// holds the previous frames' read-backs) and instead of the warm-up kernel reading them in place: 1.5 MB per frame over PCIe
+// take longer than the first warm-up phase computes, and a warm-up wave that waits for PCIe holds registers nothing else can
+// use — these few waves hold almost none, and the other lane's kernels run beside them.
+__global__ void __launch_bounds__(256) k_batch_fetch(const BatchFrame* frames) {
+    const BatchFrame* f = frames + blockIdx.y;
+    const u32x4* __restrict__ src = (const u32x4*)f->starts_host;
+    u32x4* __restrict__ dst = (u32x4*)f->starts_dev;
+    const uint32_t n = f->n_start_quads;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) dst[k] = src[k];
+}
+void launch_batch_fetch(const BatchFrame* frames, uint32_t n_frames, hipStream_t s) {
+    hipLaunchKernelGGL(k_batch_fetch, dim3(32, n_frames), dim3(256), 0, s, frames);
 }
 void launch_batch_clear(const BatchFrame* frames, uint32_t n_frames, uint32_t seg_words, hipStream_t s) {
     hipLaunchKernelGGL(k_batch_clear, dim3((seg_words + 255u) / 256u, n_frames), dim3(256), 0, s, frames);

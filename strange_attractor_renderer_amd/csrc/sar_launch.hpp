@@ -48,9 +48,11 @@ void launch_starts_soa(const double* aos, double* soa, uint32_t m, hipStream_t s
 void launch_warmup(const WarmArgs& a, hipStream_t s);
 // batched launches (sar_batch.cpp): `frames` is a table of n_frames BatchFrame in device memory, the frame is blockIdx.z
 void launch_batch_clear(const BatchFrame* frames, uint32_t n_frames, uint32_t seg_words, hipStream_t s);
-void launch_warmup_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_jobs, hipStream_t s);
+void launch_batch_fetch(const BatchFrame* frames, uint32_t n_frames, hipStream_t s);
+void launch_warmup_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_jobs, bool first_phase, hipStream_t s);
+uint32_t batch_xcd_map(uint32_t n_frames, uint32_t n_waves);
 int launch_iterate_split_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_waves, uint32_t n_bins, uint32_t records,
-                               uint32_t hint_bytes, bool xcd_aware, hipStream_t s);
+                               uint32_t hint_bytes, uint32_t xcd_map, hipStream_t s);
 int launch_bin_accumulate_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_bins, uint32_t splits, uint32_t bin_shift,
                                 uint32_t threads, uint32_t records, uint32_t lists, hipStream_t s);
 void launch_fold_resolve_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t npix, hipStream_t s);

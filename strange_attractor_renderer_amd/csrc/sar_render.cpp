@@ -66,7 +66,12 @@ int sar::ensure_scratch(sar_runtime* rt, uint32_t copies) {
 
 // Start points into rt->d_starts, laid out as consecutive per-chunk SoA blocks x[m] y[m] z[m]; `starts` is the caller's
 // [n_jobs][3] array in host memory (through one pinned staging buffer) or already in device memory.
-int sar::stage_starts(sar_runtime* rt, const LaunchPlan& pl, uint32_t n_jobs, const double* starts, bool on_device) {
+// With `upload` (a batched launch: the leader's upload stream) the copy runs there, behind the last kernel known to have read
+// d_starts, and the launch stream only waits for its event: the upload of the next batch runs under the current one.
+// With `in_place` nothing is copied: the caller's kernel reads the page-locked staging buffer itself (device-visible host
+// memory; 1.5 MB over PCIe under a kernel of a thousand iterations per point) and records starts_copied behind that kernel.
+int sar::stage_starts(sar_runtime* rt, const LaunchPlan& pl, uint32_t n_jobs, const double* starts, bool on_device, hipStream_t upload,
+                      bool in_place) {
     const size_t need = static_cast<size_t>(n_jobs) * 3;
     if (rt->starts_pending) {  // the previous call's upload still reads the staging buffer
         HIP_TRY(hipEventSynchronize(rt->starts_copied));
@@ -78,8 +83,9 @@ int sar::stage_starts(sar_runtime* rt, const LaunchPlan& pl, uint32_t n_jobs, co
         rt->h_starts = nullptr;
         rt->d_starts = nullptr;
         rt->starts_cap = 0;
-        HIP_TRY(hipHostMalloc(&rt->h_starts, need * sizeof(double), hipHostMallocDefault));
-        HIP_TRY(hipMalloc(&rt->d_starts, need * sizeof(double)));
+        // (two doubles more: k_batch_fetch moves 16-byte pieces)
+        HIP_TRY(hipHostMalloc(&rt->h_starts, (need + 2) * sizeof(double), hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&rt->d_starts, (need + 2) * sizeof(double)));
         rt->starts_cap = need;
     }
     if (on_device) {
@@ -98,6 +104,15 @@ int sar::stage_starts(sar_runtime* rt, const LaunchPlan& pl, uint32_t n_jobs, co
             blk[m + k] = starts[(off + k) * 3 + 1];
             blk[2 * m + k] = starts[(off + k) * 3 + 2];
         }
+    }
+    if (in_place) return SAR_OK;
+    if (upload) {
+        if (rt->starts_consumed_recorded) HIP_TRY(hipStreamWaitEvent(upload, rt->starts_consumed, 0));
+        HIP_TRY(hipMemcpyAsync(rt->d_starts, rt->h_starts, need * sizeof(double), hipMemcpyHostToDevice, upload));
+        HIP_TRY(hipEventRecord(rt->starts_copied, upload));
+        HIP_TRY(hipStreamWaitEvent(rt->stream, rt->starts_copied, 0));
+        rt->starts_pending = true;
+        return SAR_OK;
     }
     HIP_TRY(hipMemcpyAsync(rt->d_starts, rt->h_starts, need * sizeof(double), hipMemcpyHostToDevice, rt->stream));
     HIP_TRY(hipEventRecord(rt->starts_copied, rt->stream));
@@ -130,6 +145,7 @@ int sar::ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
         rt->d_zhint = nullptr;
         HIP_TRY(hipMalloc(&rt->d_zhint, (static_cast<size_t>(rt->npix) + 2u) * 8u * pl.hint_bytes));
         rt->zhint_bytes = pl.hint_bytes;
+        rt->hint_copies_used = 8;  // fresh memory: all of it
         SAR_TRY(clear_hints(rt));
     }
     if (pl.chunk_jobs > rt->warm_cap) {
@@ -168,7 +184,8 @@ int sar::ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
 
 // The argument blocks of one launch of the binned path on `rt` (the launch options — hint sharing, hint tiles — are `opt`'s:
 // rt itself, or the leader of a batch).
-void sar::fill_bin_iter_args(sar_runtime* rt, const sar_runtime* opt, const LaunchPlan& pl, const IterArgs& ia, BinIterArgs& ba, bool* shared_out) {
+void sar::fill_bin_iter_args(sar_runtime* rt, const sar_runtime* opt, const LaunchPlan& pl, const IterArgs& ia, BinIterArgs& ba, bool* shared_out,
+                             bool one_hint_array) {
     const uint32_t m = ia.n_jobs;
     std::memset(&ba, 0, sizeof(ba));
     ba.it = ia;
@@ -186,8 +203,11 @@ void sar::fill_bin_iter_args(sar_runtime* rt, const sar_runtime* opt, const Laun
     // the XCDs share ONE array: an XCD then sees another's updates only when its own L2 drops the line — a stale hint lets
     // more visits through stage 1, never a wrong one — and the misses stay on chip (4096^2 share: 9.15 -> 8.85 ms; below
     // that size sharing costs: 2048^2 5.90 -> 6.05 ms).
-    const bool share = opt->hint_shared == 2 || (opt->hint_shared == 0 && static_cast<uint64_t>(rt->npix) * pl.hint_bytes * 8u > (200ull << 20));
+    // (one_hint_array: a batched frame that runs on one or two XCDs of its own — what its XCDs share is all there is)
+    const bool share = opt->hint_shared == 2 || (opt->hint_shared == 0 && (one_hint_array || static_cast<uint64_t>(rt->npix) * pl.hint_bytes * 8u > (200ull << 20)));
     ba.hint_copy_mask = share ? 0u : 7u;
+    const uint32_t written = share ? 1u : 8u;
+    if (rt->hint_copies_used < written) rt->hint_copies_used = written;
     if (shared_out) *shared_out = share;
     // narrow hints of an image whose width is a power of two: 8 x 8 tiles per 128-byte line (HintTile); the permutation stays
     // inside blocks of eight rows, so the height must be a multiple of eight
@@ -268,6 +288,7 @@ sar::WarmArgs sar::warm_args(const sar::MapParams& p, const double* starts, uint
     w.active = active;
     w.nan_count = reinterpret_cast<unsigned long long*>(active + 2);
     w.hint_range = hint_range;
+    w.n_iter = 1000u;  // "skip first 1000 to get good values in the attractor" (:750-752)
     return w;
 }
 
@@ -501,6 +522,7 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
     }
     HIP_TRY(hipGetLastError());
     rt->last_iterations = static_cast<uint64_t>(n_jobs) * iters;
+    rt->starts_consumed_recorded = false;  // (what read d_starts here is ordered by this stream, not by the batch path's event)
     return SAR_OK;
 }
 

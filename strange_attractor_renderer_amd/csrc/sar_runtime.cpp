@@ -92,10 +92,13 @@ int sar::clear_hints(sar_runtime* rt) {
     // hints are lower bounds of depths already accumulated; anything that can lower zbuf voids them
     // Wide hints hold the depth itself as f32 and start at the smallest float above -1.0 (nextafter(-1, +inf) = 0xBF7FFFFF): stage 1's `z >= hint` is then the
     // reference's strict `z > -1.0` (:693, :821) for a pixel nobody has reached. Narrow hints are 16-bit fixed point from 0.
-    if (rt->d_zhint && rt->zhint_bytes == 4)
-        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(rt->d_zhint), static_cast<int>(0xBF7FFFFFu), (static_cast<size_t>(rt->npix) + 2u) * 8u, rt->stream));
-    else if (rt->d_zhint)
-        HIP_TRY(hipMemsetAsync(rt->d_zhint, 0, (static_cast<size_t>(rt->npix) + 2u) * 8u * rt->zhint_bytes, rt->stream));
+    // (only the arrays a launch has written since the last clear: a batched frame whose XCDs share one array leaves seven untouched)
+    const size_t entries = kHintStride(rt->npix) * rt->hint_copies_used;
+    if (rt->d_zhint && rt->zhint_bytes == 4 && entries)
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(rt->d_zhint), static_cast<int>(0xBF7FFFFFu), entries, rt->stream));
+    else if (rt->d_zhint && entries)
+        HIP_TRY(hipMemsetAsync(rt->d_zhint, 0, entries * rt->zhint_bytes, rt->stream));
+    rt->hint_copies_used = 0;
     rt->hint_range_set = false;  // empty hints: the next launch may measure the view's depth range anew
     return SAR_OK;
 }
@@ -242,6 +245,11 @@ int sar_runtime_free(sar_runtime* rt) {
     if (rt->iter_done) hipEventDestroy(rt->iter_done);
     if (rt->pf_done) hipEventDestroy(rt->pf_done);
     for (hipEvent_t e : rt->img_events) if (e) hipEventDestroy(e);
+    if (rt->copy_stream) hipStreamSynchronize(rt->copy_stream);  // (a borrowed one as well: a read-back may still read d_export)
+    if (rt->copy_stream && rt->own_copy_stream) hipStreamDestroy(rt->copy_stream);
+    if (rt->upload_stream) { hipStreamSynchronize(rt->upload_stream); hipStreamDestroy(rt->upload_stream); }
+    if (rt->img_ready) hipEventDestroy(rt->img_ready);
+    if (rt->starts_consumed) hipEventDestroy(rt->starts_consumed);
     if (rt->d_warm) hipFree(rt->d_warm);
     if (rt->d_joblist) hipFree(rt->d_joblist);
     if (rt->d_active) hipFree(rt->d_active);
@@ -318,6 +326,7 @@ int sar_runtime_synchronize(sar_runtime* rt) {
     if (!rt) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipStreamSynchronize(rt->stream));
+    if (rt->copy_stream) HIP_TRY(hipStreamSynchronize(rt->copy_stream));  // the read-backs of async frames
     return SAR_OK;
 }
 
@@ -332,9 +341,32 @@ int sar_runtime_set_stream(sar_runtime* rt, void* hip_stream) {
     if (!rt) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipStreamSynchronize(rt->stream));
+    if (rt->copy_stream) HIP_TRY(hipStreamSynchronize(rt->copy_stream));
+    if (rt->upload_stream) HIP_TRY(hipStreamSynchronize(rt->upload_stream));
     if (rt->own_stream && rt->stream) hipStreamDestroy(rt->stream);
     rt->stream = static_cast<hipStream_t>(hip_stream);
     rt->own_stream = false;
+    return SAR_OK;
+}
+
+int sar_runtime_get_copy_stream(sar_runtime* rt, void** hip_stream_out) {
+    if (!rt || !hip_stream_out) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    if (!rt->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&rt->copy_stream, hipStreamNonBlocking));
+        rt->own_copy_stream = true;
+    }
+    *hip_stream_out = rt->copy_stream;
+    return SAR_OK;
+}
+
+int sar_runtime_set_copy_stream(sar_runtime* rt, void* hip_stream) {
+    if (!rt || !hip_stream) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    if (rt->copy_stream) HIP_TRY(hipStreamSynchronize(rt->copy_stream));
+    if (rt->copy_stream && rt->own_copy_stream) hipStreamDestroy(rt->copy_stream);
+    rt->copy_stream = static_cast<hipStream_t>(hip_stream);
+    rt->own_copy_stream = false;
     return SAR_OK;
 }
 
@@ -355,6 +387,10 @@ int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host
     if (!rgba_out_host) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     SAR_TRY(ensure_rgba(rt));
+    if (rt->copy_in_flight) {  // an async frame's read-back still reads d_rgba
+        HIP_TRY(hipStreamWaitEvent(rt->stream, rt->img_events[(rt->img_next - 1) % 8], 0));
+        rt->copy_in_flight = false;
+    }
     SAR_TRY(do_colorize(cfg, rt, rt->d_rgba));
     HIP_TRY(hipMemcpyAsync(rgba_out_host, rt->d_rgba, static_cast<size_t>(rt->npix) * 8, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
@@ -423,12 +459,16 @@ int sar_image_convert_device(sar_runtime* rt, const void* rgba16_dev, int format
     return SAR_OK;
 }
 
-static int enqueue_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host) {
+static int enqueue_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host, bool own_copy_stream) {
     SAR_TRY(check_cfg_matches(cfg, rt));
     const size_t bytes = sar_image_bytes(format, rt->W, rt->H);
     if (!out_host || bytes == 0) { set_error("sar_colorize_format: bad format or NULL output"); return SAR_ERR_INVALID; }
     HIP_TRY(hipSetDevice(rt->device));
     SAR_TRY(ensure_rgba(rt));
+    if (rt->copy_in_flight) {  // the last async frame's read-back still reads d_rgba / d_export
+        HIP_TRY(hipStreamWaitEvent(rt->stream, rt->img_events[(rt->img_next - 1) % 8], 0));
+        rt->copy_in_flight = false;
+    }
     SAR_TRY(do_colorize(cfg, rt, rt->d_rgba));
     const void* src = rt->d_rgba;
     if (format != SAR_FMT_RGBA16) {
@@ -436,23 +476,36 @@ static int enqueue_colorize_format(const sar_config* cfg, sar_runtime* rt, int f
         SAR_TRY(sar_image_convert_device(rt, rt->d_rgba, format, rt->d_export));
         src = rt->d_export;
     }
-    // d_rgba / d_export are written again by the next frame's colorize, which the stream orders behind this copy
-    HIP_TRY(hipMemcpyAsync(out_host, src, bytes, hipMemcpyDeviceToHost, rt->stream));
+    if (!own_copy_stream || rt->readback_inline) {
+        HIP_TRY(hipMemcpyAsync(out_host, src, bytes, hipMemcpyDeviceToHost, rt->stream));
+        return SAR_OK;
+    }
+    // the copy leaves the launch stream: the next frame's kernels do not queue behind 20-30 MB over PCIe; d_rgba / d_export
+    // are written again only behind this copy's event (above)
+    if (!rt->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&rt->copy_stream, hipStreamNonBlocking));
+        rt->own_copy_stream = true;
+    }
+    if (!rt->img_ready) HIP_TRY(hipEventCreateWithFlags(&rt->img_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(rt->img_ready, rt->stream));
+    HIP_TRY(hipStreamWaitEvent(rt->copy_stream, rt->img_ready, 0));
+    HIP_TRY(hipMemcpyAsync(out_host, src, bytes, hipMemcpyDeviceToHost, rt->copy_stream));
     return SAR_OK;
 }
 
 int sar_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host) {
-    SAR_TRY(enqueue_colorize_format(cfg, rt, format, out_host));
+    SAR_TRY(enqueue_colorize_format(cfg, rt, format, out_host, false));
     HIP_TRY(hipStreamSynchronize(rt->stream));
     return SAR_OK;
 }
 
 int sar_colorize_format_async(const sar_config* cfg, sar_runtime* rt, int format, void* out_host, uint64_t* ticket_out) {
     if (!ticket_out) { set_error("sar_colorize_format_async: NULL ticket"); return SAR_ERR_INVALID; }
-    SAR_TRY(enqueue_colorize_format(cfg, rt, format, out_host));
+    SAR_TRY(enqueue_colorize_format(cfg, rt, format, out_host, true));
     hipEvent_t& ev = rt->img_events[rt->img_next % 8];
     if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(ev, rt->stream));
+    HIP_TRY(hipEventRecord(ev, rt->readback_inline ? rt->stream : rt->copy_stream));
+    rt->copy_in_flight = !rt->readback_inline;
     *ticket_out = rt->img_next++;
     return SAR_OK;
 }
@@ -714,6 +767,16 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
     } else if (!std::strcmp(name, "hint_shared")) {
         if (v > 2) { set_error("hint_shared must be 0, 1 or 2"); return SAR_ERR_INVALID; }
         rt->hint_shared = v;
+    } else if (!std::strcmp(name, "readback_inline")) {
+        rt->readback_inline = v ? 1u : 0u;
+    } else if (!std::strcmp(name, "batch_starts")) {
+        if (v > 3) { set_error("batch_starts must be 0 (automatic), 1 (upload stream), 2 (launch stream) or 3 (read in place)"); return SAR_ERR_INVALID; }
+        rt->batch_starts = v;
+    } else if (!std::strcmp(name, "batch_warm")) {
+        if (v > 2) { set_error("batch_warm must be 0 (automatic), 1 (one phase) or 2 (two phases)"); return SAR_ERR_INVALID; }
+        rt->batch_warm = v;
+    } else if (!std::strcmp(name, "batch_chain")) {
+        rt->batch_chain = v ? 1u : 0u;
     } else if (!std::strcmp(name, "batch_xcd")) {
         if (v > 1) { set_error("batch_xcd must be 0 (frames dealt to the XCDs) or 1 (every frame on all XCDs)"); return SAR_ERR_INVALID; }
         rt->batch_xcd = v;

@@ -49,6 +49,8 @@ struct sar_runtime {
     size_t heads_cap = 0;  // entries
     void* d_zhint = nullptr;
     uint32_t zhint_bytes = 0;        // bytes per hint of the current allocation (2 or 4)
+    uint32_t hint_copies_used = 8;   // of the eight per-XCD arrays, how many [0, n) a launch has written since they were last
+                                     // cleared (a launch whose XCDs share ONE array writes array 0 only): what clear_hints clears
     uint32_t hint_bits = 0;          // option: 0 = by image size, 16, 32
     uint32_t hint_tile = 0;          // option: 0 = narrow hints of power-of-two-wide images in 8 x 8 tiles, 1 = always row-major
     uint32_t hint_shared = 0;        // option: 0 = automatic, 1 = one hint array per XCD, 2 = one array for the whole chip
@@ -88,6 +90,20 @@ struct sar_runtime {
     uint32_t chunk_ahead = 0;        // option: 2 = a call of several launch chunks does not run its next chunk's warm-up ahead (A/B)
     hipEvent_t img_events[8] = {};   // sar_colorize_format_async tickets (ticket t is event t % 8: a later recording on the
     uint64_t img_next = 0;           // same stream completes no earlier, so waiting for it is always sufficient)
+    // The read-back of an async frame runs on its own stream (the copy engine), behind `img_ready`: the launch stream goes on
+    // with the next frame at once, and waits for the last read-back only before it writes d_rgba / d_export again.
+    hipStream_t copy_stream = nullptr;
+    bool own_copy_stream = false;
+    hipEvent_t img_ready = nullptr;
+    bool copy_in_flight = false;
+    uint32_t readback_inline = 0;    // option: 1 = async read-backs stay on the launch stream (A/B)
+    uint32_t batch_starts = 0;       // option: how a batched launch gets its start points: 0 = the warm-up kernel reads the page-locked
+                                     // staging buffer itself (no copy), 1 = copied on the upload stream, 2 = copied on the launch stream
+    // Start points of a batched launch are uploaded on the leader's upload stream, behind the last kernel that read d_starts
+    // (`starts_consumed`, recorded by whatever launched it): the upload of batch k+1 runs under batch k.
+    hipStream_t upload_stream = nullptr;
+    hipEvent_t starts_consumed = nullptr;
+    bool starts_consumed_recorded = false;
     char last_launch[256] = {0};     // sar_runtime_describe_last_launch
     uint32_t last_chunks = 0;
     uint32_t* d_seg_any = nullptr;   // [npix / 2048 + 1] 2048-pixel segments with a count in the current launch (k_fold_resolve skips the rest)
@@ -119,6 +135,8 @@ struct sar_runtime {
     uint64_t batch_next = 0;
     hipEvent_t batch_join = nullptr;
     uint32_t batches_launched = 0;   // statistic: batched launches this runtime led
+    uint32_t batch_warm = 0;         // option: the warm-up of a batched launch: 0 = two phases when the last launch lost a tenth of its jobs, 1 = one phase, 2 = two
+    uint32_t batch_chain = 0;        // option: 1 = the iterate kernels of this device's batches are NOT chained one behind the other (A/B)
     uint32_t batch_xcd = 0;          // option: 1 = the frames of a batch are NOT dealt to the XCDs (every frame runs on all eight: A/B)
 
     // tuning

@@ -75,8 +75,8 @@ class SequenceRenderer:
     1 = a frame per launch. One object can render several sweeps (`run`); `close` frees the device and page-locked memory."""
 
     def __init__(self, config: "api.Config", *, units: int = 0, jobs_per_thread: int = 12, seed: int = 0, device: int = 0,
-                 image_format: int | None = None, ring: int = 0, lanes: int = 2, batch: int = 0, max_batch: int = 4,
-                 device_ring: list | None = None):
+                 image_format: int | None = None, ring: int = 0, lanes: int = 2, batch: int = 0, max_batch: int = 16,
+                 device_ring: list | None = None, options: dict | None = None):
         """device_ring: device pointers of width*height*8-byte buffers — the frames are then left there as RGBA16 (colorize
         only, src/lib.rs:841: what SURVEY 8(d)'s metric ends with) instead of being converted and read back; sinks receive None."""
         if lanes < 1:
@@ -91,6 +91,8 @@ class SequenceRenderer:
         self.max_batch = max(1, min(self.max_batch, ring // (lanes + 1)))
         self.batch = batch
         self.device_ring = list(device_ring) if device_ring else None
+        self.resync = bool(int(os.environ.get("SAR_SEQ_RESYNC", "0")))   # experiment
+        self.options = dict(options or {})                         # runtime options (sar_runtime_set_option) of every runtime made here
         self.config, self.seed, self.device, self.lanes, self.ring = config, seed, device, lanes, ring
         self.fmt = api._abi.SAR_FMT_RGBA16 if image_format is None else image_format
         renderer = api.ParallelRenderer(device=device, units=units, seed=seed)
@@ -113,23 +115,33 @@ class SequenceRenderer:
 
     def _group(self, g: int, n: int, cfg: "api.Config") -> list:
         """The first n runtimes of lane g, all on the stream of the lane's first runtime."""
-        while len(self.groups) <= g:
-            self.groups.append([])
+        if not self.groups:
+            # The lanes' streams first, one after the other: the HIP runtime deals streams to its few hardware queues in the order
+            # they are first used, and two lanes that share a queue do not overlap at all (measured: 0.8 instead of 0.6 ms per
+            # frame — and every other runtime made in between moves the second lane's stream onto another queue).
+            self.groups = [[self._runtime(cfg)] for _ in range(self.lanes)]
         grp = self.groups[g]
         while len(grp) < n:
-            rt = api.Runtime(cfg, device=self.device)
-            if grp:
-                rt.set_stream(grp[0].stream())
+            rt = self._runtime(cfg)
+            rt.share_streams(grp[0])
             grp.append(rt)
         return grp[:n]
+
+    def _runtime(self, cfg: "api.Config"):
+        rt = api.Runtime(cfg, device=self.device)
+        for name, value in self.options.items():
+            rt.set_option(name, value)
+        return rt
 
     def _batch_size(self, g: int, cfg: "api.Config", left: int) -> int:
         f = self.batch
         if f == 0:
-            grp = self.groups[g] if len(self.groups) > g and self.groups[g] else None
+            grp = self.groups[g] if self.groups else None
             # the library counts the wave pairs the chip holds against the jobs that survived the last launch's warm-up
-            f = api.batch_frames(cfg, grp[0]) if grp else min(2, self.max_batch)
-        return max(1, min(f, self.max_batch, left))
+            f = api.batch_frames(cfg, grp[0]) if grp else self.max_batch
+        f = max(1, min(f, self.max_batch))
+        f = f // 8 * 8 if f >= 8 else (4 if f >= 4 else f)       # the sizes whose frames the library deals to the XCDs
+        return min(f, left)
 
     def run(self, todo: list[tuple[int, float, str]],
             sink: Callable[[int, str, np.ndarray], object] | None = None, zero_copy: bool = False) -> list[tuple[int, str, np.ndarray]]:
@@ -142,12 +154,21 @@ class SequenceRenderer:
         if not todo:
             return out
         images, busy, ring, lanes = self.images, self.busy, self.ring, self.lanes
-        # the next batch's start points (~1 ms of host time per 2e5 jobs: as long as a frame renders) are drawn on a helper
-        # thread while the GPU works on the current one (the ctypes call releases the GIL)
-        pool = ThreadPoolExecutor(max_workers=1)
-        draw = lambda ks: [api.start_points(frame_seed(self.seed, k), 0, self.total_jobs) for k in ks]  # noqa: E731
+        # the next batch's start points (~1 ms of host time per 2e5 jobs: half as long as a frame renders) are drawn on helper
+        # threads while the GPU works on the current one (the ctypes call releases the GIL)
+        pool = ThreadPoolExecutor(max_workers=3)
 
-        def deliver(g: int, rt, slot: int, ticket: int, k: int, name: str):
+        class _Drawn:
+            def __init__(self, ks):
+                self.futures = [pool.submit(api.start_points, frame_seed(seed_, k), 0, jobs_) for k in ks]
+
+            def result(self):
+                return [f.result() for f in self.futures]
+
+        seed_, jobs_ = self.seed, self.total_jobs
+        draw = _Drawn
+
+        def deliver(g: int, rt, slot: int, ticket: int, k: int, name: str, first_of_batch: bool = False):
             if self.settle.get(g, 0) < SETTLE:
                 # Measured on ROCm 7.2, in a process that uses nothing but this library: the kernels of two freshly created
                 # streams do not overlap — as if they shared a hardware queue — until one of them has been synchronised
@@ -158,6 +179,8 @@ class SequenceRenderer:
                 rt.synchronize()
                 self.settle[g] = self.settle.get(g, 0) + 1
             if self.device_ring is not None:
+                if self.resync and first_of_batch:
+                    rt.synchronize()
                 if sink is not None:
                     sink(k, name, None)
                 return
@@ -172,7 +195,7 @@ class SequenceRenderer:
             pos, turn = 0, 0
             cfg0 = self.frame_config(todo[0][1])
             size = self._batch_size(0, cfg0, len(todo))
-            pending = pool.submit(draw, [k for k, _, _ in todo[:size]])
+            pending = draw([k for k, _, _ in todo[:size]])
             while pos < len(todo):
                 g = turn % lanes
                 part = todo[pos:pos + size]
@@ -182,7 +205,7 @@ class SequenceRenderer:
                 starts = pending.result()
                 if pos < len(todo):                               # the next batch: its size is the next lane's to say
                     size = self._batch_size((turn + 1) % lanes, cfg0, len(todo) - pos)
-                    pending = pool.submit(draw, [k for k, _, _ in todo[pos:pos + size]])
+                    pending = draw([k for k, _, _ in todo[pos:pos + size]])
                 for rt in rts:
                     rt.reset()                                    # :950-951
                 if len(part) > 1:
@@ -209,11 +232,11 @@ class SequenceRenderer:
                 in_flight.append(batch)
                 turn += 1
                 if len(in_flight) > lanes:                        # the batch `lanes` back, while the GPU is busy with the later ones
-                    for fr in in_flight.popleft():
-                        deliver(*fr)
+                    for i, fr in enumerate(in_flight.popleft()):
+                        deliver(*fr, first_of_batch=i == 0)
             while in_flight:
-                for fr in in_flight.popleft():
-                    deliver(*fr)
+                for i, fr in enumerate(in_flight.popleft()):
+                    deliver(*fr, first_of_batch=i == 0)
             for i, b in enumerate(busy):
                 if hasattr(b, "result"):
                     b.result()
@@ -248,7 +271,7 @@ def render_sequence(config: "api.Config", start: float, end: float, step: float,
                     file_name: str = "attractor", image_format: int | None = None,
                     sink: Callable[[int, str, np.ndarray], object] | None = None,
                     ring: int = 0, lanes: int = 2, zero_copy: bool = False, batch: int = 0,
-                    max_batch: int = 4) -> list[tuple[int, str, np.ndarray]]:
+                    max_batch: int = 16) -> list[tuple[int, str, np.ndarray]]:
     """Renders this rank's frames of the sweep (frame k belongs to rank k % world; no collective is needed).
     Returns [(frame index, file name, image)] unless `sink` consumes the frames. The image is RGBA16, or — with
     `image_format` (SAR_FMT_*) — the CLI's converted format, converted on the device before the read-back.
@@ -299,6 +322,6 @@ def render_sequence_to_files(config: "api.Config", start: float, end: float, ste
             return f                                  # the page-locked image is reused only after its file is written
 
         lanes_ = kw.get("lanes", 2)
-        kw.setdefault("ring", max(1, encoders) + (lanes_ + 1) * (kw.get("batch", 0) or kw.get("max_batch", 4)) + 1)
+        kw.setdefault("ring", max(1, encoders) + (lanes_ + 1) * (kw.get("batch", 0) or kw.get("max_batch", 16)) + 1)
         render_sequence(config, start, end, step, file_name=file_name, image_format=fmt, sink=sink, zero_copy=True, **kw)  # the encoder's Future guards the view
         return [f.result() for f in pending]

@@ -48,16 +48,22 @@ def _oracle_state(oracle, cfg, starts, n, ort=None):
 
 
 @pytest.mark.parametrize("preset,kind", [("solar_sail", 0), ("solar_sail", 1), ("poisson_saturne", 0)])
-@pytest.mark.parametrize("shared_stream", [False, True])
-def test_batched_sweep_equals_per_frame_renders_and_oracle(sar, oracle, gpu, preset, kind, shared_stream):
-    F, W, H, jobs, n = 6, 600, 500, 4096, 300
+@pytest.mark.parametrize("shared_stream,F,options", [(False, 6, {}), (True, 6, {"batch_warm": 2}), (True, 8, {"batch_warm": 2, "hint_bits": 16}),
+                                                      (True, 4, {"batch_starts": 1}), (False, 2, {"batch_starts": 2, "batch_xcd": 1}),
+                                                      (True, 16, {}), (True, 24, {"batch_warm": 2})])
+def test_batched_sweep_equals_per_frame_renders_and_oracle(sar, oracle, gpu, preset, kind, shared_stream, F, options):
+    """F frames in one set of launches — frames dealt to the XCDs (2, 4, 8, 16) or one after the other (6), the warm-up in one or
+    two phases, the start points read in place or copied, the runtimes on one stream or on their own."""
+    W, H, jobs, n = 600, 500, 4096, 300
     cfgs, starts = _frames(sar, preset, kind, F, W, H, jobs, n, seed=11)
     rts = [sar.Runtime(c) for c in cfgs]
     if shared_stream:
         for rt in rts[1:]:
-            rt.set_stream(rts[0].stream())
+            rt.share_streams(rts[0])
+    for k, v in options.items():
+        rts[0].set_option(k, v)
     sar.render_jobs_batch(cfgs, rts, starts)
-    assert "batch of 6 frames" in rts[0].describe_last_launch() and "k_iterate_split" in rts[3].describe_last_launch()
+    assert f"batch of {F} frames" in rts[0].describe_last_launch() and "k_iterate_split" in rts[F - 1].describe_last_launch()
     differ = 0
     for i, (cfg, rt, st) in enumerate(zip(cfgs, rts, starts)):
         got = _state(sar, cfg, rt)
@@ -126,13 +132,13 @@ def test_frames_that_cannot_share_a_launch_run_one_after_the_other(sar, oracle, 
         _assert_same(_state(sar, cfgs[i], rts[i]), _oracle_state(oracle, cfgs[i], starts[i], n)[1], f"chunked frame {i}")
     for rt in rts:
         rt.close()
-    # 19 frames: a table of 16 and a table of 3
-    cfgs, starts = _frames(sar, "poisson_saturne", 0, 19, 128, 128, 256, 100, seed=8)
+    # 35 frames: a table of 32 and a table of 3
+    cfgs, starts = _frames(sar, "poisson_saturne", 0, 35, 128, 128, 256, 100, seed=8)
     rts = [sar.Runtime(c) for c in cfgs]
     sar.render_jobs_batch(cfgs, rts, starts)
-    assert "batch of 16 frames" in rts[0].describe_last_launch() and "batch of 3 frames" in rts[18].describe_last_launch()
-    for i in (0, 7, 15, 16, 18):
-        _assert_same(_state(sar, cfgs[i], rts[i]), _oracle_state(oracle, cfgs[i], starts[i], 100)[1], f"frame {i} of 19")
+    assert "batch of 32 frames" in rts[0].describe_last_launch() and "batch of 3 frames" in rts[34].describe_last_launch()
+    for i in (0, 7, 8, 15, 16, 31, 32, 34):
+        _assert_same(_state(sar, cfgs[i], rts[i]), _oracle_state(oracle, cfgs[i], starts[i], 100)[1], f"frame {i} of 35")
     with pytest.raises(sar.SarError):
         sar.render_jobs_batch(cfgs[:2], [rts[0], sar.Runtime(cfgs[0].replace(width=64, height=64))], starts[:2])
     for rt in rts:
