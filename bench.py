@@ -23,8 +23,16 @@ torch.distributed) — reported under `native`.
 
     python bench.py --native --gpus N [--config c2|c4]   only the C-ABI multi-device renderer, one process
 
-One JSON line on rank 0; see DESIGN.md "Measurement" for how each field is derived.
+One JSON line on rank 0; see DESIGN.md "Measurement" for how each field is derived. This file holds the timed loops and the
+line; what is reported NEXT to them (PMC child passes, CPU baseline, frame checksums against tests/golden, the sustained and
+two-stream loops, the `sequence` sweep, the C-ABI-only renderer) lives in tools/bench_extras.py and is imported on demand.
+
+The line proves itself: `parity` holds the FNV-1a checksums of the frame's count / zbuf / steps / RGBA16 against the committed
+golden of the same frame (tests/golden/fullsize_checksums.json: configs[1] at N = 1, configs[3] — the same frame at every N —
+under `strong_c4`), an N > 1 run checks merged count == sum of the ranks' counts by default, and `run` records the world size
+torch.distributed really saw, the backend and every rank's PCI device.
 """
+
 import argparse
 import json
 import os
@@ -33,6 +41,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(1, os.path.join(ROOT, "tools"))
 
 WIDTH = HEIGHT = 2048
 ITERS_PER_GPU = 1_000_000_000
@@ -46,149 +55,8 @@ ALG_BYTES_PER_ITER = 12.0 + 12.0 * 0.0055   # count RMW 8 B + 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_OPS_PER_ITER = 88           # unfused fp64 ops per counted iteration; FMA is not allowed
 FP64_PEAK_OPS = 78.6e12 / 2      # MI355X vector fp64 78.6 TFLOP/s counts an FMA as 2 -> 39.3e12 unfused op/s
-
-
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of the headline workload
-    (profiles/rNN_pmc.json): (2*FETCH_SIZE + WRITE_SIZE) * 1024 — the fallback when the run cannot measure them itself."""
-    import glob
-    import re
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")) if re.fullmatch(r"r\d+_pmc\.json", os.path.basename(f)))
-    if not files:
-        return None, None
-    try:
-        d = json.load(open(files[-1]))
-        d = d.get("k_iterate_split") or d.get("k_iterate_lean") or d["k_iterate_binned"]
-        return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, os.path.relpath(files[-1], ROOT)
-    except Exception:
-        return None, None
-
-
-def measure_traffic_live(kernel: str, timeout_s: float = 90.0):
-    """HBM bytes per launch of `kernel`, MEASURED by this run the way MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE
-    and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (they do not fit one pass; --kernel-trace only, no other trace domain),
-    each over a short child run of this very bench (3 timed steps), unit KiB, FETCH_SIZE doubled (on gfx950 it tallies the
-    128-byte fabric requests at 64 B). Returns (bytes per launch, description) or (None, why)."""
-    import csv
-    import glob
-    import shutil
-    import subprocess
-    import tempfile
-    if not shutil.which("rocprofv3"):
-        return None, "rocprofv3 not found"
-    vals = {}
-    tmp = tempfile.mkdtemp(prefix="sar_pmc_", dir="/tmp")
-    try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
-                   os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pipeline", "--sustained-seconds", "0",
-                   "--no-traffic"]
-            env = dict(os.environ, TMPDIR="/tmp")
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
-            got = []
-            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    if kernel in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
-                        got.append(float(r["Counter_Value"]))
-            if not got:
-                return None, f"no {counter} rows for {kernel}"
-            vals[counter] = sum(got) / len(got)
-        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (
-            f"measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in two separate passes over a 3-step child run, "
-            f"mean per launch of {kernel}, (2*FETCH_SIZE + WRITE_SIZE)*1024 with the guide's gfx950 read correction "
-            f"(FETCH_SIZE {vals['FETCH_SIZE'] * 1024 / 1e9:.3f} GB uncorrected — an upper estimate for this kernel's scattered 4-byte reads — "
-            f"+ WRITE_SIZE {vals['WRITE_SIZE'] * 1024 / 1e9:.3f} GB)")
-    except Exception as e:  # a missing tool, a time-out, a changed csv: the committed passes stand in
-        return None, f"live PMC passes failed: {e!r}"
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-
-
-def cpu_baseline(seconds_hint: float):
-    """The oracle's render_parallel-shaped port (threads + private buffers + serial merge + serial
-    colorize) on this box's host cores. Reported beside the GPU number, never part of it."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cfg = O.poisson_saturne()
-    cfg.width, cfg.height, cfg.transparent = WIDTH, HEIGHT, 0
-    # the full C2 frame when the host gets through it in the time hint (~2e7 it/s/thread), else a cut
-    est_rate = 2.0e7 * threads
-    iters = ITERS_PER_GPU if ITERS_PER_GPU / est_rate <= seconds_hint else int(est_rate * seconds_hint)
-    cfg.iterations = iters
-    # The reference runs one worker per hardware thread (available_parallelism, src/lib.rs:920-922) and merges their
-    # private buffer sets serially (:1070-1076): on a many-core host that merge dominates and FEWER threads are faster.
-    # `value` is the best thread count of a short sweep (the most favourable number for the CPU); the reference's
-    # own default (all threads) is reported next to it.
-    runs = []
-    for t in sorted({min(16, threads), min(32, threads), min(64, threads), threads}):
-        secs, done, _ = O.render_parallel(cfg, t, 12, 1, want_image=True)
-        runs.append({"cores": t, "value": done / secs, "seconds": round(secs, 2), "iterations": done})
-    best = max(runs, key=lambda r: r["value"])
-    allt = next(r for r in runs if r["cores"] == threads)
-    # `--single-thread` semantics (render + colorize on one core, src/bin/main.rs:483-490) on a shorter sample
-    import time as _t
-    import numpy as _np
-    st_iters = 100_000_000
-    rt = O.Runtime(WIDTH, HEIGHT)
-    t0 = _t.perf_counter()
-    O.render(cfg, rt, _np.array([0.05, 0.031, 0.077]), st_iters)
-    O.colorize(cfg, rt)
-    st_secs = _t.perf_counter() - t0
-    return {
-        "value": best["value"], "unit": "iterations/s", "cores": best["cores"], "kind": "port",
-        "sample": f"poisson-saturne {WIDTH}x{HEIGHT}, {best['iterations']} iterations, {best['cores']} threads x 12 "
-                  f"jobs/thread, private buffers + serial merge + serial colorize ({best['seconds']} s); best of the "
-                  f"thread counts {[r['cores'] for r in runs]}; C restatement of the reference (clang -O3 "
-                  "-ffp-contract=off), not rustc output",
-        "thread_sweep": [{"cores": r["cores"], "value": r["value"], "seconds": r["seconds"]} for r in runs],
-        "all_hardware_threads": {"cores": allt["cores"], "value": allt["value"], "unit": "iterations/s",
-                                 "sample": f"the reference's default thread count; {allt['seconds']} s, dominated by "
-                                           f"the serial merge of {allt['cores']} buffer sets"},
-        "single_thread": {"value": st_iters / st_secs, "unit": "iterations/s",
-                          "sample": f"one trajectory, {st_iters} iterations + colorize ({st_secs:.2f} s)"},
-    }
-
-
-def native_measure(S, torch, devices, config, steps, warmup):
-    """The same frame through the C ABI alone: sar_renderer_new_multi over `devices` (one host thread + one stream per
-    device, slices exchanged with hipMemcpyPeerAsync, colorized per slice into a pinned host image). A step is one
-    sar_render_parallel call: reset, render, exchange, colorize, image in host memory — the next frame's start points are
-    drawn meanwhile on one helper thread per device, uploaded from page-locked memory and announced."""
-    g = len(devices)
-    if config == "c4":
-        width, total_jobs, iters = C4_SIZE, C4_JOBS, C4_ITERS
-    else:
-        width, total_jobs, iters = WIDTH, DEFAULT_JOBS * g, ITERS_PER_GPU * g
-    jpu = 8
-    units = total_jobs // jpu
-    n = iters // units // jpu
-    cfg = S.Config.poisson_saturne(iterations=iters, width=width, height=width, transparent=0, seed=1)
-    r = S.ParallelRenderer(devices=devices, units=units, seed=1)
-    img = torch.empty((width, width, 4), dtype=torch.int16).pin_memory()
-    phases = {"render_ms": 0.0, "exchange_ms": 0.0, "colorize_ms": 0.0, "host_ms_before_exchange": 0.0, "host_ms_enqueue": 0.0,
-              "draw_ahead_ms": 0.0}
-    for _ in range(warmup):
-        S.render_parallel_into(r, cfg, jpu, img.data_ptr())
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        S.render_parallel_into(r, cfg, jpu, img.data_ptr())
-        t = r.last_timing()
-        for k in phases:
-            phases[k] += t[k]
-    el = time.perf_counter() - t0
-    t = r.last_timing()
-    r.shutdown()
-    return {"value": n * total_jobs * steps / el, "unit": "iterations/s", "ms_per_step": el / steps * 1e3, "steps": steps,
-            "scaling": "strong" if config == "c4" else "weak", "devices": list(devices), "jobs_total": total_jobs,
-            "iterations_per_job": n, "image": f"{width}x{width}",
-            "phase_ms_per_step_slowest_device": {k: v / steps for k, v in phases.items() if k.endswith("_ms") and not k.startswith(("host", "draw"))},
-            "host_ms_per_step": {"between_render_and_exchange_enqueue": phases["host_ms_before_exchange"] / steps,
-                                 "until_the_frame_is_enqueued": phases["host_ms_enqueue"] / steps,
-                                 "next_frame_points_drawn_on_helper_threads": phases["draw_ahead_ms"] / steps},
-            "exchange_bytes_per_device": int(t["exchange_bytes_per_device"]), "peer_access_failures": int(t["peer_access_failures"]),
-            "note": "sar_render_parallel end to end, image in pinned host memory (PCIe and the host-side job list included)"}
+K = {"WIDTH": WIDTH, "HEIGHT": HEIGHT, "ITERS_PER_GPU": ITERS_PER_GPU, "DEFAULT_JOBS": DEFAULT_JOBS, "C4_SIZE": C4_SIZE,
+     "C4_ITERS": C4_ITERS, "C4_JOBS": C4_JOBS}
 
 
 def main():
@@ -202,13 +70,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo only "
                     "to exercise the multi-rank path on a box with fewer GPUs than ranks)")
-    ap.add_argument("--check", action="store_true", help="N>1: verify the merged count buffer against the sum of "
-                    "the per-rank buffers (debug; not timed)")
+    ap.add_argument("--no-check", dest="check", action="store_false", help="N>1: skip the (untimed) check that the merged count buffer "
+                    "equals the sum of the per-rank buffers")
+    ap.add_argument("--no-parity", dest="parity", action="store_false", help="skip the (untimed) frame checksums against tests/golden")
     ap.add_argument("--host-starts", action="store_true", help="hand the start points over from host memory every step "
                     "(PCIe-inclusive rate; the default keeps them resident in HBM)")
     ap.add_argument("--lanes", type=int, default=2, help="--config c5: groups of runtimes (streams) per GPU the frames are rendered on in turn")
-    ap.add_argument("--batch", type=int, default=0, help="--config c5: frames per set of launches (sar_render_jobs_batch); 0 = as many "
-                    "as fill the chip (the library's advice, at most --max-batch), 1 = a frame per launch")
+    ap.add_argument("--batch", type=int, default=0, help="--config c5: frames per set of launches (sar_render_jobs_batch); 0 = the "
+                    "library's advice (a multiple of eight, at most --max-batch), 1 = a frame per launch")
     ap.add_argument("--max-batch", type=int, default=16)
     ap.add_argument("--rt-opt", action="append", default=[], help="--config c5: name=value runtime option (sar_runtime_set_option) of every runtime (A/B)")
     ap.add_argument("--c5-only", default=None, choices=["readback", "hbm"], help="--config c5: only one of the two sweeps (profiling)")
@@ -241,9 +110,10 @@ def main():
 
     if a.native:
         import torch
+        import bench_extras as X
         import strange_attractor_renderer_amd as S
         ndev = max(S.device_count(), 1)
-        res = native_measure(S, torch, [k % ndev for k in range(a.gpus)], a.config, a.steps, a.warmup)
+        res = X.native_measure(S, torch, [k % ndev for k in range(a.gpus)], a.config, a.steps, a.warmup, K)
         res.update({"metric": "attractor iterations/sec through sar_render_parallel (C ABI, multi-device)", "n_gpus": a.gpus,
                     "physical_gpus": ndev, "higher_is_better": True, "dtype": "f64", "data": "synthetic", "vs_baseline": None,
                     "config": {"workload": f"BASELINE configs[{1 if a.config == 'c2' else 3}] through sar_renderer_new_multi"}})
@@ -288,81 +158,26 @@ def main():
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
 
+    # who really runs this: the world torch.distributed saw, the backend, every rank's physical device
+    import ctypes as C
+    pci = C.create_string_buffer(64)
+    S.load_library().sar_device_pci_bus_id(local_rank, pci, 64)
+    mine = {"rank": rank, "device": local_rank, "pci": pci.value.decode()}
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+    run_record = {"world_size_seen": dist.get_world_size() if world > 1 else 1, "world_size_env": world,
+                  "backend": (a.backend + (" (RCCL)" if a.backend == "nccl" else "")) if world > 1 else None,
+                  "devices": [r["pci"] for r in ranks], "distinct_devices": len({r["pci"] for r in ranks}),
+                  "library_build_id": S.load_library().sar_build_id().decode()}
+
     if a.config == "c5":
-        # BASELINE configs[4]: `sequence --start 0 --end 360 --step 1` (src/bin/main.rs:107-176, 493-517), frame k -> rank k mod N.
-        # A step is one frame: reset, render_parallel's job split with a fresh start-point stream per frame, colorize, RGB16
-        # conversion on the device, read-back into host memory. The PNG encoder (the CLI runs it on other threads) is excluded.
-        from strange_attractor_renderer_amd.sequence import SequenceRenderer, frames as sequence_frames
-        frame_jobs = a.jobs if jobs_given else 65536
-        units, jpt = frame_jobs // 4, 4
-        scfg = S.Config.solar_sail(iterations=100_000_000, width=1800, height=2000, scale=1.0, transparent=0)
-        per_job = scfg.iterations // units // jpt
-        done = [0]
-
-        def sink(k, name, img):
-            done[0] += 1
-
-        def measure(seq):
-            """--steps frames per rank through `seq`, after an untimed sweep; the slowest rank's wall time."""
-            def sweep(frames_per_rank):
-                done[0] = 0
-                todo = [f for f in sequence_frames(0.0, float(frames_per_rank * world), 1.0) if f[0] % world == rank]
-                seq.run(todo, sink, zero_copy=True)   # the sink only counts: no copy of the page-locked image
-                torch.cuda.synchronize()
-                assert done[0] == frames_per_rank
-            sweep(max(a.warmup, a.lanes * seq.max_batch * 2))
-            if world > 1:
-                dist.barrier()
-            t0 = time.perf_counter()
-            sweep(a.steps)
-            if world > 1:
-                dist.barrier()
-            el = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([el], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el = float(t.item())
-            sizes = list(seq.frames_per_launch)
-            launch = seq.groups[0][0].describe_last_launch() if seq.groups and seq.groups[0] else ""
-            seq.close()
-            return el, sizes, launch
-
-        # the runtimes and the page-locked images live as long as the CLI's sweep does: made once, outside the timed frames
-        common = dict(units=units, jobs_per_thread=jpt, seed=4, device=local_rank, lanes=a.lanes, batch=a.batch, max_batch=a.max_batch,
-                      options={o.split("=")[0]: int(o.split("=")[1]) for o in a.rt_opt})
-        if a.c5_only == "hbm":
-            elapsed, sizes, launch = float("nan"), [], ""
-        else:
-            elapsed, sizes, launch = measure(SequenceRenderer(scfg, image_format=S.SAR_FMT_RGB16, **common))
-        # ... and the same sweep to what SURVEY 8(d)'s metric ends with: the colorized frame as RGBA16 in device memory
-        slots = (a.lanes + 1) * max(a.batch, a.max_batch) + 1
-        hbm = [torch.empty(1800 * 2000 * 4, dtype=torch.int16, device="cuda") for _ in range(slots)]
-        if a.c5_only == "readback":
-            el_hbm, sizes_hbm = float("nan"), []
-        else:
-            el_hbm, sizes_hbm, launch_hbm = measure(SequenceRenderer(scfg, device_ring=[t.data_ptr() for t in hbm], ring=slots, **common))
-            launch = launch or launch_hbm
+        import bench_extras as X
+        out = X.run_c5(a, S, torch, dist, world, rank, local_rank, jobs_given)
         if rank == 0:
-            frames = a.steps * world
-            counted = per_job * units * jpt * frames
-            print(json.dumps({
-                "metric": "attractor iterations/sec over the solar-sail sequence sweep (1e8 iterations per frame, 1800x2000), one frame per GPU",
-                "value": counted / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                "ms_per_step": elapsed / a.steps * 1e3, "ms_per_frame_per_gpu": elapsed / a.steps * 1e3, "frames_per_second": frames / elapsed,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "rgba16_in_hbm": {"value": counted / el_hbm, "unit": "iterations/s", "ms_per_frame_per_gpu": el_hbm / a.steps * 1e3,
-                                  "frames_per_second": frames / el_hbm,
-                                  "note": "the same sweep with every frame left as RGBA16 in device memory (colorize, no conversion, "
-                                          "no read-back): what SURVEY 8(d)'s metric ends with"},
-                "config": {"workload": "BASELINE configs[4]: sequence --start 0 --end 360 --step 1 (the first steps*N frames), solar-sail, "
-                                       "1e8 iterations per frame, 1800x2000, scale 1, frame k on rank k mod N; RGB16 conversion on the "
-                                       "device + read-back included, PNG encoder excluded",
-                           "jobs_per_frame": units * jpt, "iterations_per_job": per_job, "frames": frames,
-                           "lanes_per_gpu": a.lanes, "frames_per_launch": {str(f): sizes.count(f) for f in sorted(set(sizes))},
-                           "frames_per_launch_in_hbm": {str(f): sizes_hbm.count(f) for f in sorted(set(sizes_hbm))},
-                           "launch": launch,
-                           "counted_over_executed_iterations": round(per_job / (per_job + 1000.0), 4),
-                           "parallelism": f"{world} replica(s), no collective"}}), flush=True)
+            out["run"] = run_record
+            print(json.dumps(out), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -371,7 +186,7 @@ def main():
     def run_config(config, steps, warmup, extras):
         result = None
         if config == "c4":
-            # STRONG scaling: the frame (1e10 iterations, 524 288 jobs, 4096^2) is the same at every N; rank r renders the
+            # STRONG scaling: the frame (1e10 iterations, 1 048 576 jobs, 4096^2) is the same at every N; rank r renders the
             # contiguous job slice shard_jobs gives it (src/lib.rs:1056-1062 split)
             width = height = C4_SIZE
             total_jobs = a.jobs if jobs_given else C4_JOBS
@@ -384,17 +199,18 @@ def main():
             n = int(a.iters) // jobs
             total_jobs = jobs * world
             first_job = rank * jobs
-        iters_gpu = n * jobs
         cfg = S.Config.poisson_saturne(iterations=n * total_jobs, width=width, height=height,
                                        jobs_total=total_jobs, transparent=0, seed=1)
         starts = S.start_points(1, first_job, jobs)
+        tuning = dict(block_threads=a.block, checkpoint_stride=a.stride, variant=a.variant)
+        check_note, parity = None, None
 
         stream = torch.cuda.Stream()
         with torch.cuda.stream(stream):
             rt = S.Runtime(cfg, device=local_rank)
             rt.set_stream(stream.cuda_stream)
             rt.enable_timing(True)
-            rt.set_tuning(block_threads=a.block, checkpoint_stride=a.stride, variant=a.variant)
+            rt.set_tuning(**tuning)
             npix = width * height
             rgba = torch.empty(npix * 4, dtype=torch.int16, device="cuda")
             ex = None
@@ -403,16 +219,29 @@ def main():
             elif world > 1:
                 key = torch.empty(npix, dtype=torch.int64, device="cuda")
                 sums = torch.empty(3 * npix, dtype=torch.int32, device="cuda")
-            # per timed step: render end / exchange end / colorize end (read after the closing fence, never inside the region)
-            evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(max(steps, warmup, 1))] if world > 1 else []
-            exch_ms = [0.0, 0.0]
+            # per timed step: start / render end / exchange end / colorize end (read after the closing fence, never inside the region)
+            evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(max(steps, warmup, 1))] if world > 1 else []
+            phase_ms = [0.0, 0.0, 0.0]
             step_no = [0]
 
             # the inputs of the path — the start points of this rank's trajectories — are resident in HBM before the
             # timed region starts (with host start points each frame uploads 3 MiB: +0.1 ms)
             starts_dev = torch.from_numpy(np.ascontiguousarray(starts)).cuda()
 
+            def merge_ranks(rt_, ex_):
+                if ex_ is not None:
+                    # Runtime::merge folded in rank order, sliced: all-to-all of the image slices (16 B/px), the owner
+                    # folds its slice, 4 scalars all-reduced (every rank then colorizes its slice, RGBA16 gathered on rank 0)
+                    ex_.merge(dist)
+                else:
+                    # rooted: depth keys -> all-reduce MAX; counts + winner's steps -> reduce SUM; rank 0 colorizes
+                    exchange_merge(rt_, rank, dist, key, sums, dst=0)
+
             def step(more=True):
+                if world > 1:
+                    ev = evs[step_no[0] % len(evs)]
+                    step_no[0] += 1
+                    ev[3].record()
                 rt.reset()
                 if a.host_starts:
                     S.render_job_range(cfg, rt, n, starts)
@@ -424,21 +253,13 @@ def main():
                     if a.prefetch and more:
                         S.prefetch_device(cfg, rt, jobs, n, starts_dev.data_ptr())
                 if world > 1:
-                    ev = evs[step_no[0] % len(evs)]
-                    step_no[0] += 1
                     ev[0].record()
+                    merge_ranks(rt, ex)
+                    ev[1].record()
                     if ex is not None:
-                        # Runtime::merge folded in rank order, sliced: all-to-all of the image slices (16 B/px), the owner
-                        # folds its slice, 4 scalars all-reduced, every rank colorizes its slice, RGBA16 gathered on rank 0
-                        ex.merge(dist)
-                        ev[1].record()
                         ex.colorize(dist, dst=0)
-                    else:
-                        # rooted: depth keys -> all-reduce MAX; counts + winner's steps -> reduce SUM; rank 0 colorizes
-                        exchange_merge(rt, rank, dist, key, sums, dst=0)
-                        ev[1].record()
-                        if rank == 0:
-                            S.colorize_device(cfg, rt, rgba.data_ptr())
+                    elif rank == 0:
+                        S.colorize_device(cfg, rt, rgba.data_ptr())
                     ev[2].record()
                 else:
                     S.colorize_device(cfg, rt, rgba.data_ptr())
@@ -452,7 +273,7 @@ def main():
                 step(more=k + 1 < warmup)  # the last untimed frame announces nothing: no work of the timed region runs before it
             fence()
             if world > 1 and a.check:
-                # each rank's own (un-merged) count summed over ranks must equal the merged count on rank 0
+                # each rank's own (un-merged) count summed over ranks must equal the merged count (untimed, on by default)
                 def reduce_sum(a_np):  # int64 SUM onto rank 0, through whatever the backend can move
                     t = torch.from_numpy(np.ascontiguousarray(a_np))
                     t = t.cuda() if a.backend == "nccl" else t
@@ -462,20 +283,19 @@ def main():
                 rt.reset()
                 S.render_job_range(cfg, rt, n, starts)
                 own = reduce_sum(rt.count().ravel().astype(np.int64))
+                merge_ranks(rt, ex)
+                torch.cuda.synchronize()
                 if ex is not None:
-                    ex.merge(dist)
-                    torch.cuda.synchronize()
-                    mine = np.zeros(npix, np.int64)  # every rank holds the merged frame inside its own slice: assemble them
-                    mine[ex.first:ex.first + ex.count] = rt.count().ravel()[ex.first:ex.first + ex.count]
-                    merged = reduce_sum(mine)
+                    mine_ = np.zeros(npix, np.int64)  # every rank holds the merged frame inside its own slice: assemble them
+                    mine_[ex.first:ex.first + ex.count] = rt.count().ravel()[ex.first:ex.first + ex.count]
+                    merged = reduce_sum(mine_)
                 else:
-                    exchange_merge(rt, rank, dist, key, sums, dst=0)
-                    torch.cuda.synchronize()
                     merged = rt.count().ravel().astype(np.int64)
                 if rank == 0:
-                    assert np.array_equal(merged, own % (1 << 32)), "merged count != sum of rank counts"
-                    assert int(merged.sum()) == n * total_jobs
-                    print(f"[check] merged count over {world} ranks == sum of per-rank counts == {n * total_jobs}", file=sys.stderr)
+                    ok = bool(np.array_equal(merged, own % (1 << 32))) and int(merged.sum()) == n * total_jobs
+                    check_note = {"merged_count_equals_sum_of_rank_counts": ok, "iterations_in_the_merged_frame": int(merged.sum()),
+                                  "expected": n * total_jobs}
+                    print(f"[check] merged count over {world} ranks == sum of per-rank counts == {n * total_jobs}: {ok}", file=sys.stderr)
                 fence()
             # HIP events around every launch of the timed region, recorded on the launch stream by the library and
             # summed until they are read after the closing fence (reading them synchronises, so not inside the region)
@@ -487,8 +307,9 @@ def main():
             fence()
             elapsed = time.perf_counter() - t0
             for ev in evs[:steps]:
-                exch_ms[0] += ev[0].elapsed_time(ev[1])
-                exch_ms[1] += ev[1].elapsed_time(ev[2])
+                phase_ms[0] += ev[3].elapsed_time(ev[0])
+                phase_ms[1] += ev[0].elapsed_time(ev[1])
+                phase_ms[2] += ev[1].elapsed_time(ev[2])
             tm = rt.last_timing()
             iter_ms, fold_ms, launches = tm.iterate_ms, tm.resolve_ms, tm.iterate_launches
             col_ms = tm.colorize_ms
@@ -497,71 +318,44 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 elapsed = float(t.item())
 
-        # Sustained rate (reported NEXT to `value`): the same step loop for a few seconds, every frame timed by HIP events on
-        # the launch stream — min / median / max per frame, so that clock droop under a seconds-long fp64 load is on record.
-        sustained = None
-        if world == 1 and extras and a.sustained_seconds > 0:
-            try:
-                rt.enable_timing(False)  # no per-launch events in this loop: thousands of frames
-                with torch.cuda.stream(stream):
-                    per = elapsed / steps
-                    frames = int(min(4000, max(steps, a.sustained_seconds / per)))
-                    marks = [torch.cuda.Event(enable_timing=True) for _ in range(frames + 1)]
-                    marks[0].record()
-                    t0s = time.perf_counter()
-                    for k in range(frames):
-                        step(more=k + 1 < frames)
-                        marks[k + 1].record()
+            sustained = pipelined = None
+            default_shape = int(a.iters) == ITERS_PER_GPU and not jobs_given
+            if world == 1 and extras:
+                import bench_extras as X
+                if a.sustained_seconds > 0:
+                    rt.enable_timing(False)  # no per-launch events in this loop: thousands of frames
+                    sustained = X.sustained_loop(torch, stream, step, elapsed / steps, steps, a.sustained_seconds, n * total_jobs)
+                if a.pipeline:
+                    pipelined = X.pipelined_loop(S, torch, cfg, local_rank, jobs, n, starts_dev.data_ptr(), npix, steps, warmup, tuning)
+
+            # The frame's checksums against the committed golden of the same frame (untimed): configs[1] as this bench runs it at
+            # N = 1 (golden c2_131072), configs[3] — the same frame at every N — as tests/golden holds it (c4_full_1e10: seed 3,
+            # the preset's transparent flag), rendered, merged and colorized once more by the same ranks.
+            case = "c2_131072" if (config == "c2" and world == 1) else ("c4_full_1e10" if config == "c4" else None)
+            if a.parity and default_shape and case and not a.variant:
+                import bench_extras as X
+                try:
+                    rt.enable_timing(False)
+                    if config == "c4":
+                        cfg_g = S.Config.poisson_saturne(iterations=n * total_jobs, width=width, height=height, jobs_total=total_jobs, seed=3)
+                        starts_g = S.start_points(3, first_job, jobs)
+                        ex_g = SlicedExchange(S, cfg_g, rt, rank, world, "cuda") if ex is not None else None
+                    else:
+                        cfg_g, starts_g, ex_g = cfg, starts, None
+                    rt.reset()
+                    S.render_job_range(cfg_g, rt, n, starts_g)
+                    if world > 1:
+                        merge_ranks(rt, ex_g)
                     torch.cuda.synchronize()
-                    els = time.perf_counter() - t0s
-                ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(frames))
-                third = max(frames // 3, 1)
-                order = [marks[k].elapsed_time(marks[k + 1]) for k in range(frames)]
-                sustained = {"seconds": els, "frames": frames, "value": n * total_jobs * frames / els, "unit": "iterations/s",
-                             "ms_per_frame": {"min": ms[0], "median": ms[frames // 2], "max": ms[-1],
-                                              "mean_first_third": sum(order[:third]) / third, "mean_last_third": sum(order[-third:]) / third},
-                             "note": "frame k's event-to-event time on the launch stream (the first frame runs its own warm-up, "
-                                     "the others were announced)"}
-            except Exception as e:
-                sustained = {"error": repr(e)}
-
-        # Pipelined throughput (reported NEXT to `value`, never as it): the same frames on two runtimes and two streams,
-        # alternating, so that frame k's tail (accumulate, fold, colorize — memory-bound) and frame k+1's head (reset, warm-up
-        # — no LDS, arithmetic-bound) may share the chip. `value` above is the one-stream number: a frame's latency.
-        pipelined = None
-        if world == 1 and a.pipeline and extras:
-            try:
-                streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-                rts, bufs = [], []
-                for st in streams:
-                    with torch.cuda.stream(st):
-                        r2 = S.Runtime(cfg, device=local_rank)
-                        r2.set_stream(st.cuda_stream)
-                        r2.set_tuning(block_threads=a.block, checkpoint_stride=a.stride, variant=a.variant)
-                        rts.append(r2)
-                        bufs.append(torch.empty(npix * 4, dtype=torch.int16, device="cuda"))
-
-                def frame(i):
-                    r2, st = rts[i & 1], streams[i & 1]
-                    with torch.cuda.stream(st):
-                        r2.reset()
-                        S.render_job_range_device(cfg, r2, jobs, n, starts_dev.data_ptr())
-                        S.colorize_device(cfg, r2, bufs[i & 1].data_ptr())
-
-                for i in range(max(warmup, 2)):
-                    frame(i)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(steps):
-                    frame(i)
-                torch.cuda.synchronize()
-                el2 = time.perf_counter() - t0
-                pipelined = {"value": n * total_jobs * steps / el2, "unit": "iterations/s", "ms_per_step": el2 / steps * 1e3,
-                             "streams": 2, "note": "two runtimes on two streams, frames alternating; every frame does the full work"}
-                for r2 in rts:
-                    r2.close()
-            except Exception as e:  # an optional extra: never lose the bench line over it
-                pipelined = {"error": repr(e)}
+                    frame = X.gather_merged_frame(S, torch, dist, np, rt, ex_g, cfg_g, rank, world, a.backend)
+                    if rank == 0:
+                        parity = X.frame_parity(S, case, *frame[:4], frame[4])
+                        print(f"[parity] {case}: {parity['result']}", file=sys.stderr)
+                    del ex_g
+                except Exception as e:  # evidence next to the number: never lose the line over it
+                    parity = {"result": "not checked", "error": repr(e)}
+                if world > 1:
+                    dist.barrier()
 
         counted = n * total_jobs * steps
         value = counted / elapsed
@@ -569,15 +363,6 @@ def main():
             kern_s = iter_ms * 1e-3 / max(launches, 1)             # average duration of one launch of the iterate kernel
             launch_desc = rt.describe_last_launch()                # what the library really launched (not a guess made here)
             iterate_kernel = launch_desc.split(" ")[0]
-            traffic, traffic_src = None, None
-            if config == "c2" and int(a.iters) == ITERS_PER_GPU and jobs == DEFAULT_JOBS and world == 1 and a.traffic:
-                traffic, traffic_src = measure_traffic_live(iterate_kernel)
-                if traffic is None:
-                    why = traffic_src
-                    traffic, traffic_src = pmc_traffic_bytes()
-                    if traffic_src:
-                        traffic_src = (f"{traffic_src}: PMC passes of this workload committed with the round ((2*FETCH_SIZE + WRITE_SIZE)*1024 per "
-                                       f"launch), NOT measured by this run ({why})")
             per_launch = n * jobs * steps / max(launches, 1)      # counted iterations one launch processes
             ach = ALG_BYTES_PER_ITER * per_launch / kern_s / 1e9
             out = {
@@ -605,8 +390,8 @@ def main():
                                              if world > 1 else "")},
                 "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach / HBM_PEAK_GBS,
-                             "traffic": traffic,
-                             "traffic_source": traffic_src,
+                             "traffic": None,
+                             "traffic_source": None,
                              "kernel": iterate_kernel, "launch": launch_desc, "kernel_ms": kern_s * 1e3,
                              "alg_bytes_per_iteration": ALG_BYTES_PER_ITER,
                              "launches_timed": launches,
@@ -619,21 +404,41 @@ def main():
                 "kernel_ms_per_step": {"warmup_and_pack": tm.warmup_ms / steps, "iterate": iter_ms / steps,
                                        "accumulate_fold_resolve": fold_ms / steps,
                                        "colorize_last": col_ms},
+                "parity": parity,
+                "run": run_record,
             }
             if pipelined is not None:
                 out["pipelined"] = pipelined
             if world > 1:
-                out["exchange_ms_per_step"] = {"merge": exch_ms[0] / steps, "colorize_and_gather": exch_ms[1] / steps,
+                out["phase_ms_per_step"] = {"render": phase_ms[0] / steps, "exchange": phase_ms[1] / steps,
+                                            "colorize_and_gather": phase_ms[2] / steps, "form": a.exchange, "backend": a.backend,
+                                            "note": "rank 0's stream: reset + warm-up + iterate + accumulate + fold | pack + all-to-all + merge + "
+                                                    "scalars | sharded colorize + RGBA16 gather"}
+                out["exchange_ms_per_step"] = {"merge": phase_ms[1] / steps, "colorize_and_gather": phase_ms[2] / steps,
                                                "form": a.exchange, "backend": a.backend}
+                out["check"] = check_note
                 if ex is not None:
                     out["exchange_ms_per_step"]["bytes_on_the_wire_per_rank"] = ex.bytes_on_the_wire()
-            if world == 1 and not a.no_cpu_baseline and config == "c2" and extras:
-                out["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
-                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
             result = out
         if ex is not None:
             del ex
         rt.close()
+        if rank == 0 and world == 1 and extras and config == "c2":
+            import bench_extras as X
+            # the measurement is done and the runtime released: the line goes to stderr before anything else can cost it
+            print("[bench] line before the PMC passes / CPU baseline: " + json.dumps(result), file=sys.stderr, flush=True)
+            if int(a.iters) == ITERS_PER_GPU and jobs == DEFAULT_JOBS and a.traffic:
+                traffic, traffic_src = X.measure_traffic_live(iterate_kernel)
+                if traffic is None:
+                    why = traffic_src
+                    traffic, traffic_src = X.pmc_traffic_bytes()
+                    if traffic_src:
+                        traffic_src = (f"{traffic_src}: PMC passes of this workload committed with the round ((2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                                       f"launch), NOT measured by this run ({why})")
+                result["roofline"]["traffic"], result["roofline"]["traffic_source"] = traffic, traffic_src
+            if not a.no_cpu_baseline:
+                result["cpu_baseline"] = X.cpu_baseline(a.cpu_seconds, WIDTH, HEIGHT, ITERS_PER_GPU)
+                result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
         return result
 
     out = run_config(a.config, a.steps, a.warmup, True)
@@ -681,6 +486,8 @@ def main():
                     pass
                 out["strong_c4"] = {"value": c4["value"], "unit": c4["unit"], "ms_per_step": c4["ms_per_step"], "steps": c4["steps"],
                                     "scaling": "strong", "workload": c4["config"]["workload"], "jobs_total": c4["config"]["jobs_total"],
+                                    "parity": (c4["parity"] or {}).get("result", "not checked"), "parity_checksums": c4["parity"],
+                                    "phase_ms_per_step": c4.get("phase_ms_per_step"), "check": c4.get("check"),
                                     "exchange_ms_per_step": c4.get("exchange_ms_per_step"), "kernel_ms_per_step": c4["kernel_ms_per_step"],
                                     "launch": c4["roofline"]["kernel"],
                                     "n1_profile": ({"file": ref_file, "value": ref["value"], "ms_per_step": ref["ms_per_step"]}
@@ -694,10 +501,13 @@ def main():
             dist.barrier()
             if rank == 0:
                 try:
+                    import bench_extras as X
                     devs = list(range(min(world, max(torch.cuda.device_count(), 1))))
                     devs = [devs[k % len(devs)] for k in range(world)]
-                    out["native"] = {"c2": native_measure(S, torch, devs, "c2", max(2, min(a.steps, 6)), 1),
-                                     "c4": native_measure(S, torch, devs, "c4", max(2, min(a.steps, 4)), 1)}
+                    out["native"] = {"c2": X.native_measure(S, torch, devs, "c2", max(2, min(a.steps, 6)), 1, K),
+                                     "c4": X.native_measure(S, torch, devs, "c4", max(2, min(a.steps, 4)), 1, K)}
+                    out["run"]["peer_access_failures"] = max(out["native"]["c2"].get("peer_access_failures", 0),
+                                                             out["native"]["c4"].get("peer_access_failures", 0))
                 except Exception as e:  # an extra: never lose the line over it
                     out["native"] = {"error": repr(e)}
             dist.barrier()

@@ -99,6 +99,9 @@ pub struct SarRenderer {
 
 extern "C" {
     pub fn sar_abi_version() -> c_int;
+    pub fn sar_build_id() -> *const c_char;
+    pub fn sar_device_pci_bus_id(device: c_int, out: *mut c_char, cap: usize) -> c_int;
+    pub fn sar_checksum_fnv1a64(data_host: *const c_void, nbytes: usize, out: *mut u64) -> c_int;
     pub fn sar_status_string(status: c_int) -> *const c_char;
     pub fn sar_last_error() -> *const c_char;
     pub fn sar_device_count(out_count: *mut c_int) -> c_int;

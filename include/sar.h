@@ -109,9 +109,18 @@ typedef struct sar_timing {
 
 /* ---- misc ---------------------------------------------------------------------------------- */
 int         sar_abi_version(void);
+/* Which sources this binary was built from: the first 16 hex digits of the SHA-256 over the files under csrc, this header and the compiler
+ * flags (strange_attractor_renderer_amd/build.py: source_id). The Python loader recomputes it from the tree and refuses a
+ * library that was built from other sources. */
+const char* sar_build_id(void);
 const char* sar_status_string(int status);
 const char* sar_last_error(void);           /* thread-local, human readable */
 int         sar_device_count(int* out_count);
+/* "0000:c5:00.0" of a HIP device ordinal (cap >= 16): which physical GPU a rank really runs on, for run records. */
+int         sar_device_pci_bus_id(int device, char* out, size_t cap);
+/* FNV-1a (64 bit) over a host buffer: the checksum tests/golden/fullsize_checksums.json freezes the full-size frames with,
+ * so that a run record can say "this frame's count / zbuf / steps / RGBA16 are the committed ones" without shipping them. */
+int         sar_checksum_fnv1a64(const void* data_host, size_t nbytes, uint64_t* out);
 
 /* ---- Config presets (data only) -------------------------------------------------------------- */
 /* Config::new defaults (:289-307) + poisson_saturne() values (:310-352). */

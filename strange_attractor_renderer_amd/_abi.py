@@ -100,6 +100,9 @@ _vp = C.c_void_p
 # name -> (restype, argtypes); every symbol include/sar.h declares
 PROTOTYPES = {
     "sar_abi_version": (C.c_int, []),
+    "sar_build_id": (C.c_char_p, []),
+    "sar_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "sar_checksum_fnv1a64": (C.c_int, [_vp, C.c_size_t, _P(C.c_uint64)]),
     "sar_status_string": (C.c_char_p, [C.c_int]),
     "sar_last_error": (C.c_char_p, []),
     "sar_device_count": (C.c_int, [_P(C.c_int)]),
@@ -198,6 +201,25 @@ def load_library(path: str | None = None) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if p == LIB_PATH:
+        verify_library(lib)  # a variant named explicitly (path / SAR_LIBRARY) is the caller's business
     if path is None:
         _lib = lib
     return lib
+
+
+class SarLibraryStale(RuntimeError):
+    pass
+
+
+def verify_library(lib, csrc: str | None = None):
+    """The product library must have been built from the sources that lie next to it: its embedded id (sar_build_id) against
+    build.source_id() of the tree. Raises SarLibraryStale on a mismatch; silent where there is no source tree (an installed copy)."""
+    from . import build
+    if not os.path.isdir(csrc or build.CSRC):
+        return
+    want = build.source_id(csrc, extra_flags=[])
+    got = lib.sar_build_id().decode()
+    if got != want:
+        raise SarLibraryStale(f"{LIB_NAME} was built from other sources (its id {got}, the tree's {want}): run "
+                              "`python -c 'import __graft_entry__ as g; g.build()'` — or name a variant through SAR_LIBRARY")

@@ -238,6 +238,8 @@ class Runtime:
     def set_tuning(self, block_threads: int = 0, checkpoint_stride: int = 0, variant: int = 0, **more):
         """Convenience over set_option. variant: bits 0-3 path (0 automatic, 1 one atomic per visit, 3 binned), bits 8+
         debug_chunk_jobs."""
+        if (variant >> 4) & 0xF:
+            raise ValueError(f"variant {variant:#x}: bits 4-7 (the removed measurement modes) must be zero")
         self.set_option("block_threads", block_threads)
         self.set_option("checkpoint_stride", checkpoint_stride)
         self.set_option("path", variant & 0xF)

@@ -8,6 +8,7 @@ with the reference (which Rust/LLVM never contracts).
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import re
 import shutil
@@ -18,6 +19,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libsar_hip.so")
 BUILD_DIR = os.path.join(os.path.dirname(PKG), "build", "sar_hip")
+VARIANT_DIR = os.path.join(os.path.dirname(PKG), "build", "variants")   # A/B and test builds (SAR_LIBRARY=...), git-ignored
 SOURCES = ["sar_host.cpp", "sar_export.cpp", "sar_plan.cpp", "sar_render.cpp", "sar_runtime.cpp", "sar_batch.cpp", "sar_multi.cpp", "sar_iterate.hip", "sar_accumulate.hip",
            "sar_image.hip"]
 HEADERS = ["sar_internal.hpp", "sar_launch.hpp", "sar_device.hpp", "sar_runtime_impl.hpp", "sar_plan.hpp", os.path.join("..", "..", "include", "sar.h")]
@@ -39,12 +41,36 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def _extra_flags() -> list[str]:
+    return os.environ.get("SAR_EXTRA_FLAGS", "").split() + os.environ.get("SAR_KERNEL_FLAGS", "").split()
+
+
+def source_id(csrc: str | None = None, extra_flags: list[str] | None = None) -> str:
+    """What a library is built FROM, as 16 hex digits: SHA-256 over every source and header of the library (csrc/*, include/sar.h;
+    names and contents) and the compiler flags. The build embeds it (sar_build_id()); the loader recomputes it from the tree and
+    refuses a binary built from other sources (_abi.load_library)."""
+    csrc = csrc or CSRC
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS, key=os.path.basename):
+        h.update(os.path.basename(name).encode() + b"\0")
+        h.update(open(os.path.join(csrc, name), "rb").read())
+        h.update(b"\0")
+    h.update(" ".join(FLAGS + (extra_flags if extra_flags is not None else _extra_flags())).encode())
+    return h.hexdigest()[:16]
+
+
+def library_id(path: str) -> str | None:
+    """The id embedded in a built library file (without loading it), or None."""
+    try:
+        data = open(path, "rb").read()
+    except OSError:
+        return None
+    m = re.search(rb"SAR_BUILD_ID=([0-9a-f]{16})", data)
+    return m.group(1).decode() if m else None
+
+
 def _stale() -> bool:
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return library_id(OUT) != source_id()
 
 
 def audit_no_fma(asm_paths) -> dict:
@@ -71,10 +97,16 @@ def audit_no_fma(asm_paths) -> dict:
     return counts
 
 
+LAST_BUILD = {"action": None, "id": None}   # what the last build_library() call did: "built" / "reused" and the id
+
+
 def build_library(force: bool = False, verbose: bool = False, out: str | None = None, build_dir: str | None = None) -> str:
     """out / build_dir: build a VARIANT of the library somewhere else (with SAR_EXTRA_FLAGS / SAR_KERNEL_FLAGS set) for
-    A/B timing or test builds; load it through the SAR_LIBRARY environment variable. The product is the default."""
+    A/B timing or test builds; load it through the SAR_LIBRARY environment variable. The product is the default: it is
+    rebuilt whenever the id embedded in the binary is not the id of the sources (contents, not mtimes)."""
+    sid = source_id()
     if out is None and not force and not _stale():
+        LAST_BUILD.update(action="reused", id=sid)
         return OUT
     OUT_ = out or OUT
     BUILD_DIR_ = build_dir or BUILD_DIR
@@ -84,7 +116,7 @@ def build_library(force: bool = False, verbose: bool = False, out: str | None = 
     for s in SOURCES:
         obj = os.path.join(BUILD_DIR_, s + ".o")
         # SAR_EXTRA_FLAGS: extra -D flags for timing experiments (e.g. -DSAR_EXPERIMENT_...); never set by the product
-        cmd = [hipcc, *FLAGS, *os.environ.get("SAR_EXTRA_FLAGS", "").split(), "-c", os.path.join(CSRC, s), "-o", obj]
+        cmd = [hipcc, *FLAGS, *os.environ.get("SAR_EXTRA_FLAGS", "").split(), f'-DSAR_BUILD_ID="{sid}"', "-c", os.path.join(CSRC, s), "-o", obj]
         if s.endswith(".hip"):  # SAR_KERNEL_FLAGS: device-compiler flags for experiments (e.g. -mllvm options)
             cmd += ["-save-temps=obj", *os.environ.get("SAR_KERNEL_FLAGS", "").split()]
         if verbose:
@@ -98,6 +130,7 @@ def build_library(force: bool = False, verbose: bool = False, out: str | None = 
     tmp = OUT_ + ".tmp"
     subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-lz", "-lpthread", "-o", tmp], check=True)  # zlib: PNG export
     os.replace(tmp, OUT_)
+    LAST_BUILD.update(action="built", id=sid)
     return OUT_
 
 
@@ -106,7 +139,9 @@ if __name__ == "__main__":
         name = sys.argv[sys.argv.index("--variant") + 1]
         import tempfile
         scratch = os.environ.get("SAR_VARIANT_BUILD_DIR") or os.path.join(tempfile.gettempdir(), "sar_build")
-        print(build_library(force=True, verbose=True, out=os.path.join(PKG, f"libsar_hip_{name}.so"),
+        os.makedirs(VARIANT_DIR, exist_ok=True)   # variants never sit next to the product
+        print(build_library(force=True, verbose=True, out=os.path.join(VARIANT_DIR, f"libsar_hip_{name}.so"),
                             build_dir=os.path.join(scratch, f"sar_hip_{name}")))
     else:
         print(build_library(force="--force" in sys.argv, verbose=True))
+        print(f"{LAST_BUILD['action']} {LAST_BUILD['id']}")

@@ -167,6 +167,27 @@ extern "C" {
 
 int sar_abi_version(void) { return SAR_ABI_VERSION; }
 
+#ifndef SAR_BUILD_ID
+#define SAR_BUILD_ID "unidentified"
+#endif
+// (the marker lets build.py read the id of a library file without loading it)
+const char* sar_build_id(void) {
+    static const char marked[] = "SAR_BUILD_ID=" SAR_BUILD_ID;
+    return marked + sizeof("SAR_BUILD_ID=") - 1;
+}
+
+int sar_checksum_fnv1a64(const void* data_host, size_t nbytes, uint64_t* out) {
+    if ((!data_host && nbytes) || !out) return SAR_ERR_INVALID;
+    const unsigned char* p = static_cast<const unsigned char*>(data_host);
+    uint64_t h = 0xcbf29ce484222325ULL;
+    for (size_t k = 0; k < nbytes; ++k) {
+        h ^= p[k];
+        h *= 0x100000001b3ULL;
+    }
+    *out = h;
+    return SAR_OK;
+}
+
 const char* sar_status_string(int status) {
     switch (status) {
         case SAR_OK: return "ok";

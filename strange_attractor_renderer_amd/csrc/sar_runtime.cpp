@@ -201,6 +201,16 @@ int sar_device_count(int* out_count) {
     return SAR_OK;
 }
 
+int sar_device_pci_bus_id(int device, char* out, size_t cap) {
+    if (!out || cap < 16) return SAR_ERR_INVALID;
+    out[0] = 0;
+    if (hipDeviceGetPCIBusId(out, static_cast<int>(cap), device) != hipSuccess) {
+        set_error("hipDeviceGetPCIBusId(%d) failed", device);
+        return SAR_ERR_NO_DEVICE;
+    }
+    return SAR_OK;
+}
+
 int sar_runtime_new(const sar_config* cfg, int device, sar_runtime** out) {
     if (!out) return SAR_ERR_INVALID;
     *out = nullptr;

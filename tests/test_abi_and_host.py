@@ -259,3 +259,31 @@ def test_bin_map_is_a_bijection_onto_bins_and_records(sar, size, bin_shift, inte
             assert segs.max() - segs.min() <= 1
     if bin_shift == 0 and interleave == 0 and npix <= 16 << 20:
         assert g["interleaved"], "every shape up to 4096^2 gets interleaved bins by default"
+
+
+def test_library_is_tied_to_its_sources(sar, tmp_path):
+    """The binary carries the id of the sources it was built from (sar_build_id == build.source_id of the tree); a tree whose
+    kernel file was touched has another id, and the loader refuses the binary until build() has run (__graft_entry__.build
+    rebuilds on ids, not on mtimes). Variants live under build/variants, never next to the product."""
+    import glob
+    import shutil
+    from strange_attractor_renderer_amd import _abi, build
+    lib = sar.load_library()
+    assert lib.sar_build_id().decode() == build.source_id(extra_flags=[]) == build.library_id(_abi.LIB_PATH)
+    _abi.verify_library(lib)
+    # a copy of the tree with one kernel file touched: another id, and the loaded binary is refused against it
+    inc = tmp_path / "include"
+    pkg = tmp_path / "pkg"
+    shutil.copytree(os.path.join(ROOT, "include"), inc)
+    shutil.copytree(build.CSRC, pkg / "csrc")
+    touched = pkg / "csrc" / "sar_iterate.hip"
+    touched.write_text(touched.read_text() + "\n// touched\n")
+    assert build.source_id(str(pkg / "csrc"), extra_flags=[]) != build.source_id(extra_flags=[])
+    with pytest.raises(_abi.SarLibraryStale):
+        _abi.verify_library(lib, csrc=str(pkg / "csrc"))
+    # a header change counts as well (include/sar.h is hashed through csrc/../../include)
+    before = build.source_id(str(pkg / "csrc"), extra_flags=[])
+    (inc / "sar.h").write_text((inc / "sar.h").read_text() + "\n/* touched */\n")
+    assert build.source_id(str(pkg / "csrc"), extra_flags=[]) != before
+    assert build.source_id(extra_flags=["-DSAR_POOL_SPARE=2u"]) != build.source_id(extra_flags=[])   # and so do the flags
+    assert glob.glob(os.path.join(os.path.dirname(_abi.LIB_PATH), "libsar_hip_*.so")) == [], "a variant build sits next to the product"
