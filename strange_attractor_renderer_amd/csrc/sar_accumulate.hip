@@ -16,15 +16,17 @@ namespace sar {
 // Bins of 65536 pixels (the most a 16-bit record addresses — 4096^2 in 256 bins) do not fit 32-bit counters into the LDS:
 //   PACKED: two 16-bit counters per LDS word, 128 KiB for the whole bin, ONE workgroup reads the lists
 //     once. A counter is 15 bits plus a guard bit: the lane whose (returning) add sets the guard bit takes 32768 out again
-//     and notes the pixel in a short event list; every event is worth 32768 hits when the histogram is written out. A
-//     carry into the neighbouring counter would need 32768 FURTHER adds on this counter between the add that sets the guard
-//     bit and the same lane's subtraction, which follows it by a few instructions. That is a timing argument, not an
-//     enforced bound (the other fifteen waves keep issuing meanwhile): adds to one LDS address are serialised by the
-//     atomic unit at one per clock, so 32768 of them are ~16 us against a sub-microsecond window; the tests drive one pixel
-//     through 9000 guard events, and a build with -DSAR_ACC_GUARD_CHECK traps on an add that finds the guard bit set with the
-//     counter already above 0x4000 (the parity suite runs through it without one). (Round 2 counted such a bin in two halves,
-//     two workgroups reading every list: 4.35 ms per launch of configs[3] on one GPU against 2.82 ms, which is the rate of
-//     isolated 64-byte reads, 2.7 of the 3.4 TB/s MI355X serves; that form left the tree in round 4.)
+//     and notes the pixel in a short event list; every event is worth 32768 hits when the histogram is written out.
+//     No carry can reach the neighbouring counter, by a BOUND, not by timing: an add that FINDS the guard bit set (the
+//     setter's subtraction is still on its way) takes itself out again and counts its hit in memory instead (out[pixel] + 1,
+//     the write-out then adds to what is there). While the guard bit is set the counter therefore holds only adds that have
+//     not yet undone themselves — at most what the hardware lets the workgroup have in flight: 15 LDS operations per wave
+//     (lgkmcnt is four bits) x 64 lanes x 16 waves = 15360 < 32768. The tests drive one pixel through 9000 guard events and
+//     past 2^32 hits; a build with -DSAR_ACC_GUARD_CHECK asserts the bound (traps on a guarded counter above 0x4000).
+//     (Round 2 counted such a bin in two halves, two workgroups reading every list: 4.35 ms per launch of configs[3] on one
+//     GPU against 2.82 ms, which is the rate of isolated 64-byte reads, 2.7 of the 3.4 TB/s MI355X serves; that form left the
+//     tree in round 4. Rounds 2-4 let the adds under a pending subtraction stand — correct unless 32768 of them fell into
+//     that sub-microsecond window: a timing argument, replaced in round 5.)
 constexpr uint32_t kAccEvents = 2040u;  // event list of the PACKED mode (u16 records), next to two counters
 template <uint32_t R, uint32_t K, bool PACKED>
 __device__ __forceinline__ void bin_accumulate_body(const BinAccArgs& a, uint32_t* hist) {
@@ -91,19 +93,34 @@ __device__ __forceinline__ void bin_accumulate_body(const BinAccArgs& a, uint32_
                 // guard bit (inc = 1 or 1 << 16, so inc * 0x7FFF masks the counter)
                 auto packed_add = [&](uint32_t rec) {
                     const uint32_t inc = __umul24(rec & 1u, 0xFFFFu) + 1u;
-                    const uint32_t full = __umul24(inc, 0x7FFFu);
+                    const uint32_t guard = inc << 15;
                     const uint32_t old = atomicAdd(&hist[rec >> 1], inc);
-#ifdef SAR_ACC_GUARD_CHECK  // debug builds: an add that finds the guard bit set AND the counter far on its way again
-                    if ((old & (inc << 15)) && (old & full) >= __umul24(inc, 0x4000u)) __builtin_trap();
+                    // ONE test on the common path: the counter's half of the word shows its guard bit after this add — either this
+                    // add set it (the 15 bits were all set) or it was set already
+#ifdef SAR_EXPERIMENT_ACC_NO_UNDO  // A/B timing only: rounds 2-4's form (adds under a pending subtraction stand)
+                    if (__builtin_expect((old & __umul24(inc, 0x7FFFu)) == __umul24(inc, 0x7FFFu), 0)) {
+                        if (false) {
+#else
+                    if (__builtin_expect(((old + inc) & guard) != 0u, 0)) {
+                        if (old & guard) {
 #endif
-                    if (__builtin_expect((old & full) == full, 0)) {
-                        atomicSub(&hist[rec >> 1], inc << 15);
-                        const uint32_t e = atomicAdd(&ev_ctl[0], 1u);
-                        if (e < kAccEvents) {
-                            ev[e] = (unsigned short)rec;
-                        } else {  // more than 2040 x 32768 hits on a handful of pixels in one block: straight to memory
-                            atomicAdd(&out[pixel_of(rec)], 32768u);
+                            // the guard bit was set: its setter's subtraction is pending. This add steps back out — so that the
+                            // counter never holds more than the adds in flight (< 32768: no carry) — and the hit is counted in memory.
+#ifdef SAR_ACC_GUARD_CHECK  // the bound itself: a guarded counter holds at most the adds in flight
+                            if ((old & __umul24(inc, 0x7FFFu)) >= __umul24(inc, 0x4000u)) __builtin_trap();
+#endif
+                            atomicSub(&hist[rec >> 1], inc);
+                            atomicAdd(&out[pixel_of(rec)], 1u);
                             ev_ctl[1] = 1u;
+                        } else {  // this add set it: 32768 hits leave the counter as one event
+                            atomicSub(&hist[rec >> 1], guard);
+                            const uint32_t e = atomicAdd(&ev_ctl[0], 1u);
+                            if (e < kAccEvents) {
+                                ev[e] = (unsigned short)rec;
+                            } else {  // more than 2040 x 32768 hits on a handful of pixels in one block: straight to memory
+                                atomicAdd(&out[pixel_of(rec)], 32768u);
+                                ev_ctl[1] = 1u;
+                            }
                         }
                     }
                 };
