@@ -136,6 +136,11 @@ extern "C" {
     pub fn sar_render_jobs_batch(n_frames: u32, cfgs: *const *const SarConfig, rts: *const *mut SarRuntime,
                                  starts_xyz_host: *const *const f64) -> c_int;
     pub fn sar_runtime_batch_frames(cfg: *const SarConfig, rt: *mut SarRuntime, out_frames: *mut u32) -> c_int;
+    pub fn sar_runtime_exchange_touched(rt: *mut SarRuntime, flags_out_dev: *mut u8) -> c_int;
+    pub fn sar_runtime_exchange_pack_sparse(rt: *mut SarRuntime, send_slot_dev: *const i32, records_out_dev: *mut c_void) -> c_int;
+    pub fn sar_runtime_exchange_merge_sparse(rt: *mut SarRuntime, world: u32, rank: u32, recv_slot_dev: *const i32,
+                                             records_in_dev: *const c_void) -> c_int;
+    pub fn sar_renderer_set_exchange(r: *mut SarRenderer, mode: u32) -> c_int;
     pub fn sar_runtime_get_copy_stream(rt: *mut SarRuntime, hip_stream_out: *mut *mut c_void) -> c_int;
     pub fn sar_runtime_set_copy_stream(rt: *mut SarRuntime, hip_stream: *mut c_void) -> c_int;
     pub fn sar_colorize_device(cfg: *const SarConfig, rt: *mut SarRuntime, rgba_out_dev: *mut c_void) -> c_int;

@@ -312,10 +312,23 @@ int sar_runtime_exchange_import(sar_runtime* rt, const void* key_i64_reduced_dev
  *   3. scalars:       {max, wrap flag, depth range} as 4 x int64                                 -> all-reduce MAX
  *   4. sar_colorize_range_device on my slice                                                      -> gather (8 B/px)
  * After step 2 a runtime holds the merged frame only inside its own slice. */
-int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice_pixels);
-int sar_runtime_exchange_pack(sar_runtime* rt, uint32_t world, void* blocks_out_dev /* world*S*16 bytes */);
-int sar_runtime_exchange_merge_slices(sar_runtime* rt, uint32_t world, uint32_t rank,
-                                      const void* blocks_in_dev /* world*S*16 bytes */);
+int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice_pixels);   /* a multiple of 2048 */
+/* The same exchange SPARSE: a frame touches a fifth of its pixels (18.7 % / 7.8 % at the BASELINE shapes; 21 % of the 64-pixel
+ * granules of configs[1], 51 % of its 2048-pixel rows), so only the GRANULES — 64 consecutive pixels — that differ from the reset
+ * state travel, as RECORDS of 1 KiB [count u32 x 64 | sortable(zbuf) u32 x 64 | steps f64 x 64] (a rank without a record holds
+ * the reset state there: the fold skips it, same result bit for bit).
+ *   0. touched:       flags_out[g] = 1 for every granule with a count or a depth, else 0 (one byte each)   -> all-gather
+ *   1. pack_sparse:   the record of granule g at records_out + send_slot[g] * 1 KiB (send_slot[g] < 0: not sent); the caller
+ *                     orders the slots owner by owner, granule by granule                                   -> all-to-all with split sizes
+ *   2. merge_sparse:  recv_slot[world][S / 64]: where rank r's record of granule s of MY slice sits in records_in (or -1)
+ *   3. / 4. scalars and colorize as in the dense form.
+ * strange_attractor_renderer_amd/distributed.py (SlicedExchange) derives both slot tables from the gathered flags (prefix sums
+ * on the device; only the world x world record counts — the split sizes — come to the host). */
+#define SAR_EXCHANGE_GRANULE 64
+int sar_runtime_exchange_touched(sar_runtime* rt, uint8_t* flags_out_dev /* ceil(npix / 64) */);
+int sar_runtime_exchange_pack_sparse(sar_runtime* rt, const int32_t* send_slot_dev /* ceil(npix / 64) */, void* records_out_dev);
+int sar_runtime_exchange_merge_sparse(sar_runtime* rt, uint32_t world, uint32_t rank, const int32_t* recv_slot_dev /* world * S / 64 */,
+                                      const void* records_in_dev);
 int sar_runtime_exchange_scalars_export(sar_runtime* rt, void* i64x4_out_dev);
 int sar_runtime_exchange_scalars_import(sar_runtime* rt, const void* i64x4_dev);
 /* colorize (:841-904) of the pixel range [first_px, first_px + n_px) into out_dev (n_px*8 bytes, RGBA16), using the
@@ -370,6 +383,12 @@ typedef struct sar_parallel_timing {
     float    _pad;
 } sar_parallel_timing;
 int sar_renderer_last_timing(const sar_renderer* r, sar_parallel_timing* out);
+/* How a multi-device renderer exchanges its partial buffers before colorize. 2 = sparse: every device writes the records of the
+ * 64-pixel granules it has touched (1 KiB each: count, zbuf, steps) straight into their owners' buffers — kernels storing to
+ * peer memory over xGMI — and the owners fold what arrived (a fifth of a frame at the BASELINE shapes); 1 = dense: whole slices,
+ * 16 B/px, by hipMemcpyPeerAsync; 0 (default) = sparse when every pair of devices has direct peer access, dense otherwise. The
+ * merged frame is the same bit for bit. */
+int sar_renderer_set_exchange(sar_renderer* r, uint32_t mode);
 
 /* ---- measurement ----------------------------------------------------------------------------------- */
 int sar_runtime_enable_timing(sar_runtime* rt, int enabled);

@@ -156,6 +156,9 @@ PROTOTYPES = {
     "sar_exchange_slice_pixels": (C.c_int, [C.c_uint32, C.c_uint32, _P(C.c_uint32)]),
     "sar_runtime_exchange_pack": (C.c_int, [_vp, C.c_uint32, _vp]),
     "sar_runtime_exchange_merge_slices": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
+    "sar_runtime_exchange_touched": (C.c_int, [_vp, _vp]),
+    "sar_runtime_exchange_pack_sparse": (C.c_int, [_vp, _vp, _vp]),
+    "sar_runtime_exchange_merge_sparse": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _vp]),
     "sar_runtime_exchange_scalars_export": (C.c_int, [_vp, _vp]),
     "sar_runtime_exchange_scalars_import": (C.c_int, [_vp, _vp]),
     "sar_colorize_range_device": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint32, _vp]),
@@ -163,6 +166,7 @@ PROTOTYPES = {
     "sar_renderer_new_multi": (C.c_int, [_P(C.c_int), C.c_uint32, C.c_uint32, C.c_uint64, _P(_vp)]),
     "sar_renderer_num_devices": (C.c_int, [_vp, _P(C.c_uint32)]),
     "sar_renderer_last_timing": (C.c_int, [_vp, _P(SarParallelTiming)]),
+    "sar_renderer_set_exchange": (C.c_int, [_vp, C.c_uint32]),
     "sar_renderer_num_units": (C.c_int, [_vp, _P(C.c_uint32)]),
     "sar_renderer_shutdown": (C.c_int, [_vp]),
     "sar_render_parallel": (C.c_int, [_vp, _cfg_p, C.c_uint32, _P(C.c_uint16)]),

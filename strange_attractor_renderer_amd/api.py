@@ -296,6 +296,18 @@ class Runtime:
         _check(_lib().sar_runtime_exchange_merge_slices(self._h, world, rank, C.c_void_p(blocks_dev_ptr)),
                "sar_runtime_exchange_merge_slices")
 
+    # sparse form: records of the touched 2048-pixel segments
+    def exchange_touched(self, flags_dev_ptr: int):
+        _check(_lib().sar_runtime_exchange_touched(self._h, C.c_void_p(flags_dev_ptr)), "sar_runtime_exchange_touched")
+
+    def exchange_pack_sparse(self, send_slot_dev_ptr: int, records_dev_ptr: int):
+        _check(_lib().sar_runtime_exchange_pack_sparse(self._h, C.c_void_p(send_slot_dev_ptr), C.c_void_p(records_dev_ptr)),
+               "sar_runtime_exchange_pack_sparse")
+
+    def exchange_merge_sparse(self, world: int, rank: int, recv_slot_dev_ptr: int, records_dev_ptr: int):
+        _check(_lib().sar_runtime_exchange_merge_sparse(self._h, world, rank, C.c_void_p(recv_slot_dev_ptr), C.c_void_p(records_dev_ptr)),
+               "sar_runtime_exchange_merge_sparse")
+
     def exchange_scalars_export(self, i64x4_dev_ptr: int):
         _check(_lib().sar_runtime_exchange_scalars_export(self._h, C.c_void_p(i64x4_dev_ptr)),
                "sar_runtime_exchange_scalars_export")
@@ -545,6 +557,10 @@ class ParallelRenderer:
         t = SarParallelTiming()
         _check(_lib().sar_renderer_last_timing(self._h, C.byref(t)), "sar_renderer_last_timing")
         return {k: getattr(t, k) for k, _ in SarParallelTiming._fields_}
+
+    def set_exchange(self, mode: int):
+        """0 automatic, 1 dense (whole slices by peer copies), 2 sparse (kernels push the touched segments' records)."""
+        _check(_lib().sar_renderer_set_exchange(self._h, int(mode)), "sar_renderer_set_exchange")
 
     def num_threads(self) -> int:
         n = C.c_uint32()

@@ -264,6 +264,112 @@ __global__ void __launch_bounds__(256) k_exch_merge_slices(uint32_t* __restrict_
     }
 }
 
+// ---- sparse form: only the 64-pixel granules that differ from the reset state travel (a fifth of a frame) -----------------
+// One WAVE per granule, lane = pixel. A granule is touched when any of its pixels has a count or a depth.
+__device__ __forceinline__ bool exch_granule_touched(const uint32_t* __restrict__ count, const unsigned long long* __restrict__ key,
+                                                     uint32_t npix, uint32_t p, uint32_t& c, uint32_t& z) {
+    const uint32_t unset = f32_sortable(-1.0f);
+    const bool in = p < npix;
+    c = in ? count[p] : 0u;
+    z = in ? (uint32_t)(key[p] >> 32) : unset;
+    return wave_ballot(c != 0u || z != unset) != 0ull;
+}
+__device__ __forceinline__ void exch_write_record(unsigned char* rec, uint32_t lane, uint32_t c, uint32_t z, double st) {
+    ((uint32_t*)rec)[lane] = c;
+    ((uint32_t*)(rec + (size_t)kExchSeg * 4u))[lane] = z;
+    ((double*)(rec + (size_t)kExchSeg * 8u))[lane] = st;
+}
+__global__ void __launch_bounds__(256) k_exch_flags(const uint32_t* __restrict__ count, const unsigned long long* __restrict__ key, uint32_t npix,
+                                                    uint32_t nseg, unsigned char* __restrict__ flags) {
+    const uint32_t seg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seg >= nseg) return;
+    uint32_t c, z;
+    const bool touched = exch_granule_touched(count, key, npix, seg * kExchSeg + lane, c, z);
+    if (lane == 0u) flags[seg] = touched ? 1 : 0;
+}
+// one process per GPU: the records of this rank's touched granules, compacted in the order send_slot gives (derived from the
+// all-gathered flags), for a variable-size all-to-all
+__global__ void __launch_bounds__(256) k_exch_pack_sparse(const uint32_t* __restrict__ count, const unsigned long long* __restrict__ key,
+                                                          const double* __restrict__ steps, uint32_t npix, uint32_t nseg,
+                                                          const int32_t* __restrict__ send_slot, unsigned char* __restrict__ out) {
+    const uint32_t seg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seg >= nseg) return;
+    const int32_t slot = send_slot[seg];
+    if (slot < 0) return;
+    const uint32_t p = seg * kExchSeg + lane;
+    const bool in = p < npix;
+    exch_write_record(out + (size_t)slot * kExchRecordBytes, lane, in ? count[p] : 0u, in ? (uint32_t)(key[p] >> 32) : f32_sortable(-1.0f),
+                      in ? steps[p] : 0.);
+}
+// the multi-device renderer: every wave looks at one granule of the image, finds its owner and — if the granule is touched —
+// stores its record into the owner's buffer
+__global__ void __launch_bounds__(256) k_exch_push(const ExchPushArgs a) {
+    const uint32_t seg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seg >= a.G * a.sps) return;
+    const uint32_t o = seg / a.sps, s = seg - o * a.sps;
+    uint32_t c = 0u, z = 0u;
+    const uint32_t p = seg * kExchSeg + lane;
+    const bool flag = seg < a.nseg && exch_granule_touched(a.count, a.key, a.npix, p, c, z);
+    const uint32_t rec = a.src * a.sps + s;
+    if (lane == 0u) {
+        a.slot[o][rec] = flag ? (int32_t)rec : -1;
+        if (flag && o != a.src) atomicAdd(a.bytes, (unsigned long long)kExchRecordBytes);
+    }
+    if (!flag) return;
+    exch_write_record(a.recv[o] + (size_t)rec * kExchRecordBytes, lane, c, z, p < a.npix ? a.steps[p] : 0.);
+}
+// The owner folds what arrived for its slice with Runtime::merge in rank order (:708-738, :1068-1076). A rank without a record
+// for a granule holds the reset state there — count 0, zbuf -1.0: adding it changes no sum and it never wins a depth test — so
+// skipping it is exactly the dense fold (k_exch_merge_slices); a granule nobody sent is already in the reset state here.
+__global__ void __launch_bounds__(256) k_exch_merge_sparse(uint32_t* __restrict__ count, unsigned long long* __restrict__ key,
+                                                           double* __restrict__ steps, uint32_t first, uint32_t n, uint32_t sps, uint32_t G,
+                                                           const unsigned char* __restrict__ records, const int32_t* __restrict__ slot,
+                                                           uint32_t* scalars) {
+    const uint32_t unset = f32_sortable(-1.0f);
+    uint32_t local_max = 0;
+    uint32_t zmx = f32_sortable(0.0f), zmn = f32_sortable(3.40282346638528859811704183484516925e+38f);
+    for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) {
+        const uint32_t s = o / kExchSeg, w = o - s * kExchSeg;
+        uint32_t c = 0u, z = unset;
+        double st = 0.;
+        bool any = false;
+        for (uint32_t r = 0; r < G; ++r) {
+            const int32_t at = slot[r * sps + s];
+            if (at >= 0) {
+                const unsigned char* rec = records + (size_t)at * kExchRecordBytes;
+                const uint32_t oc = ((const uint32_t*)rec)[w];
+                const uint32_t oz = ((const uint32_t*)(rec + (size_t)kExchSeg * 4u))[w];
+                any = true;
+                c += oc;                                             // rank 0: the accumulator (`current`, :1070); then wrapping adds, :719
+                if (r == 0u || oz > z) {                             // strict: the earlier rank wins ties, :728
+                    z = oz;
+                    st = ((const double*)(rec + (size_t)kExchSeg * 8u))[w];
+                }
+            }
+            // the running max sees every intermediate sum of the fold (:721-723) — an absent rank's is the sum before it
+            if (r != 0u) local_max = c > local_max ? c : local_max;
+        }
+        if (!any) continue;
+        const uint32_t px = first + o;
+        count[px] = c;
+        key[px] = ((unsigned long long)z << 32) | 0xFFFFFFFFull;
+        steps[px] = st;
+        if (z != unset) {
+            zmx = z > zmx ? z : zmx;
+            zmn = z < zmn ? z : zmn;
+        }
+    }
+    __shared__ uint32_t s_tmp[4];
+    const uint32_t m = block_max_u32(local_max, s_tmp);
+    zmx = block_max_u32(zmx, s_tmp);
+    zmn = block_min_u32(zmn, s_tmp);
+    if (threadIdx.x == 0) {
+        if (m) raise_scalar(&scalars[SC_MAX], m);
+        atomicMax(&scalars[SC_ZMAX], zmx);
+        atomicMin(&scalars[SC_ZMIN], zmn);
+    }
+}
+
 // {max, wrap flag, sortable(zmax), ~sortable(zmin)} as int64: one all-reduce MAX makes them global
 __global__ void k_exch_scalars_export(const uint32_t* scalars, long long* out4) {
     out4[0] = scalars[SC_MAX];
@@ -408,6 +514,26 @@ void launch_exch_merge_slices(uint32_t* count, unsigned long long* key, double* 
     if (n)
         hipLaunchKernelGGL(k_exch_merge_slices, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, count, key, steps, first, n, S, G,
                            (const unsigned char*)in, scalars);
+}
+
+void launch_exch_flags(const uint32_t* count, const unsigned long long* key, uint32_t npix, void* flags, hipStream_t s) {
+    const uint32_t nseg = (npix + kExchSeg - 1u) / kExchSeg;
+    hipLaunchKernelGGL(k_exch_flags, dim3((nseg + 3u) / 4u), dim3(256), 0, s, count, key, npix, nseg, (unsigned char*)flags);
+}
+void launch_exch_pack_sparse(const uint32_t* count, const unsigned long long* key, const double* steps, uint32_t npix, const int32_t* send_slot,
+                             void* out, hipStream_t s) {
+    const uint32_t nseg = (npix + kExchSeg - 1u) / kExchSeg;
+    hipLaunchKernelGGL(k_exch_pack_sparse, dim3((nseg + 3u) / 4u), dim3(256), 0, s, count, key, steps, npix, nseg, send_slot, (unsigned char*)out);
+}
+void launch_exch_push(const ExchPushArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_push, dim3((a.G * a.sps + 3u) / 4u), dim3(256), 0, s, a);
+}
+void launch_exch_merge_sparse(uint32_t* count, unsigned long long* key, double* steps, uint32_t first, uint32_t n, uint32_t sps, uint32_t G,
+                              const void* records, const int32_t* slot, uint32_t* scalars, bool keep_max, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_scalars_init, dim3(1), dim3(1), 0, s, scalars, keep_max ? 1 : 0);
+    if (n)
+        hipLaunchKernelGGL(k_exch_merge_sparse, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, count, key, steps, first, n, sps, G,
+                           (const unsigned char*)records, slot, scalars);
 }
 
 void launch_exch_scalars_export(const uint32_t* scalars, void* out4, hipStream_t s) {

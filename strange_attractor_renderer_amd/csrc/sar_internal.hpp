@@ -190,6 +190,25 @@ struct BatchFrame {
 };
 constexpr uint32_t kMaxBatchFrames = 32;
 
+// Sparse exchange (sar_image.hip): a RECORD is one granule — 64 consecutive pixels — of one rank's partial buffers, 1 KiB as
+// [count u32 x 64 | sortable(zbuf) u32 x 64 | steps f64 x 64]; only granules that differ from the reset state travel (a frame
+// touches a fifth of its pixels, and 21 % of its 64-pixel granules: measured on BASELINE configs[1]; whole 2048-pixel rows: 51 %).
+constexpr uint32_t kExchSeg = 64;
+constexpr size_t kExchRecordBytes = (size_t)kExchSeg * 16u;
+constexpr uint32_t kExchSliceAlign = 2048;   // slices are whole 2048-pixel blocks (k_fold_resolve's), hence whole granules
+constexpr uint32_t kMaxExchDevices = 64;
+// k_exch_push (the multi-device renderer): device `src` writes the records of its touched granules straight into every owner's
+// record buffer (peer memory: over xGMI) and tells the owner where they are (slot table) — nothing else crosses the links
+struct ExchPushArgs {
+    const uint32_t* count;
+    const unsigned long long* key;
+    const double* steps;
+    uint32_t npix, nseg, sps, src, G, _pad;     // nseg: granules of the image, sps: granules per slice
+    unsigned long long* bytes;                  // statistic: bytes written into OTHER shards' buffers (on a node: over xGMI)
+    unsigned char* recv[kMaxExchDevices];       // owner o's record buffer [G * sps records]
+    int32_t* slot[kMaxExchDevices];             // owner o's slot table [G][sps]: record index of (source, segment) or -1
+};
+
 struct PaletteParams {
     uint32_t len;  // user entries; entry len == entry len-1 (Palette::new, src/lib.rs:416-418)
     uint32_t _pad;

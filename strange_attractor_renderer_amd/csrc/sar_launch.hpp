@@ -38,6 +38,13 @@ void launch_exch_pack(const uint32_t* count, const unsigned long long* key, cons
                       uint32_t G, void* out, hipStream_t s);
 void launch_exch_merge_slices(uint32_t* count, unsigned long long* key, double* steps, uint32_t first, uint32_t n, uint32_t S,
                               uint32_t G, const void* in, uint32_t* scalars, bool keep_max, hipStream_t s);
+// sparse form: records of 64-pixel granules (kExchRecordBytes each), placed by slot tables
+void launch_exch_flags(const uint32_t* count, const unsigned long long* key, uint32_t npix, void* flags, hipStream_t s);
+void launch_exch_pack_sparse(const uint32_t* count, const unsigned long long* key, const double* steps, uint32_t npix, const int32_t* send_slot,
+                             void* out, hipStream_t s);
+void launch_exch_push(const ExchPushArgs& a, hipStream_t s);
+void launch_exch_merge_sparse(uint32_t* count, unsigned long long* key, double* steps, uint32_t first, uint32_t n, uint32_t sps, uint32_t G,
+                              const void* records, const int32_t* slot, uint32_t* scalars, bool keep_max, hipStream_t s);
 void launch_exch_scalars_export(const uint32_t* scalars, void* out4, hipStream_t s);
 void launch_exch_scalars_import(uint32_t* scalars, const void* in4, hipStream_t s);
 void launch_exch_scalars_reduce(uint32_t* scalars, const void* board, uint32_t G, hipStream_t s);  // board: [G][4] int64 quads

@@ -42,6 +42,10 @@ struct Shard {
     void* d_pack = nullptr;   // [G][S*16] this device's partial buffers, one block per owner
     void* d_recv = nullptr;   // [G][S*16] every device's block of the slice this device owns
     void* d_rgba = nullptr;   // [S*8] colorized slice
+    // sparse form: the other devices WRITE the records of their touched segments into d_recv ([G * sps] records) and their places
+    // into d_slot ([G][sps], -1 = nothing sent); d_bytes counts what this device wrote to others (statistic)
+    int32_t* d_slot = nullptr;
+    unsigned long long* d_bytes = nullptr;
     uint16_t* h_rgba = nullptr;  // pinned [S*4]: the colorized slice on its way into a pageable host image
     std::vector<hipStream_t> pull_streams;  // one per source device: this owner's pulls run side by side
     std::vector<hipEvent_t> pulled;         // ... and are joined to the owner's stream through these
@@ -86,15 +90,17 @@ struct sar_renderer {
     long long* d_board = nullptr; // ... as the devices address it
     std::vector<Shard> shards;    // one per device, in fold order
     bool scattered = false;       // shard runtimes hold only their own merged slice (gather before handing one out)
+    uint32_t exchange_mode = 0;   // 0: sparse (kernels push the touched segments' records over xGMI) when every pair of devices has peer
+                                  // access, else dense; 1: dense (whole slices by hipMemcpyPeerAsync); 2: sparse
     uint32_t peer_access_failures = 0;  // ordered device pairs whose copies cannot go peer to peer
     sar_parallel_timing timing{};
 };
 
 namespace {
 
-uint32_t slice_pixels(uint32_t npix, uint32_t world) {
+uint32_t slice_pixels(uint32_t npix, uint32_t world) {  // == sar_exchange_slice_pixels: whole 2048-pixel segments
     const uint64_t s = (static_cast<uint64_t>(npix) + world - 1) / world;
-    return static_cast<uint32_t>((s + 3u) & ~3ull);
+    return static_cast<uint32_t>((s + (kExchSliceAlign - 1u)) & ~static_cast<uint64_t>(kExchSliceAlign - 1u));
 }
 
 int free_shard_buffers(Shard& sh) {
@@ -104,6 +110,10 @@ int free_shard_buffers(Shard& sh) {
     if (sh.d_rgba) hipFree(sh.d_rgba);
     if (sh.h_rgba) hipHostFree(sh.h_rgba);
     sh.h_rgba = nullptr;
+    if (sh.d_slot) hipFree(sh.d_slot);
+    if (sh.d_bytes) hipFree(sh.d_bytes);
+    sh.d_slot = nullptr;
+    sh.d_bytes = nullptr;
     sh.d_pack = sh.d_recv = sh.d_rgba = nullptr;
     sh.slice_cap = 0;
     return SAR_OK;
@@ -138,13 +148,16 @@ int ensure_shard(sar_renderer* r, Shard& sh, const sar_config* cfg, uint32_t S) 
         HIP_TRY(hipMalloc(&sh.d_recv, static_cast<size_t>(G) * S * 16u));
         HIP_TRY(hipMalloc(&sh.d_rgba, static_cast<size_t>(S) * 8u));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sh.h_rgba), static_cast<size_t>(S) * 8u, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sh.d_slot), static_cast<size_t>(G) * (S / kExchSeg) * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sh.d_bytes), sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(sh.d_bytes, 0, sizeof(unsigned long long)));
         sh.slice_cap = S;
     }
     return SAR_OK;
 }
 
 // what one reference worker thread does with its share of the jobs (:950-988), for a whole GPU
-void render_shard(sar_renderer* r, Shard* sh, const sar_config* cfg, uint64_t per_job, uint32_t S, bool use_next) {
+void render_shard(sar_renderer* r, Shard* sh, const sar_config* cfg, uint64_t per_job, uint32_t S, bool use_next, bool sparse) {
     const uint32_t G = static_cast<uint32_t>(r->shards.size());
     auto run = [&]() -> int {
         HIP_TRY(hipSetDevice(sh->device));
@@ -162,7 +175,28 @@ void render_shard(sar_renderer* r, Shard* sh, const sar_config* cfg, uint64_t pe
             SAR_TRY(render_chunked(cfg, rt, sh->n_jobs, per_job, sh->h_next[sh->cur_slot]));  // this slice's points as drawn (page-locked host memory)
         }
         sh->next_valid = false;
-        if (G > 1) {
+        if (G > 1 && sparse) {
+            // the records of the segments this device touched go straight into their owners' buffers (peer memory)
+            ExchPushArgs pa;
+            std::memset(&pa, 0, sizeof(pa));
+            pa.count = rt->d_count;
+            pa.key = rt->d_key;
+            pa.steps = rt->d_steps;
+            pa.npix = rt->npix;
+            pa.nseg = (rt->npix + kExchSeg - 1u) / kExchSeg;
+            pa.sps = S / kExchSeg;
+            pa.src = static_cast<uint32_t>(sh - r->shards.data());
+            pa.G = G;
+            pa.bytes = sh->d_bytes;
+            for (uint32_t o = 0; o < G; ++o) {
+                pa.recv[o] = static_cast<unsigned char*>(r->shards[o].d_recv);
+                pa.slot[o] = r->shards[o].d_slot;
+            }
+            HIP_TRY(hipMemsetAsync(sh->d_bytes, 0, sizeof(unsigned long long), rt->stream));
+            launch_exch_push(pa, rt->stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(sh->packed, rt->stream));
+        } else if (G > 1) {
             launch_exch_pack(rt->d_count, rt->d_key, rt->d_steps, rt->npix, S, G, sh->d_pack, rt->stream);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(sh->packed, rt->stream));
@@ -305,6 +339,12 @@ int sar_renderer_runtime(sar_renderer* r, sar_runtime** out_borrowed) {
     if (r->shards.empty() || !r->shards[0].rt) { set_error("the renderer has not rendered yet"); return SAR_ERR_INVALID; }
     SAR_TRY(gather_into_first(r));
     *out_borrowed = r->shards[0].rt;
+    return SAR_OK;
+}
+
+int sar_renderer_set_exchange(sar_renderer* r, uint32_t mode) {
+    if (!r || mode > 2) { set_error("sar_renderer_set_exchange: mode must be 0 (automatic), 1 (dense) or 2 (sparse)"); return SAR_ERR_INVALID; }
+    r->exchange_mode = mode;
     return SAR_OK;
 }
 
@@ -506,9 +546,10 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
         return status;
     };
 
+    const bool sparse = G > 1 && G <= kMaxExchDevices && (r->exchange_mode == 2u || (r->exchange_mode == 0u && r->peer_access_failures == 0));
     if (G == 1) {
         Shard& sh = r->shards[0];
-        render_shard(r, &sh, cfg, per_job, S, from_ahead);
+        render_shard(r, &sh, cfg, per_job, S, from_ahead, false);
         if (sh.status != SAR_OK) { set_error("%s", sh.error); return failed(sh.status); }
         r->timing.host_ms_before_exchange = static_cast<float>(now_ms() - t0);
         // the next frame's points (the helper has been drawing them since before the render was enqueued) go to the device and
@@ -527,7 +568,7 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
     {
         std::vector<std::thread> workers;
         workers.reserve(G);
-        for (uint32_t d = 0; d < G; ++d) workers.emplace_back(render_shard, r, &r->shards[d], cfg, per_job, S, from_ahead);
+        for (uint32_t d = 0; d < G; ++d) workers.emplace_back(render_shard, r, &r->shards[d], cfg, per_job, S, from_ahead, sparse);
         for (auto& w : workers) w.join();
     }
     for (Shard& sh : r->shards)
@@ -552,6 +593,20 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
             Shard& dst = r->shards[d];
             HIP_TRY(hipSetDevice(dst.device));
             hipStream_t st = dst.rt->stream;
+            const uint64_t first_px = static_cast<uint64_t>(d) * S;
+            const uint32_t n_px = first_px >= npix ? 0u : static_cast<uint32_t>((npix - first_px < S) ? npix - first_px : S);
+            if (sparse) {
+                // the records are there once every device's push kernel has ended (its own among them)
+                for (uint32_t s = 0; s < G; ++s)
+                    if (s != d) HIP_TRY(hipStreamWaitEvent(st, r->shards[s].packed, 0));
+                if (d == 0) r->timing.host_ms_before_exchange = static_cast<float>(now_ms() - t_rendered);
+                launch_exch_merge_sparse(dst.rt->d_count, dst.rt->d_key, dst.rt->d_steps, static_cast<uint32_t>(first_px >= npix ? 0 : first_px), n_px,
+                                         S / kExchSeg, G, dst.d_recv, dst.d_slot, dst.rt->d_scalars, d == 0, st);
+                launch_exch_scalars_export(dst.rt->d_scalars, r->d_board + 4 * d, st);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(dst.merged, st));
+                continue;
+            }
             for (uint32_t k = 0; k < G; ++k) {
                 const uint32_t s = (d + k) % G;  // start with the local block; stagger the sources over the links
                 Shard& src = r->shards[s];
@@ -625,6 +680,16 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
     if (st != SAR_OK) return failed(st);
     r->timing.total_ms = static_cast<float>(now_ms() - t0);
     r->timing.exchange_bytes_per_device = static_cast<uint64_t>(G - 1) * blk;
+    if (sparse) {  // what the push kernels really wrote to other devices (the busiest device's)
+        unsigned long long most = 0;
+        for (Shard& sh : r->shards) {
+            unsigned long long b = 0;
+            HIP_TRY(hipSetDevice(sh.device));
+            HIP_TRY(hipMemcpy(&b, sh.d_bytes, sizeof(b), hipMemcpyDeviceToHost));
+            most = b > most ? b : most;
+        }
+        r->timing.exchange_bytes_per_device = most;
+    }
     r->timing.peer_access_failures = r->peer_access_failures;
     return SAR_OK;
 }

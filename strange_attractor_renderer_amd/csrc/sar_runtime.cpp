@@ -620,7 +620,8 @@ int sar_runtime_exchange_import(sar_runtime* rt, const void* key_i64_reduced_dev
 
 int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice_pixels) {
     if (!out_slice_pixels || world == 0) return SAR_ERR_INVALID;
-    const uint64_t s = ((static_cast<uint64_t>(npix) + world - 1) / world + 3u) & ~3ull;
+    // whole 2048-pixel blocks (k_fold_resolve's unit; whole granules of the sparse exchange)
+    const uint64_t s = ((static_cast<uint64_t>(npix) + world - 1) / world + (kExchSliceAlign - 1u)) & ~static_cast<uint64_t>(kExchSliceAlign - 1u);
     if (s * world > 0xFFFFFFFFull) { set_error("slice geometry exceeds 2^32 pixels"); return SAR_ERR_RANGE; }
     *out_slice_pixels = static_cast<uint32_t>(s);
     return SAR_OK;
@@ -645,6 +646,35 @@ int sar_runtime_exchange_merge_slices(sar_runtime* rt, uint32_t world, uint32_t 
     const uint32_t n = first >= rt->npix ? 0u : static_cast<uint32_t>((rt->npix - first < S) ? rt->npix - first : S);
     launch_exch_merge_slices(rt->d_count, rt->d_key, rt->d_steps, n ? static_cast<uint32_t>(first) : 0u, n, S, world, blocks_in_dev,
                              rt->d_scalars, rank == 0, rt->stream);
+    HIP_TRY(hipGetLastError());  // (the depth hints stay valid: a merge only raises zbuf)
+    return SAR_OK;
+}
+
+int sar_runtime_exchange_touched(sar_runtime* rt, uint8_t* flags_out_dev) {
+    if (!rt || !flags_out_dev) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    launch_exch_flags(rt->d_count, rt->d_key, rt->npix, flags_out_dev, rt->stream);
+    HIP_TRY(hipGetLastError());
+    return SAR_OK;
+}
+
+int sar_runtime_exchange_pack_sparse(sar_runtime* rt, const int32_t* send_slot_dev, void* records_out_dev) {
+    if (!rt || !send_slot_dev || !records_out_dev) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    launch_exch_pack_sparse(rt->d_count, rt->d_key, rt->d_steps, rt->npix, send_slot_dev, records_out_dev, rt->stream);
+    HIP_TRY(hipGetLastError());
+    return SAR_OK;
+}
+
+int sar_runtime_exchange_merge_sparse(sar_runtime* rt, uint32_t world, uint32_t rank, const int32_t* recv_slot_dev, const void* records_in_dev) {
+    if (!rt || !recv_slot_dev || !records_in_dev || rank >= world) return SAR_ERR_INVALID;
+    uint32_t S = 0;
+    SAR_TRY(sar_exchange_slice_pixels(rt->npix, world, &S));
+    HIP_TRY(hipSetDevice(rt->device));
+    const uint64_t first = static_cast<uint64_t>(rank) * S;
+    const uint32_t n = first >= rt->npix ? 0u : static_cast<uint32_t>((rt->npix - first < S) ? rt->npix - first : S);
+    launch_exch_merge_sparse(rt->d_count, rt->d_key, rt->d_steps, n ? static_cast<uint32_t>(first) : 0u, n, S / kExchSeg, world, records_in_dev,
+                             recv_slot_dev, rt->d_scalars, rank == 0, rt->stream);
     HIP_TRY(hipGetLastError());  // (the depth hints stay valid: a merge only raises zbuf)
     return SAR_OK;
 }

@@ -121,6 +121,47 @@ class NumpyRuntime:
         self.zmax = max(int(sortable(np.float32([0.0]))[0]), int(seen.max()) if seen.size else 0)
         self.zmin = min(int(sortable(np.float32([np.finfo(np.float32).max]))[0]), int(seen.min()) if seen.size else 2**32 - 1)
 
+    # ---- sparse form (k_exch_flags / k_exch_pack_sparse / k_exch_merge_sparse): records of the touched 64-pixel granules ----
+    SEG = 64
+
+    def _segments(self):
+        nseg = (self.npix + self.SEG - 1) // self.SEG
+        c, z, st = np.zeros(nseg * self.SEG, np.uint32), np.full(nseg * self.SEG, UNSET, np.uint32), np.zeros(nseg * self.SEG, np.float64)
+        c[:self.npix], z[:self.npix], st[:self.npix] = self.count, self.z, self.steps
+        return nseg, c.reshape(nseg, -1), z.reshape(nseg, -1), st.reshape(nseg, -1)
+
+    def exchange_touched(self, ptr):
+        nseg, c, z, _ = self._segments()
+        _at(ptr, np.uint8, nseg)[:] = ((c != 0) | (z != UNSET)).any(axis=1)
+
+    def exchange_pack_sparse(self, slot_ptr, out_ptr):
+        nseg, c, z, st = self._segments()
+        slot = _at(slot_ptr, np.int32, nseg)
+        rec = self.SEG * 16
+        for seg in np.nonzero(slot >= 0)[0]:
+            blk = _at(out_ptr + int(slot[seg]) * rec, np.uint8, rec)
+            blk[:self.SEG * 4] = c[seg].view(np.uint8)
+            blk[self.SEG * 4:self.SEG * 8] = z[seg].view(np.uint8)
+            blk[self.SEG * 8:] = st[seg].view(np.uint8)
+
+    def exchange_merge_sparse(self, world, rank, slot_ptr, in_ptr):
+        """A rank without a record holds the reset state (count 0, zbuf unset): materialise it and fold densely."""
+        S = self._slice_pixels(self.npix, world)
+        sps, rec = S // self.SEG, self.SEG * 16
+        slot = _at(slot_ptr, np.int32, world * sps).reshape(world, sps)
+        dense = np.zeros(world * S * 16, np.uint8)
+        for r in range(world):
+            c, z, st = np.zeros(S, np.uint32), np.full(S, UNSET, np.uint32), np.zeros(S, np.float64)
+            for s in range(sps):
+                if slot[r, s] >= 0:
+                    blk = _at(in_ptr + int(slot[r, s]) * rec, np.uint8, rec)
+                    c[s * self.SEG:(s + 1) * self.SEG] = blk[:self.SEG * 4].view(np.uint32)
+                    z[s * self.SEG:(s + 1) * self.SEG] = blk[self.SEG * 4:self.SEG * 8].view(np.uint32)
+                    st[s * self.SEG:(s + 1) * self.SEG] = blk[self.SEG * 8:].view(np.float64)
+            blk = dense[r * S * 16:(r + 1) * S * 16]
+            blk[:S * 4], blk[S * 4:S * 8], blk[S * 8:] = c.view(np.uint8), z.view(np.uint8), st.view(np.uint8)
+        self.exchange_merge_slices(world, rank, dense.ctypes.data)
+
     def exchange_scalars_export(self, ptr):
         _at(ptr, np.int64, 4)[:] = [self.max, self.wrap, self.zmax, (~np.uint32(self.zmin)) & 0xFFFFFFFF]
 
@@ -151,7 +192,7 @@ class NumpyApi:
         _at(out_ptr, np.uint16, n * 4)[:] = img[first:first + n].ravel()
 
 
-def _worker(rank, world, port, W, H, jobs, n, seed, mode, q):
+def _worker(rank, world, port, W, H, jobs, n, seed, mode, q, scale=1.0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
@@ -161,7 +202,7 @@ def _worker(rank, world, port, W, H, jobs, n, seed, mode, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = O.poisson_saturne()
-    cfg.width, cfg.height, cfg.transparent = W, H, 0
+    cfg.width, cfg.height, cfg.transparent, cfg.scale = W, H, 0, scale
     first, cnt = D.shard_jobs(jobs, world, rank)
     ort = O.Runtime(W, H)
     O.render_jobs(cfg, ort, O.start_points(seed, first, cnt), n)   # this rank's partial render (the oracle stands in for the GPU)
@@ -174,11 +215,14 @@ def _worker(rank, world, port, W, H, jobs, n, seed, mode, q):
         if rank == 0:
             q.put((rt.count.reshape(H, W).copy(), unsortable(rt.z).reshape(H, W).copy(), rt.steps.reshape(H, W).copy(), rt.max, None))
     else:
-        ex = D.SlicedExchange(NumpyApi(O, S), cfg, rt, rank, world, "cpu")
+        # "sliced": whole slices; "sparse": records of the touched segments, whatever share of the image they are;
+        # "auto": sparse unless more than half of the segments are touched
+        ex = D.SlicedExchange(NumpyApi(O, S), cfg, rt, rank, world, "cpu", sparse=mode != "sliced",
+                              dense_above=2.0 if mode == "sparse" else 0.5)
         img = D.exchange_colorize(ex, dist, dst=0)                  # pack, all-to-all, merge, scalars, colorize, gather
         f, c = ex.first, ex.count
         q.put((rank, f, c, rt.count[f:f + c].copy(), unsortable(rt.z[f:f + c]).copy(), rt.steps[f:f + c].copy(), rt.max,
-               img.numpy().view(np.uint16).reshape(H, W, 4).copy() if rank == 0 else None))
+               img.numpy().view(np.uint16).reshape(H, W, 4).copy() if rank == 0 else None, ex.bytes_on_the_wire()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -191,11 +235,11 @@ def _free_port():
     return p
 
 
-def _spawn(world, mode, W, H, jobs, n, seed, n_results):
+def _spawn(world, mode, W, H, jobs, n, seed, n_results, scale=1.0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, jobs, n, seed, mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, jobs, n, seed, mode, q, scale)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in range(n_results)]
@@ -205,10 +249,10 @@ def _spawn(world, mode, W, H, jobs, n, seed, n_results):
     return got
 
 
-def _fold_in_rank_order(oracle, W, H, jobs, n, seed, world):
+def _fold_in_rank_order(oracle, W, H, jobs, n, seed, world, scale=1.0):
     from strange_attractor_renderer_amd.distributed import shard_jobs
     cfg = oracle.poisson_saturne()
-    cfg.width, cfg.height, cfg.transparent = W, H, 0
+    cfg.width, cfg.height, cfg.transparent, cfg.scale = W, H, 0, scale
     parts = []
     for r in range(world):
         first, cnt = shard_jobs(jobs, world, r)
@@ -237,13 +281,26 @@ def test_exchange_merge_equals_merge_in_rank_order(oracle):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3])
-def test_sliced_exchange_colorize_equals_merge_in_rank_order(oracle, world):
-    W, H, jobs, n, seed = 97, 83, 41, 3000, 6                      # npix % world != 0, jobs % world != 0
-    got = _spawn(world, "sliced", W, H, jobs, n, seed, world)
-    cfg, acc = _fold_in_rank_order(oracle, W, H, jobs, n, seed, world)
+@pytest.mark.parametrize("world,mode,W,H,scale", [(2, "sliced", 97, 83, 1.0), (3, "sliced", 97, 83, 1.0), (2, "sparse", 97, 83, 1.0),
+                                                  (3, "sparse", 97, 83, 1.0), (3, "auto", 150, 420, 0.3), (2, "auto", 97, 83, 1.0)])
+def test_sliced_exchange_colorize_equals_merge_in_rank_order(oracle, world, mode, W, H, scale):
+    """Dense slices, sparse records (forced, and chosen by the share of touched segments: a view that fills a tenth of a tall
+    image leaves most segments untouched; one that covers the image goes dense) — the same merged frame."""
+    jobs, n, seed = 41, 3000, 6                                    # npix % world != 0, jobs % world != 0
+    got = _spawn(world, mode, W, H, jobs, n, seed, world, scale)
+    cfg, acc = _fold_in_rank_order(oracle, W, H, jobs, n, seed, world, scale)
     count, zbuf, steps = np.zeros(W * H, np.uint32), np.zeros(W * H, np.float32), np.zeros(W * H)
     img, covered = None, 0
+    wire = {r[0]: r[8] for r in got}
+    got = [r[:8] for r in got]
+    if mode == "sliced":
+        assert all(w["form"] == "dense" for w in wire.values())
+    elif mode == "sparse":
+        assert all(w["form"] == "sparse" for w in wire.values())
+    elif scale < 1.0:   # the attractor fills a small part of the image: few segments travel
+        assert all(w["form"] == "sparse" and w["fraction_of_dense"] < 0.5 for w in wire.values()), wire
+    else:
+        assert all(w["form"] == "dense" for w in wire.values()), wire
     for rank, f, c, cs, zs, ss, mx, im in got:
         count[f:f + c], zbuf[f:f + c], steps[f:f + c] = cs, zs, ss
         covered += c

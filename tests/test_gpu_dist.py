@@ -55,7 +55,8 @@ def _worker(rank, world, port, preset, W, H, kind, jobs, n, seed, mode, q):
             if rank == 0:
                 q.put(("rooted", rt.count(), rt.zbuf(), rt.steps(), rt.max(), S.colorize(cfg, rt)))
         else:
-            ex = D.SlicedExchange(S, cfg, rt, rank, world, "cuda")
+            # "sliced": whole slices; "sparse": records of the touched 64-pixel granules whatever their share; "auto": the default
+            ex = D.SlicedExchange(S, cfg, rt, rank, world, "cuda", sparse=mode != "sliced", dense_above=2.0 if mode == "sparse" else 0.5)
             img = D.exchange_colorize(ex, dist, dst=0)
             torch.cuda.synchronize()
             # every rank's runtime holds the merged frame inside its own slice
@@ -116,26 +117,36 @@ def test_rooted_exchange_merge_two_ranks_equals_oracle_merge(sar, oracle, gpu, p
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,preset,kind", [(2, "poisson_saturne", 0), (3, "solar_sail", 1), (3, "poisson_saturne", 0)])
-def test_sliced_exchange_colorize_equals_oracle_merge(sar, oracle, gpu, world, preset, kind):
-    """distributed.exchange_colorize, 2 and 3 ranks on cuda:0 (3: uneven last slice, uneven job shards): the merged
-    slices assembled from the ranks, `max`, and the root's gathered image equal the oracle's fold in rank order."""
+@pytest.mark.parametrize("world,preset,kind,form", [(2, "poisson_saturne", 0, "sliced"), (3, "solar_sail", 1, "sliced"), (3, "poisson_saturne", 0, "sparse"),
+                                                    (2, "solar_sail", 1, "sparse"), (3, "poisson_saturne", 0, "auto"), (2, "poisson_saturne", 0, "auto")])
+def test_sliced_exchange_colorize_equals_oracle_merge(sar, oracle, gpu, world, preset, kind, form):
+    """distributed.exchange_colorize, 2 and 3 ranks on cuda:0 (3: uneven last slice, uneven job shards), whole slices or the
+    records of the touched granules: the merged slices assembled from the ranks, `max`, and the root's gathered image equal the
+    oracle's fold in rank order."""
     W, H, jobs, n, seed = 321, 199, 601, 1200, 17        # odd sizes: npix % world != 0, jobs % world != 0
-    got = _run(world, "sliced", preset, W, H, kind, jobs, n, seed)
+    got = _run(world, form, preset, W, H, kind, jobs, n, seed)
     cfg, acc = _expected(oracle, preset, W, H, kind, jobs, n, seed, world)
     count = np.zeros(W * H, np.uint32)
     zbuf = np.zeros(W * H, np.float32)
     steps = np.zeros(W * H, np.float64)
     img = None
     covered = 0
+    forms = set()
     for _, rank, f, c, cs, zs, ss, mx, im, wire in got:
         count[f:f + c], zbuf[f:f + c], steps[f:f + c] = cs, zs, ss
         covered += c
         assert mx == acc.max                                  # the scalars are global on every rank
-        assert wire["all_to_all_out_per_rank"] == (world - 1) * 16 * sar.exchange_slice_pixels(W * H, world)
+        dense = (world - 1) * 16 * sar.exchange_slice_pixels(W * H, world)
+        if form == "sliced":
+            assert wire["form"] == "dense" and wire["all_to_all_out_per_rank"] == dense
+        elif form == "sparse":
+            assert wire["form"] == "sparse" and 0 < wire["all_to_all_out_per_rank"] <= dense, wire
+        else:   # the default decides by the share of touched granules — the same way on every rank
+            forms.add(wire["form"])
+            assert wire["all_to_all_out_per_rank"] <= dense and (wire["form"] == "dense" or wire["fraction_of_dense"] <= 0.5 * world / (world - 1) + 1e-9), wire
         if rank == 0:
             img = im
-    assert covered == W * H
+    assert covered == W * H and len(forms) <= 1
     assert np.array_equal(count.reshape(H, W), acc.count)
     assert np.array_equal(_bits(zbuf.reshape(H, W)), _bits(acc.zbuf))
     assert np.array_equal(_bits(steps.reshape(H, W)), _bits(acc.steps))
@@ -155,10 +166,12 @@ def test_c_abi_multi_device_renderer_equals_single_device_and_oracle(sar, oracle
     multi = sar.ParallelRenderer(devices=devices, units=units, seed=seed)
     single = sar.ParallelRenderer(device=0, units=units, seed=seed)
     assert multi.num_devices() == len(devices) and multi.num_threads() == units
+    dense_bytes = (len(devices) - 1) * 16 * sar.exchange_slice_pixels(W * H, len(devices))
     jobs, n = units * jpu, cfg.iterations // units // jpu
     ocfg = getattr(oracle, preset)()
     ocfg.width, ocfg.height, ocfg.scale, ocfg.render_kind, ocfg.transparent = W, H, 1.0, kind, 0
-    for frame in range(2):
+    for frame in range(3):
+        multi.set_exchange([0, 1, 2][frame])          # the default (sparse here: one device has peer access to itself), dense, sparse
         img_m = sar.render_parallel(multi, cfg, jpu)
         img_s = sar.render_parallel(single, cfg, jpu)
         # oracle: the frame's jobs (start points continue across frames), sharded like the devices, folded in order
@@ -178,8 +191,11 @@ def test_c_abi_multi_device_renderer_equals_single_device_and_oracle(sar, oracle
         assert np.array_equal(rm.count(), acc.count) and rm.max() == acc.max
         assert np.array_equal(_bits(rm.zbuf()), _bits(acc.zbuf)) and np.array_equal(_bits(rm.steps()), _bits(acc.steps))
         t = multi.last_timing()
-        assert t["n_devices"] == len(devices) and t["exchange_bytes_per_device"] == (len(devices) - 1) * 16 * \
-            sar.exchange_slice_pixels(W * H, len(devices))
+        assert t["n_devices"] == len(devices)
+        if frame == 1:
+            assert t["exchange_bytes_per_device"] == dense_bytes
+        else:   # the records of the touched 64-pixel granules only
+            assert 0 < t["exchange_bytes_per_device"] < 0.6 * dense_bytes
     multi.shutdown()
     single.shutdown()
 
@@ -205,7 +221,12 @@ def test_eight_shards_pull_their_slices_on_copy_streams(sar, gpu):
         assert np.array_equal(got, want), f"{g} shards, pageable image"
         assert np.array_equal(multi.runtime().count(), want_count)
         assert t["n_devices"] == g and t["peer_access_failures"] == 0
-        assert t["exchange_bytes_per_device"] == (g - 1) * 16 * sar.exchange_slice_pixels(W * H, g)
+        dense_bytes = (g - 1) * 16 * sar.exchange_slice_pixels(W * H, g)
+        assert 0 < t["exchange_bytes_per_device"] <= 0.25 * dense_bytes    # sparse by default: a fifth of the granules are touched
+        multi.set_exchange(1)                                              # the next frame the dense way: whole slices
+        sar.render_parallel(multi, cfg, jpu)
+        t = multi.last_timing()
+        assert t["exchange_bytes_per_device"] == dense_bytes
         ms[g] = t["exchange_ms"]
         multi.shutdown()
     # (exchange_ms counts from a shard's own "packed" event, so with eight shards taking turns on ONE device it mostly
