@@ -329,6 +329,9 @@ int sar_runtime_exchange_touched(sar_runtime* rt, uint8_t* flags_out_dev /* ceil
 int sar_runtime_exchange_pack_sparse(sar_runtime* rt, const int32_t* send_slot_dev /* ceil(npix / 64) */, void* records_out_dev);
 int sar_runtime_exchange_merge_sparse(sar_runtime* rt, uint32_t world, uint32_t rank, const int32_t* recv_slot_dev /* world * S / 64 */,
                                       const void* records_in_dev);
+int sar_runtime_exchange_pack(sar_runtime* rt, uint32_t world, void* blocks_out_dev /* world*S*16 bytes */);
+int sar_runtime_exchange_merge_slices(sar_runtime* rt, uint32_t world, uint32_t rank,
+                                      const void* blocks_in_dev /* world*S*16 bytes */);
 int sar_runtime_exchange_scalars_export(sar_runtime* rt, void* i64x4_out_dev);
 int sar_runtime_exchange_scalars_import(sar_runtime* rt, const void* i64x4_dev);
 /* colorize (:841-904) of the pixel range [first_px, first_px + n_px) into out_dev (n_px*8 bytes, RGBA16), using the
