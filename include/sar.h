@@ -371,8 +371,8 @@ int sar_renderer_runtime(sar_renderer* r, sar_runtime** out_borrowed);
 typedef struct sar_parallel_timing {
     float    total_ms;      /* host wall time of the call */
     float    render_ms;     /* reset + warm-up + iterate + accumulate + fold + pack */
-    float    exchange_ms;   /* peer copies + merge of the owned slice (includes waiting for the slowest peer) */
-    float    colorize_ms;   /* scalars + colorize of the slice + its copy to the host image */
+    float    exchange_ms;   /* records / peer copies + merge of the owned slice + the scalar reduce (includes waiting for the slowest peer) */
+    float    colorize_ms;   /* colorize of the own slice + its copy to the host image (from behind the scalar reduce) */
     uint32_t n_devices;
     uint32_t peer_access_failures;  /* ordered pairs of distinct devices WITHOUT direct peer access (hipDeviceCanAccessPeer said
                                        no, or hipDeviceEnablePeerAccess failed; sar_last_error keeps the last reason): their
@@ -402,36 +402,18 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out);
  * bin geometry, the accumulate mode, the launch chunks of the call and how many render calls so far found their warm-up
  * already done (sar_runtime_prefetch_device). Writes at most cap bytes including the terminating 0. */
 int sar_runtime_describe_last_launch(const sar_runtime* rt, char* out, size_t cap);
-/* Tuning / test options by name (value 0 restores the default unless noted):
+/* Options by name (value 0 restores the default):
  *   "block_threads"      lanes per workgroup of the iterate kernel (64, 128, 192, 256)
  *   "checkpoint_stride"  iterations between trajectory checkpoints used by the payload resolve (default 32)
- *   "path"               accumulate path: 0 default (= 3 when the image fits, up to 64 Mpx), 1 one global atomic per
- *                        visit, 3 LDS-binned records (an error where they do not fit)
- *   "bin_shift"          log2(pixels per bin) of the binned path (12..16; 16: the accumulate kernel packs two 16-bit counters
- *                        with a guard bit into an LDS word)
- *   "bin_interleave"     which pixels form a bin: 1 consecutive pixels, 2 every B-th 2048-pixel segment of the image
- *                        (B bins, a power of two: every bin carries the same share of the visits whatever the attractor
- *                        covers); 0 = 2 when the power-of-two bin count costs at most a third more bins, else 1
- *   "splits"             workgroups per bin in the record-accumulate kernel (1..16)
- *   "chunk_records"      u16 records per chunk: 12, 20, 28 or 60 (32/48/64/128-byte chunks; fewer = less LDS per wave)
- *   "split_waves"        the iterate kernel as producer / consumer wave pairs (one wave runs the map, its partner stages the
- *                        visits): 1 never, 2 wherever the kernel exists (64- or 128-byte chunks); 0 = 2 for
- *                        launches whose jobs are all resident at once (512 per CU), 1 for larger ones
  *   "hint_bits"          per-XCD depth hints of the iterate kernel: 16 (fixed point over the depth range the warm-up saw) or
  *                        32 (the depth itself as f32); 0 = by image size
- *   "hint_shared"        1: one array of depth hints per XCD, 2: one array for the whole chip (each XCD's L2 then sees the
- *                        others' updates late — more visits pass the filter, none wrongly); 0 = per XCD unless the eight
- *                        copies exceed 200 MB (then they would not fit the Infinity Cache)
- *   "hint_tile"          1: 16-bit hints always in row-major order; 0 = in 8 x 8 tiles (one 128-byte line each) where the
- *                        image width is a power of two and the height a multiple of eight
- *   "chunk_ahead"        a render call of several launch chunks runs its next chunk's warm-up ahead, under the current chunk's
- *                        accumulate and fold (0 / 1, the default); 2 = not (A/B)
- *   "acc_threads"        threads per block of the record-accumulate kernel (256, 512, 1024)
- *   "acc_lists"          (bin, wave) record lists a lane group of that kernel walks at the same time: 1 or 4
+ *   "split_waves"        the iterate kernel as producer / consumer wave pairs: 1 never, 2 wherever the kernel exists; 0 = 2 for
+ *                        launches whose jobs are all resident at once (512 per CU), 1 for larger ones
  *   "timing_accumulate"  1: the spans of successive render calls add up (sar_timing sums, iterate_launches counts
  *                        them) until sar_runtime_last_timing reads and clears them; 0: last render call only
- *   "debug_chunk_jobs"   test hook: cap on jobs per launch chunk
- *   "debug_max_ordinals" test hook: visits one launch may order (default 2^32-2); jobs with more iterations run as segments
+ * Everything else a laboratory wants to turn — accumulate path, bin geometry, chunk sizes, hint layout, launch-chunk caps,
+ * the batched launch's variants — is NOT in this library: include/sar_test_hooks.h declares sar_runtime_set_test_option, which
+ * only the hooks build of the test-suite links (tests/hooks/libsar_hip_hooks.so: the same object files plus that one function).
  *
  * Jobs of more than 2^32-2 iterations (Config::iterations is a usize, :267): a launch orders its visits with a 32-bit
  * ordinal, so such a job runs as successive launches that hand its state on — and it runs them ALONE, one lane of the

@@ -177,11 +177,29 @@ PROTOTYPES = {
     "sar_bin_geometry": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32)]),
 }
 
+# the hooks build only (include/sar_test_hooks.h): attached when the loaded library exports it
+OPTIONAL_PROTOTYPES = {
+    "sar_runtime_set_test_option": (C.c_int, [_vp, C.c_char_p, C.c_uint64]),
+}
+STABLE_OPTIONS = ("block_threads", "checkpoint_stride", "hint_bits", "split_waves", "timing_accumulate")
+
 LIB_NAME = "libsar_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, LIB_NAME)
+HOOKS_PATH = os.path.join(os.path.dirname(_PKG_DIR), "tests", "hooks", "libsar_hip_hooks.so")   # product objects + the test hooks
 
 _lib = None
+_default_path = LIB_PATH
+
+
+def use_hooks_build():
+    """From now on load_library() loads the hooks build (the product's object files + sar_runtime_set_test_option): what the
+    test-suite and the A/B tools do before their first call. The product is never replaced on disk."""
+    global _default_path, _lib
+    if not os.path.exists(HOOKS_PATH):
+        raise SarLibraryMissing(f"{HOOKS_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    if _default_path != HOOKS_PATH:
+        _default_path, _lib = HOOKS_PATH, None
 
 
 class SarLibraryMissing(RuntimeError):
@@ -194,7 +212,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or os.environ.get("SAR_LIBRARY") or LIB_PATH  # SAR_LIBRARY: A/B timing of another build of the same ABI
+    p = path or os.environ.get("SAR_LIBRARY") or _default_path  # SAR_LIBRARY: A/B timing of another build of the same ABI
     if not os.path.exists(p):
         raise SarLibraryMissing(
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -205,7 +223,12 @@ def load_library(path: str | None = None) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if p == LIB_PATH:
+    for name, (res, args) in OPTIONAL_PROTOTYPES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
+    if p in (LIB_PATH, HOOKS_PATH):
         verify_library(lib)  # a variant named explicitly (path / SAR_LIBRARY) is the caller's business
     if path is None:
         _lib = lib

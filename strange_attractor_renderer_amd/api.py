@@ -233,7 +233,16 @@ class Runtime:
                       t.iterations_counted, t.depth_atomics, t.warmup_ms, t.depth_candidates)
 
     def set_option(self, name: str, value: int):
-        _check(_lib().sar_runtime_set_option(self._h, name.encode(), int(value)), f"sar_runtime_set_option({name})")
+        """A stable option (include/sar.h) — or, on the hooks build the test-suite loads, an A/B / test option
+        (include/sar_test_hooks.h); the product library has no such entry point."""
+        if name in _abi.STABLE_OPTIONS:
+            _check(_lib().sar_runtime_set_option(self._h, name.encode(), int(value)), f"sar_runtime_set_option({name})")
+            return
+        hook = getattr(_lib(), "sar_runtime_set_test_option", None)
+        if hook is None:
+            raise RuntimeError(f"option {name!r} is a test hook: load the hooks build (strange_attractor_renderer_amd._abi.use_hooks_build(), "
+                               "or SAR_LIBRARY=tests/hooks/libsar_hip_hooks.so)")
+        _check(hook(self._h, name.encode(), int(value)), f"sar_runtime_set_test_option({name})")
 
     def set_tuning(self, block_threads: int = 0, checkpoint_stride: int = 0, variant: int = 0, **more):
         """Convenience over set_option. variant: bits 0-3 path (0 automatic, 1 one atomic per visit, 3 binned), bits 8+
@@ -242,8 +251,11 @@ class Runtime:
             raise ValueError(f"variant {variant:#x}: bits 4-7 (the removed measurement modes) must be zero")
         self.set_option("block_threads", block_threads)
         self.set_option("checkpoint_stride", checkpoint_stride)
-        self.set_option("path", variant & 0xF)
-        self.set_option("debug_chunk_jobs", variant >> 8)
+        hooks = hasattr(_lib(), "sar_runtime_set_test_option")
+        if hooks or variant & 0xF:
+            self.set_option("path", variant & 0xF)          # (test hooks: only the hooks build has them; 0 is the product's behaviour)
+        if hooks or variant >> 8:
+            self.set_option("debug_chunk_jobs", variant >> 8)
         for k, v in more.items():
             self.set_option(k, v)
 

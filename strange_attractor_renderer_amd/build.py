@@ -20,9 +20,11 @@ CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libsar_hip.so")
 BUILD_DIR = os.path.join(os.path.dirname(PKG), "build", "sar_hip")
 VARIANT_DIR = os.path.join(os.path.dirname(PKG), "build", "variants")   # A/B and test builds (SAR_LIBRARY=...), git-ignored
+HOOKS_OUT = os.path.join(os.path.dirname(PKG), "tests", "hooks", "libsar_hip_hooks.so")   # product objects + sar_test_hooks.cpp
+HOOKS_SOURCE = "sar_test_hooks.cpp"
 SOURCES = ["sar_host.cpp", "sar_export.cpp", "sar_plan.cpp", "sar_render.cpp", "sar_runtime.cpp", "sar_batch.cpp", "sar_multi.cpp", "sar_iterate.hip", "sar_accumulate.hip",
            "sar_image.hip"]
-HEADERS = ["sar_internal.hpp", "sar_launch.hpp", "sar_device.hpp", "sar_runtime_impl.hpp", "sar_plan.hpp", os.path.join("..", "..", "include", "sar.h")]
+HEADERS = [HOOKS_SOURCE, os.path.join("..", "..", "include", "sar_test_hooks.h"), "sar_internal.hpp", "sar_launch.hpp", "sar_device.hpp", "sar_runtime_impl.hpp", "sar_plan.hpp", os.path.join("..", "..", "include", "sar.h")]
 ARCH = "gfx950"
 FOLD_FUSED_OPS = 6   # v_fma_f64 in k_fold_resolve: the sqrt + div expansions of color_transform, nothing else
 
@@ -70,7 +72,7 @@ def library_id(path: str) -> str | None:
 
 
 def _stale() -> bool:
-    return library_id(OUT) != source_id()
+    return library_id(OUT) != source_id() or library_id(HOOKS_OUT) != source_id()
 
 
 def audit_no_fma(asm_paths) -> dict:
@@ -130,6 +132,13 @@ def build_library(force: bool = False, verbose: bool = False, out: str | None = 
     tmp = OUT_ + ".tmp"
     subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-lz", "-lpthread", "-o", tmp], check=True)  # zlib: PNG export
     os.replace(tmp, OUT_)
+    # the hooks build of the test-suite: the SAME object files plus the one that defines sar_runtime_set_test_option
+    hooks_out = HOOKS_OUT if out is None else OUT_[:-3] + "_hooks.so"
+    os.makedirs(os.path.dirname(hooks_out), exist_ok=True)
+    hobj = os.path.join(BUILD_DIR_, HOOKS_SOURCE + ".o")
+    subprocess.run([hipcc, *FLAGS, *os.environ.get("SAR_EXTRA_FLAGS", "").split(), "-c", os.path.join(CSRC, HOOKS_SOURCE), "-o", hobj], check=True, cwd=BUILD_DIR_)
+    subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, hobj, "-lz", "-lpthread", "-o", hooks_out + ".tmp"], check=True)
+    os.replace(hooks_out + ".tmp", hooks_out)
     LAST_BUILD.update(action="built", id=sid)
     return OUT_
 

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -50,7 +51,7 @@ struct Shard {
     std::vector<hipStream_t> pull_streams;  // one per source device: this owner's pulls run side by side
     std::vector<hipEvent_t> pulled;         // ... and are joined to the owner's stream through these
     size_t slice_cap = 0;     // S the buffers were sized for
-    hipEvent_t packed = nullptr, merged = nullptr, begin = nullptr, end = nullptr;
+    hipEvent_t packed = nullptr, merged = nullptr, reduced = nullptr, begin = nullptr, end = nullptr;
     // job slice of the current frame
     uint32_t first_job = 0, n_jobs = 0;
     // the NEXT frame's slice of start points, uploaded and announced (sar_runtime_prefetch_device) while this frame renders:
@@ -132,6 +133,7 @@ int ensure_shard(sar_renderer* r, Shard& sh, const sar_config* cfg, uint32_t S) 
     if (!sh.packed) {
         HIP_TRY(hipEventCreate(&sh.packed));
         HIP_TRY(hipEventCreate(&sh.merged));
+        HIP_TRY(hipEventCreate(&sh.reduced));
         HIP_TRY(hipEventCreate(&sh.begin));
         HIP_TRY(hipEventCreate(&sh.end));
         sh.pull_streams.assign(G, nullptr);
@@ -325,6 +327,7 @@ int sar_renderer_shutdown(sar_renderer* r) {
         for (hipEvent_t ev : sh.pulled) if (ev) hipEventDestroy(ev);
         if (sh.packed) hipEventDestroy(sh.packed);
         if (sh.merged) hipEventDestroy(sh.merged);
+        if (sh.reduced) hipEventDestroy(sh.reduced);
         if (sh.begin) hipEventDestroy(sh.begin);
         if (sh.end) hipEventDestroy(sh.end);
     }
@@ -424,7 +427,11 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
         }
         for (uint32_t d = 0; d < G; ++d) {
             Shard& sh = r->shards[d];
-            drawers.emplace_back(draw_slice, std::cref(frame_rng), static_cast<uint64_t>(sh.first_job), sh.n_jobs, sh.h_next[sh.cur_slot]);
+            try {
+                drawers.emplace_back(draw_slice, std::cref(frame_rng), static_cast<uint64_t>(sh.first_job), sh.n_jobs, sh.h_next[sh.cur_slot]);
+            } catch (const std::system_error&) {  // no thread to be had: this slice is drawn here (nothing unwinds across the ABI)
+                draw_slice(frame_rng, static_cast<uint64_t>(sh.first_job), sh.n_jobs, sh.h_next[sh.cur_slot]);
+            }
         }
         for (auto& t : drawers) t.join();
     }
@@ -445,15 +452,22 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
         const double td = now_ms();
         for (uint32_t d = 0; d < G; ++d) {
             Shard* sh = &r->shards[d];
-            helpers.emplace_back([=, &frame_rng, &draw_ms]() {
-                Rng nx = frame_rng;
-                nx.skip_points(total_jobs);              // the stream behind this frame
-                if (d == 0) r->rng_next = nx;
-                nx.skip_points(sh->first_job);
-                double* out = sh->h_next[sh->next_slot];
-                for (uint32_t k = 0; k < sh->n_jobs; ++k) nx.start_point(out + 3 * static_cast<size_t>(k));
-                if (d == 0) draw_ms = now_ms() - td;     // (device 0's slice: they are equal)
-            });
+            try {
+                helpers.emplace_back([=, &frame_rng, &draw_ms]() {
+                    Rng nx = frame_rng;
+                    nx.skip_points(total_jobs);              // the stream behind this frame
+                    if (d == 0) r->rng_next = nx;
+                    nx.skip_points(sh->first_job);
+                    double* out = sh->h_next[sh->next_slot];
+                    for (uint32_t k = 0; k < sh->n_jobs; ++k) nx.start_point(out + 3 * static_cast<size_t>(k));
+                    if (d == 0) draw_ms = now_ms() - td;     // (device 0's slice: they are equal)
+                });
+            } catch (const std::system_error&) {  // no thread to be had: nothing is drawn ahead this frame (the next one draws its own)
+                for (auto& t : helpers) t.join();
+                helpers.clear();
+                ahead_ok = false;
+                break;
+            }
         }
     }
     auto join_helpers = [&]() {
@@ -493,6 +507,9 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
                 if (ok) sh.next_cap[slot] = nj;
             }
             sh.d_next = sh.d_next_buf[slot];
+            // an announced warm-up that nobody consumed (another job count, a failed frame) may still read this buffer on the
+            // runtime's side stream: the upload goes behind it (an event never recorded waits for nothing)
+            if (ok && sh.rt->pf_done) ok = hipStreamWaitEvent(sh.up, sh.rt->pf_done, 0) == hipSuccess;
             ok = ok && hipMemcpyAsync(sh.d_next, sh.h_next[slot], static_cast<size_t>(nj) * 3 * sizeof(double), hipMemcpyHostToDevice, sh.up) == hipSuccess &&
                  hipEventRecord(sh.uploaded, sh.up) == hipSuccess;
             if (ok) {
@@ -568,7 +585,13 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
     {
         std::vector<std::thread> workers;
         workers.reserve(G);
-        for (uint32_t d = 0; d < G; ++d) workers.emplace_back(render_shard, r, &r->shards[d], cfg, per_job, S, from_ahead, sparse);
+        for (uint32_t d = 0; d < G; ++d) {
+            try {
+                workers.emplace_back(render_shard, r, &r->shards[d], cfg, per_job, S, from_ahead, sparse);
+            } catch (const std::system_error&) {  // no thread to be had: this device's frame is enqueued from here
+                render_shard(r, &r->shards[d], cfg, per_job, S, from_ahead, sparse);
+            }
+        }
         for (auto& w : workers) w.join();
     }
     for (Shard& sh : r->shards)
@@ -639,6 +662,7 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
             for (uint32_t e = 0; e < G; ++e)
                 if (e != d) HIP_TRY(hipStreamWaitEvent(st, r->shards[e].merged, 0));
             launch_exch_scalars_reduce(sh.rt->d_scalars, r->d_board, G, st);
+            HIP_TRY(hipEventRecord(sh.reduced, st));  // (from here on the device works on its own slice again)
             const uint64_t first = static_cast<uint64_t>(d) * S;
             const uint32_t n = first >= npix ? 0u : static_cast<uint32_t>((npix - first < S) ? npix - first : S);
             if (rgba_out_host && n) {
@@ -656,13 +680,18 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
         std::vector<std::thread> movers;
         std::vector<int> sync_status(G, SAR_OK);
         for (uint32_t d = 0; d < G; ++d) {
-            movers.emplace_back([&, d]() {
+            auto move = [&, d]() {
                 Shard& sh = r->shards[d];
                 if (hipSetDevice(sh.device) != hipSuccess || hipStreamSynchronize(sh.rt->stream) != hipSuccess) { sync_status[d] = SAR_ERR_HIP; return; }
                 const uint64_t first = static_cast<uint64_t>(d) * S;
                 const uint32_t n = first >= npix ? 0u : static_cast<uint32_t>((npix - first < S) ? npix - first : S);
                 if (rgba_out_host && n && !pinned_out) std::memcpy(rgba_out_host + first * 4u, sh.h_rgba, static_cast<size_t>(n) * 8u);
-            });
+            };
+            try {
+                movers.emplace_back(move);
+            } catch (const std::system_error&) {
+                move();
+            }
         }
         for (auto& m : movers) m.join();
         for (uint32_t d = 0; d < G; ++d)
@@ -671,8 +700,10 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
             HIP_TRY(hipSetDevice(sh.device));
             float ms = 0.f;  // per-device stream time of the three phases; the frame is as slow as the slowest device
             if (hipEventElapsedTime(&ms, sh.begin, sh.packed) == hipSuccess && ms > r->timing.render_ms) r->timing.render_ms = ms;
-            if (hipEventElapsedTime(&ms, sh.packed, sh.merged) == hipSuccess && ms > r->timing.exchange_ms) r->timing.exchange_ms = ms;
-            if (hipEventElapsedTime(&ms, sh.merged, sh.end) == hipSuccess && ms > r->timing.colorize_ms) r->timing.colorize_ms = ms;
+            // exchange: until every device's quad is reduced here (that includes waiting for the slowest device's merge);
+            // colorize: this device's own slice from then on
+            if (hipEventElapsedTime(&ms, sh.packed, sh.reduced) == hipSuccess && ms > r->timing.exchange_ms) r->timing.exchange_ms = ms;
+            if (hipEventElapsedTime(&ms, sh.reduced, sh.end) == hipSuccess && ms > r->timing.colorize_ms) r->timing.colorize_ms = ms;
         }
         return SAR_OK;
     };

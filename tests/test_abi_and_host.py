@@ -287,3 +287,22 @@ def test_library_is_tied_to_its_sources(sar, tmp_path):
     assert build.source_id(str(pkg / "csrc"), extra_flags=[]) != before
     assert build.source_id(extra_flags=["-DSAR_POOL_SPARE=2u"]) != build.source_id(extra_flags=[])   # and so do the flags
     assert glob.glob(os.path.join(os.path.dirname(_abi.LIB_PATH), "libsar_hip_*.so")) == [], "a variant build sits next to the product"
+
+
+def test_test_hooks_are_not_in_the_product(sar):
+    """include/sar.h is the product's whole ABI: sar_runtime_set_test_option (include/sar_test_hooks.h) is exported by the hooks
+    build of the test-suite alone — the same object files plus one — and sar_runtime_set_option knows five stable options."""
+    from strange_attractor_renderer_amd import _abi, build
+    product = C.CDLL(_abi.LIB_PATH)
+    hooks = C.CDLL(_abi.HOOKS_PATH)
+    assert not hasattr(product, "sar_runtime_set_test_option") and hasattr(hooks, "sar_runtime_set_test_option")
+    assert build.library_id(_abi.LIB_PATH) == build.library_id(_abi.HOOKS_PATH) == build.source_id(extra_flags=[])
+    header = open(HEADER).read()
+    assert "sar_runtime_set_test_option(" not in re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    doc = header[header.index("/* Options by name"):header.index("int sar_runtime_set_option(")]
+    assert sorted(re.findall(r'^ \*   "([a-z_]+)"', doc, flags=re.M)) == sorted(_abi.STABLE_OPTIONS)
+    with tempfile.TemporaryDirectory() as d:   # the hooks header is plain C as well
+        src = os.path.join(d, "t.c")
+        open(src, "w").write('#include "sar_test_hooks.h"\nint main(void) { int (*f)(sar_runtime*, const char*, uint64_t) = sar_runtime_set_test_option; return f ? 0 : 1; }\n')
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", src, "-o", os.path.join(d, "t.o")],
+                       check=True)

@@ -26,6 +26,8 @@ def main():
     a = ap.parse_args()
     import torch
     import strange_attractor_renderer_amd as S
+    if a.opt:
+        S.use_hooks_build()   # A/B options live in the hooks build (include/sar_test_hooks.h)
     from strange_attractor_renderer_amd.sequence import frame_seed
     w, h = (int(v) for v in a.size.split("x"))
     n = a.iters // a.jobs

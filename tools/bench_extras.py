@@ -293,6 +293,8 @@ def run_c5(a, S, torch, dist, world: int, rank: int, local_rank: int, jobs_given
     read-back into host memory (the PNG encoder, which the CLI runs on other threads, is excluded). Frames go through the library in
     BATCHES (sar_render_jobs_batch). Two sweeps: with the read-back (`value`), and to RGBA16 in HBM (`rgba16_in_hbm`)."""
     from strange_attractor_renderer_amd.sequence import SequenceRenderer, frames as sequence_frames
+    if a.rt_opt:
+        S.use_hooks_build()   # A/B options live in the hooks build (include/sar_test_hooks.h); the default sweep runs on the product
     frame_jobs = a.jobs if jobs_given else 65536
     units, jpt = frame_jobs // 4, 4
     scfg = S.Config.solar_sail(iterations=100_000_000, width=1800, height=2000, scale=1.0, transparent=0)

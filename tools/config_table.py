@@ -16,6 +16,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import strange_attractor_renderer_amd as S  # noqa: E402
+S.use_hooks_build()   # this tool turns A/B options (include/sar_test_hooks.h)
 import torch  # noqa: E402
 
 CONFIGS = {

@@ -4,6 +4,7 @@ import sys, os, traceback
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
 import strange_attractor_renderer_amd as sar
+sar.use_hooks_build()   # this tool turns A/B options (include/sar_test_hooks.h)
 import oracle_lib as oracle
 import test_gpu_parity as T
 oracle.lib()
