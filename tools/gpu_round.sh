@@ -9,7 +9,7 @@ timeout 1500 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; echo "
 if [ -z "$fast" ]; then
   for v in 1 2; do SAR_SPLIT=$v timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q > $out/pytest_split$v.log 2>&1; echo "SAR_SPLIT=$v: $(tail -1 $out/pytest_split$v.log)"; done
   [ -f build/variants/libsar_hip_spare2.so ] || SAR_EXTRA_FLAGS=-DSAR_POOL_SPARE=2u python -m strange_attractor_renderer_amd.build --variant spare2 > $out/build_spare2.log 2>&1
-  SAR_LIBRARY=$GRAFT_REPO_ROOT/build/variants/libsar_hip_spare2.so timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q > $out/pytest_spare2.log 2>&1; echo "spare2: $(tail -1 $out/pytest_spare2.log)"
+  SAR_LIBRARY=$GRAFT_REPO_ROOT/build/variants/libsar_hip_spare2_hooks.so timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q > $out/pytest_spare2.log 2>&1; echo "spare2: $(tail -1 $out/pytest_spare2.log)"
 fi
 python __graft_entry__.py --smoke 2>&1 | tail -1
 python bench.py > $out/bench_n1.json 2> $out/bench_n1.err; python - <<PY

@@ -10,8 +10,8 @@ out=gpurun_out/$tag; mkdir -p $out
 bash tools/gpu_round.sh $tag
 B="--no-cpu-baseline --no-pipeline --sustained-seconds 0 --no-traffic"
 python bench.py --config c4 --steps 6 --warmup 2 $B > $out/bench_c4_n1.json 2> $out/bench_c4_n1.err
-python bench.py --config c5 --steps 360 --warmup 4 > $out/bench_c5_n1.json 2> $out/bench_c5_n1.err
-timeout 900 python bench.py --gpus 2 --steps 6 --warmup 2 --check --extras-seconds 400 > $out/bench_n2_gloo_one_gpu.json 2> $out/bench_n2_gloo_one_gpu.err
+python bench.py --config c5 --steps 1440 --warmup 32 > $out/bench_c5_n1.json 2> $out/bench_c5_n1.err
+timeout 900 python bench.py --gpus 2 --steps 6 --warmup 2 --extras-seconds 400 > $out/bench_n2_gloo_one_gpu.json 2> $out/bench_n2_gloo_one_gpu.err
 for c in c2 c4; do python bench.py --native --gpus 8 --config $c --steps 4 --warmup 2 > $out/bench_native_8shards_$c.json 2> /dev/null; done
 python bench.py --native --gpus 1 --steps 20 --warmup 3 > $out/bench_native_1dev_c2.json 2> /dev/null
 python - <<PY
@@ -26,3 +26,4 @@ for f in sorted(glob.glob("$out/bench_*.json")):
 PY
 bash tools/profile_round.sh $tag > $out/profile_round.log 2>&1; tail -5 $out/profile_round.log
 bash tools/pmc_c4.sh $tag both > $out/pmc_c4.log 2>&1; grep -c derived $out/pmc_c4.log
+bash tools/profile_c5.sh $tag > $out/profile_c5.log 2>&1; tail -30 $out/profile_c5.log

@@ -21,9 +21,11 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if "k_iterate" in r["Kernel_Name"]]
     if d:
+        timed = d[3:23]
         print("the iterate kernel per dispatch (ms): " + ", ".join(f"{x:.3f}" for x in d) +
-              f" — the first three dispatches are bench.py's untimed warm-up steps (cold caches, first touch of the arena); mean of "
-              f"the 20 timed ones {sum(d[3:]) / max(len(d) - 3, 1):.3f} ms, which is what bench.py's HIP events average.\n")
+              f" — the first three dispatches are bench.py's untimed warm-up steps (cold caches, first touch of the arena), the 24th "
+              f"is the untimed frame whose checksums the line's `parity` reports; mean of the 20 timed ones "
+              f"{sum(timed) / max(len(timed), 1):.3f} ms, which is what bench.py's HIP events average.\n")
 try:
     line = [l for l in open(os.path.join(root, "trace_bench.json")) if l.startswith("{")][-1]
     b = json.loads(line)
