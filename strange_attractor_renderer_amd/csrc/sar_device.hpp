@@ -135,11 +135,7 @@ constexpr uint32_t kChunkLanes(uint32_t R) { return kChunkQuads(R) <= 2u ? 2u : 
 constexpr uint32_t kPoolSpareOf(uint32_t R) { return SAR_POOL_SPARE < 64u / kChunkLanes(R) ? SAR_POOL_SPARE : 64u / kChunkLanes(R); }
 constexpr uint32_t kPoolWaveLds(uint32_t bins, uint32_t R) {
     // buffers | ctl words | ring, rounded up to a multiple of 16 bytes
-#ifdef SAR_EXPERIMENT_UNMASKED_SLOT  // + one word that the slot requests of lanes without a visit count on
-    return ((bins + kPoolSpareOf(R)) * kPoolChunkBytes(R) + bins * 4u + kPoolSpareOf(R) * 4u + 4u + 15u) & ~15u;
-#else
     return ((bins + kPoolSpareOf(R)) * kPoolChunkBytes(R) + bins * 4u + kPoolSpareOf(R) * 4u + 15u) & ~15u;
-#endif
 }
 // Chunks never straddle a 64-byte sector of the arena: the 48-byte chunk (R = 20) is laid out on a 64-byte stride.
 // The accumulate kernel's chunk reads are isolated, and an isolated read moves whole sectors (measured, tools/ubench/

@@ -320,7 +320,6 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
     BinMap map;
     uint32_t bin_bits_v;  // map.bin_bits, held in a vector register
     bool b_have;          // previous visit, waiting for its LDS slot
-    unsigned long long b_mask;  // ... as a lane mask, taken straight from the compare that made it (SAR_EXPERIMENT_BALLOT_MASK)
     uint32_t b_bin, b_old, b_local;
 #ifdef SAR_EXPERIMENT_PROF
     // timing experiment: wave-cycles per segment of the loop body (s_memtime; every mark drains lgkmcnt, so the LDS round
@@ -362,7 +361,6 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         bin_bits_v = map_.bin_bits;
         asm volatile("" : "+v"(bin_bits_v));  // stays in a VGPR: v_bfe_u32 takes one scalar operand, the field offset
         b_have = false;
-        b_mask = 0ull;
         b_bin = b_old = b_local = 0;
     }
 
@@ -417,11 +415,7 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         if (w0) *(unsigned short*)lds_ptr(rec + 2u * slot) = (unsigned short)b_local;
         // lanes that took the last slot: the mask comes straight from one compare, the lanes without a visit drop out of it
         // in the scalar unit
-#ifdef SAR_EXPERIMENT_BALLOT_MASK  // (the ballot of a predicate that crossed a loop iteration costs v_cndmask + v_cmp_ne)
-        const unsigned long long fb = lanes_eq(slot, R - 1u) & b_mask;
-#else
         const unsigned long long fb = lanes_eq(slot, R - 1u) & wave_ballot(b_have);
-#endif
         const bool fl = b_have && slot == R - 1u;
         if (fb) {
             swap_full(fl, fb, b_bin, rec);
@@ -455,16 +449,9 @@ struct PoolStager : DepthPipe<DEPTH, U, H> {
         const bool cand = depth_candidate(k, inb, idx, zf, t);
         SAR_MARK(3);
         b_have = inb;
-        b_mask = wave_ballot(inb);
         b_bin = __builtin_amdgcn_ubfe(idx, map.seg_shift, bin_bits_v);
         b_local = bfi(map.low_mask, idx, idx >> map.hi_shift);
-#ifdef SAR_EXPERIMENT_UNMASKED_SLOT
-        // every lane requests (the ones without a visit on a word nobody reads): no exec-masked region for the compiler to
-        // sink the first use of the returned word into — with the mask it waits for the LDS round trip right behind the request
-        b_old = atomicAdd(inb ? &ctl[b_bin] : ring + P, 1u);
-#else
         if (inb) b_old = atomicAdd(&ctl[b_bin], 1u);  // ds_add_rtn_u32: slot and buffer in one word
-#endif
         depth_request(k, cand, idx);
         __builtin_amdgcn_s_setprio(0);
         SAR_MARK(4);
