@@ -143,7 +143,22 @@ def native_measure(S, torch, devices, config, steps, warmup, K):
     el = time.perf_counter() - t0
     t = r.last_timing()
     r.shutdown()
-    return {"value": n * total_jobs * steps / el, "unit": "iterations/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+    parity = None
+    if config == "c4" and total_jobs == K["C4_JOBS"]:
+        # the same frame as tests/golden holds it (c4_full_1e10: seed 3, the preset's transparent flag): the FIRST frame of a renderer
+        # seeded with 3, rendered by these devices, exchanged, colorized — its merged buffers gathered into device 0's runtime
+        try:
+            import numpy as np
+            cfg_g = S.Config.poisson_saturne(iterations=iters, width=width, height=width, seed=3)
+            rg = S.ParallelRenderer(devices=devices, units=units, seed=3)
+            img_g = S.render_parallel(rg, cfg_g, jpu)
+            rm = rg.runtime()
+            parity = frame_parity(S, "c4_full_1e10", rm.count(), rm.zbuf(), rm.steps(), img_g, rm.max())
+            rg.shutdown()
+            print(f"[parity] native c4_full_1e10 over {g} shard(s): {parity['result']}", file=sys.stderr)
+        except Exception as e:  # evidence next to the number: never lose the line over it
+            parity = {"result": "not checked", "error": repr(e)}
+    return {"value": n * total_jobs * steps / el, "parity": parity, "unit": "iterations/s", "ms_per_step": el / steps * 1e3, "steps": steps,
             "scaling": "strong" if config == "c4" else "weak", "devices": list(devices), "jobs_total": total_jobs,
             "iterations_per_job": n, "image": f"{width}x{width}",
             "phase_ms_per_step_slowest_device": {k: v / steps for k, v in phases.items() if k.endswith("_ms") and not k.startswith(("host", "draw"))},
