@@ -75,7 +75,8 @@ def main():
     ap.add_argument("--no-parity", dest="parity", action="store_false", help="skip the (untimed) frame checksums against tests/golden")
     ap.add_argument("--host-starts", action="store_true", help="hand the start points over from host memory every step "
                     "(PCIe-inclusive rate; the default keeps them resident in HBM)")
-    ap.add_argument("--lanes", type=int, default=2, help="--config c5: groups of runtimes (streams) per GPU the frames are rendered on in turn")
+    ap.add_argument("--lanes", type=int, default=0, help="--config c5: groups of runtimes (streams) per GPU the batches are rendered on in turn "
+                    "(0: one for the read-back sweep, two for the sweep that leaves the frames in HBM)")
     ap.add_argument("--batch", type=int, default=0, help="--config c5: frames per set of launches (sar_render_jobs_batch); 0 = the "
                     "library's advice (a multiple of eight, at most --max-batch), 1 = a frame per launch")
     ap.add_argument("--max-batch", type=int, default=16)

@@ -327,7 +327,7 @@ def run_c5(a, S, torch, dist, world: int, rank: int, local_rank: int, jobs_given
             seq.run(todo, sink, zero_copy=True)   # the sink only counts: no copy of the page-locked image
             torch.cuda.synchronize()
             assert done[0] == frames_per_rank
-        sweep(max(a.warmup, a.lanes * seq.max_batch * 2))
+        sweep(max(a.warmup, seq.lanes * seq.max_batch * 2))
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
@@ -352,7 +352,7 @@ def run_c5(a, S, torch, dist, world: int, rank: int, local_rank: int, jobs_given
     else:
         elapsed, sizes, launch = measure(SequenceRenderer(scfg, image_format=S.SAR_FMT_RGB16, **common))
     # ... and the same sweep to what SURVEY 8(d)'s metric ends with: the colorized frame as RGBA16 in device memory
-    slots = (a.lanes + 1) * max(a.batch, a.max_batch) + 1
+    slots = ((a.lanes or 2) + 1) * max(a.batch, a.max_batch) + 1
     hbm = [torch.empty(1800 * 2000 * 4, dtype=torch.int16, device="cuda") for _ in range(slots)]
     if a.c5_only == "readback":
         el_hbm, sizes_hbm = float("nan"), []
@@ -376,7 +376,7 @@ def run_c5(a, S, torch, dist, world: int, rank: int, local_rank: int, jobs_given
                                "1e8 iterations per frame, 1800x2000, scale 1, frame k on rank k mod N; RGB16 conversion on the "
                                "device + read-back included, PNG encoder excluded",
                    "jobs_per_frame": units * jpt, "iterations_per_job": per_job, "frames": frames,
-                   "lanes_per_gpu": a.lanes, "frames_per_launch": {str(f): sizes.count(f) for f in sorted(set(sizes))},
+                   "lanes_per_gpu": {"read_back": a.lanes or 1, "in_hbm": a.lanes or 2}, "frames_per_launch": {str(f): sizes.count(f) for f in sorted(set(sizes))},
                    "frames_per_launch_in_hbm": {str(f): sizes_hbm.count(f) for f in sorted(set(sizes_hbm))},
                    "launch": launch,
                    "counted_over_executed_iterations": round(per_job / (per_job + 1000.0), 4),
