@@ -77,6 +77,18 @@ inline void render(const Config& config, Runtime& runtime) { check(sar_render(&c
 inline void render_jobs(const Config& config, Runtime& runtime, const double* starts_xyz = nullptr) {
     check(sar_render_jobs(&config, runtime.handle(), starts_xyz), "render_jobs");
 }
+// F frames of a sweep (the CLI's frame loop, src/bin/main.rs:493-517) through ONE set of launches: frame i is
+// render_jobs(configs[i], *runtimes[i], starts[i]) — bit for bit; the frames share the chip instead of following each other
+inline void render_jobs_batch(const std::vector<const Config*>& configs, const std::vector<Runtime*>& runtimes,
+                              const std::vector<const double*>& starts_xyz = {}) {
+    if (configs.size() != runtimes.size() || (!starts_xyz.empty() && starts_xyz.size() != configs.size()))
+        throw Error(SAR_ERR_INVALID, "render_jobs_batch: configs, runtimes and starts must have the same length");
+    std::vector<const sar_config*> c(configs.begin(), configs.end());
+    std::vector<sar_runtime*> r;
+    for (Runtime* rt : runtimes) r.push_back(rt->handle());
+    check(sar_render_jobs_batch(static_cast<uint32_t>(c.size()), c.data(), r.data(), starts_xyz.empty() ? nullptr : starts_xyz.data()),
+          "render_jobs_batch");
+}
 // colorize(&config, &runtime) -> FinalImage (:841)
 inline FinalImage colorize(const Config& config, Runtime& runtime) {
     FinalImage img;

@@ -104,6 +104,7 @@ def _all_to_all_v(dist, out, inp, out_bytes, in_bytes, rt):
     """all-to-all with split sizes (bytes per peer, in rank order): out / inp are flat uint8 buffers at least as long as the sums."""
     import torch
     if _device_native(dist):
+        # (every rank calls the collective, also one with nothing to send or receive: the others may have)
         dist.all_to_all_single(out[: sum(out_bytes)], inp[: sum(in_bytes)], list(out_bytes), list(in_bytes))
         return
     # gloo (ranks sharing a GPU, CPU-only CI): point-to-point through host memory — same data movement, test-path only
