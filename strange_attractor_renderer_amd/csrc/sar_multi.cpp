@@ -147,10 +147,22 @@ int ensure_shard(sar_renderer* r, Shard& sh, const sar_config* cfg, uint32_t S) 
         HIP_TRY(hipStreamSynchronize(sh.rt->stream));
         free_shard_buffers(sh);
         HIP_TRY(hipMalloc(&sh.d_pack, static_cast<size_t>(G) * S * 16u));
-        HIP_TRY(hipMalloc(&sh.d_recv, static_cast<size_t>(G) * S * 16u));
+        // What the OTHER devices' kernels store into (sparse exchange): fine-grained device memory — coherent between devices, no
+        // stale line of the previous frame in this device's L2 when the owner folds (plain device memory is only guaranteed
+        // coherent at kernel boundaries for its own device). A device that cannot provide it gets plain memory.
+        if (hipExtMallocWithFlags(&sh.d_recv, static_cast<size_t>(G) * S * 16u, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            sh.d_recv = nullptr;
+            HIP_TRY(hipMalloc(&sh.d_recv, static_cast<size_t>(G) * S * 16u));
+        }
         HIP_TRY(hipMalloc(&sh.d_rgba, static_cast<size_t>(S) * 8u));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sh.h_rgba), static_cast<size_t>(S) * 8u, hipHostMallocDefault));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sh.d_slot), static_cast<size_t>(G) * (S / kExchSeg) * sizeof(int32_t)));
+        if (hipExtMallocWithFlags(reinterpret_cast<void**>(&sh.d_slot), static_cast<size_t>(G) * (S / kExchSeg) * sizeof(int32_t),
+                                  hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            sh.d_slot = nullptr;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sh.d_slot), static_cast<size_t>(G) * (S / kExchSeg) * sizeof(int32_t)));
+        }
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sh.d_bytes), sizeof(unsigned long long)));
         HIP_TRY(hipMemset(sh.d_bytes, 0, sizeof(unsigned long long)));
         sh.slice_cap = S;

@@ -306,3 +306,27 @@ def test_test_hooks_are_not_in_the_product(sar):
         open(src, "w").write('#include "sar_test_hooks.h"\nint main(void) { int (*f)(sar_runtime*, const char*, uint64_t) = sar_runtime_set_test_option; return f ? 0 : 1; }\n')
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", src, "-o", os.path.join(d, "t.o")],
                        check=True)
+
+
+def test_checksum_is_the_oracles_fnv1a64_and_bench_extras_read_the_goldens(sar, oracle):
+    """bench.py's `parity` rests on two things that need no GPU: sar_checksum_fnv1a64 (the product's) equals the oracle's FNV-1a,
+    and tools/bench_extras.py finds the committed checksums of the full-size frames and compares field by field."""
+    sys_path = os.path.join(ROOT, "tools")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import bench_extras as X
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 4096, 100_003):
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        assert X.fnv1a64(sar, a) == f"{oracle.fnv1a64(a):016x}"
+    g = X.golden_case("c4_full_1e10")
+    assert g and g["jobs"] == 1048576 and len(g["count_fnv"]) == 16 and X.golden_case("no such case") is None
+    # a frame that is not the golden's: "differs", and the differing fields are named
+    z = np.zeros((4, 4), np.uint32)
+    p = X.frame_parity(sar, "c4_full_1e10", z, z.astype(np.float32), z.astype(np.float64), np.zeros((4, 4, 4), np.uint16), 0)
+    assert p["result"] == "differs" and "count_fnv" in p["differing_fields"] and p["against"].endswith("[c4_full_1e10]")
+    assert X.frame_parity(sar, "nope", z, z, z, z, 0)["result"] == "no golden"
+    buf = C.create_string_buffer(64)
+    if sar.device_count() == 0:
+        assert sar.load_library().sar_device_pci_bus_id(0, buf, 64) != 0
