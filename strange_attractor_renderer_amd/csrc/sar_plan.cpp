@@ -147,7 +147,9 @@ int sar::plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, ui
     }
     if (pl.binned && scratch_bytes(1) > kCkptBytesCap) pl.binned = false;  // one job alone overflows the arena cap: atomics path
     if (rt->debug_chunk_jobs && rt->debug_chunk_jobs < pl.chunk_jobs) pl.chunk_jobs = rt->debug_chunk_jobs;
-    if (pl.chunk_jobs > pl.block) pl.chunk_jobs -= pl.chunk_jobs % pl.block;
+    // several launch chunks: their boundaries fall on whole workgroups (a job list that fits ONE launch is launched as it is — round
+    // 5: 1447 jobs used to run as 1280 + 167)
+    if (pl.chunk_jobs > pl.block && pl.chunk_jobs < n_jobs) pl.chunk_jobs -= pl.chunk_jobs % pl.block;
     // jobs that need several launches anyway (the 2^32 visit ordinals, the scratch cap): launches of whole rounds of resident
     // workgroups, so that no launch ends on a nearly empty round. (Jobs that fit ONE launch stay one launch: its rounds overlap.)
     if (pl.binned && pl.resident_jobs && n_jobs > pl.chunk_jobs && pl.chunk_jobs > pl.resident_jobs && !rt->debug_chunk_jobs)

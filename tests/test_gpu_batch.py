@@ -215,3 +215,45 @@ def test_sequence_sweep_in_batches_equals_frame_per_launch(sar, oracle, gpu, bat
         seq.run(frames(0.0, 11.0, 1.0))
         sizes = seq.frames_per_launch
     assert sum(sizes) == 11 and (batch == 0 or max(sizes) == batch)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_seeded_random_batches_equal_the_oracle(sar, oracle, gpu, seed):
+    """Ten seeded random batches away from the round numbers: odd image sizes, job counts that leave a wave partly filled, odd
+    iteration counts (the last n % 2 iterations run as a short phase of the wave pairs), 2..12 frames, both presets and render
+    kinds, views turned and scaled per batch, random A/B options — every frame bit for bit the oracle's."""
+    rng = np.random.default_rng(1000 + seed)
+    preset = ["poisson_saturne", "solar_sail"][int(rng.integers(2))]
+    kind = int(rng.integers(2))
+    F = int(rng.integers(2, 13))
+    W, H = int(rng.integers(97, 700)), int(rng.integers(83, 600))
+    jobs = int(rng.integers(65, 3000))
+    n = int(rng.integers(33, 500)) | int(rng.integers(2))          # odd half of the time
+    scale = float(rng.choice([0.6, 1.0, 1.0, 1.7]))
+    options = {}
+    if rng.integers(2):
+        options["batch_warm"] = int(rng.integers(1, 3))
+    if rng.integers(3) == 0:
+        options["hint_bits"] = int(rng.choice([16, 32]))
+    if rng.integers(4) == 0:
+        options["batch_xcd"] = 1
+    if rng.integers(4) == 0:
+        options["batch_starts"] = int(rng.integers(1, 4))
+    cfgs, starts = [], []
+    for k in range(F):
+        cfgs.append(getattr(sar.Config, preset)(iterations=jobs * n, width=W, height=H, jobs_total=jobs, render_kind=kind, scale=scale,
+                                                transparent=int(rng.integers(2)), angle=float(rng.uniform(0, 6.28)), seed=seed))
+        starts.append(sar.start_points(frame_seed(seed, k), 0, jobs))
+    rts = [sar.Runtime(c) for c in cfgs]
+    if rng.integers(2):
+        for rt in rts[1:]:
+            rt.share_streams(rts[0])
+    for k, v in options.items():
+        rts[0].set_option(k, v)
+    sar.render_jobs_batch(cfgs, rts, starts)
+    assert f"batch of {F} frames" in rts[0].describe_last_launch(), (rts[0].describe_last_launch(), W, H, jobs, n)
+    for i in range(F):
+        _, want = _oracle_state(oracle, cfgs[i], starts[i], n)
+        _assert_same(_state(sar, cfgs[i], rts[i]), want, f"seed {seed}: frame {i} of {F} ({preset}, {W}x{H}, {jobs} jobs x {n}, {options})")
+    for rt in reversed(rts):
+        rt.close()
