@@ -148,6 +148,8 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
         }
         f.warm = warm_args(ia.p, ia.starts, n_jobs, iters, rt->d_warm, rt->d_joblist, rt->d_active, ia.width, measure);
         if (two_phase) {
+            // (an announced warm-up nobody consumed may still write that second set on the runtime's side stream: behind it)
+            if (rt->pf_done) HIP_TRY(hipStreamWaitEvent(lead->stream, rt->pf_done, 0));
             if (n_jobs > rt->warm_alt_cap) {  // the second set of warm-up buffers (an announced call's otherwise): the first phase's output
                 if (rt->side) HIP_TRY(hipStreamSynchronize(rt->side));
                 HIP_TRY(hipStreamSynchronize(lead->stream));

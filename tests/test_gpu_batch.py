@@ -257,3 +257,32 @@ def test_seeded_random_batches_equal_the_oracle(sar, oracle, gpu, seed):
         _assert_same(_state(sar, cfgs[i], rts[i]), want, f"seed {seed}: frame {i} of {F} ({preset}, {W}x{H}, {jobs} jobs x {n}, {options})")
     for rt in reversed(rts):
         rt.close()
+
+
+def test_batch_after_an_announced_frame_nobody_rendered(sar, oracle, gpu):
+    """An announced warm-up (sar_runtime_prefetch_device) writes the runtime's second set of warm-up buffers on its side stream; a
+    two-phase batch uses that set for its first phase. The announcement is simply dropped, the batch is right, and the runtime
+    still renders announced frames afterwards."""
+    import torch
+    F, W, H, jobs, n = 4, 400, 300, 3000, 201
+    cfgs, starts = _frames(sar, "solar_sail", 0, F, W, H, jobs, n, seed=31)
+    rts = [sar.Runtime(c) for c in cfgs]
+    for rt in rts[1:]:
+        rt.share_streams(rts[0])
+    rts[0].set_option("batch_warm", 2)
+    dev = [torch.from_numpy(np.ascontiguousarray(s)).cuda() for s in starts]
+    torch.cuda.synchronize()
+    for rt, c, d in zip(rts, cfgs, dev):
+        sar.prefetch_device(c, rt, jobs, n, d.data_ptr())           # announced ... and never rendered
+    sar.render_jobs_batch(cfgs, rts, starts)
+    assert "batch of 4 frames" in rts[0].describe_last_launch()
+    for i in range(F):
+        _assert_same(_state(sar, cfgs[i], rts[i]), _oracle_state(oracle, cfgs[i], starts[i], n)[1], f"frame {i} after a dropped announcement")
+    rt = rts[2]
+    rt.reset()
+    sar.prefetch_device(cfgs[2], rt, jobs, n, dev[2].data_ptr())
+    sar.render_job_range_device(cfgs[2], rt, jobs, n, dev[2].data_ptr())
+    assert "warmup_ahead=1" in rt.describe_last_launch()
+    _assert_same(_state(sar, cfgs[2], rt), _oracle_state(oracle, cfgs[2], starts[2], n)[1], "an announced frame after the batch")
+    for rt in reversed(rts):
+        rt.close()
