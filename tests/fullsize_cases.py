@@ -4,7 +4,8 @@ import math
 
 import numpy as np
 
-CASES = ("c2_131072", "c2_65536", "c3_solar_depth", "c4_rank5_share", "c4_all_jobs", "c4_full_1e10", "c5_frame37")
+CASES = ("c2_131072", "c2_65536", "c3_solar_depth", "c4_rank5_share", "c4_all_jobs", "c4_full_1e10", "c5_frame37",
+         "c5_frame37_65536")
 
 
 def frame_seed(seed: int, k: int) -> int:   # strange_attractor_renderer_amd.sequence.frame_seed, restated
@@ -41,14 +42,17 @@ def build_case(name: str, O):
         cfg = O.poisson_saturne()
         cfg.width = cfg.height = 4096
         return _fin(cfg, jobs, n), O.start_points(3, 0, jobs), n
-    if name == "c5_frame37":                       # configs[4]: frame 37 of the 360-frame solar-sail sweep, 1e8 iterations
+    if name in ("c5_frame37", "c5_frame37_65536"):  # configs[4]: frame 37 of the 360-frame solar-sail sweep, 1e8 iterations
         units, jpt, k = 16384, 12, 37              # (CLI defaults: 12 jobs per thread, scale 1, Gas)
+        seed = 0
+        if name == "c5_frame37_65536":             # ... as `bench.py --config c5` cuts it: 65 536 jobs per frame, seed 4 — the
+            jpt, seed = 4, 4                       # frame its line checks itself against
         jobs = units * jpt
         n = 100_000_000 // units // jpt
         cfg = O.solar_sail()
         cfg.width, cfg.height, cfg.scale, cfg.transparent = 1800, 2000, 1.0, 0
         cfg.angle = k * math.pi / 180.0
-        return _fin(cfg, jobs, n), O.start_points(frame_seed(0, k), 0, jobs), n
+        return _fin(cfg, jobs, n), O.start_points(frame_seed(seed, k), 0, jobs), n
     raise KeyError(name)
 
 

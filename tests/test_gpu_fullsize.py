@@ -60,12 +60,14 @@ def _meets_oracle(sar, oracle, name, **options):
     assert got == {k: g[k] for k in got}, f"{name}: checksums differ from tests/golden/fullsize_checksums.json"
 
 
-@pytest.mark.parametrize("name", ["c2_131072", "c2_65536", "c3_solar_depth", "c4_rank5_share", "c4_all_jobs", "c4_full_1e10", "c5_frame37"])
+@pytest.mark.parametrize("name", ["c2_131072", "c2_65536", "c3_solar_depth", "c4_rank5_share", "c4_all_jobs", "c4_full_1e10", "c5_frame37",
+                                  "c5_frame37_65536"])
 def test_fullsize_frame_equals_oracle_bit_for_bit(sar, oracle, gpu, name):
     """BASELINE configs[1] (both the bench's 131 072 jobs and SURVEY's 65 536), configs[2], one rank's share of
     configs[3], configs[3]'s whole list of 1 048 576 jobs on one GPU (a launch of eight rounds of workgroups, the 65536-pixel
     bins counted with packed 16-bit counters; once with a tenth of the iterations, once — c4_full_1e10 — with all 1e10 of them:
-    three launch chunks, ~40 s of the threaded oracle on the GPU box's host cores) and one frame of configs[4], all at full size."""
+    three launch chunks, ~40 s of the threaded oracle on the GPU box's host cores) and one frame of configs[4] (with the CLI's 12 jobs
+    per thread, and as `bench.py --config c5` cuts it), all at full size."""
     _meets_oracle(sar, oracle, name)
 
 

@@ -361,13 +361,29 @@ def run_c5(a, S, torch, dist, world: int, rank: int, local_rank: int, jobs_given
         launch = launch or launch_hbm
     if rank != 0:
         return None
+    parity = None
+    if a.parity:
+        # (untimed) the line proves itself: frames 32..39 of the sweep as ONE batched launch, frame 37's buffers and RGBA16 against
+        # the oracle's frozen checksums of that frame (tests/golden/fullsize_checksums.json[c5_frame37_65536], held by
+        # tests/test_gpu_fullsize.py); a --jobs other than 65 536 has no golden
+        import numpy as np
+        ring = [torch.empty(1800 * 2000 * 4, dtype=torch.int16, device="cuda") for _ in range(16)]
+        proof = dict(common, lanes=1, batch=8, max_batch=8)
+        with SequenceRenderer(scfg, device_ring=[t.data_ptr() for t in ring], ring=16, **proof) as seq:
+            seq.run([f for f in sequence_frames(0.0, 40.0, 1.0) if f[0] >= 32])
+            torch.cuda.synchronize()
+            rt37 = seq.groups[0][5]
+            img = ring[5].cpu().numpy().view(np.uint16)
+            parity = frame_parity(S, "c5_frame37_65536" if frame_jobs == 65536 else f"c5_frame37_{frame_jobs}", rt37.count(), rt37.zbuf(),
+                                  rt37.steps(), img, rt37.max())
+            parity["frames_in_the_launch"] = list(seq.frames_per_launch)
     frames = a.steps * world
     counted = per_job * units * jpt * frames
     return {
         "metric": "attractor iterations/sec over the solar-sail sequence sweep (1e8 iterations per frame, 1800x2000), one frame per GPU",
         "value": counted / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "ms_per_frame_per_gpu": elapsed / a.steps * 1e3, "frames_per_second": frames / elapsed,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "parity": parity,
         "rgba16_in_hbm": {"value": counted / el_hbm, "unit": "iterations/s", "ms_per_frame_per_gpu": el_hbm / a.steps * 1e3,
                           "frames_per_second": frames / el_hbm,
                           "note": "the same sweep with every frame left as RGBA16 in device memory (colorize, no conversion, "
