@@ -11,6 +11,9 @@ import sys
 import numpy as np
 import pytest
 
+# SAR_FUZZ_BASE=<k>: the seeded random test of this file draws OTHER cases (tools/soak.sh)
+_FUZZ_BASE = 1_000_003 * int(os.environ.get("SAR_FUZZ_BASE", "0"))
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -372,6 +375,36 @@ def _nccl_single_rank(port, W, H, jobs, n, seed, q):
         rt.close()
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_seeded_random_shard_counts_and_shapes_through_both_exchange_forms(sar, oracle, gpu, seed):
+    """2..8 shards of one device, image sizes whose slices end inside a granule and inside a row, job counts that do not divide
+    by the shards, both presets and render kinds, view turned and scaled: the frame through the sparse and through the dense
+    exchange, bit for bit the sequential oracle's (contiguous shards folded in device order, src/lib.rs:1068-1076)."""
+    rng = np.random.default_rng(4000 + seed + _FUZZ_BASE)
+    G = int(rng.integers(2, 9))
+    preset = ["poisson_saturne", "solar_sail"][int(rng.integers(2))]
+    kind = int(rng.integers(2))
+    w, h = int(rng.integers(33, 900)), int(rng.integers(17, 700))
+    units, jpu, n = int(rng.integers(G, 700)), int(rng.integers(1, 5)), int(rng.integers(40, 700))
+    cfg = getattr(sar.Config, preset)(iterations=units * jpu * n + int(rng.integers(units)), width=w, height=h, render_kind=kind,
+                                      transparent=int(rng.integers(2)), angle=float(rng.uniform(0, 6.28)),
+                                      scale=float(rng.choice([0.5, 1.0, 1.0, 2.2])))
+    jobs = units * jpu
+    ort = oracle.Runtime(w, h)
+    oracle.render_jobs(cfg.replace(jobs_total=jobs).c, ort, sar.start_points(seed + 3, 0, jobs), cfg.iterations // units // jpu)
+    want = oracle.colorize(cfg.c, ort)
+    for mode in (2, 1):
+        pr = sar.ParallelRenderer(devices=[0] * G, units=units, seed=seed + 3)
+        pr.set_exchange(mode)
+        img = sar.render_parallel(pr, cfg, jpu)
+        rm = pr.runtime()
+        what = f"seed {seed}: {G} shards, {preset} kind {kind}, {w}x{h}, {units} x {jpu} jobs x {n}, exchange mode {mode}"
+        assert np.array_equal(rm.count(), ort.count) and rm.max() == ort.max, what
+        assert np.array_equal(_bits(rm.zbuf()), _bits(ort.zbuf)) and np.array_equal(_bits(rm.steps()), _bits(ort.steps)), what
+        assert np.array_equal(img, want), what
+        pr.shutdown()
 
 
 @pytest.mark.parametrize("devices,units,jpu", [([0], 1516, 5), ([0, 0, 0], 1516, 5), ([0, 0], 4000, 3)])
