@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
     const uint64_t n = (uint64_t)atoll(argv[5]), seed = (uint64_t)atoll(argv[6]);
     const uint32_t shards = (uint32_t)atoi(argv[7]);
     if (sar_abi_version() != SAR_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 1; }
+    if (strlen(sar_build_id()) != 16) { fprintf(stderr, "no build id\n"); return 1; }
     const size_t npix = (size_t)W * H;
 
     /* Config { iterations, width, height, ..Config::poisson_saturne() } (src/lib.rs:9-15) */
@@ -65,6 +66,37 @@ int main(int argc, char** argv) {
     for (size_t k = 0; k < npix; ++k) if (count[k]) { fprintf(stderr, "reset left a count\n"); return 1; }
     CHECK(sar_runtime_free(rt));
 
+    /* a `sequence` sweep's frames (main.rs:493-517 renders them one after the other) through ONE set of launches:
+     * sar_render_jobs_batch — three frames, each with its own Runtime, view angle and start-point stream */
+    enum { FRAMES = 3 };
+    sar_config fc[FRAMES];
+    const sar_config* fcp[FRAMES];
+    sar_runtime* fr[FRAMES];
+    for (int i = 0; i < FRAMES; ++i) {
+        fc[i] = cfg;
+        fc[i].angle = 0.3 * i;
+        fc[i].seed = seed + 1u + (uint64_t)i;
+        fcp[i] = &fc[i];
+        CHECK(sar_runtime_new(&fc[i], 0, &fr[i]));
+    }
+    uint32_t advice = 0;
+    CHECK(sar_runtime_batch_frames(&fc[0], fr[0], &advice));
+    if (advice < 1u) { fprintf(stderr, "sar_runtime_batch_frames said %u\n", advice); return 1; }
+    CHECK(sar_render_jobs_batch(FRAMES, fcp, (sar_runtime* const*)fr, NULL));
+    uint64_t sums[FRAMES];
+    for (int i = 0; i < FRAMES; ++i) {
+        char name[64];
+        CHECK(sar_runtime_count(fr[i], count));
+        CHECK(sar_checksum_fnv1a64(count, npix * 4, &sums[i]));
+        CHECK(sar_colorize(&fc[i], fr[i], rgba));
+        snprintf(name, sizeof name, "count_batch_%d.bin", i);
+        if (dump(dir, name, count, npix * 4)) return 1;
+        snprintf(name, sizeof name, "rgba_batch_%d.bin", i);
+        if (dump(dir, name, rgba, npix * 8)) return 1;
+        CHECK(sar_runtime_free(fr[i]));
+    }
+    if (dump(dir, "count_batch_fnv.bin", sums, sizeof sums)) return 1;
+
     /* default shape (main.rs:493-517): ParallelRenderer::new, render_parallel, shutdown — over `shards` shards */
     int devices[16];
     for (uint32_t k = 0; k < shards && k < 16; ++k) devices[k] = 0;
@@ -77,6 +109,14 @@ int main(int argc, char** argv) {
     CHECK(sar_renderer_runtime(r, &borrowed));
     CHECK(sar_runtime_count(borrowed, count));
     if (dump(dir, "count_parallel.bin", count, npix * 4)) return 1;
+    if (shards > 1) {   /* the next frame of the renderer through the dense exchange (the first went through the default: sparse records) */
+        uint16_t* again = malloc(npix * 8);
+        if (!again) return 1;
+        CHECK(sar_renderer_set_exchange(r, 1u));
+        CHECK(sar_render_parallel(r, &cfg, 1, again));
+        if (dump(dir, "rgba_parallel_dense.bin", again, npix * 8)) return 1;
+        free(again);
+    }
     CHECK(sar_renderer_shutdown(r));
     free(count); free(rgba); free(steps); free(zbuf);
     puts("ok");

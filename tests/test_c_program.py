@@ -51,3 +51,17 @@ def test_c_driver_results_equal_the_oracle(sar, oracle, gpu, tmp_path, shards):
     # on one device or sharded over three — contiguous shards folded in order == the sequential result
     assert np.array_equal(rd("count_parallel.bin", np.uint32).reshape(H, W), ort.count)
     assert np.array_equal(rd("rgba_parallel.bin", np.uint16).reshape(H, W, 4), want)
+    # sar_render_jobs_batch from C: three frames (own runtime, angle 0.3 i, stream seeded seed + 1 + i) in one set of launches
+    sums = rd("count_batch_fnv.bin", np.uint64)
+    for i in range(3):
+        c = oracle.copy_config(cfg)
+        c.angle = 0.3 * i
+        o = oracle.Runtime(W, H)
+        oracle.render_jobs(c, o, oracle.start_points(seed + 1 + i, 0, jobs), n)
+        assert np.array_equal(rd(f"count_batch_{i}.bin", np.uint32).reshape(H, W), o.count), f"batched frame {i}"
+        assert np.array_equal(rd(f"rgba_batch_{i}.bin", np.uint16).reshape(H, W, 4), oracle.colorize(c, o)), f"batched frame {i}"
+        assert int(sums[i]) == oracle.fnv1a64(o.count)                      # sar_checksum_fnv1a64
+    if shards > 1:   # the second frame of the renderer went through the dense exchange: the stream ran on, other jobs
+        o2 = oracle.Runtime(W, H)
+        oracle.render_jobs(cfg, o2, oracle.start_points(seed, jobs, jobs), n)
+        assert np.array_equal(rd("rgba_parallel_dense.bin", np.uint16).reshape(H, W, 4), oracle.colorize(cfg, o2))
