@@ -214,6 +214,41 @@ pub fn render_jobs<T: Mi355xTransform>(config: &Config<PolynomialSprott2Degree, 
     check(unsafe { sys::sar_render_jobs(&abi, runtime.raw, std::ptr::null()) });
 }
 
+/// The frames of a `sequence` sweep (src/bin/main.rs:493-517 renders them one after the other, each a reset and a
+/// render of fresh jobs) through ONE set of launches: frame i is `render_jobs(&configs[i], &mut runtimes[i], jobs)`, bit for
+/// bit — a frame of 65 536 jobs fills a third of an MI355X, eight or sixteen of them fill it. The frames must share the
+/// image size, the job split and the scale; anything else runs frame after frame inside the call.
+pub fn render_jobs_batch<T: Mi355xTransform>(configs: &[Config<PolynomialSprott2Degree, T>], runtimes: &mut [GpuRuntime], jobs: u32) {
+    assert!(configs.len() == runtimes.len(), "one runtime per frame");
+    let abis: Vec<sys::SarConfig> = configs
+        .iter()
+        .zip(runtimes.iter())
+        .map(|(c, rt)| {
+            let mut abi = to_abi(c, &rt.opts);
+            abi.jobs_total = jobs;
+            abi
+        })
+        .collect();
+    let cfg_ptrs: Vec<*const sys::SarConfig> = abis.iter().map(|a| a as *const _).collect();
+    let rt_ptrs: Vec<*mut sys::SarRuntime> = runtimes.iter().map(|rt| rt.raw).collect();
+    // start points NULL: every frame draws from its own runtime's stream, as `render` does (:748)
+    check(unsafe { sys::sar_render_jobs_batch(abis.len() as u32, cfg_ptrs.as_ptr(), rt_ptrs.as_ptr(), std::ptr::null()) });
+}
+
+/// How many frames of this shape the library would put into one `render_jobs_batch` (a multiple of eight: the chip has eight XCDs).
+pub fn batch_frames<T: Mi355xTransform>(config: &Config<PolynomialSprott2Degree, T>, runtime: &mut GpuRuntime, jobs: u32) -> usize {
+    let mut abi = to_abi(config, &runtime.opts);
+    abi.jobs_total = jobs;
+    let mut n = 0u32;
+    check(unsafe { sys::sar_runtime_batch_frames(&abi, runtime.raw, &mut n) });
+    n as usize
+}
+
+/// The id of the sources `libsar_hip.so` was built from (16 hex digits): what a deployment logs next to its results.
+pub fn build_id() -> String {
+    unsafe { std::ffi::CStr::from_ptr(sys::sar_build_id()) }.to_string_lossy().into_owned()
+}
+
 /// `colorize(&config, &runtime) -> FinalImage` (:841-904).
 pub fn colorize<T: Mi355xTransform>(config: &Config<PolynomialSprott2Degree, T>, runtime: &GpuRuntime) -> FinalImage {
     let abi = to_abi(config, &runtime.opts);
@@ -308,6 +343,11 @@ impl GpuRenderer {
         let mut raw = std::ptr::null_mut();
         check(unsafe { sys::sar_renderer_new_multi(devices.as_ptr(), devices.len() as u32, units, opts.seed, &mut raw) });
         Self { raw, opts }
+    }
+    /// How the devices exchange their partial buffers before the fold (:1068-1076): 0 automatic, 1 whole image slices by peer
+    /// copies, 2 only the records of the 64-pixel granules a device has touched (a quarter of the bytes for the presets).
+    pub fn set_exchange(&mut self, mode: u32) {
+        check(unsafe { sys::sar_renderer_set_exchange(self.raw, mode) });
     }
     /// `num_threads()` (:1016-1018): the divisor of the job split.
     pub fn num_threads(&self) -> usize {
