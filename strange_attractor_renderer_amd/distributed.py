@@ -62,6 +62,17 @@ def _all_reduce(dist, t, op, rt):
         t.copy_(h)
 
 
+def _require_shared_stream(dist, rt):
+    """The device-native collectives order themselves against torch's CURRENT stream, the pack / merge kernels run on the
+    runtime's: unless the two are one stream the collective reads a buffer the pack kernel has not written yet. Loud, not racy."""
+    if not _device_native(dist):
+        return
+    import torch
+    if int(rt.stream() or 0) != int(torch.cuda.current_stream().cuda_stream or 0):
+        raise RuntimeError("exchange over a device-native backend: the runtime enqueues on another stream than torch's current one; "
+                           "call rt.set_stream(torch.cuda.current_stream().cuda_stream) (inside `with torch.cuda.stream(s):`) first")
+
+
 def _reduce(dist, t, dst, op, rt):
     if _device_native(dist):
         dist.reduce(t, dst=dst, op=op)
@@ -148,6 +159,7 @@ def exchange_merge(rt, rank: int, dist, key_buf, sum_buf, dst: int = 0):
     sum_buf: int32[3*npix] torch tensors on the runtime's device. The pack/unpack kernels run on the RUNTIME's stream
     (a non-blocking stream of its own unless set), the collectives on torch's current stream: give the runtime that
     stream first — ``rt.set_stream(torch.cuda.current_stream().cuda_stream)`` — as bench.py does."""
+    _require_shared_stream(dist, rt)
     rt.exchange_export(rank, key_buf.data_ptr())
     _all_reduce(dist, key_buf, dist.ReduceOp.MAX, rt)
     rt.exchange_select(rank, key_buf.data_ptr(), sum_buf.data_ptr())
@@ -218,6 +230,7 @@ class SlicedExchange:
         """Steps 1-3: after this the runtime holds the merged frame inside its own slice and global scalars."""
         import torch
         rt = self.rt
+        _require_shared_stream(dist, rt)
         sparse = self.sparse
         if sparse:
             rt.exchange_touched(self.flags.data_ptr())
