@@ -356,6 +356,14 @@ def _nccl_single_rank(port, W, H, jobs, n, seed, q):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     cfg = S.Config.poisson_saturne(iterations=jobs * n, width=W, height=H, jobs_total=jobs, seed=seed, transparent=0)
+    # a runtime left on its own stream: the collective would not wait for its pack kernel — refused, not raced
+    stray = S.Runtime(cfg, device=0)
+    try:
+        D.SlicedExchange(S, cfg, stray, 0, 1, "cuda").merge(dist)
+        loud = False
+    except RuntimeError as e:
+        loud = "another stream" in str(e)
+    stray.close()
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         rt = S.Runtime(cfg, device=0)
@@ -371,7 +379,7 @@ def _nccl_single_rank(port, W, H, jobs, n, seed, q):
         before = rt.count().copy()
         D.exchange_merge(rt, 0, dist, key, sums, dst=0)        # rooted form over RCCL
         torch.cuda.synchronize()
-        q.put((np.array_equal(got, want), np.array_equal(rt.count(), before), np.array_equal(S.colorize(cfg, rt), want)))
+        q.put((np.array_equal(got, want), np.array_equal(rt.count(), before), np.array_equal(S.colorize(cfg, rt), want), loud))
         rt.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -429,7 +437,7 @@ def test_frames_announced_by_render_parallel_without_anybody_waiting(sar, oracle
 def test_exchange_runs_over_rccl_itself_with_one_rank(sar, gpu):
     """A 1-GPU box cannot hold two RCCL ranks, but it can hold one: the device-native branch of distributed.py
     (all_to_all_single on uint8 blocks, all_reduce MAX on int64, gather, reduce) runs through the real "nccl" backend with
-    world size 1 and must leave the frame unchanged."""
+    world size 1 and must leave the frame unchanged. A runtime that enqueues on another stream than torch's current one is refused."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -437,7 +445,7 @@ def test_exchange_runs_over_rccl_itself_with_one_rank(sar, gpu):
     p.start()
     ok = q.get(timeout=240)
     p.join(timeout=60)
-    assert p.exitcode == 0 and ok == (True, True, True), ok
+    assert p.exitcode == 0 and ok == (True, True, True, True), ok
 
 
 def test_host_is_off_the_critical_path_of_a_multi_device_frame(sar, oracle, gpu):
