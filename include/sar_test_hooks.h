@@ -33,6 +33,8 @@ extern "C" {
  *   "acc_threads"        threads per block of the record-accumulate kernel (256, 512, 1024)
  *   "acc_lists"          (bin, wave) record lists a lane group of that kernel walks at the same time: 1 or 4
  *   "debug_chunk_jobs"   test hook: cap on jobs per launch chunk
+ *   "debug_throw"        test hook (rt may be NULL): 1 / 2 / 3 throw std::bad_alloc / std::runtime_error / an int inside the entry point —
+ *                        the call returns SAR_ERR_OOM / SAR_ERR_INVALID with the text in sar_last_error(): nothing unwinds across the ABI
  *   "debug_max_ordinals" test hook: visits one launch may order (default 2^32-2); jobs with more iterations run as segments
  *
  *   "readback_inline"    1: the read-back of sar_colorize_format_async stays on the launch stream (A/B of the copy stream)

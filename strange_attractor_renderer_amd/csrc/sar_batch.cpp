@@ -273,7 +273,7 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
 
 extern "C" {
 
-int sar_render_jobs_batch(uint32_t n_frames, const sar_config* const* cfgs, sar_runtime* const* rts, const double* const* starts_xyz_host) {
+int sar_render_jobs_batch(uint32_t n_frames, const sar_config* const* cfgs, sar_runtime* const* rts, const double* const* starts_xyz_host) try {
     if (n_frames == 0) return SAR_OK;
     if (!cfgs || !rts) { set_error("sar_render_jobs_batch: NULL argument"); return SAR_ERR_INVALID; }
     for (uint32_t i = 0; i < n_frames; ++i) {
@@ -289,9 +289,9 @@ int sar_render_jobs_batch(uint32_t n_frames, const sar_config* const* cfgs, sar_
         if (!batched) SAR_TRY(sequential(F, cfgs + first, rts + first, st));
     }
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_batch_frames(const sar_config* cfg, sar_runtime* rt, uint32_t* out_frames) {
+int sar_runtime_batch_frames(const sar_config* cfg, sar_runtime* rt, uint32_t* out_frames) try {
     if (!out_frames) return SAR_ERR_INVALID;
     *out_frames = 1;
     SAR_TRY(check_cfg_matches(cfg, rt));
@@ -318,6 +318,6 @@ int sar_runtime_batch_frames(const sar_config* cfg, sar_runtime* rt, uint32_t* o
     }
     *out_frames = best;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 }  // extern "C"

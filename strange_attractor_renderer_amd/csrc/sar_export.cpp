@@ -101,11 +101,11 @@ uint64_t png_filter_row(int type, const unsigned char* cur, const unsigned char*
 
 extern "C" {
 
-int sar_image_format(int transparent, int eight_bit) {
+int sar_image_format(int transparent, int eight_bit) try {
     // src/bin/main.rs:52-57
     if (transparent) return eight_bit ? SAR_FMT_RGBA8 : SAR_FMT_RGBA16;
     return eight_bit ? SAR_FMT_RGB8 : SAR_FMT_RGB16;
-}
+} catch (...) { return sar::abi_caught(); }
 
 size_t sar_image_bytes(int format, uint32_t width, uint32_t height) {
     Layout l;
@@ -113,7 +113,7 @@ size_t sar_image_bytes(int format, uint32_t width, uint32_t height) {
     return static_cast<size_t>(width) * height * l.channels * l.bytes_per_sample;
 }
 
-int sar_write_png(const char* path, int format, uint32_t width, uint32_t height, const void* pixels) {
+int sar_write_png(const char* path, int format, uint32_t width, uint32_t height, const void* pixels) try {
     Layout l;
     if (!path || !pixels || !layout_of(format, l) || width == 0 || height == 0) {
         set_error("sar_write_png: bad argument");
@@ -236,9 +236,9 @@ int sar_write_png(const char* path, int format, uint32_t width, uint32_t height,
     }
     ok = ok && png_chunk(fout, "IEND", nullptr, 0);
     return ok ? SAR_OK : io_error(path);
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_write_bmp(const char* path, int format, uint32_t width, uint32_t height, const void* pixels) {
+int sar_write_bmp(const char* path, int format, uint32_t width, uint32_t height, const void* pixels) try {
     if (!path || !pixels || width == 0 || height == 0 || (format != SAR_FMT_RGB8 && format != SAR_FMT_RGBA8)) {
         set_error("sar_write_bmp: 8-bit RGB or RGBA only (the CLI requires --8bit with --bmp, main.rs:256-258)");
         return SAR_ERR_INVALID;
@@ -290,9 +290,9 @@ int sar_write_bmp(const char* path, int format, uint32_t width, uint32_t height,
         if (!out.put(line.data(), row)) return io_error(path);
     }
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_write_pam(const char* path, int format, uint32_t width, uint32_t height, const void* pixels) {
+int sar_write_pam(const char* path, int format, uint32_t width, uint32_t height, const void* pixels) try {
     if (!path || !pixels || width == 0 || height == 0 || (format != SAR_FMT_RGB8 && format != SAR_FMT_RGBA8)) {
         set_error("sar_write_pam: 8-bit RGB or RGBA only (the CLI requires --8bit with --pam, main.rs:256-258)");
         return SAR_ERR_INVALID;
@@ -306,6 +306,6 @@ int sar_write_pam(const char* path, int format, uint32_t width, uint32_t height,
     if (!out.f) return io_error(path);
     if (!out.put(head, static_cast<size_t>(n)) || !out.put(pixels, sar_image_bytes(format, width, height))) return io_error(path);
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 }  // extern "C"

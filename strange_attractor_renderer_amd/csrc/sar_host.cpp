@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <new>
 
 namespace sar {
 
@@ -18,6 +20,21 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
     va_end(ap);
+}
+
+int abi_caught() noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory");
+        return SAR_ERR_OOM;
+    } catch (const std::exception& e) {
+        set_error("internal error: %s", e.what());
+        return SAR_ERR_INVALID;
+    } catch (...) {
+        set_error("internal error (unknown exception)");
+        return SAR_ERR_INVALID;
+    }
 }
 
 // Config::new defaults, src/lib.rs:289-307; Colors::default :480-492; BrighnessConstants::default :397-404
@@ -176,7 +193,7 @@ const char* sar_build_id(void) {
     return marked + sizeof("SAR_BUILD_ID=") - 1;
 }
 
-int sar_checksum_fnv1a64(const void* data_host, size_t nbytes, uint64_t* out) {
+int sar_checksum_fnv1a64(const void* data_host, size_t nbytes, uint64_t* out) try {
     if ((!data_host && nbytes) || !out) return SAR_ERR_INVALID;
     const unsigned char* p = static_cast<const unsigned char*>(data_host);
     uint64_t h = 0xcbf29ce484222325ULL;
@@ -186,7 +203,7 @@ int sar_checksum_fnv1a64(const void* data_host, size_t nbytes, uint64_t* out) {
     }
     *out = h;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 const char* sar_status_string(int status) {
     switch (status) {
@@ -204,7 +221,7 @@ const char* sar_status_string(int status) {
 
 const char* sar_last_error(void) { return sar::g_last_error; }
 
-int sar_config_poisson_saturne(sar_config* out) {
+int sar_config_poisson_saturne(sar_config* out) try {
     if (!out) return SAR_ERR_INVALID;
     sar::config_defaults(out);
     // values: src/lib.rs:311-350
@@ -223,9 +240,9 @@ int sar_config_poisson_saturne(sar_config* out) {
     out->scale = 1.;
     out->color_transform = SAR_CT_POISSON_SATURNE;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_config_solar_sail(sar_config* out) {
+int sar_config_solar_sail(sar_config* out) try {
     if (!out) return SAR_ERR_INVALID;
     sar::config_defaults(out);
     // values: src/lib.rs:356-385
@@ -247,17 +264,17 @@ int sar_config_solar_sail(sar_config* out) {
     out->ct_factor = -0.2;
     out->ct_offset = 0.8;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 int sar_config_validate(const sar_config* cfg) { return sar::validate(cfg); }
 
-int sar_rotation_matrix(const sar_config* cfg, double m_out[9]) {
+int sar_rotation_matrix(const sar_config* cfg, double m_out[9]) try {
     if (!cfg || !m_out) return SAR_ERR_INVALID;
     sar::rotation_matrix(*cfg, m_out);
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double* xyz_out_host) {
+int sar_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double* xyz_out_host) try {
     if (!xyz_out_host && n_jobs) return SAR_ERR_INVALID;
     // reaching job k takes k / 4096 jumps of ~1 us each: 2^36 jobs (seconds) is far beyond any frame list and still bounded
     if (first_job > (1ull << 36)) { sar::set_error("sar_start_points: first_job beyond 2^36"); return SAR_ERR_RANGE; }
@@ -266,6 +283,6 @@ int sar_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double*
     rng.skip_points(first_job);
     for (uint32_t k = 0; k < n_jobs; ++k) rng.start_point(xyz_out_host + 3 * static_cast<size_t>(k));
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 }  // extern "C"

@@ -11,6 +11,10 @@ namespace sar {
 
 extern thread_local char g_last_error[512];
 void set_error(const char* fmt, ...);
+// What an exception becomes at the C ABI (every entry returns a status, nothing unwinds across the boundary): every
+// int-returning entry point is a function-try-block whose handler returns this — std::bad_alloc -> SAR_ERR_OOM, anything else ->
+// SAR_ERR_INVALID with what() in sar_last_error().
+int abi_caught() noexcept;
 
 // Start-point stream (include/sar.h: sar_start_points): xoshiro256++ seeded through SplitMix64, in BLOCKS of
 // kStartBlockJobs jobs — block b draws from the generator after b applications of xoshiro256's published jump()

@@ -217,7 +217,11 @@ void render_shard(sar_renderer* r, Shard* sh, const sar_config* cfg, uint64_t pe
         }
         return SAR_OK;
     };
-    sh->status = run();
+    try {
+        sh->status = run();
+    } catch (...) {  // (a worker thread: an exception that left it would end the process)
+        sh->status = abi_caught();
+    }
     if (sh->status != SAR_OK) std::snprintf(sh->error, sizeof(sh->error), "%s", sar_last_error());
 }
 
@@ -252,7 +256,7 @@ double now_ms() {
 
 extern "C" {
 
-int sar_renderer_new_multi(const int* devices, uint32_t n_devices, uint32_t units, uint64_t seed, sar_renderer** out) {
+int sar_renderer_new_multi(const int* devices, uint32_t n_devices, uint32_t units, uint64_t seed, sar_renderer** out) try {
     if (!out) return SAR_ERR_INVALID;
     *out = nullptr;
     if (!devices || n_devices == 0 || n_devices > 64) { set_error("sar_renderer_new_multi: 1..64 devices"); return SAR_ERR_INVALID; }
@@ -301,25 +305,25 @@ int sar_renderer_new_multi(const int* devices, uint32_t n_devices, uint32_t unit
         }
     *out = r;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_renderer_new(int device, uint32_t units, uint64_t seed, sar_renderer** out) {
+int sar_renderer_new(int device, uint32_t units, uint64_t seed, sar_renderer** out) try {
     return sar_renderer_new_multi(&device, 1, units, seed, out);
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_renderer_num_units(const sar_renderer* r, uint32_t* out_units) {
+int sar_renderer_num_units(const sar_renderer* r, uint32_t* out_units) try {
     if (!r || !out_units) return SAR_ERR_INVALID;
     *out_units = r->units;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_renderer_num_devices(const sar_renderer* r, uint32_t* out_devices) {
+int sar_renderer_num_devices(const sar_renderer* r, uint32_t* out_devices) try {
     if (!r || !out_devices) return SAR_ERR_INVALID;
     *out_devices = static_cast<uint32_t>(r->shards.size());
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_renderer_shutdown(sar_renderer* r) {
+int sar_renderer_shutdown(sar_renderer* r) try {
     if (!r) return SAR_OK;
     for (Shard& sh : r->shards) {
         hipSetDevice(sh.device);
@@ -346,30 +350,30 @@ int sar_renderer_shutdown(sar_renderer* r) {
     if (r->h_board) hipHostFree(r->h_board);
     delete r;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_renderer_runtime(sar_renderer* r, sar_runtime** out_borrowed) {
+int sar_renderer_runtime(sar_renderer* r, sar_runtime** out_borrowed) try {
     if (!r || !out_borrowed) return SAR_ERR_INVALID;
     *out_borrowed = nullptr;
     if (r->shards.empty() || !r->shards[0].rt) { set_error("the renderer has not rendered yet"); return SAR_ERR_INVALID; }
     SAR_TRY(gather_into_first(r));
     *out_borrowed = r->shards[0].rt;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_renderer_set_exchange(sar_renderer* r, uint32_t mode) {
+int sar_renderer_set_exchange(sar_renderer* r, uint32_t mode) try {
     if (!r || mode > 2) { set_error("sar_renderer_set_exchange: mode must be 0 (automatic), 1 (dense) or 2 (sparse)"); return SAR_ERR_INVALID; }
     r->exchange_mode = mode;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_renderer_last_timing(const sar_renderer* r, sar_parallel_timing* out) {
+int sar_renderer_last_timing(const sar_renderer* r, sar_parallel_timing* out) try {
     if (!r || !out) return SAR_ERR_INVALID;
     *out = r->timing;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_per_unit, uint16_t* rgba_out_host) {
+int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_per_unit, uint16_t* rgba_out_host) try {
     if (!r) return SAR_ERR_INVALID;
     SAR_TRY(validate(cfg));
     if (jobs_per_unit == 0) { set_error("jobs_per_unit is 0"); return SAR_ERR_INVALID; }
@@ -735,6 +739,6 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
     }
     r->timing.peer_access_failures = r->peer_access_failures;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 }  // extern "C"

@@ -186,7 +186,7 @@ int sar::plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, ui
 
 extern "C" {
 
-int sar_bin_geometry(uint32_t width, uint32_t height, uint32_t bin_shift, uint32_t bin_interleave, uint32_t out[8]) {
+int sar_bin_geometry(uint32_t width, uint32_t height, uint32_t bin_shift, uint32_t bin_interleave, uint32_t out[8]) try {
     if (!out || width == 0 || height == 0 || (bin_shift && (bin_shift < 12 || bin_shift > 16)) || bin_interleave > 2) return SAR_ERR_INVALID;
     const uint64_t npix64 = static_cast<uint64_t>(width) * height;
     if (npix64 > 0x7FFFFFFFull) return SAR_ERR_RANGE;  // what a runtime accepts (alloc_image_buffers)
@@ -213,6 +213,6 @@ int sar_bin_geometry(uint32_t width, uint32_t height, uint32_t bin_shift, uint32
     out[6] = g.map.hi_shift;
     out[7] = g.map.low_mask;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 }  // extern "C"

@@ -528,14 +528,14 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
 
 extern "C" {
 
-int sar_render(const sar_config* cfg, sar_runtime* rt) {
+int sar_render(const sar_config* cfg, sar_runtime* rt) try {
     SAR_TRY(check_cfg_matches(cfg, rt));
     double p0[3];
     rt->rng.start_point(p0);  // :748
     return render_chunked(cfg, rt, 1, cfg->iterations, p0);
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_render_jobs(const sar_config* cfg, sar_runtime* rt, const double* starts_xyz_host) {
+int sar_render_jobs(const sar_config* cfg, sar_runtime* rt, const double* starts_xyz_host) try {
     SAR_TRY(check_cfg_matches(cfg, rt));
     if (cfg->jobs_total == 0) { set_error("jobs_total is 0"); return SAR_ERR_INVALID; }
     const uint64_t per_job = cfg->iterations / cfg->jobs_total;  // :1058
@@ -546,31 +546,31 @@ int sar_render_jobs(const sar_config* cfg, sar_runtime* rt, const double* starts
         starts_xyz_host = drawn.data();
     }
     return render_chunked(cfg, rt, cfg->jobs_total, per_job, starts_xyz_host);
-}
+} catch (...) { return sar::abi_caught(); }
 
 int sar_render_job_range(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters_per_job,
-                         const double* starts_xyz_host) {
+                         const double* starts_xyz_host) try {
     SAR_TRY(check_cfg_matches(cfg, rt));
     if (n_jobs && !starts_xyz_host) { set_error("starts_xyz_host is NULL"); return SAR_ERR_INVALID; }
     return render_chunked(cfg, rt, n_jobs, iters_per_job, starts_xyz_host);
-}
+} catch (...) { return sar::abi_caught(); }
 
 int sar_render_job_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters_per_job,
-                                const double* starts_xyz_dev) {
+                                const double* starts_xyz_dev) try {
     SAR_TRY(check_cfg_matches(cfg, rt));
     if (n_jobs && !starts_xyz_dev) { set_error("starts_xyz_dev is NULL"); return SAR_ERR_INVALID; }
     return render_chunked(cfg, rt, n_jobs, iters_per_job, starts_xyz_dev, true);
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_describe_last_launch(const sar_runtime* rt, char* out, size_t cap) {
+int sar_runtime_describe_last_launch(const sar_runtime* rt, char* out, size_t cap) try {
     if (!rt || !out || cap == 0) return SAR_ERR_INVALID;
     std::snprintf(out, cap, "%s | chunks=%u warmup_ahead=%u", rt->last_launch[0] ? rt->last_launch : "nothing launched", rt->last_chunks,
                   rt->prefetch_used);
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 int sar_runtime_prefetch_device(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters_per_job,
-                                const double* starts_xyz_dev) {
+                                const double* starts_xyz_dev) try {
     SAR_TRY(check_cfg_matches(cfg, rt));
     if (!starts_xyz_dev) { set_error("starts_xyz_dev is NULL"); return SAR_ERR_INVALID; }
     rt->pf.valid = false;
@@ -588,6 +588,6 @@ int sar_runtime_prefetch_device(const sar_config* cfg, sar_runtime* rt, uint32_t
     rt->pf.n_jobs = n_jobs;
     rt->pf.starts = starts_xyz_dev;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 }  // extern "C"

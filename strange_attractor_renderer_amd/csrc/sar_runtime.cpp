@@ -188,7 +188,7 @@ int ensure_rgba(sar_runtime* rt) {
 
 extern "C" {
 
-int sar_device_count(int* out_count) {
+int sar_device_count(int* out_count) try {
     if (!out_count) return SAR_ERR_INVALID;
     int n = 0;
     const hipError_t e = hipGetDeviceCount(&n);
@@ -199,9 +199,9 @@ int sar_device_count(int* out_count) {
     }
     *out_count = n;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_device_pci_bus_id(int device, char* out, size_t cap) {
+int sar_device_pci_bus_id(int device, char* out, size_t cap) try {
     if (!out || cap < 16) return SAR_ERR_INVALID;
     out[0] = 0;
     if (hipDeviceGetPCIBusId(out, static_cast<int>(cap), device) != hipSuccess) {
@@ -209,9 +209,9 @@ int sar_device_pci_bus_id(int device, char* out, size_t cap) {
         return SAR_ERR_NO_DEVICE;
     }
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_new(const sar_config* cfg, int device, sar_runtime** out) {
+int sar_runtime_new(const sar_config* cfg, int device, sar_runtime** out) try {
     if (!out) return SAR_ERR_INVALID;
     *out = nullptr;
     SAR_TRY(validate(cfg));
@@ -242,9 +242,9 @@ int sar_runtime_new(const sar_config* cfg, int device, sar_runtime** out) {
     if (hipStreamSynchronize(rt->stream) != hipSuccess) return fail(SAR_ERR_HIP);
     *out = rt;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_free(sar_runtime* rt) {
+int sar_runtime_free(sar_runtime* rt) try {
     if (!rt) return SAR_OK;
     hipSetDevice(rt->device);
     if (rt->stream) hipStreamSynchronize(rt->stream);
@@ -291,30 +291,30 @@ int sar_runtime_free(sar_runtime* rt) {
     if (rt->own_stream && rt->stream) hipStreamDestroy(rt->stream);
     delete rt;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_reset(sar_runtime* rt) {
+int sar_runtime_reset(sar_runtime* rt) try {
     if (!rt) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     return do_reset(rt);
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_set_width_height(sar_runtime* rt, uint32_t width, uint32_t height) {
+int sar_runtime_set_width_height(sar_runtime* rt, uint32_t width, uint32_t height) try {
     if (!rt) return SAR_ERR_INVALID;
     if (rt->W == width && rt->H == height) return SAR_OK;  // :668
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipStreamSynchronize(rt->stream));
     SAR_TRY(alloc_image_buffers(rt, width, height));
     return do_reset(rt);
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_seed(sar_runtime* rt, uint64_t seed) {
+int sar_runtime_seed(sar_runtime* rt, uint64_t seed) try {
     if (!rt) return SAR_ERR_INVALID;
     rt->rng.seed(seed);
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_merge(sar_runtime* dst, const sar_runtime* src) {
+int sar_runtime_merge(sar_runtime* dst, const sar_runtime* src) try {
     if (!dst || !src) return SAR_ERR_INVALID;
     if (dst->W != src->W || dst->H != src->H) {  // assert_eq! in the reference (:709-710)
         set_error("merge: %ux%u vs %ux%u", dst->W, dst->H, src->W, src->H);
@@ -330,24 +330,24 @@ int sar_runtime_merge(sar_runtime* dst, const sar_runtime* src) {
     single_end(dst, dst->merge_span, dst->merge_timed);
     HIP_TRY(hipGetLastError());
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_synchronize(sar_runtime* rt) {
+int sar_runtime_synchronize(sar_runtime* rt) try {
     if (!rt) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipStreamSynchronize(rt->stream));
     if (rt->copy_stream) HIP_TRY(hipStreamSynchronize(rt->copy_stream));  // the read-backs of async frames
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_dims(const sar_runtime* rt, uint32_t* width, uint32_t* height) {
+int sar_runtime_dims(const sar_runtime* rt, uint32_t* width, uint32_t* height) try {
     if (!rt || !width || !height) return SAR_ERR_INVALID;
     *width = rt->W;
     *height = rt->H;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_set_stream(sar_runtime* rt, void* hip_stream) {
+int sar_runtime_set_stream(sar_runtime* rt, void* hip_stream) try {
     if (!rt) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipStreamSynchronize(rt->stream));
@@ -357,9 +357,9 @@ int sar_runtime_set_stream(sar_runtime* rt, void* hip_stream) {
     rt->stream = static_cast<hipStream_t>(hip_stream);
     rt->own_stream = false;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_get_copy_stream(sar_runtime* rt, void** hip_stream_out) {
+int sar_runtime_get_copy_stream(sar_runtime* rt, void** hip_stream_out) try {
     if (!rt || !hip_stream_out) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     if (!rt->copy_stream) {
@@ -368,9 +368,9 @@ int sar_runtime_get_copy_stream(sar_runtime* rt, void** hip_stream_out) {
     }
     *hip_stream_out = rt->copy_stream;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_set_copy_stream(sar_runtime* rt, void* hip_stream) {
+int sar_runtime_set_copy_stream(sar_runtime* rt, void* hip_stream) try {
     if (!rt || !hip_stream) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     if (rt->copy_stream) HIP_TRY(hipStreamSynchronize(rt->copy_stream));
@@ -378,21 +378,21 @@ int sar_runtime_set_copy_stream(sar_runtime* rt, void* hip_stream) {
     rt->copy_stream = static_cast<hipStream_t>(hip_stream);
     rt->own_copy_stream = false;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_get_stream(const sar_runtime* rt, void** hip_stream_out) {
+int sar_runtime_get_stream(const sar_runtime* rt, void** hip_stream_out) try {
     if (!rt || !hip_stream_out) return SAR_ERR_INVALID;
     *hip_stream_out = rt->stream;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_colorize_device(const sar_config* cfg, sar_runtime* rt, void* rgba_out_dev) {
+int sar_colorize_device(const sar_config* cfg, sar_runtime* rt, void* rgba_out_dev) try {
     SAR_TRY(check_cfg_matches(cfg, rt));
     if (!rgba_out_dev) return SAR_ERR_INVALID;
     return do_colorize(cfg, rt, rgba_out_dev);
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host) {
+int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host) try {
     SAR_TRY(check_cfg_matches(cfg, rt));
     if (!rgba_out_host) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
@@ -405,10 +405,10 @@ int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host
     HIP_TRY(hipMemcpyAsync(rgba_out_host, rt->d_rgba, static_cast<size_t>(rt->npix) * 8, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 int sar_runtime_extent(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_t iters_per_job,
-                       const double* starts_xyz_host, double* out12) {
+                       const double* starts_xyz_host, double* out12) try {
     if (!cfg || !rt || !out12 || n_jobs == 0) return SAR_ERR_INVALID;
     SAR_TRY(sar_config_validate(cfg));
     HIP_TRY(hipSetDevice(rt->device));
@@ -452,9 +452,9 @@ int sar_runtime_extent(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, 
         out12[k] = v;
     }
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_image_convert_device(sar_runtime* rt, const void* rgba16_dev, int format, void* out_dev) {
+int sar_image_convert_device(sar_runtime* rt, const void* rgba16_dev, int format, void* out_dev) try {
     if (!rt || !rgba16_dev || !out_dev) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     if (format == SAR_FMT_RGBA16) {
@@ -467,7 +467,7 @@ int sar_image_convert_device(sar_runtime* rt, const void* rgba16_dev, int format
     }
     HIP_TRY(hipGetLastError());
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 static int enqueue_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host, bool own_copy_stream) {
     SAR_TRY(check_cfg_matches(cfg, rt));
@@ -503,13 +503,13 @@ static int enqueue_colorize_format(const sar_config* cfg, sar_runtime* rt, int f
     return SAR_OK;
 }
 
-int sar_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host) {
+int sar_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host) try {
     SAR_TRY(enqueue_colorize_format(cfg, rt, format, out_host, false));
     HIP_TRY(hipStreamSynchronize(rt->stream));
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_colorize_format_async(const sar_config* cfg, sar_runtime* rt, int format, void* out_host, uint64_t* ticket_out) {
+int sar_colorize_format_async(const sar_config* cfg, sar_runtime* rt, int format, void* out_host, uint64_t* ticket_out) try {
     if (!ticket_out) { set_error("sar_colorize_format_async: NULL ticket"); return SAR_ERR_INVALID; }
     SAR_TRY(enqueue_colorize_format(cfg, rt, format, out_host, true));
     hipEvent_t& ev = rt->img_events[rt->img_next % 8];
@@ -518,43 +518,43 @@ int sar_colorize_format_async(const sar_config* cfg, sar_runtime* rt, int format
     rt->copy_in_flight = !rt->readback_inline;
     *ticket_out = rt->img_next++;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_wait_image(sar_runtime* rt, uint64_t ticket) {
+int sar_runtime_wait_image(sar_runtime* rt, uint64_t ticket) try {
     if (!rt || ticket >= rt->img_next) { set_error("sar_runtime_wait_image: no such ticket"); return SAR_ERR_INVALID; }
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipEventSynchronize(rt->img_events[ticket % 8]));
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_host_alloc(size_t bytes, void** out) {
+int sar_host_alloc(size_t bytes, void** out) try {
     if (!out || bytes == 0) { set_error("sar_host_alloc: NULL output or zero size"); return SAR_ERR_INVALID; }
     HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_host_free(void* p) {
+int sar_host_free(void* p) try {
     if (p) HIP_TRY(hipHostFree(p));
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_count(sar_runtime* rt, uint32_t* out_host) {
+int sar_runtime_count(sar_runtime* rt, uint32_t* out_host) try {
     if (!rt || !out_host) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipMemcpyAsync(out_host, rt->d_count, static_cast<size_t>(rt->npix) * 4, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_steps(sar_runtime* rt, double* out_host) {
+int sar_runtime_steps(sar_runtime* rt, double* out_host) try {
     if (!rt || !out_host) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipMemcpyAsync(out_host, rt->d_steps, static_cast<size_t>(rt->npix) * 8, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_zbuf(sar_runtime* rt, float* out_host) {
+int sar_runtime_zbuf(sar_runtime* rt, float* out_host) try {
     if (!rt || !out_host) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     if (!rt->d_ztmp) HIP_TRY(hipMalloc(&rt->d_ztmp, static_cast<size_t>(rt->npix) * 4));
@@ -562,9 +562,9 @@ int sar_runtime_zbuf(sar_runtime* rt, float* out_host) {
     HIP_TRY(hipMemcpyAsync(out_host, rt->d_ztmp, static_cast<size_t>(rt->npix) * 4, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_max(sar_runtime* rt, uint32_t* out_max) {
+int sar_runtime_max(sar_runtime* rt, uint32_t* out_max) try {
     if (!rt || !out_max) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     uint32_t sc[SC_COUNT];
@@ -572,10 +572,10 @@ int sar_runtime_max(sar_runtime* rt, uint32_t* out_max) {
     HIP_TRY(hipStreamSynchronize(rt->stream));
     *out_max = sc[SC_WRAP] ? 0xFFFFFFFFu : sc[SC_MAX];
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 int sar_runtime_load(sar_runtime* rt, const uint32_t* count_host, const double* steps_host,
-                     const float* zbuf_host, uint32_t max) {
+                     const float* zbuf_host, uint32_t max) try {
     if (!rt || !count_host || !steps_host || !zbuf_host) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     if (!rt->d_ztmp) HIP_TRY(hipMalloc(&rt->d_ztmp, static_cast<size_t>(rt->npix) * 4));
@@ -589,45 +589,45 @@ int sar_runtime_load(sar_runtime* rt, const uint32_t* count_host, const double* 
     HIP_TRY(hipMemcpyAsync(rt->d_scalars, sc, sizeof(sc), hipMemcpyHostToDevice, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_exchange_export(sar_runtime* rt, uint32_t rank, void* key_i64_out_dev) {
+int sar_runtime_exchange_export(sar_runtime* rt, uint32_t rank, void* key_i64_out_dev) try {
     if (!rt || !key_i64_out_dev) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     launch_exch_export(rt->d_key, rank, key_i64_out_dev, rt->npix, rt->stream);
     HIP_TRY(hipGetLastError());
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 int sar_runtime_exchange_select(sar_runtime* rt, uint32_t rank, const void* key_i64_reduced_dev,
-                                void* sum_i32_out_dev) {
+                                void* sum_i32_out_dev) try {
     if (!rt || !key_i64_reduced_dev || !sum_i32_out_dev) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     launch_exch_select(rt->d_count, rt->d_key, rt->d_steps, rank, key_i64_reduced_dev, sum_i32_out_dev, rt->npix,
                        rt->stream);
     HIP_TRY(hipGetLastError());
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_exchange_import(sar_runtime* rt, const void* key_i64_reduced_dev, const void* sum_i32_reduced_dev) {
+int sar_runtime_exchange_import(sar_runtime* rt, const void* key_i64_reduced_dev, const void* sum_i32_reduced_dev) try {
     if (!rt || !key_i64_reduced_dev || !sum_i32_reduced_dev) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     launch_exch_import(rt->d_count, rt->d_key, rt->d_steps, key_i64_reduced_dev, sum_i32_reduced_dev, rt->npix,
                        rt->d_scalars, rt->stream);
     HIP_TRY(hipGetLastError());
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice_pixels) {
+int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice_pixels) try {
     if (!out_slice_pixels || world == 0) return SAR_ERR_INVALID;
     // whole 2048-pixel blocks (k_fold_resolve's unit; whole granules of the sparse exchange)
     const uint64_t s = ((static_cast<uint64_t>(npix) + world - 1) / world + (kExchSliceAlign - 1u)) & ~static_cast<uint64_t>(kExchSliceAlign - 1u);
     if (s * world > 0xFFFFFFFFull) { set_error("slice geometry exceeds 2^32 pixels"); return SAR_ERR_RANGE; }
     *out_slice_pixels = static_cast<uint32_t>(s);
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_exchange_pack(sar_runtime* rt, uint32_t world, void* blocks_out_dev) {
+int sar_runtime_exchange_pack(sar_runtime* rt, uint32_t world, void* blocks_out_dev) try {
     if (!rt || !blocks_out_dev) return SAR_ERR_INVALID;
     uint32_t S = 0;
     SAR_TRY(sar_exchange_slice_pixels(rt->npix, world, &S));
@@ -635,9 +635,9 @@ int sar_runtime_exchange_pack(sar_runtime* rt, uint32_t world, void* blocks_out_
     launch_exch_pack(rt->d_count, rt->d_key, rt->d_steps, rt->npix, S, world, blocks_out_dev, rt->stream);
     HIP_TRY(hipGetLastError());
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_exchange_merge_slices(sar_runtime* rt, uint32_t world, uint32_t rank, const void* blocks_in_dev) {
+int sar_runtime_exchange_merge_slices(sar_runtime* rt, uint32_t world, uint32_t rank, const void* blocks_in_dev) try {
     if (!rt || !blocks_in_dev || rank >= world) return SAR_ERR_INVALID;
     uint32_t S = 0;
     SAR_TRY(sar_exchange_slice_pixels(rt->npix, world, &S));
@@ -648,25 +648,25 @@ int sar_runtime_exchange_merge_slices(sar_runtime* rt, uint32_t world, uint32_t 
                              rt->d_scalars, rank == 0, rt->stream);
     HIP_TRY(hipGetLastError());  // (the depth hints stay valid: a merge only raises zbuf)
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_exchange_touched(sar_runtime* rt, uint8_t* flags_out_dev) {
+int sar_runtime_exchange_touched(sar_runtime* rt, uint8_t* flags_out_dev) try {
     if (!rt || !flags_out_dev) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     launch_exch_flags(rt->d_count, rt->d_key, rt->npix, flags_out_dev, rt->stream);
     HIP_TRY(hipGetLastError());
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_exchange_pack_sparse(sar_runtime* rt, const int32_t* send_slot_dev, void* records_out_dev) {
+int sar_runtime_exchange_pack_sparse(sar_runtime* rt, const int32_t* send_slot_dev, void* records_out_dev) try {
     if (!rt || !send_slot_dev || !records_out_dev) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     launch_exch_pack_sparse(rt->d_count, rt->d_key, rt->d_steps, rt->npix, send_slot_dev, records_out_dev, rt->stream);
     HIP_TRY(hipGetLastError());
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_exchange_merge_sparse(sar_runtime* rt, uint32_t world, uint32_t rank, const int32_t* recv_slot_dev, const void* records_in_dev) {
+int sar_runtime_exchange_merge_sparse(sar_runtime* rt, uint32_t world, uint32_t rank, const int32_t* recv_slot_dev, const void* records_in_dev) try {
     if (!rt || !recv_slot_dev || !records_in_dev || rank >= world) return SAR_ERR_INVALID;
     uint32_t S = 0;
     SAR_TRY(sar_exchange_slice_pixels(rt->npix, world, &S));
@@ -677,39 +677,39 @@ int sar_runtime_exchange_merge_sparse(sar_runtime* rt, uint32_t world, uint32_t 
                              recv_slot_dev, rt->d_scalars, rank == 0, rt->stream);
     HIP_TRY(hipGetLastError());  // (the depth hints stay valid: a merge only raises zbuf)
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_exchange_scalars_export(sar_runtime* rt, void* i64x4_out_dev) {
+int sar_runtime_exchange_scalars_export(sar_runtime* rt, void* i64x4_out_dev) try {
     if (!rt || !i64x4_out_dev) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     launch_exch_scalars_export(rt->d_scalars, i64x4_out_dev, rt->stream);
     HIP_TRY(hipGetLastError());
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_exchange_scalars_import(sar_runtime* rt, const void* i64x4_dev) {
+int sar_runtime_exchange_scalars_import(sar_runtime* rt, const void* i64x4_dev) try {
     if (!rt || !i64x4_dev) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     launch_exch_scalars_import(rt->d_scalars, i64x4_dev, rt->stream);
     HIP_TRY(hipGetLastError());
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_colorize_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t first_px, uint32_t n_px, void* rgba_out_dev) {
+int sar_colorize_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t first_px, uint32_t n_px, void* rgba_out_dev) try {
     SAR_TRY(check_cfg_matches(cfg, rt));
     if (!rgba_out_dev) return SAR_ERR_INVALID;
     return colorize_range(cfg, rt, first_px, n_px, rgba_out_dev, true);
-}
+} catch (...) { return sar::abi_caught(); }
 
 // ---- measurement --------------------------------------------------------------------------------------
 
-int sar_runtime_enable_timing(sar_runtime* rt, int enabled) {
+int sar_runtime_enable_timing(sar_runtime* rt, int enabled) try {
     if (!rt) return SAR_ERR_INVALID;
     rt->timing = enabled != 0;
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
+int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) try {
     if (!rt || !out) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
     HIP_TRY(hipStreamSynchronize(rt->stream));
@@ -765,9 +765,9 @@ int sar_runtime_last_timing(sar_runtime* rt, sar_timing* out) {
         rt->warm_used = 0;
     }
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
-int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
+int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) try {
     if (!rt || !name) return SAR_ERR_INVALID;
     const uint32_t v = static_cast<uint32_t>(value);
     if (!std::strcmp(name, "block_threads")) {
@@ -793,6 +793,6 @@ int sar_runtime_set_option(sar_runtime* rt, const char* name, uint64_t value) {
         return SAR_ERR_INVALID;
     }
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 }  // extern "C"

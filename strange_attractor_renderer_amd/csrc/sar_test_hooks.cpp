@@ -2,6 +2,8 @@
 // linked only into the hooks build the test-suite and the A/B tools load (tests/hooks/libsar_hip_hooks.so: the product's own object
 // files plus this one), so that the shipped library's ABI is include/sar.h and nothing else.
 #include <cstring>
+#include <new>
+#include <stdexcept>
 
 #include "../../include/sar_test_hooks.h"
 #include "sar_plan.hpp"
@@ -10,7 +12,13 @@ using namespace sar;
 
 extern "C" {
 
-int sar_runtime_set_test_option(sar_runtime* rt, const char* name, uint64_t value) {
+int sar_runtime_set_test_option(sar_runtime* rt, const char* name, uint64_t value) try {
+    if (name && !std::strcmp(name, "debug_throw")) {  // (no runtime needed) what an exception inside an entry point becomes at the ABI
+        if (value == 1) throw std::bad_alloc();
+        if (value == 2) throw std::runtime_error("thrown on request");
+        if (value == 3) throw 42;
+        return SAR_OK;
+    }
     if (!rt || !name) return SAR_ERR_INVALID;
     const uint32_t v = static_cast<uint32_t>(value);
     if (!std::strcmp(name, "path")) {
@@ -66,6 +74,6 @@ int sar_runtime_set_test_option(sar_runtime* rt, const char* name, uint64_t valu
         return SAR_ERR_INVALID;
     }
     return SAR_OK;
-}
+} catch (...) { return sar::abi_caught(); }
 
 }  // extern "C"
