@@ -37,14 +37,17 @@ extern "C" {
 
 #define SAR_ABI_VERSION 5  /* 5: sar_render_jobs_batch, sar_runtime_batch_frames */
 
-/* ---- status codes ------------------------------------------------------------------------ */
+/* ---- status codes ------------------------------------------------------------------------
+ * Every function that can fail returns one of these (the reference panics instead: assert_eq! / unwrap / expect); the text is
+ * in sar_last_error(). No C++ exception leaves the library: one thrown inside an entry point comes back as SAR_ERR_OOM
+ * (std::bad_alloc) or SAR_ERR_INVALID (anything else). */
 enum {
     SAR_OK = 0,
     SAR_ERR_INVALID = 1,      /* NULL pointer / bad enum / empty palette (ref: Palette::new panics, :413-418) */
     SAR_ERR_DIM_MISMATCH = 2, /* merge of runtimes with different sizes (ref: assert_eq!, :709-710) */
     SAR_ERR_NO_DEVICE = 3,    /* no HIP device / HIP runtime unavailable */
     SAR_ERR_HIP = 4,          /* a HIP call failed; see sar_last_error() */
-    SAR_ERR_OOM = 5,
+    SAR_ERR_OOM = 5,          /* device or host memory exhausted */
     SAR_ERR_RANGE = 6,        /* a size is out of range: width*height > 2^31-1, units*jobs_per_unit > 2^32-1 */
     SAR_ERR_IO = 7            /* an image file could not be created or written (ref: File::create(..).unwrap(), main.rs:103) */
 };
