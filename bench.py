@@ -81,6 +81,8 @@ def main():
                     "library's advice (a multiple of eight, at most --max-batch), 1 = a frame per launch")
     ap.add_argument("--max-batch", type=int, default=16)
     ap.add_argument("--rt-opt", action="append", default=[], help="--config c5: name=value runtime option (sar_runtime_set_option) of every runtime (A/B)")
+    ap.add_argument("--cold-frames", type=int, default=360, help="--config c5: frames of the COLD sweep (BASELINE configs[4] as stated: 360, "
+                    "360 / N per GPU; wall time from the construction of the renderer to the last delivered frame); 0 = skip")
     ap.add_argument("--c5-only", default=None, choices=["readback", "hbm"], help="--config c5: only one of the two sweeps (profiling)")
     ap.add_argument("--config", default=None, choices=["c2", "c4", "c5"], help="c2: BASELINE configs[1], weak scaling (default); "
                     "c4: BASELINE configs[3] (1e10 iterations, 4096^2, 1048576 jobs sharded over the ranks), strong scaling. "
@@ -220,6 +222,7 @@ def main():
             elif world > 1:
                 key = torch.empty(npix, dtype=torch.int64, device="cuda")
                 sums = torch.empty(3 * npix, dtype=torch.int32, device="cuda")
+                rooted = S.Exchange(rt, world, rank)
             # per timed step: start / render end / exchange end / colorize end (read after the closing fence, never inside the region)
             evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(max(steps, warmup, 1))] if world > 1 else []
             phase_ms = [0.0, 0.0, 0.0]
@@ -236,7 +239,7 @@ def main():
                     ex_.merge(dist)
                 else:
                     # rooted: depth keys -> all-reduce MAX; counts + winner's steps -> reduce SUM; rank 0 colorizes
-                    exchange_merge(rt_, rank, dist, key, sums, dst=0)
+                    exchange_merge(rooted, dist, key, sums, dst=0)
 
             def step(more=True):
                 if world > 1:

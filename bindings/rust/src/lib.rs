@@ -96,6 +96,22 @@ pub struct SarRuntime {
 pub struct SarRenderer {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct SarExchange {
+    _private: [u8; 0],
+}
+/// Geometry of the sliced exchange (sar_exchange_new).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct SarExchangeLayout {
+    pub world: u32,
+    pub rank: u32,
+    pub slice_pixels: u32,
+    pub first_px: u32,
+    pub n_px: u32,
+    pub granules: u32,
+    pub block_bytes: u64,
+}
 
 extern "C" {
     pub fn sar_abi_version() -> c_int;
@@ -135,11 +151,9 @@ extern "C" {
     /// F frames of a sweep (src/bin/main.rs:493-517) through one set of launches: frame i == sar_render_jobs(cfgs[i], rts[i], starts[i]).
     pub fn sar_render_jobs_batch(n_frames: u32, cfgs: *const *const SarConfig, rts: *const *mut SarRuntime,
                                  starts_xyz_host: *const *const f64) -> c_int;
+    /// n runtimes for the frames of one batch: one stream, one device and one page-locked allocation for all of them.
+    pub fn sar_runtime_new_group(cfg: *const SarConfig, device: c_int, n: u32, out: *mut *mut SarRuntime) -> c_int;
     pub fn sar_runtime_batch_frames(cfg: *const SarConfig, rt: *mut SarRuntime, out_frames: *mut u32) -> c_int;
-    pub fn sar_runtime_exchange_touched(rt: *mut SarRuntime, flags_out_dev: *mut u8) -> c_int;
-    pub fn sar_runtime_exchange_pack_sparse(rt: *mut SarRuntime, send_slot_dev: *const i32, records_out_dev: *mut c_void) -> c_int;
-    pub fn sar_runtime_exchange_merge_sparse(rt: *mut SarRuntime, world: u32, rank: u32, recv_slot_dev: *const i32,
-                                             records_in_dev: *const c_void) -> c_int;
     pub fn sar_renderer_set_exchange(r: *mut SarRenderer, mode: u32) -> c_int;
     pub fn sar_runtime_get_copy_stream(rt: *mut SarRuntime, hip_stream_out: *mut *mut c_void) -> c_int;
     pub fn sar_runtime_set_copy_stream(rt: *mut SarRuntime, hip_stream: *mut c_void) -> c_int;
@@ -167,18 +181,17 @@ extern "C" {
     pub fn sar_runtime_load(rt: *mut SarRuntime, count_host: *const u32, steps_host: *const f64,
                             zbuf_host: *const f32, max: u32) -> c_int;
 
-    pub fn sar_runtime_exchange_export(rt: *mut SarRuntime, rank: u32, key_i64_out_dev: *mut c_void) -> c_int;
-    pub fn sar_runtime_exchange_select(rt: *mut SarRuntime, rank: u32, key_i64_reduced_dev: *const c_void,
-                                       sum_i32_out_dev: *mut c_void) -> c_int;
-    pub fn sar_runtime_exchange_import(rt: *mut SarRuntime, key_i64_reduced_dev: *const c_void,
-                                       sum_i32_reduced_dev: *const c_void) -> c_int;
-
-    // sliced exchange: every rank owns one slice of the image (all-to-all 16 B/px, merge in rank order, sharded colorize)
+    // The ONE exchange step before colorize of a one-process-per-GPU host (Runtime::merge folded in rank order, :708-738, :1068-1076)
+    // behind one context object; the collectives between the steps are the caller's.
     pub fn sar_exchange_slice_pixels(npix: u32, world: u32, out_slice_pixels: *mut u32) -> c_int;
-    pub fn sar_runtime_exchange_pack(rt: *mut SarRuntime, world: u32, blocks_out_dev: *mut c_void) -> c_int;
-    pub fn sar_runtime_exchange_merge_slices(rt: *mut SarRuntime, world: u32, rank: u32, blocks_in_dev: *const c_void) -> c_int;
-    pub fn sar_runtime_exchange_scalars_export(rt: *mut SarRuntime, i64x4_out_dev: *mut c_void) -> c_int;
-    pub fn sar_runtime_exchange_scalars_import(rt: *mut SarRuntime, i64x4_dev: *const c_void) -> c_int;
+    pub fn sar_exchange_new(rt: *mut SarRuntime, world: u32, rank: u32, out: *mut *mut SarExchange, layout_out: *mut SarExchangeLayout) -> c_int;
+    pub fn sar_exchange_free(ex: *mut SarExchange) -> c_int;
+    pub fn sar_exchange_flags(ex: *mut SarExchange, flags_out_dev: *mut u8) -> c_int;
+    pub fn sar_exchange_pack(ex: *mut SarExchange, flags_all_dev: *const u8, dense_above: f64, send_dev: *mut c_void,
+                             send_bytes: *mut u64, recv_bytes: *mut u64, sparse_out: *mut c_int) -> c_int;
+    pub fn sar_exchange_merge(ex: *mut SarExchange, recv_dev: *const c_void, scalars_out_dev: *mut i64) -> c_int;
+    pub fn sar_exchange_finish(ex: *mut SarExchange, scalars_reduced_dev: *const i64) -> c_int;
+    pub fn sar_exchange_rooted(ex: *mut SarExchange, step: u32, key_i64_dev: *mut c_void, sum_i32_dev: *mut c_void) -> c_int;
     pub fn sar_colorize_range_device(cfg: *const SarConfig, rt: *mut SarRuntime, first_px: u32, n_px: u32,
                                      rgba_out_dev: *mut c_void) -> c_int;
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SAR_ABI_VERSION 5  /* 5: sar_render_jobs_batch, sar_runtime_batch_frames */
+#define SAR_ABI_VERSION 6  /* 6: sar_runtime_new_group, sar_exchange_* (one context object for the multi-process exchange) */
 
 /* ---- status codes ------------------------------------------------------------------------
  * Every function that can fail returns one of these (the reference panics instead: assert_eq! / unwrap / expect); the text is
@@ -153,6 +153,12 @@ int sar_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double*
  * resets them, seeds the start-point stream with cfg->seed. */
 int sar_runtime_new(const sar_config* cfg, int device, sar_runtime** out);
 int sar_runtime_free(sar_runtime* rt);
+/* n runtimes like sar_runtime_new's for the frames of ONE batch (sar_render_jobs_batch; the `sequence` loop, src/bin/main.rs:493-517,
+ * keeps one renderer for all its frames): they share one stream and one read-back stream, and their buffers — sized for frames
+ * like cfg (its image, jobs_total and iterations) in batches of n — are carved from ONE device and ONE page-locked allocation
+ * instead of some twenty each (a 45-frame sweep renders in 32 ms; sixteen runtimes built one by one cost 15 ms). Every out[i] is
+ * an ordinary runtime (1 <= n <= 32), freed with sar_runtime_free in any order; the shared parts go with the last one. */
+int sar_runtime_new_group(const sar_config* cfg, int device, uint32_t n, sar_runtime** out /* [n] */);
 /* Runtime::reset (:682-699): count<-0, steps<-0.0, zbuf<--1.0, max<-0. The RNG stream is NOT reseeded. */
 int sar_runtime_reset(sar_runtime* rt);
 /* Runtime::set_width_height (:667-675): reallocates + resets only when the size changes. */
@@ -210,10 +216,12 @@ int sar_render_job_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t
  */
 int sar_render_jobs_batch(uint32_t n_frames, const sar_config* const* cfgs, sar_runtime* const* rts,
                           const double* const* starts_xyz_host);
-/* How many frames like cfg to render per batch: a multiple of eight (every XCD then runs its own frames, one after the other;
- * sar_render_jobs_batch also deals 2 or 4 frames to the XCDs, any other number runs frame after frame on all of them), the
- * smallest whose last round of equally long wave pairs fills the XCD — eight pairs per CU, a frame takes one per 64 jobs that
- * survive the warm-up (the survivor share of this runtime's last launch). 8..32. */
+/* How many frames like cfg to render per batch: 1 when frames of this shape cannot share launches (the test sar_render_jobs_batch
+ * makes: beyond 4 Mpx, jobs of several launch chunks — a caller then builds ONE runtime per lane, not a batch of them); otherwise
+ * a multiple of eight, 8..32 (every XCD runs its own frames, one after the other; any other number is dealt as well — three frames
+ * or more in eight equal runs of wave pairs): the smallest whose last round of equally long wave pairs fills the XCD — eight pairs
+ * per CU, a frame takes one per 64 jobs that survive the warm-up (the survivor share of this runtime's last launch; before any
+ * launch has reported: 16). rt may be NULL: the answer for a runtime yet to be made. */
 int sar_runtime_batch_frames(const sar_config* cfg, sar_runtime* rt, uint32_t* out_frames);
 
 /* Announces the NEXT sar_render_job_range_device call on this runtime — these start points, job count and iterations per
@@ -290,53 +298,51 @@ int sar_runtime_max(sar_runtime* rt, uint32_t* out_max);
 int sar_runtime_load(sar_runtime* rt, const uint32_t* count_host, const double* steps_host,
                      const float* zbuf_host, uint32_t max);
 
-/* ---- multi-GPU exchange (Runtime::merge folded in rank order, over device buffers) ------------------
- * One process per GPU; the collective itself (RCCL via torch.distributed, or anything else) is the
- * caller's. All buffers are device pointers on the runtime's device, npix = width*height.
- *   1. export:  key_out[p]  = sortable int64 of (zbuf[p], lowest-rank-wins)     -> all-reduce MAX
- *   2. select:  sum_out[0..npix)       = count[p] as int32 (wrapping == u32 add)
- *               sum_out[npix..3*npix)  = the two int32 halves of steps[p] if this rank holds the
- *                                        winning key, else 0                     -> reduce SUM (int32)
- *   3. import:  count/zbuf/steps/max of rt replaced by the reduced buffers.
- */
-int sar_runtime_exchange_export(sar_runtime* rt, uint32_t rank, void* key_i64_out_dev);
-int sar_runtime_exchange_select(sar_runtime* rt, uint32_t rank, const void* key_i64_reduced_dev,
-                                void* sum_i32_out_dev /* 3*npix int32 */);
-int sar_runtime_exchange_import(sar_runtime* rt, const void* key_i64_reduced_dev,
-                                const void* sum_i32_reduced_dev);
-
-/* ---- multi-GPU exchange, sliced form (preferred) ------------------------------------------------------
- * Every rank OWNS the slice [rank*S, min(npix, (rank+1)*S)) of the image, S = sar_exchange_slice_pixels(npix, world).
- *   1. pack:          out = `world` blocks of S*16 bytes, block d = this rank's partial buffers of rank d's slice as
- *                     [count u32 x S | sortable(zbuf) u32 x S | steps f64 x S]                  -> all-to-all (16 B/px)
- *   2. merge_slices:  in = `world` blocks of S*16 bytes, block s = rank s's partial buffers of MY slice; folded with
- *                     Runtime::merge (:708-738) in rank order (rank 0 = the accumulator of :1070, the earlier rank
- *                     wins depth ties, `max` follows every intermediate sum) into rt's own buffers at my slice
- *   3. scalars:       {max, wrap flag, depth range} as 4 x int64                                 -> all-reduce MAX
- *   4. sar_colorize_range_device on my slice                                                      -> gather (8 B/px)
- * After step 2 a runtime holds the merged frame only inside its own slice. */
-int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice_pixels);   /* a multiple of 2048 */
-/* The same exchange SPARSE: a frame touches a fifth of its pixels (18.7 % / 7.8 % at the BASELINE shapes; 21 % of the 64-pixel
- * granules of configs[1], 51 % of its 2048-pixel rows), so only the GRANULES — 64 consecutive pixels — that differ from the reset
- * state travel, as RECORDS of 1 KiB [count u32 x 64 | sortable(zbuf) u32 x 64 | steps f64 x 64] (a rank without a record holds
- * the reset state there: the fold skips it, same result bit for bit).
- *   0. touched:       flags_out[g] = 1 for every granule with a count or a depth, else 0 (one byte each)   -> all-gather
- *   1. pack_sparse:   the record of granule g at records_out + send_slot[g] * 1 KiB (send_slot[g] < 0: not sent); the caller
- *                     orders the slots owner by owner, granule by granule                                   -> all-to-all with split sizes
- *   2. merge_sparse:  recv_slot[world][S / 64]: where rank r's record of granule s of MY slice sits in records_in (or -1)
- *   3. / 4. scalars and colorize as in the dense form.
- * strange_attractor_renderer_amd/distributed.py (SlicedExchange) derives both slot tables from the gathered flags (prefix sums
- * on the device; only the world x world record counts — the split sizes — come to the host). */
+/* ---- multi-GPU exchange, one process per GPU: Runtime::merge (:708-738) folded in rank order (:1068-1076) -----------------------
+ * ONE context object per runtime and world; the collectives (RCCL through torch.distributed, or anything else) are the caller's,
+ * on buffers the caller owns (device memory the collective library can address); everything between them happens here.
+ * Every rank OWNS the slice [rank*S, min(npix, (rank+1)*S)) of the image, S a multiple of 2048 (sar_exchange_slice_pixels):
+ *
+ *   sar_exchange_flags   flags[g] = 1 for every 64-pixel GRANULE of this rank's partial buffers with a count or a depth  -> all-gather (1 B / granule)
+ *   sar_exchange_pack    from every rank's flags the library PLANS the exchange on the device (two block scans: where each of my
+ *                        records goes, where each record I receive arrives) and packs the send buffer — records of 1 KiB
+ *                        [count u32 x 64 | sortable(zbuf) u32 x 64 | steps f64 x 64], owner by owner (a frame touches a fifth of
+ *                        its pixels: 21 % of the granules of BASELINE configs[1]); a rank without a record holds the reset state
+ *                        there, the fold skips it, same result bit for bit. A frame whose flags cover more than dense_above of
+ *                        the image — or flags_all == NULL — goes DENSE: `world` blocks of S*16 bytes [count x S | zbuf x S |
+ *                        steps x S]. send_bytes / recv_bytes[world] are the split sizes of the all-to-all: the call waits for
+ *                        them (2 world + 1 numbers), the ONE host wait of a frame's exchange                    -> all-to-all (split sizes)
+ *   sar_exchange_merge   the owner folds what arrived in rank order (rank 0 = the accumulator of :1070, the earlier rank wins depth
+ *                        ties, `max` follows every intermediate sum) into rt's own buffers at its slice, and writes {max, wrap
+ *                        flag, depth range} as 4 x int64                                                         -> all-reduce MAX (32 B)
+ *   sar_exchange_finish  the reduced scalars become the runtime's; sar_colorize_range_device on my slice         -> gather (8 B/px)
+ *
+ * After merge a runtime holds the merged frame only inside its own slice. strange_attractor_renderer_amd/distributed.py
+ * (SlicedExchange) is this sequence around torch.distributed. */
+typedef struct sar_exchange sar_exchange;
+typedef struct sar_exchange_layout {
+    uint32_t world, rank;
+    uint32_t slice_pixels;    /* S */
+    uint32_t first_px, n_px;  /* this rank's slice */
+    uint32_t granules;        /* ceil(npix / 64): the bytes of one rank's flags */
+    uint64_t block_bytes;     /* world * S * 16: the size of the send and of the receive buffer */
+} sar_exchange_layout;
 #define SAR_EXCHANGE_GRANULE 64
-int sar_runtime_exchange_touched(sar_runtime* rt, uint8_t* flags_out_dev /* ceil(npix / 64) */);
-int sar_runtime_exchange_pack_sparse(sar_runtime* rt, const int32_t* send_slot_dev /* ceil(npix / 64) */, void* records_out_dev);
-int sar_runtime_exchange_merge_sparse(sar_runtime* rt, uint32_t world, uint32_t rank, const int32_t* recv_slot_dev /* world * S / 64 */,
-                                      const void* records_in_dev);
-int sar_runtime_exchange_pack(sar_runtime* rt, uint32_t world, void* blocks_out_dev /* world*S*16 bytes */);
-int sar_runtime_exchange_merge_slices(sar_runtime* rt, uint32_t world, uint32_t rank,
-                                      const void* blocks_in_dev /* world*S*16 bytes */);
-int sar_runtime_exchange_scalars_export(sar_runtime* rt, void* i64x4_out_dev);
-int sar_runtime_exchange_scalars_import(sar_runtime* rt, const void* i64x4_dev);
+int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice_pixels);   /* host arithmetic only */
+/* rt is borrowed and must outlive the exchange; layout_out may be NULL. */
+int sar_exchange_new(sar_runtime* rt, uint32_t world, uint32_t rank, sar_exchange** out, sar_exchange_layout* layout_out);
+int sar_exchange_free(sar_exchange* ex);
+int sar_exchange_flags(sar_exchange* ex, uint8_t* flags_out_dev /* [granules] */);
+int sar_exchange_pack(sar_exchange* ex, const uint8_t* flags_all_dev /* [world][granules], or NULL */, double dense_above,
+                      void* send_dev /* block_bytes */, uint64_t* send_bytes /* [world] */, uint64_t* recv_bytes /* [world] */, int* sparse_out);
+int sar_exchange_merge(sar_exchange* ex, const void* recv_dev /* block_bytes */, int64_t* scalars_out_dev /* [4] */);
+int sar_exchange_finish(sar_exchange* ex, const int64_t* scalars_reduced_dev /* [4] */);
+/* The ROOTED form, for a caller that wants the whole merged Runtime on one rank (20 B/px through two ring collectives):
+ *   step 0  key[p] = sortable int64 of (zbuf[p], lowest-rank-wins)                                        -> all-reduce MAX
+ *   step 1  sum[0..npix) = count[p] as int32 (wrapping == u32 add), sum[npix..3 npix) = the two int32 halves of steps[p] where this
+ *           rank holds the winning key, else 0                                                            -> reduce SUM (int32)
+ *   step 2  (the root) count / zbuf / steps / max of rt replaced by the reduced buffers. */
+int sar_exchange_rooted(sar_exchange* ex, uint32_t step, void* key_i64_dev /* [npix] */, void* sum_i32_dev /* [3 npix]; step 0: NULL */);
 /* colorize (:841-904) of the pixel range [first_px, first_px + n_px) into out_dev (n_px*8 bytes, RGBA16), using the
  * max / depth range the runtime's scalars hold (made global by step 3); stream-ordered. */
 int sar_colorize_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t first_px, uint32_t n_px, void* rgba_out_dev);

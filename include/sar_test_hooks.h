@@ -46,6 +46,12 @@ extern "C" {
  */
 int sar_runtime_set_test_option(sar_runtime* rt, const char* name, uint64_t value);
 
+/* Measurement hook: the individual HIP-event spans the runtime holds ("timing_accumulate": one per launch of every render call
+ * since sar_runtime_last_timing last read them), in launch order. which = 0 the iterate kernel, 1 accumulate + fold, 2 warm-up.
+ * Writes min(*out_n, cap) values; synchronises the runtime's stream. (tools/dispatch_times.py: one kernel's dispatch-by-dispatch
+ * durations with and without a tracer attached.) */
+int sar_runtime_debug_spans(sar_runtime* rt, uint32_t which, float* out_ms, uint32_t cap, uint32_t* out_n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,11 @@ class SarParallelTiming(C.Structure):
     ]
 
 
+class SarExchangeLayout(C.Structure):
+    _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("slice_pixels", C.c_uint32), ("first_px", C.c_uint32), ("n_px", C.c_uint32),
+                ("granules", C.c_uint32), ("block_bytes", C.c_uint64)]
+
+
 class SarTiming(C.Structure):
     _fields_ = [
         ("iterate_ms", C.c_float),
@@ -112,6 +117,7 @@ PROTOTYPES = {
     "sar_rotation_matrix": (C.c_int, [_cfg_p, _P(C.c_double)]),
     "sar_start_points": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, _P(C.c_double)]),
     "sar_runtime_new": (C.c_int, [_cfg_p, C.c_int, _P(_vp)]),
+    "sar_runtime_new_group": (C.c_int, [_cfg_p, C.c_int, C.c_uint32, _P(_vp)]),
     "sar_runtime_free": (C.c_int, [_vp]),
     "sar_runtime_reset": (C.c_int, [_vp]),
     "sar_runtime_set_width_height": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
@@ -150,17 +156,14 @@ PROTOTYPES = {
     "sar_runtime_zbuf": (C.c_int, [_vp, _P(C.c_float)]),
     "sar_runtime_max": (C.c_int, [_vp, _P(C.c_uint32)]),
     "sar_runtime_load": (C.c_int, [_vp, _P(C.c_uint32), _P(C.c_double), _P(C.c_float), C.c_uint32]),
-    "sar_runtime_exchange_export": (C.c_int, [_vp, C.c_uint32, _vp]),
-    "sar_runtime_exchange_select": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
-    "sar_runtime_exchange_import": (C.c_int, [_vp, _vp, _vp]),
     "sar_exchange_slice_pixels": (C.c_int, [C.c_uint32, C.c_uint32, _P(C.c_uint32)]),
-    "sar_runtime_exchange_pack": (C.c_int, [_vp, C.c_uint32, _vp]),
-    "sar_runtime_exchange_merge_slices": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
-    "sar_runtime_exchange_touched": (C.c_int, [_vp, _vp]),
-    "sar_runtime_exchange_pack_sparse": (C.c_int, [_vp, _vp, _vp]),
-    "sar_runtime_exchange_merge_sparse": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _vp]),
-    "sar_runtime_exchange_scalars_export": (C.c_int, [_vp, _vp]),
-    "sar_runtime_exchange_scalars_import": (C.c_int, [_vp, _vp]),
+    "sar_exchange_new": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _P(_vp), _P(SarExchangeLayout)]),
+    "sar_exchange_free": (C.c_int, [_vp]),
+    "sar_exchange_flags": (C.c_int, [_vp, _vp]),
+    "sar_exchange_pack": (C.c_int, [_vp, _vp, C.c_double, _vp, _P(C.c_uint64), _P(C.c_uint64), _P(C.c_int)]),
+    "sar_exchange_merge": (C.c_int, [_vp, _vp, _vp]),
+    "sar_exchange_finish": (C.c_int, [_vp, _vp]),
+    "sar_exchange_rooted": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
     "sar_colorize_range_device": (C.c_int, [_cfg_p, _vp, C.c_uint32, C.c_uint32, _vp]),
     "sar_renderer_new": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, _P(_vp)]),
     "sar_renderer_new_multi": (C.c_int, [_P(C.c_int), C.c_uint32, C.c_uint32, C.c_uint64, _P(_vp)]),
@@ -180,6 +183,7 @@ PROTOTYPES = {
 # the hooks build only (include/sar_test_hooks.h): attached when the loaded library exports it
 OPTIONAL_PROTOTYPES = {
     "sar_runtime_set_test_option": (C.c_int, [_vp, C.c_char_p, C.c_uint64]),
+    "sar_runtime_debug_spans": (C.c_int, [_vp, C.c_uint32, _P(C.c_float), C.c_uint32, _P(C.c_uint32)]),
 }
 STABLE_OPTIONS = ("block_threads", "checkpoint_stride", "hint_bits", "split_waves", "timing_accumulate")
 

@@ -155,6 +155,22 @@ class Runtime:
                     _check(_lib().sar_runtime_set_option(self._h, opt.encode(), int(os.environ[env])), "sar_runtime_set_option")
         self.device = device
 
+    @classmethod
+    def group(cls, config: Config, n: int, device: int = 0) -> list:
+        """n runtimes for the frames of one batch (sar_runtime_new_group): one stream, one read-back stream, their buffers carved
+        from one device and one page-locked allocation. Each is an ordinary Runtime; close them in any order."""
+        handles = (C.c_void_p * n)()
+        _check(_lib().sar_runtime_new_group(C.byref(config.c), device, n, handles), "sar_runtime_new_group")
+        out = []
+        for h in handles:
+            rt = cls(config, device, _borrowed=C.c_void_p(h))
+            rt._own = True
+            for env, opt in (("SAR_SPLIT", "split_waves"),):
+                if os.environ.get(env, "") in ("1", "2"):
+                    _check(_lib().sar_runtime_set_option(rt._h, opt.encode(), int(os.environ[env])), "sar_runtime_set_option")
+            out.append(rt)
+        return out
+
     def close(self):
         if getattr(self, "_h", None) and self._own:
             _lib().sar_runtime_free(self._h)
@@ -232,6 +248,18 @@ class Runtime:
         return Timing(t.iterate_ms, t.resolve_ms, t.colorize_ms, t.merge_ms, t.iterate_launches,
                       t.iterations_counted, t.depth_atomics, t.warmup_ms, t.depth_candidates)
 
+    def debug_spans(self, which: int = 0) -> list:
+        """(hooks build) the individual HIP-event spans held since they were last read, in launch order: 0 iterate, 1 accumulate +
+        fold, 2 warm-up (include/sar_test_hooks.h)."""
+        hook = getattr(_lib(), "sar_runtime_debug_spans", None)
+        if hook is None:
+            raise RuntimeError("debug_spans is a test hook: load the hooks build (_abi.use_hooks_build())")
+        n = C.c_uint32(0)
+        _check(hook(self._h, which, None, 0, C.byref(n)), "sar_runtime_debug_spans")
+        buf = (C.c_float * max(n.value, 1))()
+        _check(hook(self._h, which, buf, n.value, C.byref(n)), "sar_runtime_debug_spans")
+        return [float(buf[k]) for k in range(n.value)]
+
     def set_option(self, name: str, value: int):
         """A stable option (include/sar.h) — or, on the hooks build the test-suite loads, an A/B / test option
         (include/sar_test_hooks.h); the product library has no such entry point."""
@@ -286,47 +314,53 @@ class Runtime:
         self.set_stream(leader.stream())
         self.set_copy_stream(leader.copy_stream())
 
-    # ---- multi-GPU exchange over caller-provided device buffers ------------------------------------
-    def exchange_export(self, rank: int, key_i64_dev_ptr: int):
-        _check(_lib().sar_runtime_exchange_export(self._h, rank, C.c_void_p(key_i64_dev_ptr)),
-               "sar_runtime_exchange_export")
 
-    def exchange_select(self, rank: int, key_reduced_dev_ptr: int, sum_i32_dev_ptr: int):
-        _check(_lib().sar_runtime_exchange_select(self._h, rank, C.c_void_p(key_reduced_dev_ptr),
-                                                  C.c_void_p(sum_i32_dev_ptr)), "sar_runtime_exchange_select")
+class Exchange:
+    """The ONE exchange step before colorize of the one-process-per-GPU path (sar_exchange_*, include/sar.h): Runtime::merge
+    (src/lib.rs:708-738) folded in rank order over image slices. The collectives are the caller's (distributed.py), on buffers the
+    caller owns; all arguments are device pointers."""
 
-    def exchange_import(self, key_reduced_dev_ptr: int, sum_reduced_dev_ptr: int):
-        _check(_lib().sar_runtime_exchange_import(self._h, C.c_void_p(key_reduced_dev_ptr),
-                                                  C.c_void_p(sum_reduced_dev_ptr)), "sar_runtime_exchange_import")
+    RECORD = 64 * 16   # bytes of one record of the sparse form (SAR_EXCHANGE_GRANULE pixels x 16 B)
 
+    def __init__(self, runtime: Runtime, world: int, rank: int):
+        h, lay = C.c_void_p(), _abi.SarExchangeLayout()
+        _check(_lib().sar_exchange_new(runtime.handle, world, rank, C.byref(h), C.byref(lay)), "sar_exchange_new")
+        self._h, self.runtime = h, runtime      # (keeps the runtime alive: the context borrows it)
+        self.world, self.rank = world, rank
+        self.slice_pixels, self.first, self.count = lay.slice_pixels, lay.first_px, lay.n_px
+        self.granules, self.block_bytes = lay.granules, lay.block_bytes
 
-    # sliced form: every rank owns one slice of the image (include/sar.h)
-    def exchange_pack(self, world: int, blocks_dev_ptr: int):
-        _check(_lib().sar_runtime_exchange_pack(self._h, world, C.c_void_p(blocks_dev_ptr)), "sar_runtime_exchange_pack")
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib().sar_exchange_free(self._h)
+        self._h = None
 
-    def exchange_merge_slices(self, world: int, rank: int, blocks_dev_ptr: int):
-        _check(_lib().sar_runtime_exchange_merge_slices(self._h, world, rank, C.c_void_p(blocks_dev_ptr)),
-               "sar_runtime_exchange_merge_slices")
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
-    # sparse form: records of the touched 2048-pixel segments
-    def exchange_touched(self, flags_dev_ptr: int):
-        _check(_lib().sar_runtime_exchange_touched(self._h, C.c_void_p(flags_dev_ptr)), "sar_runtime_exchange_touched")
+    def flags(self, flags_dev_ptr: int):
+        _check(_lib().sar_exchange_flags(self._h, C.c_void_p(flags_dev_ptr)), "sar_exchange_flags")
 
-    def exchange_pack_sparse(self, send_slot_dev_ptr: int, records_dev_ptr: int):
-        _check(_lib().sar_runtime_exchange_pack_sparse(self._h, C.c_void_p(send_slot_dev_ptr), C.c_void_p(records_dev_ptr)),
-               "sar_runtime_exchange_pack_sparse")
+    def pack(self, flags_all_dev_ptr: int | None, dense_above: float, send_dev_ptr: int):
+        """Plans (from the gathered flags; None: dense) and packs. Returns (sparse, send_bytes[world], recv_bytes[world]) — the
+        one host wait of a frame's exchange."""
+        sb, rb, sp = (C.c_uint64 * self.world)(), (C.c_uint64 * self.world)(), C.c_int(0)
+        _check(_lib().sar_exchange_pack(self._h, C.c_void_p(flags_all_dev_ptr) if flags_all_dev_ptr else None, float(dense_above),
+                                        C.c_void_p(send_dev_ptr), sb, rb, C.byref(sp)), "sar_exchange_pack")
+        return bool(sp.value), [int(v) for v in sb], [int(v) for v in rb]
 
-    def exchange_merge_sparse(self, world: int, rank: int, recv_slot_dev_ptr: int, records_dev_ptr: int):
-        _check(_lib().sar_runtime_exchange_merge_sparse(self._h, world, rank, C.c_void_p(recv_slot_dev_ptr), C.c_void_p(records_dev_ptr)),
-               "sar_runtime_exchange_merge_sparse")
+    def merge(self, recv_dev_ptr: int, scalars_dev_ptr: int):
+        _check(_lib().sar_exchange_merge(self._h, C.c_void_p(recv_dev_ptr), C.c_void_p(scalars_dev_ptr)), "sar_exchange_merge")
 
-    def exchange_scalars_export(self, i64x4_dev_ptr: int):
-        _check(_lib().sar_runtime_exchange_scalars_export(self._h, C.c_void_p(i64x4_dev_ptr)),
-               "sar_runtime_exchange_scalars_export")
+    def finish(self, scalars_dev_ptr: int):
+        _check(_lib().sar_exchange_finish(self._h, C.c_void_p(scalars_dev_ptr)), "sar_exchange_finish")
 
-    def exchange_scalars_import(self, i64x4_dev_ptr: int):
-        _check(_lib().sar_runtime_exchange_scalars_import(self._h, C.c_void_p(i64x4_dev_ptr)),
-               "sar_runtime_exchange_scalars_import")
+    def rooted(self, step: int, key_i64_dev_ptr: int, sum_i32_dev_ptr: int = 0):
+        _check(_lib().sar_exchange_rooted(self._h, step, C.c_void_p(key_i64_dev_ptr), C.c_void_p(sum_i32_dev_ptr) if sum_i32_dev_ptr else None),
+               "sar_exchange_rooted")
 
 
 def exchange_slice_pixels(npix: int, world: int) -> int:
@@ -392,10 +426,11 @@ def render_jobs_batch(configs, runtimes, starts=None):
     del keep
 
 
-def batch_frames(config: Config, runtime: Runtime) -> int:
-    """How many frames like `config` fill the chip (sar_runtime_batch_frames): the length to call render_jobs_batch with."""
+def batch_frames(config: Config, runtime: "Runtime | None" = None) -> int:
+    """How many frames like `config` fill the chip (sar_runtime_batch_frames): the length to call render_jobs_batch with; 1 = frames
+    of this shape do not share launches. runtime None: the answer for a runtime yet to be made."""
     n = C.c_uint32()
-    _check(_lib().sar_runtime_batch_frames(C.byref(config.c), runtime.handle, C.byref(n)), "sar_runtime_batch_frames")
+    _check(_lib().sar_runtime_batch_frames(C.byref(config.c), runtime.handle if runtime is not None else None, C.byref(n)), "sar_runtime_batch_frames")
     return int(n.value)
 
 

@@ -22,7 +22,7 @@ BUILD_DIR = os.path.join(os.path.dirname(PKG), "build", "sar_hip")
 VARIANT_DIR = os.path.join(os.path.dirname(PKG), "build", "variants")   # A/B and test builds (SAR_LIBRARY=...), git-ignored
 HOOKS_OUT = os.path.join(os.path.dirname(PKG), "tests", "hooks", "libsar_hip_hooks.so")   # product objects + sar_test_hooks.cpp
 HOOKS_SOURCE = "sar_test_hooks.cpp"
-SOURCES = ["sar_host.cpp", "sar_export.cpp", "sar_plan.cpp", "sar_render.cpp", "sar_runtime.cpp", "sar_batch.cpp", "sar_multi.cpp", "sar_iterate.hip", "sar_accumulate.hip",
+SOURCES = ["sar_host.cpp", "sar_export.cpp", "sar_plan.cpp", "sar_render.cpp", "sar_runtime.cpp", "sar_batch.cpp", "sar_exchange.cpp", "sar_multi.cpp", "sar_iterate.hip", "sar_accumulate.hip",
            "sar_image.hip"]
 HEADERS = [HOOKS_SOURCE, os.path.join("..", "..", "include", "sar_test_hooks.h"), "sar_internal.hpp", "sar_launch.hpp", "sar_device.hpp", "sar_runtime_impl.hpp", "sar_plan.hpp", os.path.join("..", "..", "include", "sar.h")]
 ARCH = "gfx950"

@@ -33,6 +33,20 @@ int sequential(uint32_t n_frames, const sar_config* const* cfgs, sar_runtime* co
     return SAR_OK;
 }
 
+// Whether F frames of (cfg's job split) on runtimes like `lead` can share ONE set of launches — and the plan they would share: the
+// batched kernels are wave pairs over bins with 32-bit counters, every frame one launch chunk of one segment. What
+// sar_render_jobs_batch launches and what sar_runtime_batch_frames answers go through this one test.
+int batch_plan(const sar_config* cfg, sar_runtime* lead, uint32_t F, LaunchPlan& pl, bool& applies) {
+    applies = false;
+    const uint32_t n_jobs = cfg->jobs_total;
+    const uint64_t iters = n_jobs ? cfg->iterations / n_jobs : 0;  // :1058
+    if (n_jobs == 0 || iters == 0 || F < 2) return SAR_OK;
+    if (iters > (lead->max_ordinals ? lead->max_ordinals : kMaxChunkOrdinals)) return SAR_OK;  // jobs of several segments
+    SAR_TRY(plan_launch(cfg, lead, n_jobs, iters, pl, F));
+    applies = pl.binned && pl.split && pl.geo.shift <= 15u && pl.chunk_jobs >= n_jobs;
+    return SAR_OK;
+}
+
 // Frames [0, F) as one batched launch on rts[0]'s stream; `batched` says whether that form applied (otherwise nothing was done).
 int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* rts, const double* const* starts, bool& batched) {
     batched = false;
@@ -44,15 +58,17 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
         const sar_runtime* rt = rts[i];
         if (rt->device != lead->device || rt->W != lead->W || rt->H != lead->H) return SAR_OK;
         if (cfgs[i]->jobs_total != n_jobs || cfgs[i]->iterations / n_jobs != iters || cfgs[i]->scale != cfgs[0]->scale) return SAR_OK;
+        // the frames' hints are laid out by the LEADER's options: a member that may hold hints written in another layout (its own
+        // hint_tile option) renders on its own — a hint read in the wrong layout belongs to another pixel and could reject a winner
+        if (rt->hint_tile != lead->hint_tile) return SAR_OK;
         for (uint32_t j = 0; j < i; ++j)
             if (rts[j] == rt) return SAR_OK;
     }
-    if (iters > (lead->max_ordinals ? lead->max_ordinals : kMaxChunkOrdinals)) return SAR_OK;  // jobs of several segments
     HIP_TRY(hipSetDevice(lead->device));
     LaunchPlan pl;
-    SAR_TRY(plan_launch(cfgs[0], lead, n_jobs, iters, pl, F));
-    // the batched kernels: wave pairs, bins with 32-bit counters, every frame ONE launch chunk
-    if (!pl.binned || !pl.split || pl.geo.shift > 15u || pl.chunk_jobs < n_jobs) return SAR_OK;
+    bool applies = false;
+    SAR_TRY(batch_plan(cfgs[0], lead, F, pl, applies));
+    if (!applies) return SAR_OK;
 
     // the members' own streams meet the leader's: what they hold (a reset, a read-back) comes first, what follows waits for the batch
     hipStream_t own[kMaxBatchFrames];
@@ -66,9 +82,14 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
         }
     }
     struct Restore {  // the helpers below enqueue on rt->stream: the leader's, for the length of this call
-        uint32_t F; sar_runtime* const* rts; hipStream_t* own;
-        ~Restore() { for (uint32_t i = 0; i < F; ++i) rts[i]->stream = own[i]; }
-    } restore{F, rts, own};
+        uint32_t F; sar_runtime* const* rts; hipStream_t* own; hipStream_t lead_stream; bool joined;
+        ~Restore() {
+            for (uint32_t i = 0; i < F; ++i) rts[i]->stream = own[i];
+            // an error return after work was enqueued: the members' own streams never waited for the leader's — what is in flight
+            // there (kernels on the members' buffers) ends before anybody resets, colorizes or frees them
+            if (!joined) hipStreamSynchronize(lead_stream);
+        }
+    } restore{F, rts, own, lead->stream, false};
     for (uint32_t i = 0; i < F; ++i) rts[i]->stream = lead->stream;
     // A preset that loses jobs in the warm-up (solar-sail: 38 %, all within the first ~100 iterations) warms up in two phases:
     // kFirstPhase iterations, the survivors packed, the rest on full waves. (A launch of one frame runs one wave per SIMD and gains
@@ -94,8 +115,8 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
     }
 
     if (!lead->d_batch) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&lead->d_batch), sizeof(BatchFrame) * kMaxBatchFrames));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&lead->h_batch), sizeof(BatchFrame) * kMaxBatchFrames * kBatchRing, hipHostMallocDefault));
+        HIP_TRY(dev_alloc(lead, &lead->d_batch, sizeof(BatchFrame) * kMaxBatchFrames));
+        HIP_TRY(host_alloc(lead, &lead->h_batch, sizeof(BatchFrame) * kMaxBatchFrames * kBatchRing));
         for (hipEvent_t& e : lead->batch_copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     const uint32_t ring = static_cast<uint32_t>(lead->batch_next % kBatchRing);
@@ -106,7 +127,7 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
     // (a frame on every XCD keeps one per XCD, as a single-frame launch does)
     const uint32_t n_waves = static_cast<uint32_t>(((n_jobs + pl.block - 1) / pl.block) * (pl.block / 64u));
     const uint32_t xcd_map = lead->batch_xcd == 1u ? 0u : batch_xcd_map(F, n_waves);
-    const bool one_hint_array = xcd_map == 2u || (xcd_map == 1u && F >= 4u);
+    const bool one_hint_array = xcd_map == 2u || xcd_map == 3u || (xcd_map == 1u && F >= 4u);
     std::vector<double> drawn;
     bool share = false;
     for (uint32_t i = 0; i < F; ++i) {
@@ -125,8 +146,8 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
         }
         SAR_TRY(ensure_scratch(rt, pl.splits));
         SAR_TRY(stage_starts(rt, pl, n_jobs, st, false, starts_mode == 1u ? lead->upload_stream : nullptr, in_place || fetch));
-        SAR_TRY(grow_device(rt->d_ckpt, rt->ckpt_cap, static_cast<size_t>(pl.n_ckpt) * 3 * pl.chunk_jobs));
-        SAR_TRY(ensure_binned_buffers(rt, pl));
+        SAR_TRY(grow_device(rt, rt->d_ckpt, rt->ckpt_cap, static_cast<size_t>(pl.n_ckpt) * 3 * pl.chunk_jobs));
+        SAR_TRY(ensure_binned_buffers(rt, pl, hints_shared(rt, lead, pl, one_hint_array) ? 1u : 8u));
 
         BatchFrame& f = table[i];
         std::memset(&f, 0, sizeof(f));
@@ -153,15 +174,15 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
             if (n_jobs > rt->warm_alt_cap) {  // the second set of warm-up buffers (an announced call's otherwise): the first phase's output
                 if (rt->side) HIP_TRY(hipStreamSynchronize(rt->side));
                 HIP_TRY(hipStreamSynchronize(lead->stream));
-                if (rt->d_warm_alt) hipFree(rt->d_warm_alt);
-                if (rt->d_joblist_alt) hipFree(rt->d_joblist_alt);
+                if (rt->d_warm_alt) dev_free(rt, rt->d_warm_alt);
+                if (rt->d_joblist_alt) dev_free(rt, rt->d_joblist_alt);
                 rt->d_warm_alt = nullptr; rt->d_joblist_alt = nullptr;
                 rt->warm_alt_cap = 0;
-                HIP_TRY(hipMalloc(&rt->d_warm_alt, static_cast<size_t>(n_jobs) * 3 * sizeof(double)));
-                HIP_TRY(hipMalloc(&rt->d_joblist_alt, static_cast<size_t>(n_jobs) * sizeof(uint32_t)));
+                HIP_TRY(dev_alloc(rt, &rt->d_warm_alt, static_cast<size_t>(n_jobs) * 3 * sizeof(double)));
+                HIP_TRY(dev_alloc(rt, &rt->d_joblist_alt, static_cast<size_t>(n_jobs) * sizeof(uint32_t)));
                 rt->warm_alt_cap = n_jobs;
             }
-            if (!rt->d_active_alt) HIP_TRY(hipMalloc(&rt->d_active_alt, 4 * sizeof(uint32_t)));
+            if (!rt->d_active_alt) HIP_TRY(dev_alloc(rt, &rt->d_active_alt, 4 * sizeof(uint32_t)));
             f.warm_first = warm_args(ia.p, ia.starts, n_jobs, iters, rt->d_warm_alt, rt->d_joblist_alt, rt->d_active_alt, ia.width, nullptr);
             f.warm_first.n_iter = kFirstPhase;
             f.warm_first.nan_count = f.warm.nan_count;  // the jobs it drops count where the iterate kernel looks
@@ -252,8 +273,8 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
         sar_runtime* rt = rts[i];
         rt->last_chunks = 1;
         rt->last_iterations += static_cast<uint64_t>(n_jobs) * iters;
-        describe_launch(rt, pl, share, F);
-        if (i) rt->survivor_fraction = lead->survivor_fraction;
+        describe_launch(rt, pl, share, F, xcd_map);
+        if (i) { rt->survivor_fraction = lead->survivor_fraction; rt->survivors_known = lead->survivors_known; }
     }
     bool joined = false;
     for (uint32_t i = 0; i < F; ++i) {
@@ -265,6 +286,7 @@ int launch_batch(uint32_t F, const sar_config* const* cfgs, sar_runtime* const* 
         }
         HIP_TRY(hipStreamWaitEvent(own[i], lead->batch_join, 0));
     }
+    restore.joined = true;
     batched = true;
     return SAR_OK;
 }
@@ -294,11 +316,21 @@ int sar_render_jobs_batch(uint32_t n_frames, const sar_config* const* cfgs, sar_
 int sar_runtime_batch_frames(const sar_config* cfg, sar_runtime* rt, uint32_t* out_frames) try {
     if (!out_frames) return SAR_ERR_INVALID;
     *out_frames = 1;
+    sar_runtime probe;  // rt == NULL: the answer for a runtime yet to be made (default options, no launch behind it)
+    if (!rt) {
+        SAR_TRY(sar_config_validate(cfg));
+        probe.W = cfg->width; probe.H = cfg->height;
+        probe.npix = static_cast<uint32_t>(static_cast<uint64_t>(cfg->width) * cfg->height);
+        rt = &probe;
+    }
     SAR_TRY(check_cfg_matches(cfg, rt));
     if (cfg->jobs_total == 0) return SAR_OK;
     if (rt->active_pending && hipEventQuery(rt->active_copied) == hipSuccess) {
         rt->active_pending = false;
-        if (rt->active_jobs_launched) rt->survivor_fraction = static_cast<double>(*rt->h_active) / rt->active_jobs_launched;
+        if (rt->active_jobs_launched) {
+            rt->survivor_fraction = static_cast<double>(*rt->h_active) / rt->active_jobs_launched;
+            rt->survivors_known = true;
+        }
     }
     // A batch of 8k frames gives every XCD k frames, one after the other (k_iterate_split_batch); an XCD holds eight wave pairs per
     // CU, a frame occupies one per 64 jobs that survive the warm-up, and all pairs run equally long: the XCD works in ROUNDS. The
@@ -310,13 +342,21 @@ int sar_runtime_batch_frames(const sar_config* cfg, sar_runtime* rt, uint32_t* o
     const double pairs = std::ceil(live / 64.0);
     uint32_t best = 8;
     double best_fill = 0.0;
-    for (uint32_t k = 1; 8u * k <= kMaxBatchFrames; ++k) {
+    // (no launch of this runtime has reported its survivors yet: two frames per XCD — a full last round matters less the more
+    // rounds there are, and a preset that loses no job fills its rounds at 8 and at 16 alike)
+    for (uint32_t k = rt->survivors_known ? 1u : 2u; 8u * k <= kMaxBatchFrames; ++k) {
         const double rounds = k * pairs / slots;
         const double fill = rounds / std::ceil(rounds);
         if (fill > best_fill + 1e-9) { best_fill = fill; best = 8u * k; }
         if (fill >= 0.95) break;
     }
-    *out_frames = best;
+    // ... if frames of this shape share launches at all (the same test sar_render_jobs_batch makes: images beyond 4 Mpx, jobs of
+    // several launch chunks or segments, the one-atomic-per-visit path render frame after frame — a caller that builds `best`
+    // runtimes per lane for those would hold 8..32 times the memory for nothing)
+    LaunchPlan pl;
+    bool applies = false;
+    SAR_TRY(batch_plan(cfg, rt, best, pl, applies));
+    *out_frames = applies ? best : 1u;
     return SAR_OK;
 } catch (...) { return sar::abi_caught(); }
 

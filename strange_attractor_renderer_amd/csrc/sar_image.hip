@@ -287,8 +287,81 @@ __global__ void __launch_bounds__(256) k_exch_flags(const uint32_t* __restrict__
     const bool touched = exch_granule_touched(count, key, npix, seg * kExchSeg + lane, c, z);
     if (lane == 0u) flags[seg] = touched ? 1 : 0;
 }
-// one process per GPU: the records of this rank's touched granules, compacted in the order send_slot gives (derived from the
-// all-gathered flags), for a variable-size all-to-all
+// one process per GPU: THE PLAN of a sparse exchange, from every rank's granule flags (flags_all[world][nseg], all-gathered) —
+//   send_slot[g]      where my record of granule g goes in the send buffer: owner by owner (an owner's granules are consecutive),
+//                     granule by granule; -1 = not sent
+//   recv_slot[r][s]   where rank r's record of granule s of MY slice arrives, source by source; -1 = none
+//   counts[0..world) records I send to each owner, [world..2 world) records I receive from each source (the split sizes of the
+//   all-to-all: the only numbers that go to the host), [2 world] granules touched on all ranks together (dense or sparse)
+// Block 0 scans my row, block 1 the column of my slice, the other blocks count: every rank runs the same arithmetic on the same
+// flags. A scan is two passes over a thread's consecutive elements around ONE block-wide exclusive sum.
+__device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* s_wave /* [17] */) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
+            const uint32_t t = s_wave[w];
+            s_wave[w] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+    return s_wave[wave] + inc - v;
+}
+
+template <typename FlagAt>
+__device__ __forceinline__ void exch_plan_scan(uint32_t n, uint32_t sps, FlagAt flag, int32_t* __restrict__ slot, uint32_t* __restrict__ group_counts,
+                                               uint32_t* s_wave) {
+    const uint32_t per = (n + blockDim.x - 1u) / blockDim.x;
+    const uint32_t b = threadIdx.x * per < n ? threadIdx.x * per : n, e = b + per < n ? b + per : n;
+    uint32_t c = 0;
+    for (uint32_t i = b; i < e; ++i) c += flag(i) ? 1u : 0u;
+    uint32_t at = block_exclusive_sum(c, s_wave);
+    uint32_t g_cur = b / sps, g_cnt = 0;
+    for (uint32_t i = b; i < e; ++i) {
+        const bool f = flag(i);
+        const uint32_t g = i / sps;
+        if (g != g_cur) {
+            if (g_cnt) atomicAdd(&group_counts[g_cur], g_cnt);
+            g_cur = g;
+            g_cnt = 0;
+        }
+        slot[i] = f ? (int32_t)at : -1;
+        at += f ? 1u : 0u;
+        g_cnt += f ? 1u : 0u;
+    }
+    if (g_cnt) atomicAdd(&group_counts[g_cur], g_cnt);
+}
+
+__global__ void __launch_bounds__(1024) k_exch_plan(const unsigned char* __restrict__ flags_all, uint32_t world, uint32_t rank, uint32_t nseg, uint32_t sps,
+                                                    int32_t* __restrict__ send_slot, int32_t* __restrict__ recv_slot, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t s_wave[17];
+    if (blockIdx.x == 0u) {
+        const unsigned char* mine = flags_all + (size_t)rank * nseg;
+        exch_plan_scan(nseg, sps, [&](uint32_t g) { return mine[g] != 0; }, send_slot, counts, s_wave);
+    } else if (blockIdx.x == 1u) {
+        const uint32_t g0 = rank * sps;
+        exch_plan_scan(world * sps, sps, [&](uint32_t e) {
+            const uint32_t r = e / sps, g = g0 + (e - r * sps);
+            return g < nseg && flags_all[(size_t)r * nseg + g] != 0;
+        }, recv_slot, counts + world, s_wave);
+    } else {
+        const size_t total = (size_t)world * nseg;
+        uint32_t c = 0;
+        for (size_t i = (size_t)(blockIdx.x - 2u) * blockDim.x + threadIdx.x; i < total; i += (size_t)(gridDim.x - 2u) * blockDim.x) c += flags_all[i] ? 1u : 0u;
+        c = block_exclusive_sum(c, s_wave) + c;   // (the last thread holds the block's sum)
+        if (threadIdx.x == blockDim.x - 1u && c) atomicAdd(&counts[2u * world], c);
+    }
+}
+// the records of this rank's touched granules, compacted in the order send_slot gives, for a variable-size all-to-all
 __global__ void __launch_bounds__(256) k_exch_pack_sparse(const uint32_t* __restrict__ count, const unsigned long long* __restrict__ key,
                                                           const double* __restrict__ steps, uint32_t npix, uint32_t nseg,
                                                           const int32_t* __restrict__ send_slot, unsigned char* __restrict__ out) {
@@ -519,6 +592,10 @@ void launch_exch_merge_slices(uint32_t* count, unsigned long long* key, double* 
 void launch_exch_flags(const uint32_t* count, const unsigned long long* key, uint32_t npix, void* flags, hipStream_t s) {
     const uint32_t nseg = (npix + kExchSeg - 1u) / kExchSeg;
     hipLaunchKernelGGL(k_exch_flags, dim3((nseg + 3u) / 4u), dim3(256), 0, s, count, key, npix, nseg, (unsigned char*)flags);
+}
+void launch_exch_plan(const void* flags_all, uint32_t world, uint32_t rank, uint32_t nseg, uint32_t sps, int32_t* send_slot, int32_t* recv_slot,
+                      uint32_t* counts /* [2 * world + 1], zeroed */, hipStream_t s) {
+    hipLaunchKernelGGL(k_exch_plan, dim3(2u + 30u), dim3(1024), 0, s, (const unsigned char*)flags_all, world, rank, nseg, sps, send_slot, recv_slot, counts);
 }
 void launch_exch_pack_sparse(const uint32_t* count, const unsigned long long* key, const double* steps, uint32_t npix, const int32_t* send_slot,
                              void* out, hipStream_t s) {

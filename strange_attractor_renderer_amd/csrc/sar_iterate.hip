@@ -868,7 +868,8 @@ __global__ void __launch_bounds__(128) k_iterate_split(const BinIterArgs a) {
 // dispatcher deals consecutive workgroups to the eight XCDs round-robin, and every frame has its own depth hints and depth
 // keys — F working sets in every XCD's 4 MiB L2 if every frame ran everywhere (three frames of configs[4]: 1.0 us per
 // iteration step against 0.65 alone). With xcd_map the frames are dealt to the XCDs instead: 8 / F XCDs per frame (F = 2, 4,
-// 8), or F / 8 frames per XCD (16, 24, ...): an XCD's L2 sees the hints of its own frames only. Any other F: frame after frame.
+// 8), F / 8 frames per XCD (16, 24, ...), or — any other F of three or more — eight equal runs of consecutive wave pairs: an XCD's
+// L2 sees the hints of its own frames only, one frame at a time. One or two frames whose pairs do not divide: frame after frame.
 template <bool DEPTH, uint32_t R, uint32_t U, typename H, uint32_t PH>
 __global__ void __launch_bounds__(128) k_iterate_split_batch(const BatchFrame* frames, uint32_t n_frames, uint32_t n_waves, uint32_t xcd_map) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -882,6 +883,12 @@ __global__ void __launch_bounds__(128) k_iterate_split_batch(const BatchFrame* f
         const uint32_t xcd = lin & 7u, pos = lin >> 3, turn = pos / n_waves;  // hints at a time, and its CUs never wait for a round of
         frame = xcd + 8u * turn;                                              // equally long workgroups to end before the next frame starts
         wave = pos - turn * n_waves;
+    } else if (xcd_map == 3u) {  // any F: the F * n_waves wave pairs in frame order, cut into eight runs of consecutive pairs — XCD x takes
+        const uint32_t total = n_frames * n_waves, xcd = lin & 7u, pos = lin >> 3;  // run x (the workgroups lin = x mod 8 are q + (x < r) many):
+        const uint32_t q = total >> 3, r = total & 7u;                            // an XCD works through F / 8 frames' worth of pairs one frame
+        const uint32_t g = xcd * q + (xcd < r ? xcd : r) + pos;                   // after the other, a frame lies on one or two XCDs (more below F = 8)
+        frame = g / n_waves;
+        wave = g - frame * n_waves;
     } else {
         frame = lin / n_waves;
         wave = lin - frame * n_waves;
@@ -1003,12 +1010,14 @@ int launch_iterate_lean(const BinIterArgs& a, uint32_t block, uint32_t records, 
     return launched ? 0 : 1;
 }
 
-// how k_iterate_split_batch deals F frames of n_waves wave pairs to the XCDs: 1 = 8 / F XCDs per frame, 2 = F / 8 frames per
-// XCD, 0 = frame after frame (every frame on all XCDs)
+// how k_iterate_split_batch deals F frames of n_waves wave pairs to the XCDs: 1 = 8 / F XCDs per frame (F = 1, 2, 4, 8), 2 = F / 8
+// frames per XCD (F = 16, 24, ...), 3 = any other F of three frames or more: eight equal runs of consecutive wave pairs (13 frames:
+// 1.625 frames' worth per XCD — the tail of a sweep is dealt like its full batches), 0 = frame after frame on every XCD (what is
+// left: one or two frames whose pairs do not divide)
 uint32_t batch_xcd_map(uint32_t n_frames, uint32_t n_waves) {
-    if ((n_frames * n_waves) % 8u != 0u) return 0;
     if (n_frames <= 8u && 8u % n_frames == 0u && n_waves % (8u / n_frames) == 0u) return 1;
     if (n_frames % 8u == 0u) return 2;
+    if (n_frames >= 3u) return 3;
     return 0;
 }
 

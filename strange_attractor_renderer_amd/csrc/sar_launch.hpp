@@ -40,6 +40,8 @@ void launch_exch_merge_slices(uint32_t* count, unsigned long long* key, double* 
                               uint32_t G, const void* in, uint32_t* scalars, bool keep_max, hipStream_t s);
 // sparse form: records of 64-pixel granules (kExchRecordBytes each), placed by slot tables
 void launch_exch_flags(const uint32_t* count, const unsigned long long* key, uint32_t npix, void* flags, hipStream_t s);
+void launch_exch_plan(const void* flags_all, uint32_t world, uint32_t rank, uint32_t nseg, uint32_t sps, int32_t* send_slot, int32_t* recv_slot,
+                      uint32_t* counts, hipStream_t s);
 void launch_exch_pack_sparse(const uint32_t* count, const unsigned long long* key, const double* steps, uint32_t npix, const int32_t* send_slot,
                              void* out, hipStream_t s);
 void launch_exch_push(const ExchPushArgs& a, hipStream_t s);

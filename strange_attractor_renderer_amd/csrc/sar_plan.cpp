@@ -50,7 +50,10 @@ uint32_t choose_chunk_records(sar_runtime* rt, uint64_t n_jobs, bool batched, ui
     interleave = rt->bin_interleave;
     if (rt->active_pending && hipEventQuery(rt->active_copied) == hipSuccess) {
         rt->active_pending = false;
-        if (rt->active_jobs_launched) rt->survivor_fraction = static_cast<double>(*rt->h_active) / rt->active_jobs_launched;
+        if (rt->active_jobs_launched) {
+            rt->survivor_fraction = static_cast<double>(*rt->h_active) / rt->active_jobs_launched;
+            rt->survivors_known = true;
+        }
     }
     const uint64_t cus = rt->sm_count ? rt->sm_count : 256u;
     const uint64_t busy = static_cast<uint64_t>(n_jobs * rt->survivor_fraction + 0.5);

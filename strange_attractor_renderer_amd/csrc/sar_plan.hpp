@@ -44,13 +44,14 @@ int plan_launch(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs, uint64_
 int ensure_scratch(sar_runtime* rt, uint32_t copies);
 int stage_starts(sar_runtime* rt, const LaunchPlan& pl, uint32_t n_jobs, const double* starts, bool on_device, hipStream_t upload = nullptr,
                  bool in_place = false);
-int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl);
+bool hints_shared(const sar_runtime* rt, const sar_runtime* opt, const LaunchPlan& pl, bool one_hint_array);  // a launch's XCDs use ONE hint array
+int ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl, uint32_t hint_copies);
 void fill_iter_fold_args(const sar_config* cfg, sar_runtime* rt, const LaunchPlan& pl, IterArgs& ia, FoldArgs& fa);
 void fill_bin_iter_args(sar_runtime* rt, const sar_runtime* opt, const LaunchPlan& pl, const IterArgs& ia, BinIterArgs& ba, bool* shared_out,
                         bool one_hint_array = false);
 void fill_bin_acc_args(sar_runtime* rt, const LaunchPlan& pl, const BinIterArgs& ba, BinAccArgs& ca);
 WarmArgs warm_args(const MapParams& p, const double* starts, uint32_t n_jobs, uint64_t iters, double* warm, uint32_t* joblist,
                    uint32_t* active, uint32_t width, uint32_t* hint_range);
-void describe_launch(sar_runtime* rt, const LaunchPlan& pl, bool share, uint32_t batch_frames);
+void describe_launch(sar_runtime* rt, const LaunchPlan& pl, bool share, uint32_t batch_frames, uint32_t xcd_map = 0);
 
 }  // namespace sar

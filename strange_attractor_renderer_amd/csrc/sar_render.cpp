@@ -49,16 +49,16 @@ void sar::fill_ct_params(const sar_config& cfg, ColorTransformParams& ct) {
 // (one per accumulate workgroup of a bin; one on the atomic path) and one array of depth keys
 int sar::ensure_scratch(sar_runtime* rt, uint32_t copies) {
     if (rt->copies != copies || !rt->d_scratch_count) {
-        if (rt->d_scratch_count) hipFree(rt->d_scratch_count);
+        if (rt->d_scratch_count) dev_free(rt, rt->d_scratch_count);
         rt->d_scratch_count = nullptr;
         rt->copies = 0;
         const size_t n = static_cast<size_t>(copies) * rt->npix;
-        HIP_TRY(hipMalloc(&rt->d_scratch_count, n * sizeof(uint32_t)));
+        HIP_TRY(dev_alloc(rt, &rt->d_scratch_count, n * sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(rt->d_scratch_count, 0, n * sizeof(uint32_t), rt->stream));
         rt->copies = copies;
     }
     if (!rt->d_scratch_key) {
-        HIP_TRY(hipMalloc(&rt->d_scratch_key, static_cast<size_t>(rt->npix) * sizeof(unsigned long long)));
+        HIP_TRY(dev_alloc(rt, &rt->d_scratch_key, static_cast<size_t>(rt->npix) * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(rt->d_scratch_key, 0, static_cast<size_t>(rt->npix) * sizeof(unsigned long long), rt->stream));
     }
     return SAR_OK;
@@ -78,14 +78,14 @@ int sar::stage_starts(sar_runtime* rt, const LaunchPlan& pl, uint32_t n_jobs, co
         rt->starts_pending = false;
     }
     if (need > rt->starts_cap) {
-        if (rt->h_starts) hipHostFree(rt->h_starts);
-        if (rt->d_starts) hipFree(rt->d_starts);
+        if (rt->h_starts) host_free(rt, rt->h_starts);
+        if (rt->d_starts) dev_free(rt, rt->d_starts);
         rt->h_starts = nullptr;
         rt->d_starts = nullptr;
         rt->starts_cap = 0;
         // (two doubles more: k_batch_fetch moves 16-byte pieces)
-        HIP_TRY(hipHostMalloc(&rt->h_starts, (need + 2) * sizeof(double), hipHostMallocDefault));
-        HIP_TRY(hipMalloc(&rt->d_starts, (need + 2) * sizeof(double)));
+        HIP_TRY(host_alloc(rt, &rt->h_starts, (need + 2) * sizeof(double)));
+        HIP_TRY(dev_alloc(rt, &rt->d_starts, (need + 2) * sizeof(double)));
         rt->starts_cap = need;
     }
     if (on_device) {
@@ -120,8 +120,22 @@ int sar::stage_starts(sar_runtime* rt, const LaunchPlan& pl, uint32_t n_jobs, co
     return SAR_OK;
 }
 
-// Device buffers of the binned path: record arena, list heads, depth hints, warm-up output, counters.
-int sar::ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
+// One hint array per XCD lets every XCD's L2 serve its own hints coherently; but eight copies of a 4096^2 image's hints
+// (268 MB at 16 bits) no longer fit the 256 MB Infinity Cache behind the L2s, and the misses go to HBM. From 200 MB on
+// the XCDs share ONE array: an XCD then sees another's updates only when its own L2 drops the line — a stale hint lets
+// more visits through stage 1, never a wrong one — and the misses stay on chip (4096^2 share: 9.15 -> 8.85 ms; below
+// that size sharing costs: 2048^2 5.90 -> 6.05 ms).
+// one_hint_array: a batched frame that runs on one or two XCDs of its own — what its XCDs share is all there is; a runtime of a
+// frame group holds one array for that reason and shares it in its other launches as well (a sweep's last frame or two).
+bool sar::hints_shared(const sar_runtime* rt, const sar_runtime* opt, const LaunchPlan& pl, bool one_hint_array) {
+    if (opt->hint_shared == 2) return true;
+    if (opt->hint_shared == 1) return false;
+    return one_hint_array || rt->single_hint_array || static_cast<uint64_t>(rt->npix) * pl.hint_bytes * 8u > (200ull << 20);
+}
+
+// Device buffers of the binned path: record arena, list heads, depth hints (hint_copies arrays: one per XCD, or one), warm-up
+// output, counters.
+int sar::ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl, uint32_t hint_copies) {
     {   // hipFuncSetAttribute is per device and function: once for every device a runtime lives on
         static std::mutex attr_mu;
         static bool attr_done[64] = {false};
@@ -135,48 +149,52 @@ int sar::ensure_binned_buffers(sar_runtime* rt, const LaunchPlan& pl) {
     }
     {
         char* arena = static_cast<char*>(rt->d_arena);
-        const int rc = grow_device(arena, rt->arena_cap, static_cast<size_t>(pl.arena_waves) * pl.chunks_per_wave * chunk_bytes(pl.R));
+        const int rc = grow_device(rt, arena, rt->arena_cap, static_cast<size_t>(pl.arena_waves) * pl.chunks_per_wave * chunk_bytes(pl.R));
         rt->d_arena = arena;  // also when the allocation failed: the old buffer is gone
         SAR_TRY(rc);
     }
-    SAR_TRY(grow_device(rt->d_heads, rt->heads_cap, static_cast<size_t>(pl.max_waves) * pl.geo.bins));
-    if (!rt->d_zhint || rt->zhint_bytes != pl.hint_bytes) {
-        if (rt->d_zhint) hipFree(rt->d_zhint);
+    SAR_TRY(grow_device(rt, rt->d_heads, rt->heads_cap, static_cast<size_t>(pl.max_waves) * pl.geo.bins));
+    if (!rt->d_zhint || rt->zhint_bytes != pl.hint_bytes || rt->hint_copies_alloc < hint_copies) {
+        // (hints only ever reject visits that cannot win: starting over with empty ones is always right. What may still read the
+        // old arrays is on this runtime's streams; hipFree waits for the device, memory of a frame group is simply left behind)
+        if (rt->d_zhint) dev_free(rt, rt->d_zhint);
         rt->d_zhint = nullptr;
-        HIP_TRY(hipMalloc(&rt->d_zhint, (static_cast<size_t>(rt->npix) + 2u) * 8u * pl.hint_bytes));
+        rt->hint_copies_alloc = 0;
+        HIP_TRY(dev_alloc(rt, &rt->d_zhint, (static_cast<size_t>(rt->npix) + 2u) * hint_copies * pl.hint_bytes));
         rt->zhint_bytes = pl.hint_bytes;
-        rt->hint_copies_used = 8;  // fresh memory: all of it
+        rt->hint_copies_alloc = hint_copies;
+        rt->hint_copies_used = hint_copies;  // fresh memory: all of it
         SAR_TRY(clear_hints(rt));
     }
     if (pl.chunk_jobs > rt->warm_cap) {
         size_t cap3 = 0, cap1 = 0;  // both buffers are replaced together
         rt->warm_cap = 0;
-        SAR_TRY(grow_device(rt->d_warm, cap3, static_cast<size_t>(pl.chunk_jobs) * 3));
-        SAR_TRY(grow_device(rt->d_joblist, cap1, static_cast<size_t>(pl.chunk_jobs)));
+        SAR_TRY(grow_device(rt, rt->d_warm, cap3, static_cast<size_t>(pl.chunk_jobs) * 3));
+        SAR_TRY(grow_device(rt, rt->d_joblist, cap1, static_cast<size_t>(pl.chunk_jobs)));
         rt->warm_cap = pl.chunk_jobs;
     }
-    if (!rt->d_active) HIP_TRY(hipMalloc(&rt->d_active, 4 * sizeof(uint32_t)));
+    if (!rt->d_active) HIP_TRY(dev_alloc(rt, &rt->d_active, 4 * sizeof(uint32_t)));
     const size_t segs = static_cast<size_t>(rt->npix) / 2048u + 1u;
     if (rt->seg_any_cap < segs) {
-        if (rt->d_seg_any) hipFree(rt->d_seg_any);
+        if (rt->d_seg_any) dev_free(rt, rt->d_seg_any);
         rt->d_seg_any = nullptr;
         rt->seg_any_cap = 0;
-        HIP_TRY(hipMalloc(&rt->d_seg_any, segs * sizeof(uint32_t)));
+        HIP_TRY(dev_alloc(rt, &rt->d_seg_any, segs * sizeof(uint32_t)));
         rt->seg_any_cap = segs;
     }
     if (!rt->h_active) {
-        HIP_TRY(hipHostMalloc(&rt->h_active, sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(host_alloc(rt, &rt->h_active, sizeof(uint32_t)));
         *rt->h_active = 0;
         HIP_TRY(hipEventCreateWithFlags(&rt->active_copied, hipEventDisableTiming));
     }
     if (!rt->d_hint_range) {
-        HIP_TRY(hipMalloc(&rt->d_hint_range, 2 * sizeof(uint32_t)));
+        HIP_TRY(dev_alloc(rt, &rt->d_hint_range, 2 * sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(rt->d_hint_range, 0, 2 * sizeof(uint32_t), rt->stream));
     }
     if (!rt->d_nan_count) {
         // [0] NaN iterations, [1] depth atomics (stat), [2..5] segment cycles of the SAR_EXPERIMENT_PROF build
         // [6..7] producer wave, [8..12] consumer wave of k_iterate_split in that build
-        HIP_TRY(hipMalloc(&rt->d_nan_count, 16 * sizeof(unsigned long long)));
+        HIP_TRY(dev_alloc(rt, &rt->d_nan_count, 16 * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(rt->d_nan_count, 0, 16 * sizeof(unsigned long long), rt->stream));
     }
     return SAR_OK;
@@ -198,13 +216,7 @@ void sar::fill_bin_iter_args(sar_runtime* rt, const sar_runtime* opt, const Laun
     ba.zhint = rt->d_zhint;
     ba.nan_count = rt->d_nan_count;
     ba.hint_range = pl.hint_bytes == 2 ? rt->d_hint_range : nullptr;
-    // One hint array per XCD lets every XCD's L2 serve its own hints coherently; but eight copies of a 4096^2 image's hints
-    // (268 MB at 16 bits) no longer fit the 256 MB Infinity Cache behind the L2s, and the misses go to HBM. From 200 MB on
-    // the XCDs share ONE array: an XCD then sees another's updates only when its own L2 drops the line — a stale hint lets
-    // more visits through stage 1, never a wrong one — and the misses stay on chip (4096^2 share: 9.15 -> 8.85 ms; below
-    // that size sharing costs: 2048^2 5.90 -> 6.05 ms).
-    // (one_hint_array: a batched frame that runs on one or two XCDs of its own — what its XCDs share is all there is)
-    const bool share = opt->hint_shared == 2 || (opt->hint_shared == 0 && (one_hint_array || static_cast<uint64_t>(rt->npix) * pl.hint_bytes * 8u > (200ull << 20)));
+    const bool share = hints_shared(rt, opt, pl, one_hint_array);
     ba.hint_copy_mask = share ? 0u : 7u;
     const uint32_t written = share ? 1u : 8u;
     if (rt->hint_copies_used < written) rt->hint_copies_used = written;
@@ -236,9 +248,9 @@ void sar::fill_bin_acc_args(sar_runtime* rt, const LaunchPlan& pl, const BinIter
     ca.seg_any = rt->d_seg_any;
 }
 
-void sar::describe_launch(sar_runtime* rt, const LaunchPlan& pl, bool share, uint32_t batch_frames) {
-    char batch[32] = "";
-    if (batch_frames) std::snprintf(batch, sizeof(batch), " | batch of %u frames", batch_frames);
+void sar::describe_launch(sar_runtime* rt, const LaunchPlan& pl, bool share, uint32_t batch_frames, uint32_t xcd_map) {
+    char batch[64] = "";
+    if (batch_frames) std::snprintf(batch, sizeof(batch), " | batch of %u frames (xcd map %u)", batch_frames, xcd_map);
     std::snprintf(rt->last_launch, sizeof(rt->last_launch),
                   "%s R=%u bins=%ux%upx %s hints=%s pipe=%u | k_bin_accumulate splits=%u lists=%u counters=%s%s",
                   pl.split ? "k_iterate_split" : "k_iterate_lean", pl.R, pl.geo.bins, 1u << pl.geo.shift, pl.geo.interleaved ? "interleaved" : "consecutive",
@@ -403,24 +415,24 @@ int warmup_ahead(sar_runtime* rt, const sar::MapParams& p, const double* starts,
         HIP_TRY(hipStreamSynchronize(rt->side));
         HIP_TRY(hipStreamSynchronize(rt->stream));
         for (void* q : {static_cast<void*>(rt->d_warm_alt), static_cast<void*>(rt->d_joblist_alt)})
-            if (q) hipFree(q);
+            if (q) dev_free(rt, q);
         rt->d_warm_alt = nullptr; rt->d_joblist_alt = nullptr;
         rt->warm_alt_cap = 0;
-        HIP_TRY(hipMalloc(&rt->d_warm_alt, static_cast<size_t>(m) * 3 * sizeof(double)));
-        HIP_TRY(hipMalloc(&rt->d_joblist_alt, static_cast<size_t>(m) * sizeof(uint32_t)));
+        HIP_TRY(dev_alloc(rt, &rt->d_warm_alt, static_cast<size_t>(m) * 3 * sizeof(double)));
+        HIP_TRY(dev_alloc(rt, &rt->d_joblist_alt, static_cast<size_t>(m) * sizeof(uint32_t)));
         rt->warm_alt_cap = m;
     }
     // the converted start points of an announced call: NOT one of the two sets that swap (its capacity is its own)
     if (!soa && m > rt->starts_alt_cap) {
         HIP_TRY(hipStreamSynchronize(rt->side));
-        if (rt->d_starts_alt) hipFree(rt->d_starts_alt);
+        if (rt->d_starts_alt) dev_free(rt, rt->d_starts_alt);
         rt->d_starts_alt = nullptr;
         rt->starts_alt_cap = 0;
-        HIP_TRY(hipMalloc(&rt->d_starts_alt, static_cast<size_t>(m) * 3 * sizeof(double)));
+        HIP_TRY(dev_alloc(rt, &rt->d_starts_alt, static_cast<size_t>(m) * 3 * sizeof(double)));
         rt->starts_alt_cap = m;
     }
-    if (!rt->d_active_alt) HIP_TRY(hipMalloc(&rt->d_active_alt, 4 * sizeof(uint32_t)));
-    if (!rt->d_hint_range_alt) HIP_TRY(hipMalloc(&rt->d_hint_range_alt, 2 * sizeof(uint32_t)));
+    if (!rt->d_active_alt) HIP_TRY(dev_alloc(rt, &rt->d_active_alt, 4 * sizeof(uint32_t)));
+    if (!rt->d_hint_range_alt) HIP_TRY(dev_alloc(rt, &rt->d_hint_range_alt, 2 * sizeof(uint32_t)));
     sar_runtime::Prefetch& pf = rt->pf;
     pf.p = p;
     pf.n_jobs = m;
@@ -470,8 +482,8 @@ int sar::render_chunked(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
     SAR_TRY(plan_launch(cfg, rt, n_jobs, seg, pl));
     SAR_TRY(ensure_scratch(rt, pl.binned ? pl.splits : 1u));
     SAR_TRY(stage_starts(rt, pl, n_jobs, starts, starts_on_device));
-    SAR_TRY(grow_device(rt->d_ckpt, rt->ckpt_cap, static_cast<size_t>(pl.n_ckpt) * 3 * pl.chunk_jobs));
-    if (pl.binned) SAR_TRY(ensure_binned_buffers(rt, pl));
+    SAR_TRY(grow_device(rt, rt->d_ckpt, rt->ckpt_cap, static_cast<size_t>(pl.n_ckpt) * 3 * pl.chunk_jobs));
+    if (pl.binned) SAR_TRY(ensure_binned_buffers(rt, pl, hints_shared(rt, rt, pl, false) ? 1u : 8u));
 
     IterArgs ia;
     FoldArgs fa;

@@ -1,6 +1,6 @@
 // sar_runtime.cpp — the C ABI of the Runtime (include/sar.h): life cycle, reset, merge, colorize and image export, read-back
-// accessors, the exchange helpers of the one-process-per-GPU path, timing and the tuning options. The render call itself is
-// sar_render.cpp, its planning sar_plan.cpp, the multi-device ParallelRenderer sar_multi.cpp.
+// accessors, timing and the tuning options. The render call itself is sar_render.cpp, its planning sar_plan.cpp, the multi-device
+// ParallelRenderer sar_multi.cpp, the exchange of the one-process-per-GPU path sar_exchange.cpp.
 //
 // Host logic only (allocation, argument blocks, stream ordering); all arithmetic on image data happens in the kernel files
 // (sar_iterate.hip, sar_accumulate.hip, sar_image.hip). There is no CPU fallback: without a HIP device every entry point
@@ -31,21 +31,95 @@ const double* host_ln_lut() {
     return lut.data();
 }
 
+// The table in device memory: ONE per device, shared by every runtime there (read-only; it used to be 8 MiB of allocation and
+// upload per runtime — 0.35 ms of each of a sweep's sixteen), released with the device's last runtime.
+struct DeviceLnLut {
+    std::mutex mu;
+    double* table = nullptr;
+    int refs = 0;
+} g_lnlut[64];
+
+int acquire_ln_lut(sar_runtime* rt) {
+    if (rt->device < 0 || rt->device >= 64) { set_error("device %d: this library addresses devices 0..63", rt->device); return SAR_ERR_INVALID; }
+    DeviceLnLut& d = g_lnlut[rt->device];
+    std::lock_guard<std::mutex> lock(d.mu);
+    if (!d.table) {
+        double* t = nullptr;
+        if (hipMalloc(&t, kLnLutEntries * sizeof(double)) != hipSuccess) return SAR_ERR_OOM;
+        // (a blocking copy: the table is complete before any stream of any runtime can read it)
+        if (hipMemcpy(t, host_ln_lut(), kLnLutEntries * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { hipFree(t); return SAR_ERR_HIP; }
+        d.table = t;
+    }
+    ++d.refs;
+    rt->d_lnlut = d.table;
+    return SAR_OK;
+}
+
+void release_ln_lut(sar_runtime* rt) {
+    if (!rt->d_lnlut || rt->device < 0 || rt->device >= 64) return;
+    DeviceLnLut& d = g_lnlut[rt->device];
+    std::lock_guard<std::mutex> lock(d.mu);
+    if (--d.refs == 0) {
+        hipFree(d.table);
+        d.table = nullptr;
+    }
+    rt->d_lnlut = nullptr;
+}
+
+std::mutex g_group_mu;  // the reference counts of the frame groups
+
+constexpr size_t kSlabAlign = 256;
+size_t slab_round(size_t bytes) { return (bytes + kSlabAlign - 1) & ~(kSlabAlign - 1); }
+
 }  // namespace
+
+hipError_t sar::dev_alloc_bytes(sar_runtime* rt, void** out, size_t bytes) {
+    const size_t need = slab_round(bytes ? bytes : 1);
+    if (rt->sub && need <= rt->sub_bytes - rt->sub_used) {
+        *out = rt->sub + rt->sub_used;
+        rt->sub_used += need;
+        return hipSuccess;
+    }
+    return hipMalloc(out, bytes);
+}
+
+hipError_t sar::host_alloc_bytes(sar_runtime* rt, void** out, size_t bytes) {
+    const size_t need = slab_round(bytes ? bytes : 1);
+    if (rt->hsub && need <= rt->hsub_bytes - rt->hsub_used) {
+        *out = rt->hsub + rt->hsub_used;
+        rt->hsub_used += need;
+        return hipSuccess;
+    }
+    return hipHostMalloc(out, bytes, hipHostMallocDefault);
+}
+
+void sar::dev_free(sar_runtime* rt, void* p) {
+    if (!p) return;
+    const char* q = static_cast<const char*>(p);
+    if (rt->sub && q >= rt->sub && q < rt->sub + rt->sub_bytes) return;  // goes with the runtime
+    hipFree(p);
+}
+
+void sar::host_free(sar_runtime* rt, void* p) {
+    if (!p) return;
+    const char* q = static_cast<const char*>(p);
+    if (rt->group && q >= rt->group->hslab && q < rt->group->hslab + rt->group->hslab_bytes) return;
+    hipHostFree(p);
+}
 
 namespace {
 
 int free_device_buffers(sar_runtime* rt) {
-    if (rt->d_count) hipFree(rt->d_count);
-    if (rt->d_key) hipFree(rt->d_key);
-    if (rt->d_steps) hipFree(rt->d_steps);
-    if (rt->d_scratch_count) hipFree(rt->d_scratch_count);
-    if (rt->d_scratch_key) hipFree(rt->d_scratch_key);
-    if (rt->d_rgba) hipFree(rt->d_rgba);
-    if (rt->d_export) hipFree(rt->d_export);
+    if (rt->d_count) dev_free(rt, rt->d_count);
+    if (rt->d_key) dev_free(rt, rt->d_key);
+    if (rt->d_steps) dev_free(rt, rt->d_steps);
+    if (rt->d_scratch_count) dev_free(rt, rt->d_scratch_count);
+    if (rt->d_scratch_key) dev_free(rt, rt->d_scratch_key);
+    if (rt->d_rgba) dev_free(rt, rt->d_rgba);
+    if (rt->d_export) dev_free(rt, rt->d_export);
     rt->d_export = nullptr;
-    if (rt->d_ztmp) hipFree(rt->d_ztmp);
-    if (rt->d_zhint) hipFree(rt->d_zhint);
+    if (rt->d_ztmp) dev_free(rt, rt->d_ztmp);
+    if (rt->d_zhint) dev_free(rt, rt->d_zhint);
     rt->d_zhint = nullptr;
     rt->d_count = nullptr;
     rt->d_key = nullptr;
@@ -66,13 +140,13 @@ int alloc_image_buffers(sar_runtime* rt, uint32_t w, uint32_t h) {
     uint32_t* count = nullptr;
     unsigned long long* key = nullptr;
     double* steps = nullptr;
-    hipError_t e = hipMalloc(&count, npix64 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&key, npix64 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc(&steps, npix64 * sizeof(double));
+    hipError_t e = dev_alloc(rt, &count, npix64 * sizeof(uint32_t));
+    if (e == hipSuccess) e = dev_alloc(rt, &key, npix64 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = dev_alloc(rt, &steps, npix64 * sizeof(double));
     if (e != hipSuccess) {
-        if (count) hipFree(count);
-        if (key) hipFree(key);
-        if (steps) hipFree(steps);
+        if (count) dev_free(rt, count);
+        if (key) dev_free(rt, key);
+        if (steps) dev_free(rt, steps);
         set_error("image buffers for %ux%u: %s", w, h, hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? SAR_ERR_OOM : SAR_ERR_HIP;
     }
@@ -179,8 +253,87 @@ namespace {
 
 int do_colorize(const sar_config* cfg, sar_runtime* rt, void* out_dev) { return colorize_range(cfg, rt, 0, rt->npix, out_dev, false); }
 
+int check_device(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (this library has no CPU fallback)");
+        return SAR_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return SAR_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(device));
+    return SAR_OK;
+}
+
+// Streams, events, the persistent buffers and the reset state of a new runtime (enqueued on its stream; the caller waits). A
+// runtime of a frame group runs on the group's streams and draws its memory from the group's allocations.
+int init_runtime(sar_runtime* rt, const sar_config* cfg, int device) {
+    rt->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) rt->sm_count = static_cast<uint32_t>(prop.multiProcessorCount);
+    if (rt->group) {
+        rt->stream = rt->group->stream;
+        rt->copy_stream = rt->group->copy_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&rt->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return SAR_ERR_HIP; }
+        rt->own_stream = true;
+    }
+    if (hipEventCreateWithFlags(&rt->starts_copied, hipEventDisableTiming) != hipSuccess) return SAR_ERR_HIP;
+    if (dev_alloc(rt, &rt->d_scalars, SC_COUNT * sizeof(uint32_t)) != hipSuccess) return SAR_ERR_OOM;
+    SAR_TRY(acquire_ln_lut(rt));
+    SAR_TRY(alloc_image_buffers(rt, cfg->width, cfg->height));
+    SAR_TRY(do_reset(rt));
+    rt->rng.seed(cfg->seed);
+    return SAR_OK;
+}
+
+// the last runtime of a group takes the group's streams and allocations with it (force: a group no runtime ever joined)
+void release_group(RuntimeGroup* g, bool force) {
+    {
+        std::lock_guard<std::mutex> lock(g_group_mu);
+        if (!force && --g->refs > 0) return;
+    }
+    hipSetDevice(g->device);
+    if (g->stream) { hipStreamSynchronize(g->stream); hipStreamDestroy(g->stream); }
+    if (g->copy_stream) { hipStreamSynchronize(g->copy_stream); hipStreamDestroy(g->copy_stream); }
+    if (g->hslab) hipHostFree(g->hslab);
+    delete g;
+}
+
+// Device and page-locked bytes ONE runtime of a frame group holds once it renders frames like cfg in batches of n: the persistent
+// buffers, the scratch, one array of depth hints, the record arena, checkpoints, warm-up sets, start points, the colorized and the
+// converted image. An estimate with slack — what it misses is allocated separately.
+void group_bytes_per_runtime(const sar_config* cfg, sar_runtime* probe, uint32_t n, size_t& dev_bytes, size_t& host_bytes) {
+    const size_t npix = probe->npix;
+    size_t dev = 0, host = 0, items = 0;
+    auto add = [&](size_t b) { dev += slab_round(b); ++items; };
+    add(SC_COUNT * sizeof(uint32_t));
+    add(npix * 4); add(npix * 8); add(npix * 8);  // count, key, steps
+    add(npix * 8);                                // colorized image
+    add(npix * 6);                                // converted image
+    const uint32_t n_jobs = cfg->jobs_total;
+    const uint64_t iters = n_jobs ? cfg->iterations / n_jobs : 0;
+    LaunchPlan pl;
+    if (n_jobs && iters && iters <= kMaxChunkOrdinals && plan_launch(cfg, probe, n_jobs, iters, pl, n) == SAR_OK && pl.binned) {
+        add(npix * 8);                                                                            // depth keys of a launch
+        add(npix * 4 * pl.splits);                                                                // partial histograms
+        add((npix + 2) * pl.hint_bytes * (n >= 3u ? 1u : 8u));                                    // depth hints
+        add(static_cast<size_t>(pl.arena_waves) * pl.chunks_per_wave * chunk_bytes(pl.R));        // record arena
+        add(static_cast<size_t>(pl.max_waves) * pl.geo.bins * 4);                                 // list heads
+        add(static_cast<size_t>(pl.n_ckpt) * 3 * pl.chunk_jobs * 8);                              // checkpoints
+        for (int set = 0; set < 2; ++set) { add(static_cast<size_t>(pl.chunk_jobs) * 24); add(static_cast<size_t>(pl.chunk_jobs) * 4); }  // warm-up sets
+        add((static_cast<size_t>(n_jobs) * 3 + 2) * 8);                                           // start points
+        add((npix / 2048 + 1) * 4);                                                               // segment flags
+        host += slab_round((static_cast<size_t>(n_jobs) * 3 + 2) * 8);
+    }
+    dev += slab_round(sizeof(BatchFrame) * kMaxBatchFrames);                                      // (a leader's argument table)
+    host += slab_round(sizeof(BatchFrame) * kMaxBatchFrames * kBatchRing);
+    dev_bytes = dev + 16 * kSlabAlign;   // the handful of counters
+    host_bytes = host + 4 * kSlabAlign;
+    (void)items;
+}
+
 int ensure_rgba(sar_runtime* rt) {
-    if (!rt->d_rgba) HIP_TRY(hipMalloc(&rt->d_rgba, static_cast<size_t>(rt->npix) * 8));
+    if (!rt->d_rgba) HIP_TRY(dev_alloc(rt, &rt->d_rgba, static_cast<size_t>(rt->npix) * 8));
     return SAR_OK;
 }
 
@@ -215,32 +368,62 @@ int sar_runtime_new(const sar_config* cfg, int device, sar_runtime** out) try {
     if (!out) return SAR_ERR_INVALID;
     *out = nullptr;
     SAR_TRY(validate(cfg));
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        set_error("no HIP device available (this library has no CPU fallback)");
-        return SAR_ERR_NO_DEVICE;
-    }
-    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return SAR_ERR_INVALID; }
-    HIP_TRY(hipSetDevice(device));
+    SAR_TRY(check_device(device));
     sar_runtime* rt = new (std::nothrow) sar_runtime();
     if (!rt) return SAR_ERR_OOM;
-    rt->device = device;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) rt->sm_count = static_cast<uint32_t>(prop.multiProcessorCount);
-    int st = SAR_OK;
-    auto fail = [&](int code) { sar_runtime_free(rt); return code; };
-    if (hipStreamCreateWithFlags(&rt->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(SAR_ERR_HIP); }
-    rt->own_stream = true;
-    if (hipEventCreateWithFlags(&rt->starts_copied, hipEventDisableTiming) != hipSuccess) return fail(SAR_ERR_HIP);
-    if (hipMalloc(&rt->d_scalars, SC_COUNT * sizeof(uint32_t)) != hipSuccess) return fail(SAR_ERR_OOM);
-    if (hipMalloc(&rt->d_lnlut, kLnLutEntries * sizeof(double)) != hipSuccess) return fail(SAR_ERR_OOM);
-    if (hipMemcpyAsync(rt->d_lnlut, host_ln_lut(), kLnLutEntries * sizeof(double), hipMemcpyHostToDevice, rt->stream) != hipSuccess)
-        return fail(SAR_ERR_HIP);
-    if ((st = alloc_image_buffers(rt, cfg->width, cfg->height)) != SAR_OK) return fail(st);
-    if ((st = do_reset(rt)) != SAR_OK) return fail(st);
-    rt->rng.seed(cfg->seed);
-    if (hipStreamSynchronize(rt->stream) != hipSuccess) return fail(SAR_ERR_HIP);
+    const int st = init_runtime(rt, cfg, device);
+    if (st != SAR_OK) { sar_runtime_free(rt); return st; }
+    if (hipStreamSynchronize(rt->stream) != hipSuccess) { sar_runtime_free(rt); return SAR_ERR_HIP; }
     *out = rt;
+    return SAR_OK;
+} catch (...) { return sar::abi_caught(); }
+
+int sar_runtime_new_group(const sar_config* cfg, int device, uint32_t n, sar_runtime** out) try {
+    if (!out || n == 0 || n > kMaxBatchFrames) { set_error("sar_runtime_new_group: 1..%u runtimes", kMaxBatchFrames); return SAR_ERR_INVALID; }
+    for (uint32_t i = 0; i < n; ++i) out[i] = nullptr;
+    SAR_TRY(validate(cfg));
+    SAR_TRY(check_device(device));
+    RuntimeGroup* g = new (std::nothrow) RuntimeGroup();
+    if (!g) return SAR_ERR_OOM;
+    g->device = device;
+    auto fail = [&](int code) {
+        bool any = false;
+        for (uint32_t i = 0; i < n; ++i)
+            if (out[i]) { any = true; sar_runtime_free(out[i]); out[i] = nullptr; }  // (the last one releases the group)
+        if (!any) release_group(g, true);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(SAR_ERR_HIP); }
+    // what one runtime of the group will hold for frames like cfg in batches of n (the plan its first batched launch will make;
+    // a need the estimate misses is served by hipMalloc as before)
+    size_t dev_bytes = 0, host_bytes = 0;
+    {
+        sar_runtime probe;
+        probe.device = device;
+        probe.W = cfg->width; probe.H = cfg->height;
+        probe.npix = static_cast<uint32_t>(static_cast<uint64_t>(cfg->width) * cfg->height);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) probe.sm_count = static_cast<uint32_t>(prop.multiProcessorCount);
+        group_bytes_per_runtime(cfg, &probe, n, dev_bytes, host_bytes);
+    }
+    g->hslab_bytes = host_bytes * n;
+    if (hipHostMalloc(reinterpret_cast<void**>(&g->hslab), g->hslab_bytes, hipHostMallocDefault) != hipSuccess) { g->hslab = nullptr; g->hslab_bytes = 0; (void)hipGetLastError(); }
+    for (uint32_t i = 0; i < n; ++i) {
+        sar_runtime* rt = new (std::nothrow) sar_runtime();
+        if (!rt) return fail(SAR_ERR_OOM);
+        rt->group = g;
+        { std::lock_guard<std::mutex> lock(g_group_mu); ++g->refs; }
+        out[i] = rt;
+        // (one allocation per runtime, not one for the group: see sar_runtime_impl.hpp; beyond 4 GiB the buffers stay separate)
+        if (dev_bytes <= (4ull << 30) && hipMalloc(reinterpret_cast<void**>(&rt->sub), dev_bytes) == hipSuccess) rt->sub_bytes = dev_bytes;
+        else { rt->sub = nullptr; (void)hipGetLastError(); }
+        if (g->hslab) { rt->hsub = g->hslab + host_bytes * i; rt->hsub_bytes = host_bytes; }
+        rt->single_hint_array = n >= 3u;  // (batches of three frames or more deal their frames to the XCDs)
+        const int st = init_runtime(rt, cfg, device);
+        if (st != SAR_OK) return fail(st);
+    }
+    if (hipStreamSynchronize(g->stream) != hipSuccess) return fail(SAR_ERR_HIP);
     return SAR_OK;
 } catch (...) { return sar::abi_caught(); }
 
@@ -249,8 +432,8 @@ int sar_runtime_free(sar_runtime* rt) try {
     hipSetDevice(rt->device);
     if (rt->stream) hipStreamSynchronize(rt->stream);
     free_device_buffers(rt);
-    if (rt->d_scalars) hipFree(rt->d_scalars);
-    if (rt->d_lnlut) hipFree(rt->d_lnlut);
+    if (rt->d_scalars) dev_free(rt, rt->d_scalars);
+    release_ln_lut(rt);
     if (rt->side) { hipStreamSynchronize(rt->side); hipStreamDestroy(rt->side); }
     if (rt->iter_done) hipEventDestroy(rt->iter_done);
     if (rt->pf_done) hipEventDestroy(rt->pf_done);
@@ -260,28 +443,28 @@ int sar_runtime_free(sar_runtime* rt) try {
     if (rt->upload_stream) { hipStreamSynchronize(rt->upload_stream); hipStreamDestroy(rt->upload_stream); }
     if (rt->img_ready) hipEventDestroy(rt->img_ready);
     if (rt->starts_consumed) hipEventDestroy(rt->starts_consumed);
-    if (rt->d_warm) hipFree(rt->d_warm);
-    if (rt->d_joblist) hipFree(rt->d_joblist);
-    if (rt->d_active) hipFree(rt->d_active);
-    if (rt->d_warm_alt) hipFree(rt->d_warm_alt);
-    if (rt->d_joblist_alt) hipFree(rt->d_joblist_alt);
-    if (rt->d_active_alt) hipFree(rt->d_active_alt);
-    if (rt->d_hint_range_alt) hipFree(rt->d_hint_range_alt);
-    if (rt->d_starts_alt) hipFree(rt->d_starts_alt);
-    if (rt->d_batch) hipFree(rt->d_batch);
-    if (rt->h_batch) hipHostFree(rt->h_batch);
+    if (rt->d_warm) dev_free(rt, rt->d_warm);
+    if (rt->d_joblist) dev_free(rt, rt->d_joblist);
+    if (rt->d_active) dev_free(rt, rt->d_active);
+    if (rt->d_warm_alt) dev_free(rt, rt->d_warm_alt);
+    if (rt->d_joblist_alt) dev_free(rt, rt->d_joblist_alt);
+    if (rt->d_active_alt) dev_free(rt, rt->d_active_alt);
+    if (rt->d_hint_range_alt) dev_free(rt, rt->d_hint_range_alt);
+    if (rt->d_starts_alt) dev_free(rt, rt->d_starts_alt);
+    if (rt->d_batch) dev_free(rt, rt->d_batch);
+    if (rt->h_batch) host_free(rt, rt->h_batch);
     for (hipEvent_t e : rt->batch_copied) if (e) hipEventDestroy(e);
     if (rt->batch_join) hipEventDestroy(rt->batch_join);
-    if (rt->d_seg_any) hipFree(rt->d_seg_any);
-    if (rt->h_active) hipHostFree(rt->h_active);
+    if (rt->d_seg_any) dev_free(rt, rt->d_seg_any);
+    if (rt->h_active) host_free(rt, rt->h_active);
     if (rt->active_copied) hipEventDestroy(rt->active_copied);
-    if (rt->d_starts) hipFree(rt->d_starts);
-    if (rt->h_starts) hipHostFree(rt->h_starts);
-    if (rt->d_ckpt) hipFree(rt->d_ckpt);
-    if (rt->d_arena) hipFree(rt->d_arena);
-    if (rt->d_heads) hipFree(rt->d_heads);
-    if (rt->d_nan_count) hipFree(rt->d_nan_count);
-    if (rt->d_hint_range) hipFree(rt->d_hint_range);
+    if (rt->d_starts) dev_free(rt, rt->d_starts);
+    if (rt->h_starts) host_free(rt, rt->h_starts);
+    if (rt->d_ckpt) dev_free(rt, rt->d_ckpt);
+    if (rt->d_arena) dev_free(rt, rt->d_arena);
+    if (rt->d_heads) dev_free(rt, rt->d_heads);
+    if (rt->d_nan_count) dev_free(rt, rt->d_nan_count);
+    if (rt->d_hint_range) dev_free(rt, rt->d_hint_range);
     if (rt->starts_copied) hipEventDestroy(rt->starts_copied);
     for (auto& s : rt->iter_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto& s : rt->fold_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
@@ -289,7 +472,10 @@ int sar_runtime_free(sar_runtime* rt) try {
     if (rt->colorize_span.a) { hipEventDestroy(rt->colorize_span.a); hipEventDestroy(rt->colorize_span.b); }
     if (rt->merge_span.a) { hipEventDestroy(rt->merge_span.a); hipEventDestroy(rt->merge_span.b); }
     if (rt->own_stream && rt->stream) hipStreamDestroy(rt->stream);
+    RuntimeGroup* g = rt->group;
+    if (rt->sub) hipFree(rt->sub);
     delete rt;
+    if (g) release_group(g, false);
     return SAR_OK;
 } catch (...) { return sar::abi_caught(); }
 
@@ -482,7 +668,7 @@ static int enqueue_colorize_format(const sar_config* cfg, sar_runtime* rt, int f
     SAR_TRY(do_colorize(cfg, rt, rt->d_rgba));
     const void* src = rt->d_rgba;
     if (format != SAR_FMT_RGBA16) {
-        if (!rt->d_export) HIP_TRY(hipMalloc(&rt->d_export, static_cast<size_t>(rt->npix) * 6));  // largest converted format
+        if (!rt->d_export) HIP_TRY(dev_alloc(rt, &rt->d_export, static_cast<size_t>(rt->npix) * 6));  // largest converted format
         SAR_TRY(sar_image_convert_device(rt, rt->d_rgba, format, rt->d_export));
         src = rt->d_export;
     }
@@ -557,7 +743,7 @@ int sar_runtime_steps(sar_runtime* rt, double* out_host) try {
 int sar_runtime_zbuf(sar_runtime* rt, float* out_host) try {
     if (!rt || !out_host) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
-    if (!rt->d_ztmp) HIP_TRY(hipMalloc(&rt->d_ztmp, static_cast<size_t>(rt->npix) * 4));
+    if (!rt->d_ztmp) HIP_TRY(dev_alloc(rt, &rt->d_ztmp, static_cast<size_t>(rt->npix) * 4));
     launch_zbuf_out(rt->d_key, rt->d_ztmp, rt->npix, rt->stream);
     HIP_TRY(hipMemcpyAsync(out_host, rt->d_ztmp, static_cast<size_t>(rt->npix) * 4, hipMemcpyDeviceToHost, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
@@ -578,7 +764,7 @@ int sar_runtime_load(sar_runtime* rt, const uint32_t* count_host, const double* 
                      const float* zbuf_host, uint32_t max) try {
     if (!rt || !count_host || !steps_host || !zbuf_host) return SAR_ERR_INVALID;
     HIP_TRY(hipSetDevice(rt->device));
-    if (!rt->d_ztmp) HIP_TRY(hipMalloc(&rt->d_ztmp, static_cast<size_t>(rt->npix) * 4));
+    if (!rt->d_ztmp) HIP_TRY(dev_alloc(rt, &rt->d_ztmp, static_cast<size_t>(rt->npix) * 4));
     HIP_TRY(hipMemcpyAsync(rt->d_count, count_host, static_cast<size_t>(rt->npix) * 4, hipMemcpyHostToDevice, rt->stream));
     HIP_TRY(hipMemcpyAsync(rt->d_steps, steps_host, static_cast<size_t>(rt->npix) * 8, hipMemcpyHostToDevice, rt->stream));
     HIP_TRY(hipMemcpyAsync(rt->d_ztmp, zbuf_host, static_cast<size_t>(rt->npix) * 4, hipMemcpyHostToDevice, rt->stream));
@@ -588,110 +774,6 @@ int sar_runtime_load(sar_runtime* rt, const uint32_t* count_host, const double* 
     sc[SC_MAX] = max;
     HIP_TRY(hipMemcpyAsync(rt->d_scalars, sc, sizeof(sc), hipMemcpyHostToDevice, rt->stream));
     HIP_TRY(hipStreamSynchronize(rt->stream));
-    return SAR_OK;
-} catch (...) { return sar::abi_caught(); }
-
-int sar_runtime_exchange_export(sar_runtime* rt, uint32_t rank, void* key_i64_out_dev) try {
-    if (!rt || !key_i64_out_dev) return SAR_ERR_INVALID;
-    HIP_TRY(hipSetDevice(rt->device));
-    launch_exch_export(rt->d_key, rank, key_i64_out_dev, rt->npix, rt->stream);
-    HIP_TRY(hipGetLastError());
-    return SAR_OK;
-} catch (...) { return sar::abi_caught(); }
-
-int sar_runtime_exchange_select(sar_runtime* rt, uint32_t rank, const void* key_i64_reduced_dev,
-                                void* sum_i32_out_dev) try {
-    if (!rt || !key_i64_reduced_dev || !sum_i32_out_dev) return SAR_ERR_INVALID;
-    HIP_TRY(hipSetDevice(rt->device));
-    launch_exch_select(rt->d_count, rt->d_key, rt->d_steps, rank, key_i64_reduced_dev, sum_i32_out_dev, rt->npix,
-                       rt->stream);
-    HIP_TRY(hipGetLastError());
-    return SAR_OK;
-} catch (...) { return sar::abi_caught(); }
-
-int sar_runtime_exchange_import(sar_runtime* rt, const void* key_i64_reduced_dev, const void* sum_i32_reduced_dev) try {
-    if (!rt || !key_i64_reduced_dev || !sum_i32_reduced_dev) return SAR_ERR_INVALID;
-    HIP_TRY(hipSetDevice(rt->device));
-    launch_exch_import(rt->d_count, rt->d_key, rt->d_steps, key_i64_reduced_dev, sum_i32_reduced_dev, rt->npix,
-                       rt->d_scalars, rt->stream);
-    HIP_TRY(hipGetLastError());
-    return SAR_OK;
-} catch (...) { return sar::abi_caught(); }
-
-int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice_pixels) try {
-    if (!out_slice_pixels || world == 0) return SAR_ERR_INVALID;
-    // whole 2048-pixel blocks (k_fold_resolve's unit; whole granules of the sparse exchange)
-    const uint64_t s = ((static_cast<uint64_t>(npix) + world - 1) / world + (kExchSliceAlign - 1u)) & ~static_cast<uint64_t>(kExchSliceAlign - 1u);
-    if (s * world > 0xFFFFFFFFull) { set_error("slice geometry exceeds 2^32 pixels"); return SAR_ERR_RANGE; }
-    *out_slice_pixels = static_cast<uint32_t>(s);
-    return SAR_OK;
-} catch (...) { return sar::abi_caught(); }
-
-int sar_runtime_exchange_pack(sar_runtime* rt, uint32_t world, void* blocks_out_dev) try {
-    if (!rt || !blocks_out_dev) return SAR_ERR_INVALID;
-    uint32_t S = 0;
-    SAR_TRY(sar_exchange_slice_pixels(rt->npix, world, &S));
-    HIP_TRY(hipSetDevice(rt->device));
-    launch_exch_pack(rt->d_count, rt->d_key, rt->d_steps, rt->npix, S, world, blocks_out_dev, rt->stream);
-    HIP_TRY(hipGetLastError());
-    return SAR_OK;
-} catch (...) { return sar::abi_caught(); }
-
-int sar_runtime_exchange_merge_slices(sar_runtime* rt, uint32_t world, uint32_t rank, const void* blocks_in_dev) try {
-    if (!rt || !blocks_in_dev || rank >= world) return SAR_ERR_INVALID;
-    uint32_t S = 0;
-    SAR_TRY(sar_exchange_slice_pixels(rt->npix, world, &S));
-    HIP_TRY(hipSetDevice(rt->device));
-    const uint64_t first = static_cast<uint64_t>(rank) * S;
-    const uint32_t n = first >= rt->npix ? 0u : static_cast<uint32_t>((rt->npix - first < S) ? rt->npix - first : S);
-    launch_exch_merge_slices(rt->d_count, rt->d_key, rt->d_steps, n ? static_cast<uint32_t>(first) : 0u, n, S, world, blocks_in_dev,
-                             rt->d_scalars, rank == 0, rt->stream);
-    HIP_TRY(hipGetLastError());  // (the depth hints stay valid: a merge only raises zbuf)
-    return SAR_OK;
-} catch (...) { return sar::abi_caught(); }
-
-int sar_runtime_exchange_touched(sar_runtime* rt, uint8_t* flags_out_dev) try {
-    if (!rt || !flags_out_dev) return SAR_ERR_INVALID;
-    HIP_TRY(hipSetDevice(rt->device));
-    launch_exch_flags(rt->d_count, rt->d_key, rt->npix, flags_out_dev, rt->stream);
-    HIP_TRY(hipGetLastError());
-    return SAR_OK;
-} catch (...) { return sar::abi_caught(); }
-
-int sar_runtime_exchange_pack_sparse(sar_runtime* rt, const int32_t* send_slot_dev, void* records_out_dev) try {
-    if (!rt || !send_slot_dev || !records_out_dev) return SAR_ERR_INVALID;
-    HIP_TRY(hipSetDevice(rt->device));
-    launch_exch_pack_sparse(rt->d_count, rt->d_key, rt->d_steps, rt->npix, send_slot_dev, records_out_dev, rt->stream);
-    HIP_TRY(hipGetLastError());
-    return SAR_OK;
-} catch (...) { return sar::abi_caught(); }
-
-int sar_runtime_exchange_merge_sparse(sar_runtime* rt, uint32_t world, uint32_t rank, const int32_t* recv_slot_dev, const void* records_in_dev) try {
-    if (!rt || !recv_slot_dev || !records_in_dev || rank >= world) return SAR_ERR_INVALID;
-    uint32_t S = 0;
-    SAR_TRY(sar_exchange_slice_pixels(rt->npix, world, &S));
-    HIP_TRY(hipSetDevice(rt->device));
-    const uint64_t first = static_cast<uint64_t>(rank) * S;
-    const uint32_t n = first >= rt->npix ? 0u : static_cast<uint32_t>((rt->npix - first < S) ? rt->npix - first : S);
-    launch_exch_merge_sparse(rt->d_count, rt->d_key, rt->d_steps, n ? static_cast<uint32_t>(first) : 0u, n, S / kExchSeg, world, records_in_dev,
-                             recv_slot_dev, rt->d_scalars, rank == 0, rt->stream);
-    HIP_TRY(hipGetLastError());  // (the depth hints stay valid: a merge only raises zbuf)
-    return SAR_OK;
-} catch (...) { return sar::abi_caught(); }
-
-int sar_runtime_exchange_scalars_export(sar_runtime* rt, void* i64x4_out_dev) try {
-    if (!rt || !i64x4_out_dev) return SAR_ERR_INVALID;
-    HIP_TRY(hipSetDevice(rt->device));
-    launch_exch_scalars_export(rt->d_scalars, i64x4_out_dev, rt->stream);
-    HIP_TRY(hipGetLastError());
-    return SAR_OK;
-} catch (...) { return sar::abi_caught(); }
-
-int sar_runtime_exchange_scalars_import(sar_runtime* rt, const void* i64x4_dev) try {
-    if (!rt || !i64x4_dev) return SAR_ERR_INVALID;
-    HIP_TRY(hipSetDevice(rt->device));
-    launch_exch_scalars_import(rt->d_scalars, i64x4_dev, rt->stream);
-    HIP_TRY(hipGetLastError());
     return SAR_OK;
 } catch (...) { return sar::abi_caught(); }
 

@@ -21,10 +21,30 @@ constexpr uint32_t kDefaultCkptStride = 32;
 constexpr uint32_t kBatchRing = 8;               // page-locked copies of a batch's argument table in flight
 constexpr uint64_t kCkptBytesCap = 24ull << 30;  // checkpoint + record-arena scratch per launch chunk (HBM is 288 GB)
 
+// What the runtimes of a frame group (sar_runtime_new_group: the frames of one batched launch) share — the launch stream, the
+// read-back stream and one page-locked allocation for their start points.
+struct RuntimeGroup {
+    int refs = 0;  // runtimes alive
+    int device = 0;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    char* hslab = nullptr;
+    size_t hslab_bytes = 0;
+};
+
 }  // namespace sar
 
 struct sar_runtime {
     int device = 0;
+    // frame group (nullptr: a runtime of its own). `sub` is ONE device allocation of this runtime its buffers are carved from
+    // (sized from the plan of the frames the group was made for: some twenty hipMalloc / hipFree calls less per runtime — a hipFree
+    // costs 0.16 ms; one allocation for the WHOLE group, 10 GB, took between 0.3 ms and two seconds on the same box), `hsub` its
+    // share of the group's page-locked allocation; both handed out front to back by dev_alloc / host_alloc and never reused (what
+    // does not fit comes from hipMalloc / hipHostMalloc)
+    sar::RuntimeGroup* group = nullptr;
+    char* sub = nullptr;
+    size_t sub_bytes = 0, sub_used = 0;
+    char* hsub = nullptr;
+    size_t hsub_bytes = 0, hsub_used = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     uint32_t W = 0, H = 0, npix = 0;
@@ -51,6 +71,9 @@ struct sar_runtime {
     uint32_t zhint_bytes = 0;        // bytes per hint of the current allocation (2 or 4)
     uint32_t hint_copies_used = 8;   // of the eight per-XCD arrays, how many [0, n) a launch has written since they were last
                                      // cleared (a launch whose XCDs share ONE array writes array 0 only): what clear_hints clears
+    uint32_t hint_copies_alloc = 0;  // arrays the allocation holds: 8, or 1 where every launch so far shared one array (a runtime of
+                                     // a frame group — its frames are dealt to XCDs of their own —, an image beyond 200 MB of hints)
+    bool single_hint_array = false;  // a runtime of a frame group: its launches share ONE hint array whatever their form
     uint32_t hint_bits = 0;          // option: 0 = by image size, 16, 32
     uint32_t hint_tile = 0;          // option: 0 = narrow hints of power-of-two-wide images in 8 x 8 tiles, 1 = always row-major
     uint32_t hint_shared = 0;        // option: 0 = automatic, 1 = one hint array per XCD, 2 = one array for the whole chip
@@ -116,6 +139,7 @@ struct sar_runtime {
     bool active_pending = false;
     uint32_t active_jobs_launched = 0;
     double survivor_fraction = 1.0;
+    bool survivors_known = false;    // a launch has reported its survivors (until then the fraction is the optimistic default)
     size_t starts_cap = 0;       // doubles
     hipEvent_t starts_copied = nullptr;
     bool starts_pending = false;
@@ -181,14 +205,26 @@ struct sar_runtime {
 
 namespace sar {
 
-// Grows a device buffer (contents are not preserved). cap and need in elements of T.
+// Device / page-locked memory of a runtime: from its own slab / its share of its frame group's page-locked allocation while that
+// lasts (256-byte granules, never reused), from hipMalloc / hipHostMalloc otherwise. dev_free / host_free leave slab memory alone
+// (it goes with the runtime / with the group's last runtime).
+hipError_t dev_alloc_bytes(sar_runtime* rt, void** out, size_t bytes);
+hipError_t host_alloc_bytes(sar_runtime* rt, void** out, size_t bytes);
+void dev_free(sar_runtime* rt, void* p);
+void host_free(sar_runtime* rt, void* p);
 template <typename T>
-int grow_device(T*& ptr, size_t& cap, size_t need) {
+hipError_t dev_alloc(sar_runtime* rt, T** out, size_t bytes) { return dev_alloc_bytes(rt, reinterpret_cast<void**>(out), bytes); }
+template <typename T>
+hipError_t host_alloc(sar_runtime* rt, T** out, size_t bytes) { return host_alloc_bytes(rt, reinterpret_cast<void**>(out), bytes); }
+
+// Grows a device buffer of `rt` (contents are not preserved). cap and need in elements of T.
+template <typename T>
+int grow_device(sar_runtime* rt, T*& ptr, size_t& cap, size_t need) {
     if (need <= cap) return SAR_OK;
-    if (ptr) hipFree(ptr);
+    if (ptr) dev_free(rt, ptr);
     ptr = nullptr;
     cap = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ptr), need * sizeof(T)));
+    HIP_TRY(dev_alloc(rt, &ptr, need * sizeof(T)));
     cap = need;
     return SAR_OK;
 }

@@ -76,4 +76,20 @@ int sar_runtime_set_test_option(sar_runtime* rt, const char* name, uint64_t valu
     return SAR_OK;
 } catch (...) { return sar::abi_caught(); }
 
+// The individual spans a runtime holds (timing_accumulate: one per launch of every render call since they were last read), in
+// launch order: which = 0 iterate, 1 accumulate + fold, 2 warm-up. Synchronises the runtime's stream; clears nothing.
+int sar_runtime_debug_spans(sar_runtime* rt, uint32_t which, float* out_ms, uint32_t cap, uint32_t* out_n) try {
+    if (!rt || !out_n || which > 2u) return SAR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(rt->device));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    const std::vector<Span>& spans = which == 0u ? rt->iter_spans : which == 1u ? rt->fold_spans : rt->warm_spans;
+    const size_t used = which == 0u ? rt->iter_used : which == 1u ? rt->fold_used : rt->warm_used;
+    *out_n = static_cast<uint32_t>(used);
+    for (size_t k = 0; k < used && k < cap && out_ms; ++k) {
+        float ms = 0.f;
+        out_ms[k] = hipEventElapsedTime(&ms, spans[k].a, spans[k].b) == hipSuccess ? ms : -1.f;
+    }
+    return SAR_OK;
+} catch (...) { return sar::abi_caught(); }
+
 }  // extern "C"

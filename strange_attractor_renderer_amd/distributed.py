@@ -1,6 +1,7 @@
 """Multi-GPU glue: one process per GPU, trajectories sharded by rank, Runtime::merge (reference
 src/lib.rs:708-738) folded in rank order (:1068-1076) over xGMI. PyTorch is plumbing here (device buffers, streams,
-torch.distributed == RCCL on ROCm); the arithmetic is in libsar_hip.so behind the C ABI (sar_runtime_exchange_*).
+torch.distributed == RCCL on ROCm); the arithmetic — the plan of the sparse exchange included — is in libsar_hip.so behind the C
+ABI (sar_exchange_*, one context object per runtime and world: api.Exchange).
 
 Two forms of the one exchange step before colorize:
 
@@ -12,10 +13,10 @@ Two forms of the one exchange step before colorize:
     16 B * npix * (world-1)/world out, the same in, + 8 B * npix / world to the root.
 
     SPARSE by default: a frame touches a fifth of its pixels, so only the 64-pixel granules that differ from the reset state
-    travel, as 1 KiB records — the ranks all-gather their granule flags (one byte per granule), every rank derives from
-    them (prefix sums where the flags are, the same on every rank) which records it sends to whom and where the records it
+    travel, as 1 KiB records — the ranks all-gather their granule flags (one byte per granule), every rank's library plans
+    from them (two block scans on the device, the same on every rank) which records it sends to whom and where the records it
     receives sit, and the all-to-all carries split sizes (the only numbers that come to the host: world x 2 record
-    counts). A frame whose flags cover more than half the image goes the dense way.
+    counts, behind ONE wait per frame). A frame whose flags cover more than half the image goes the dense way.
 
 ``exchange_merge`` (rooted, two collectives)
     all-reduce(MAX, int64 keys: sortable(z) << 32 | ~rank) + reduce(SUM, int32[3*npix]: count and the two halves of the
@@ -154,18 +155,19 @@ def _gather(dist, gathered, t, dst, rt):
         dist.gather(h, None, dst=dst)
 
 
-def exchange_merge(rt, rank: int, dist, key_buf, sum_buf, dst: int = 0):
-    """Rooted form: folds every rank's Runtime into rank `dst`'s (rank order == merge order). key_buf: int64[npix],
-    sum_buf: int32[3*npix] torch tensors on the runtime's device. The pack/unpack kernels run on the RUNTIME's stream
+def exchange_merge(ex, dist, key_buf, sum_buf, dst: int = 0):
+    """Rooted form: folds every rank's Runtime into rank `dst`'s (rank order == merge order). ex: the rank's api.Exchange; key_buf:
+    int64[npix], sum_buf: int32[3*npix] torch tensors on the runtime's device. The pack/unpack kernels run on the RUNTIME's stream
     (a non-blocking stream of its own unless set), the collectives on torch's current stream: give the runtime that
     stream first — ``rt.set_stream(torch.cuda.current_stream().cuda_stream)`` — as bench.py does."""
+    rt = ex.runtime
     _require_shared_stream(dist, rt)
-    rt.exchange_export(rank, key_buf.data_ptr())
+    ex.rooted(0, key_buf.data_ptr())
     _all_reduce(dist, key_buf, dist.ReduceOp.MAX, rt)
-    rt.exchange_select(rank, key_buf.data_ptr(), sum_buf.data_ptr())
+    ex.rooted(1, key_buf.data_ptr(), sum_buf.data_ptr())
     _reduce(dist, sum_buf, dst, dist.ReduceOp.SUM, rt)
-    if rank == dst:
-        rt.exchange_import(key_buf.data_ptr(), sum_buf.data_ptr())
+    if ex.rank == dst:
+        ex.rooted(2, key_buf.data_ptr(), sum_buf.data_ptr())
 
 
 class SlicedExchange:
@@ -177,12 +179,13 @@ class SlicedExchange:
     def __init__(self, S_mod, cfg, rt, rank: int, world: int, device, sparse: bool = True, dense_above: float = 0.5):
         import torch
         self.S, self.cfg, self.rt, self.rank, self.world = S_mod, cfg, rt, rank, world
-        self.sparse = sparse and hasattr(rt, "exchange_touched")
+        self.ex = S_mod.Exchange(rt, world, rank)     # the library's context: geometry, plan, pack, fold
+        self.sparse = sparse
         self.dense_above = dense_above   # share of touched segments (over all ranks) above which a frame goes the dense way
         self.last = {"form": None, "records_sent": None}
         w, h = rt.dims()
         self.npix = w * h
-        self.slice_pixels = S_mod.exchange_slice_pixels(self.npix, world)
+        self.slice_pixels = self.ex.slice_pixels
         blk = self.slice_pixels * 16
         self.pack = torch.empty(world * blk, dtype=torch.uint8, device=device)
         self.recv = torch.empty(world * blk, dtype=torch.uint8, device=device)
@@ -191,9 +194,8 @@ class SlicedExchange:
         self.rgba_slice = torch.empty(self.slice_pixels * 8, dtype=torch.uint8, device=device)
         # the root's image: `world` slices back to back (a few pixels of padding after npix)
         self.rgba = torch.empty(world * self.slice_pixels * 8, dtype=torch.uint8, device=device)
-        self.first, self.count = slice_of(self.npix, world, rank, self.slice_pixels)
-        self.nseg = (self.npix + self.SEG - 1) // self.SEG
-        self.sps = self.slice_pixels // self.SEG   # granules per slice (the slice is whole granules)
+        self.first, self.count = self.ex.first, self.ex.count
+        self.nseg = self.ex.granules
         if self.sparse:
             self.flags = torch.empty(self.nseg, dtype=torch.uint8, device=device)
             self.flags_all = torch.empty(world * self.nseg, dtype=torch.uint8, device=device)
@@ -210,49 +212,27 @@ class SlicedExchange:
                         "fraction_of_dense": self.last["records_sent"] * self.RECORD / dense if dense else None})
         return out
 
-    def slot_tables(self, flags_all):
-        """From every rank's granule flags ([world][nseg] bool tensor, wherever it lives): where my records go (send_slot[nseg],
-        owner by owner, granule by granule), how many to each owner, where the records I receive sit (recv_slot[world * sps],
-        source by source) and how many come from each source. The same arithmetic on every rank; prefix sums on the flags' device."""
-        import torch
-        world, sps, rank = self.world, self.sps, self.rank
-        fp = torch.zeros((world, world * sps), dtype=torch.bool, device=flags_all.device)
-        fp[:, : self.nseg] = flags_all
-        mine = fp[rank]
-        minus1 = torch.tensor(-1, dtype=torch.int32, device=fp.device)
-        send_slot = torch.where(mine, (torch.cumsum(mine, 0) - 1).to(torch.int32), minus1)[: self.nseg].contiguous()
-        sub = fp[:, rank * sps:(rank + 1) * sps].reshape(-1)
-        recv_slot = torch.where(sub, (torch.cumsum(sub, 0) - 1).to(torch.int32), minus1).contiguous()
-        counts = torch.cat([mine.reshape(world, sps).sum(dim=1), sub.reshape(world, sps).sum(dim=1), flags_all.sum().reshape(1)]).cpu()  # (the one host copy)
-        return send_slot, [int(c) for c in counts[:world]], recv_slot, [int(c) for c in counts[world:2 * world]], int(counts[-1])
-
     def merge(self, dist):
         """Steps 1-3: after this the runtime holds the merged frame inside its own slice and global scalars."""
-        import torch
-        rt = self.rt
+        rt, ex = self.rt, self.ex
         _require_shared_stream(dist, rt)
-        sparse = self.sparse
-        if sparse:
-            rt.exchange_touched(self.flags.data_ptr())
+        flags_all = None
+        if self.sparse:
+            ex.flags(self.flags.data_ptr())
             _all_gather(dist, self.flags_all, self.flags, rt)
-            flags_all = self.flags_all.reshape(self.world, self.nseg) != 0
-            send_slot, send_counts, recv_slot, recv_counts, touched = self.slot_tables(flags_all)
-            # a frame that covers the image goes the dense way (every rank sees the same flags, so every rank decides alike)
-            sparse = touched <= self.dense_above * self.world * self.nseg
+            flags_all = self.flags_all.data_ptr()
+        # the plan (which records go where: two scans on the device), the choice between sparse and dense (every rank holds the same
+        # flags and decides alike) and the packing are the library's; the split sizes are the one thing the host waits for
+        sparse, send_bytes, recv_bytes = ex.pack(flags_all, self.dense_above, self.pack.data_ptr())
         if sparse:
-            self._slots = (send_slot, recv_slot)   # (alive until the kernels that read them have run)
-            rt.exchange_pack_sparse(send_slot.data_ptr(), self.pack.data_ptr())
-            _all_to_all_v(dist, self.recv, self.pack, [c * self.RECORD for c in recv_counts], [c * self.RECORD for c in send_counts], rt)
-            rt.exchange_merge_sparse(self.world, self.rank, recv_slot.data_ptr(), self.recv.data_ptr())
-            self.last = {"form": "sparse", "records_sent": sum(send_counts) - send_counts[self.rank]}
+            _all_to_all_v(dist, self.recv, self.pack, recv_bytes, send_bytes, rt)
+            self.last = {"form": "sparse", "records_sent": (sum(send_bytes) - send_bytes[self.rank]) // self.RECORD}
         else:
-            rt.exchange_pack(self.world, self.pack.data_ptr())
             _all_to_all(dist, self.recv, self.pack, rt)
-            rt.exchange_merge_slices(self.world, self.rank, self.recv.data_ptr())
             self.last = {"form": "dense", "records_sent": None}
-        rt.exchange_scalars_export(self.scalars.data_ptr())
+        ex.merge(self.recv.data_ptr(), self.scalars.data_ptr())
         _all_reduce(dist, self.scalars, dist.ReduceOp.MAX, rt)
-        rt.exchange_scalars_import(self.scalars.data_ptr())
+        ex.finish(self.scalars.data_ptr())
 
     def colorize(self, dist, dst: int = 0):
         """Step 4: every rank colorizes its slice; the root gathers the image (the first npix*8 bytes of self.rgba there)."""

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import math
 import os
+import time
 from typing import Callable, Iterator
 
 import numpy as np
@@ -69,35 +70,38 @@ SETTLE = 1  # stream synchronisations a new runtime's first frames are waited fo
 
 class SequenceRenderer:
     """What a `sequence` sweep keeps between frames: the job split of one ParallelRenderer, `lanes` groups of runtimes (each
-    group on its own stream) used in turn, and a ring of page-locked host images the converted frames are read back into.
+    a frame group of the library: one stream, one allocation per runtime) used in turn, and a ring of page-locked host images the
+    converted frames are read back into.
     A group renders a BATCH of consecutive frames per turn — `batch` frames through one set of launches
     (sar_render_jobs_batch): 0 = as many as fill the chip (asked of the library before every batch, at most `max_batch`),
     1 = a frame per launch. One object can render several sweeps (`run`); `close` frees the device and page-locked memory."""
 
     def __init__(self, config: "api.Config", *, units: int = 0, jobs_per_thread: int = 12, seed: int = 0, device: int = 0,
                  image_format: int | None = None, ring: int = 0, lanes: int = 0, batch: int = 0, max_batch: int = 16,
-                 device_ring: list | None = None, options: dict | None = None):
+                 device_ring: list | None = None, options: dict | None = None, delivery: str = "batch"):
         """device_ring: device pointers of width*height*8-byte buffers — the frames are then left there as RGBA16 (colorize
         only, src/lib.rs:841: what SURVEY 8(d)'s metric ends with) instead of being converted and read back; sinks receive None."""
         if lanes < 0:
             raise ValueError("lanes must be at least 1 (0: automatic)")
-        # lanes 0: ONE lane of batches when the frames are read back (the read-back runs on the lane's copy stream under the
-        # next batch anyway, and a second lane's streams only crowd the process's few hardware queues: 0.73 against 0.79 ms per
-        # frame of configs[4]), two when they stay in device memory (0.60 against 0.65)
-        lanes = lanes or (2 if device_ring else 1)
         if batch < 0 or max_batch < 1:
             raise ValueError("batch must be >= 0 and max_batch >= 1")
-        self.max_batch = batch if batch else max_batch
-        ring = ring or (lanes + 1) * self.max_batch + 1
-        if ring < lanes + 1:
+        if ring and ring < (lanes or 1) + 1:
             raise ValueError("ring must be at least lanes + 1")
-        # a frame keeps its host image until it is delivered, `lanes` batches after it was enqueued
-        self.max_batch = max(1, min(self.max_batch, ring // (lanes + 1)))
+        # lanes, ring and the batch size are settled by the first run (_setup): whether frames of this shape share launches at all
+        # is the library's to say
+        if delivery not in ("frame", "batch"):
+            raise ValueError("delivery must be 'frame' or 'batch'")
+        # "batch": a batch's frames are delivered together, once the next batch is enqueued (ring: lanes + 1 batches of images).
+        # "frame": each frame right before the read-back that takes its place in the ring (ring: lanes batches + 1 — half the
+        # page-locked memory; measured: 1.7 instead of 1.4 ms per frame on the box of the A/B, the read-backs start later)
+        self.delivery = delivery
+        self.want_lanes, self.want_ring, self.want_max_batch = lanes, ring, batch if batch else max_batch
+        self.lanes = self.ring = self.max_batch = 0
         self.batch = batch
         self.device_ring = list(device_ring) if device_ring else None
         self.resync = bool(int(os.environ.get("SAR_SEQ_RESYNC", "0")))   # experiment
         self.options = dict(options or {})                         # runtime options (sar_runtime_set_option) of every runtime made here
-        self.config, self.seed, self.device, self.lanes, self.ring = config, seed, device, lanes, ring
+        self.config, self.seed, self.device = config, seed, device
         self.fmt = api._abi.SAR_FMT_RGBA16 if image_format is None else image_format
         renderer = api.ParallelRenderer(device=device, units=units, seed=seed)
         try:
@@ -106,46 +110,76 @@ class SequenceRenderer:
             renderer.shutdown()
         self.total_jobs = T * jobs_per_thread
         self.per_job = config.iterations // T // jobs_per_thread   # src/lib.rs:1058
-        self.groups: list = []                                     # per lane: its runtimes (the first one's stream is the group's)
+        self.groups: list = []                                     # per lane: its runtimes (one frame group: one stream)
         self.settle: dict = {}                                     # stream synchronisations done per group (see run)
         self.images: list = []
         self.busy: list = []                                       # per host image: what its last consumer returned
         self.next_slot = 0
         self.frames_per_launch: list = []                          # statistic: the batch sizes of the last run
+        self.first_enqueued_at = None                              # statistic: time.perf_counter() when the last run's first batch was enqueued
+
+    def _setup(self, cfg: "api.Config"):
+        """Lanes, ring and batch size, once the shape of a frame is known. Frames that cannot share launches (beyond 4 Mpx, jobs of
+        several launch chunks: the library answers 1) go frame by frame on two lanes with a ring of lanes + 2 images — ONE runtime
+        per lane, not a batch of them. Otherwise: ONE lane of batches when the frames are read back (the read-back runs on the lane's
+        copy stream under the next batch anyway, and a second lane's streams only crowd the process's few hardware queues: 0.73
+        against 0.79 ms per frame of configs[4]), two when they stay in device memory (0.60 against 0.65)."""
+        if self.lanes:
+            return
+        batching = self.want_max_batch > 1 and (self.batch > 1 or api.batch_frames(cfg, None) > 1)
+        if not batching:
+            self.lanes = self.want_lanes or 2
+            self.max_batch = 1
+            self.ring = self.want_ring or self.lanes + 2
+        else:
+            self.lanes = self.want_lanes or (2 if self.device_ring else 1)
+            self.max_batch = self.want_max_batch
+            # a frame keeps its host image from the enqueue of its read-back until it is delivered, `lanes` batches later — frame by
+            # frame, each delivery right before the read-back that takes its place in the ring (page-locking an image costs 1-3 ms:
+            # a ring of two batches per lane was 100 ms of a cold sweep, and half of it never held two frames at once)
+            per_lane = self.lanes + (1 if self.delivery == "batch" else 0)
+            self.ring = self.want_ring or per_lane * self.max_batch + 1
+            self.max_batch = max(1, min(self.max_batch, (self.ring - 1) // per_lane))
+        if self.ring < self.lanes + 1:
+            raise ValueError("ring must be at least lanes + 1")
 
     def frame_config(self, angle: float) -> "api.Config":
         return self.config.replace(angle=angle, jobs_total=self.total_jobs, iterations=self.per_job * self.total_jobs,
                                    seed=self.seed)
 
     def _group(self, g: int, n: int, cfg: "api.Config") -> list:
-        """The first n runtimes of lane g, all on the stream of the lane's first runtime."""
-        if not self.groups:
-            # The lanes' streams first, one after the other: the HIP runtime deals streams to its few hardware queues in the order
-            # they are first used, and two lanes that share a queue do not overlap at all (measured: 0.8 instead of 0.6 ms per
-            # frame — and every other runtime made in between moves the second lane's stream onto another queue).
-            self.groups = [[self._runtime(cfg)] for _ in range(self.lanes)]
-        grp = self.groups[g]
-        while len(grp) < n:
-            rt = self._runtime(cfg)
-            rt.share_streams(grp[0])
-            grp.append(rt)
-        return grp[:n]
-
-    def _runtime(self, cfg: "api.Config"):
-        rt = api.Runtime(cfg, device=self.device)
-        for name, value in self.options.items():
-            rt.set_option(name, value)
-        return rt
+        """The first n runtimes of lane g. A lane of batches is ONE frame group (sar_runtime_new_group): one stream, one read-back
+        stream, one device and one page-locked allocation for all its runtimes — built when the lane is first used, lane 1's
+        while lane 0's first batch renders."""
+        while len(self.groups) <= g:
+            # (the lanes' streams are made in lane order: the HIP runtime deals streams to its few hardware queues in the order
+            # they are first used, and two lanes that share a queue do not overlap at all — 0.8 instead of 0.6 ms per frame)
+            if self.max_batch > 1:
+                grp = api.Runtime.group(cfg, self.max_batch, self.device)
+            else:
+                grp = [api.Runtime(cfg, device=self.device)]
+            for rt in grp:
+                for name, value in self.options.items():
+                    rt.set_option(name, value)
+            self.groups.append(grp)
+        return self.groups[g][:n]
 
     def _batch_size(self, g: int, cfg: "api.Config", left: int) -> int:
         f = self.batch
-        if f == 0:
-            grp = self.groups[g] if self.groups else None
+        if f == 0 and self.max_batch > 1:
+            grp = self.groups[g] if len(self.groups) > g else None
             # the library counts the wave pairs the chip holds against the jobs that survived the last launch's warm-up
-            f = api.batch_frames(cfg, grp[0]) if grp else self.max_batch
-        f = max(1, min(f, self.max_batch))
-        f = f // 8 * 8 if f >= 8 else (4 if f >= 4 else f)       # the sizes whose frames the library deals to the XCDs
-        return min(f, left)
+            f = api.batch_frames(cfg, grp[0] if grp else None)
+        f = max(1, min(f or 1, self.max_batch))
+        return min(f, left)                                       # (any number of frames is dealt to the XCDs: a sweep's tail too)
+
+    def _image(self, slot: int, cfg: "api.Config"):
+        """Host image `slot`, page-locked at its first use, on this thread: a helper thread that locks pages ahead contends with
+        every other HIP call of the process (measured: the sweep got slower), and the GPU is busy with the batch's render meanwhile."""
+        while len(self.images) <= slot:
+            self.images.append(api.HostImage(cfg.c.width, cfg.c.height, self.fmt))
+            self.busy.append(None)
+        return self.images[slot]
 
     def run(self, todo: list[tuple[int, float, str]],
             sink: Callable[[int, str, np.ndarray], object] | None = None, zero_copy: bool = False) -> list[tuple[int, str, np.ndarray]]:
@@ -157,7 +191,6 @@ class SequenceRenderer:
         self.frames_per_launch = []
         if not todo:
             return out
-        images, busy, ring, lanes = self.images, self.busy, self.ring, self.lanes
         # the next batch's start points (~1 ms of host time per 2e5 jobs: half as long as a frame renders) are drawn on helper
         # threads while the GPU works on the current one (the ctypes call releases the GIL)
         pool = ThreadPoolExecutor(max_workers=3)
@@ -195,11 +228,18 @@ class SequenceRenderer:
                 out.append((k, name, np.array(images[slot].array)))
 
         try:
-            in_flight = deque()                                   # batches: lists of (lane, runtime, slot, ticket, k, name)
+            waiting = deque()                                     # frames enqueued and not yet delivered: (batch, lane, runtime, slot, ticket, k, name, first)
             pos, turn = 0, 0
             cfg0 = self.frame_config(todo[0][1])
+            self._setup(cfg0)
+            images, busy, ring, lanes = self.images, self.busy, self.ring, self.lanes
             size = self._batch_size(0, cfg0, len(todo))
             pending = draw([k for k, _, _ in todo[:size]])
+
+            def deliver_one():
+                fr = waiting.popleft()
+                deliver(*fr[1:7], first_of_batch=fr[7])
+
             while pos < len(todo):
                 g = turn % lanes
                 part = todo[pos:pos + size]
@@ -216,31 +256,32 @@ class SequenceRenderer:
                     api.render_jobs_batch(cfgs, rts, starts)
                 else:
                     api.render_jobs(cfgs[0], rts[0], starts[0])
+                if not self.frames_per_launch:
+                    self.first_enqueued_at = time.perf_counter()  # statistic: everything before this was set-up
                 self.frames_per_launch.append(len(part))
-                batch = []
-                for (k, _, name), cfg, rt in zip(part, cfgs, rts):
+                for i, ((k, _, name), cfg, rt) in enumerate(zip(part, cfgs, rts)):
+                    # the frame `lanes` batches back, while the GPU is busy with the later ones: one delivery per read-back enqueued
+                    if self.delivery == "frame" and waiting and waiting[0][0] <= turn - lanes:
+                        deliver_one()
                     slot = self.next_slot % ring
                     self.next_slot += 1
+                    while any(fr[3] == slot for fr in waiting):   # (a ring smaller than the frames in flight: deliver until the slot is free)
+                        deliver_one()
                     if self.device_ring is not None:
                         api.colorize_device(cfg, rt, self.device_ring[slot % len(self.device_ring)])
-                        batch.append((g, rt, slot, 0, k, name))
+                        waiting.append((turn, g, rt, slot, 0, k, name, i == 0))
                         continue
-                    while len(images) <= slot:
-                        images.append(api.HostImage(cfg.c.width, cfg.c.height, self.fmt))
-                        busy.append(None)
+                    self._image(slot, cfg)
                     if hasattr(busy[slot], "result"):             # the consumer of the frame that last used this image
                         busy[slot].result()
                     busy[slot] = None
                     ticket = api.colorize_format_async(cfg, rt, images[slot])  # :1080
-                    batch.append((g, rt, slot, ticket, k, name))
-                in_flight.append(batch)
+                    waiting.append((turn, g, rt, slot, ticket, k, name, i == 0))
+                while waiting and waiting[0][0] <= turn - lanes:  # (a longer batch than this one `lanes` back: the rest of it)
+                    deliver_one()
                 turn += 1
-                if len(in_flight) > lanes:                        # the batch `lanes` back, while the GPU is busy with the later ones
-                    for i, fr in enumerate(in_flight.popleft()):
-                        deliver(*fr, first_of_batch=i == 0)
-            while in_flight:
-                for i, fr in enumerate(in_flight.popleft()):
-                    deliver(*fr, first_of_batch=i == 0)
+            while waiting:
+                deliver_one()
             for i, b in enumerate(busy):
                 if hasattr(b, "result"):
                     b.result()
@@ -259,9 +300,10 @@ class SequenceRenderer:
         for im in self.images:
             im.close()
         for grp in self.groups:
-            for rt in reversed(grp):                              # the group's stream belongs to its first runtime: freed last
+            for rt in reversed(grp):
                 rt.close()
         self.groups, self.images, self.busy, self.settle = [], [], [], {}
+        self.next_slot = 0
 
     def __enter__(self):
         return self
@@ -287,13 +329,13 @@ def render_sequence(config: "api.Config", start: float, end: float, step: float,
     (each has its own Runtime state, :950-951 resets it), so with two lanes the GPU fills one frame's latency-bound parts
     (the 1000-iteration warm-up of a few waves per SIMD, the kernel tails, the read-back on the copy engine) with the other
     frame's arithmetic. A sink receives its own copy of the frame (as every frame was a fresh array before the images were
-    recycled). With `zero_copy` it receives a VIEW of one of the `ring` page-locked images instead: frame k + ring's
-    read-back is enqueued before frame k + ring - lanes is delivered, so the view stays valid for `ring - lanes - 1` further
-    deliveries (ONE with the default ring of lanes + 2) — or, when the sink returns an object with `.result()` (a Future of
-    its consumer), until that has returned, which the loop waits for before it reuses the image. `batch` consecutive frames go
-    through ONE set of launches (sar_render_jobs_batch; 0 = as many as fill the chip, at most `max_batch`; 1 = a frame per
-    launch) — a frame of 65 536 jobs fills a third of an MI355X — and a lane's turn is then a batch. ring 0 = (lanes + 1) *
-    max_batch + 1; a smaller ring caps the batch at ring // (lanes + 1)."""
+    recycled). With `zero_copy` it receives a VIEW of one of the `ring` page-locked images instead; the image is written again
+    when the frame `ring` later is read back, which is enqueued once the frames up to `lanes` batches before THAT one are delivered —
+    with the default ring the view stays valid until the next delivery but one, or, when the sink returns an object with
+    `.result()` (a Future of its consumer), until that has returned, which the loop waits for before it reuses the image. `batch`
+    consecutive frames go through ONE set of launches (sar_render_jobs_batch; 0 = as many as fill the chip, at most `max_batch`;
+    1 = a frame per launch) — a frame of 65 536 jobs fills a third of an MI355X — and a lane's turn is then a batch. ring 0 = lanes *
+    max_batch + 1 (a frame per launch: lanes + 2); a smaller ring caps the batch at (ring - 1) // lanes."""
     todo = [(k, a, f) for (k, a, f) in frames(start, end, step, file_name) if k % world == rank]
     if not todo:
         return []
@@ -326,6 +368,6 @@ def render_sequence_to_files(config: "api.Config", start: float, end: float, ste
             return f                                  # the page-locked image is reused only after its file is written
 
         lanes_ = kw.get("lanes", 0) or 1
-        kw.setdefault("ring", max(1, encoders) + (lanes_ + 1) * (kw.get("batch", 0) or kw.get("max_batch", 16)) + 1)
+        kw.setdefault("ring", max(1, encoders) + lanes_ * (kw.get("batch", 0) or kw.get("max_batch", 16)) + 1)
         render_sequence(config, start, end, step, file_name=file_name, image_format=fmt, sink=sink, zero_copy=True, **kw)  # the encoder's Future guards the view
         return [f.result() for f in pending]

@@ -357,3 +357,18 @@ def test_checksum_is_the_oracles_fnv1a64_and_bench_extras_read_the_goldens(sar, 
     buf = C.create_string_buffer(64)
     if sar.device_count() == 0:
         assert sar.load_library().sar_device_pci_bus_id(0, buf, 64) != 0
+
+
+def test_batch_frames_answers_one_where_frames_cannot_share_launches():
+    """sar_runtime_batch_frames makes the test sar_render_jobs_batch makes (host arithmetic; rt == NULL: a runtime yet to be made):
+    frames beyond 4 Mpx (bins of 65 536 pixels), of several launch chunks or on the one-atomic-per-visit path render one after
+    the other — the caller builds ONE runtime per lane for them, not a batch of runtimes."""
+    import strange_attractor_renderer_amd as S
+    c5 = S.Config.solar_sail(iterations=100_000_000, width=1800, height=2000, scale=1.0, jobs_total=65536)
+    assert S.batch_frames(c5) == 16                                     # no launch has reported its survivors yet: two frames per XCD
+    c2 = S.Config.poisson_saturne(iterations=1_000_000_000, width=2048, height=2048, jobs_total=131072)
+    assert S.batch_frames(c2) in (8, 16)
+    assert S.batch_frames(c2.replace(width=4096, height=4096)) == 1     # bins of 65 536 pixels: packed counters, no batched kernel
+    assert S.batch_frames(c2.replace(width=9000, height=9000)) == 1     # 81 Mpx: one global atomic per visit
+    assert S.batch_frames(c2.replace(jobs_total=16, iterations=16 * (1 << 33))) == 1   # jobs of several segments
+    assert S.batch_frames(c2.replace(iterations=400_000_000_000, jobs_total=1 << 22)) == 1   # several launch chunks (the 24 GiB scratch cap)

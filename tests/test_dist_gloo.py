@@ -3,9 +3,9 @@ MAX of depth keys + reduce SUM of counts / steps halves) and SlicedExchange / ex
 slices, merge in rank order, scalar all-reduce, sharded colorize, gather) — reproduces Runtime::merge folded in rank order
 (reference src/lib.rs:708-738, 1068-1076), and job sharding covers every job once.
 
-There is no HIP device here, so the Runtime handed to distributed.py is a numpy stand-in for the six exchange kernels of
-csrc/sar_image.hip (k_exch_export / _select / _import, k_exch_pack / _merge_slices / scalars) working on the same raw
-buffers through the same pointers; the oracle stands in for the renderer. The process groups, the collectives, the
+There is no HIP device here, so the Runtime and the exchange context handed to distributed.py are numpy stand-ins for the
+exchange kernels of csrc/sar_image.hip (k_exch_export / _select / _import, k_exch_pack / _merge_slices / scalars, k_exch_flags /
+_plan / _pack_sparse / _merge_sparse) working on the same raw buffers through the same pointers; the oracle stands in for the renderer. The process groups, the collectives, the
 buffer geometry and the call sequence are the real ones; the HIP kernels run through the very same distributed.py
 calls in tests/test_gpu_dist.py (-m gpu)."""
 import ctypes
@@ -171,9 +171,67 @@ class NumpyRuntime:
         self.zmin = int(~np.uint32(v[3]) & 0xFFFFFFFF)
 
 
+class NumpyExchange:
+    """api.Exchange (the library's context object, csrc/sar_exchange.cpp) over a NumpyRuntime: the same geometry, the plan of the
+    sparse form (k_exch_plan: where each of my records goes, where each record I receive arrives, the split sizes), the choice
+    between sparse and dense, and the kernels' stand-ins above."""
+
+    def __init__(self, rt, world, rank):
+        self.runtime, self.world, self.rank = rt, world, rank
+        self.slice_pixels = rt._slice_pixels(rt.npix, world)
+        self.first = min(rt.npix, rank * self.slice_pixels)
+        self.count = min(rt.npix, self.first + self.slice_pixels) - self.first
+        self.granules = (rt.npix + rt.SEG - 1) // rt.SEG
+        self.block_bytes = world * self.slice_pixels * 16
+        self._sparse = False
+
+    def flags(self, ptr):
+        self.runtime.exchange_touched(ptr)
+
+    def pack(self, flags_all_ptr, dense_above, send_ptr):
+        world, rank, nseg, sps = self.world, self.rank, self.granules, self.slice_pixels // self.runtime.SEG
+        sparse = False
+        if flags_all_ptr:
+            fa = _at(flags_all_ptr, np.uint8, world * nseg).reshape(world, nseg) != 0
+            sparse = int(fa.sum()) <= dense_above * world * nseg
+        self._sparse = sparse
+        if not sparse:
+            self.runtime.exchange_pack(world, send_ptr)
+            return False, [self.slice_pixels * 16] * world, [self.slice_pixels * 16] * world
+        fp = np.zeros((world, world * sps), bool)
+        fp[:, :nseg] = fa
+        mine = fp[rank]
+        send_slot = np.where(mine, np.cumsum(mine) - 1, -1).astype(np.int32)[:nseg]
+        sub = fp[:, rank * sps:(rank + 1) * sps].reshape(-1)
+        self._recv_slot = np.where(sub, np.cumsum(sub) - 1, -1).astype(np.int32)
+        self.runtime.exchange_pack_sparse(np.ascontiguousarray(send_slot).ctypes.data, send_ptr)
+        rec = self.runtime.SEG * 16
+        return True, [int(c) * rec for c in mine.reshape(world, sps).sum(axis=1)], [int(c) * rec for c in sub.reshape(world, sps).sum(axis=1)]
+
+    def merge(self, recv_ptr, scalars_ptr):
+        if self._sparse:
+            self.runtime.exchange_merge_sparse(self.world, self.rank, self._recv_slot.ctypes.data, recv_ptr)
+        else:
+            self.runtime.exchange_merge_slices(self.world, self.rank, recv_ptr)
+        self.runtime.exchange_scalars_export(scalars_ptr)
+
+    def finish(self, scalars_ptr):
+        self.runtime.exchange_scalars_import(scalars_ptr)
+
+    def rooted(self, step, key_ptr, sum_ptr=0):
+        if step == 0:
+            self.runtime.exchange_export(self.rank, key_ptr)
+        elif step == 1:
+            self.runtime.exchange_select(self.rank, key_ptr, sum_ptr)
+        else:
+            self.runtime.exchange_import(key_ptr, sum_ptr)
+
+
 class NumpyApi:
-    """The two api.* functions SlicedExchange calls, for a NumpyRuntime: slice geometry from the real library (a host
-    function), colorize through the oracle with the GLOBAL max."""
+    """The api.* names SlicedExchange uses, for a NumpyRuntime: the exchange context above (slice geometry from the real library, a
+    host function), colorize through the oracle with the GLOBAL max."""
+
+    Exchange = NumpyExchange
 
     def __init__(self, O, S):
         self.O, self.S = O, S
@@ -211,7 +269,7 @@ def _worker(rank, world, port, W, H, jobs, n, seed, mode, q, scale=1.0):
     if mode == "rooted":
         key = torch.empty(npix, dtype=torch.int64)
         sums = torch.empty(3 * npix, dtype=torch.int32)
-        D.exchange_merge(rt, rank, dist, key, sums, dst=0)          # the real function, real collectives
+        D.exchange_merge(NumpyExchange(rt, world, rank), dist, key, sums, dst=0)   # the real function, real collectives
         if rank == 0:
             q.put((rt.count.reshape(H, W).copy(), unsortable(rt.z).reshape(H, W).copy(), rt.steps.reshape(H, W).copy(), rt.max, None))
     else:

@@ -53,10 +53,12 @@ def _oracle_state(oracle, cfg, starts, n, ort=None):
 @pytest.mark.parametrize("preset,kind", [("solar_sail", 0), ("solar_sail", 1), ("poisson_saturne", 0)])
 @pytest.mark.parametrize("shared_stream,F,options", [(False, 6, {}), (True, 6, {"batch_warm": 2}), (True, 8, {"batch_warm": 2, "hint_bits": 16}),
                                                       (True, 4, {"batch_starts": 1}), (False, 2, {"batch_starts": 2, "batch_xcd": 1}),
-                                                      (True, 16, {}), (True, 24, {"batch_warm": 2})])
+                                                      (True, 16, {}), (True, 24, {"batch_warm": 2}), (True, 13, {}), (False, 3, {}),
+                                                      (True, 11, {"batch_warm": 2, "hint_bits": 16})])
 def test_batched_sweep_equals_per_frame_renders_and_oracle(sar, oracle, gpu, preset, kind, shared_stream, F, options):
-    """F frames in one set of launches — frames dealt to the XCDs (2, 4, 8, 16) or one after the other (6), the warm-up in one or
-    two phases, the start points read in place or copied, the runtimes on one stream or on their own."""
+    """F frames in one set of launches — frames dealt to the XCDs (2, 4, 8: XCDs per frame; 16, 24: frames per XCD; 3, 6, 11, 13:
+    eight equal runs of wave pairs, what a sweep's tail is) or every frame everywhere (batch_xcd 1), the warm-up in one or two
+    phases, the start points read in place or copied, the runtimes on one stream or on their own."""
     W, H, jobs, n = 600, 500, 4096, 300
     cfgs, starts = _frames(sar, preset, kind, F, W, H, jobs, n, seed=11)
     rts = [sar.Runtime(c) for c in cfgs]
@@ -67,6 +69,8 @@ def test_batched_sweep_equals_per_frame_renders_and_oracle(sar, oracle, gpu, pre
         rts[0].set_option(k, v)
     sar.render_jobs_batch(cfgs, rts, starts)
     assert f"batch of {F} frames" in rts[0].describe_last_launch() and "k_iterate_split" in rts[F - 1].describe_last_launch()
+    want_map = 0 if options.get("batch_xcd") == 1 else (1 if F in (2, 4, 8) else (2 if F % 8 == 0 else 3))
+    assert f"(xcd map {want_map})" in rts[0].describe_last_launch(), rts[0].describe_last_launch()
     differ = 0
     for i, (cfg, rt, st) in enumerate(zip(cfgs, rts, starts)):
         got = _state(sar, cfg, rt)
@@ -289,3 +293,65 @@ def test_batch_after_an_announced_frame_nobody_rendered(sar, oracle, gpu):
     _assert_same(_state(sar, cfgs[2], rt), _oracle_state(oracle, cfgs[2], starts[2], n)[1], "an announced frame after the batch")
     for rt in reversed(rts):
         rt.close()
+
+
+def test_a_45_frame_sweep_in_batches_of_16_16_13_equals_per_frame_renders_and_oracle(sar, oracle, gpu):
+    """BASELINE configs[4] at 8 GPUs is 45 frames per GPU (src/bin/main.rs:107-176: 360 frames; frame k -> GPU k mod 8): batches of 16,
+    16 and a tail of 13, the tail dealt to the XCDs like the full batches (xcd map 3), on the runtimes of ONE frame group — every
+    frame bit for bit the frame-per-launch sweep's, and the oracle's."""
+    from strange_attractor_renderer_amd.sequence import SequenceRenderer, frames, render_sequence
+    cfg = sar.Config.solar_sail(iterations=700_000, width=360, height=280, scale=1.0, transparent=0)
+    kw = dict(units=320, jobs_per_thread=4, seed=33)
+    todo = [f for f in frames(0.0, 360.0, 1.0) if f[0] % 8 == 3]                    # rank 3 of 8: frames 3, 11, ..., 355
+    assert len(todo) == 45
+    with SequenceRenderer(cfg, batch=16, **kw) as seq:
+        got = seq.run(todo)
+        assert seq.frames_per_launch == [16, 16, 13]
+        assert len(seq.groups) == 1 and len(seq.groups[0]) == 16
+        assert "batch of 13 frames (xcd map 3)" in seq.groups[0][0].describe_last_launch()
+    with SequenceRenderer(cfg, batch=1, lanes=1, **kw) as seq:
+        want = seq.run(todo)
+        assert seq.frames_per_launch == [1] * 45 and seq.ring == 3
+    assert [k for k, _, _ in got] == [k for k, _, _ in todo]
+    for (k, name, img), (wk, wname, w) in zip(got, want):
+        assert (k, name) == (wk, wname)
+        np.testing.assert_array_equal(img, w)
+    n, jobs = 700_000 // 320 // 4, 1280
+    for i in (0, 15, 16, 31, 32, 38, 44):                                          # the edges of the three batches
+        k = todo[i][0]
+        c = cfg.replace(angle=k * math.pi / 180.0, jobs_total=jobs, iterations=n * jobs)
+        _, o = _oracle_state(oracle, c, oracle.start_points(frame_seed(33, k), 0, jobs), n)
+        np.testing.assert_array_equal(got[i][2], o[4])
+
+
+def test_runtimes_of_a_frame_group_are_ordinary_runtimes(sar, oracle, gpu):
+    """sar_runtime_new_group: one stream, one slab — and every member renders alone, is resized, reset and freed like any runtime
+    (in any order; the group's allocations go with the last one)."""
+    W, H, jobs, n = 300, 200, 700, 257
+    cfgs, starts = _frames(sar, "solar_sail", 1, 5, W, H, jobs, n, seed=3)
+    rts = sar.Runtime.group(cfgs[0], 5)
+    assert len({rt.stream() for rt in rts}) == 1 and len({rt.copy_stream() for rt in rts}) == 1
+    for i in (4, 0, 2):                                                           # alone, frame per launch
+        sar.render_jobs(cfgs[i], rts[i], starts[i])
+        assert "batch" not in rts[i].describe_last_launch()
+        _assert_same(_state(sar, cfgs[i], rts[i]), _oracle_state(oracle, cfgs[i], starts[i], n)[1], f"group member {i} alone")
+    for rt in rts:
+        rt.reset()
+    sar.render_jobs_batch(cfgs, rts, starts)                                      # together
+    assert "batch of 5 frames (xcd map 3)" in rts[0].describe_last_launch() and "/chip" in rts[0].describe_last_launch()
+    for i in range(5):
+        _assert_same(_state(sar, cfgs[i], rts[i]), _oracle_state(oracle, cfgs[i], starts[i], n)[1], f"group member {i} in a batch")
+    rts[1].close()                                                                # a member leaves; the others go on
+    big = cfgs[3].replace(width=700, height=500)                                  # a member outgrows its share of the slab
+    rts[3].set_width_height(700, 500)
+    sar.render_jobs(big, rts[3], starts[3])
+    _assert_same(_state(sar, big, rts[3]), _oracle_state(oracle, big, starts[3], n)[1], "group member 3, resized")
+    rts[0].reset()
+    sar.render_jobs(cfgs[0], rts[0], starts[0])
+    _assert_same(_state(sar, cfgs[0], rts[0]), _oracle_state(oracle, cfgs[0], starts[0], n)[1], "group member 0 after a neighbour left")
+    for i in (0, 3, 4, 2):
+        rts[i].close()
+    one = sar.Runtime(cfgs[2])                                                    # and the device still works afterwards
+    sar.render_jobs(cfgs[2], one, starts[2])
+    _assert_same(_state(sar, cfgs[2], one), _oracle_state(oracle, cfgs[2], starts[2], n)[1], "after the group")
+    one.close()

@@ -54,7 +54,7 @@ def _worker(rank, world, port, preset, W, H, kind, jobs, n, seed, mode, q):
         if mode == "rooted":
             key = torch.empty(npix, dtype=torch.int64, device="cuda")
             sums = torch.empty(3 * npix, dtype=torch.int32, device="cuda")
-            D.exchange_merge(rt, rank, dist, key, sums, dst=0)
+            D.exchange_merge(S.Exchange(rt, world, rank), dist, key, sums, dst=0)
             if rank == 0:
                 q.put(("rooted", rt.count(), rt.zbuf(), rt.steps(), rt.max(), S.colorize(cfg, rt)))
         else:
@@ -300,7 +300,7 @@ def _nccl_rank_all_gpus(rank, world, port, W, H, jobs, n, seed, form, q):
         else:
             key = torch.empty(W * H, dtype=torch.int64, device="cuda")
             sums = torch.empty(3 * W * H, dtype=torch.int32, device="cuda")
-            D.exchange_merge(rt, rank, dist, key, sums, dst=0)
+            D.exchange_merge(S.Exchange(rt, world, rank), dist, key, sums, dst=0)
             torch.cuda.synchronize()
             if rank == 0:
                 q.put(("image", S.colorize(cfg, rt)))
@@ -377,7 +377,7 @@ def _nccl_single_rank(port, W, H, jobs, n, seed, q):
         key = torch.empty(W * H, dtype=torch.int64, device="cuda")
         sums = torch.empty(3 * W * H, dtype=torch.int32, device="cuda")
         before = rt.count().copy()
-        D.exchange_merge(rt, 0, dist, key, sums, dst=0)        # rooted form over RCCL
+        D.exchange_merge(S.Exchange(rt, 1, 0), dist, key, sums, dst=0)        # rooted form over RCCL
         torch.cuda.synchronize()
         q.put((np.array_equal(got, want), np.array_equal(rt.count(), before), np.array_equal(S.colorize(cfg, rt), want), loud))
         rt.close()

@@ -454,19 +454,22 @@ def test_exchange_kernels_reproduce_merge_in_rank_order(sar, oracle, gpu):
     npix = w * h
     keys = [torch.empty(npix, dtype=torch.int64, device="cuda") for _ in range(world)]
     torch.cuda.synchronize()
+    exs = [sar.Exchange(rts[r], world, r) for r in range(world)]
     for r in range(world):
-        rts[r].exchange_export(r, keys[r].data_ptr())
+        exs[r].rooted(0, keys[r].data_ptr())
         rts[r].synchronize()
     red = torch.stack(keys).max(dim=0).values.contiguous()          # all-reduce MAX
     torch.cuda.synchronize()  # torch's stream before the runtimes' streams
     sums = [torch.empty(3 * npix, dtype=torch.int32, device="cuda") for _ in range(world)]
     for r in range(world):
-        rts[r].exchange_select(r, red.data_ptr(), sums[r].data_ptr())
+        exs[r].rooted(1, red.data_ptr(), sums[r].data_ptr())
         rts[r].synchronize()
     total = torch.stack(sums).sum(dim=0, dtype=torch.int32).contiguous()   # reduce SUM (wrapping int32)
     torch.cuda.synchronize()
-    rts[0].exchange_import(red.data_ptr(), total.data_ptr())
+    exs[0].rooted(2, red.data_ptr(), total.data_ptr())
     rts[0].synchronize()
+    for ex in exs:
+        ex.close()
     acc = orts[0]
     for other in orts[1:]:
         assert oracle.merge(acc, other) == 0

@@ -1,0 +1,141 @@
+"""BASELINE configs[4] at the shape BASELINE states it: ONE cold `sequence --start 0 --end 360 --step 1` sweep (reference
+src/bin/main.rs:107-176 frames, :493-517 loop), 360 / N frames per GPU — wall time from the construction of the SequenceRenderer
+to the last delivered frame, with the host-side time of every kind of call on the way (where a cold sweep's setup goes).
+
+python tools/cold_sweep.py [--frames 360] [--world 1] [--mode readback|hbm] [--reps 2] [--json out.json]
+
+Each repetition builds everything anew (runtimes, page-locked images, streams); the process itself is warm after the first
+(HIP context, code objects), which is why the first repetition is reported separately as `process_cold`."""
+import argparse
+import json
+import sys
+import time
+
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=360)
+    ap.add_argument("--world", type=int, default=1, help="frames / world frames are rendered (rank 0's share)")
+    ap.add_argument("--mode", default="readback", choices=["readback", "hbm"])
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--max-batch", type=int, default=16)
+    ap.add_argument("--jobs", type=int, default=65536)
+    ap.add_argument("--keep", action="store_true", help="keep every repetition's renderer alive until the end (no reuse of just-freed memory)")
+    ap.add_argument("--delivery", default="batch", choices=["frame", "batch"])
+    ap.add_argument("--json", default="")
+    ap.add_argument("--timeline", type=int, default=0, help="record the first N host calls of every repetition (start ms, duration ms, call)")
+    a = ap.parse_args()
+
+    import torch
+    import strange_attractor_renderer_amd as S
+    from strange_attractor_renderer_amd import api, sequence
+    from strange_attractor_renderer_amd.sequence import SequenceRenderer, frames as sequence_frames
+
+    acc: dict = {}
+    timeline: list = []
+    t_origin = [0.0]
+
+    def timed(owner, name, label):
+        fn = getattr(owner, name)
+
+        def wrapper(*args, **kw):
+            t = time.perf_counter()
+            try:
+                return fn(*args, **kw)
+            finally:
+                e = time.perf_counter()
+                d = acc.setdefault(label, [0.0, 0])
+                d[0] += e - t
+                d[1] += 1
+                if len(timeline) < a.timeline:
+                    timeline.append([round((t - t_origin[0]) * 1e3, 3), round((e - t) * 1e3, 3), label])
+        setattr(owner, name, wrapper)
+
+    timed(api.Runtime, "__init__", "Runtime()")
+    if hasattr(api.Runtime, "group"):
+        inner_group = api.Runtime.group.__func__
+
+        def timed_group(cls, *args, **kw):
+            t = time.perf_counter()
+            try:
+                return inner_group(cls, *args, **kw)
+            finally:
+                e = time.perf_counter()
+                d = acc.setdefault("Runtime.group()", [0.0, 0])
+                d[0] += e - t
+                d[1] += 1
+                if len(timeline) < a.timeline:
+                    timeline.append([round((t - t_origin[0]) * 1e3, 3), round((e - t) * 1e3, 3), "Runtime.group()"])
+        api.Runtime.group = classmethod(timed_group)
+    timed(api.Runtime, "reset", "reset")
+    timed(api.Runtime, "synchronize", "synchronize")
+    timed(api.Runtime, "close", "Runtime.close")
+    timed(api.HostImage, "__init__", "HostImage()")
+    timed(api.HostImage, "close", "HostImage.close")
+    timed(api, "render_jobs_batch", "render_jobs_batch")
+    timed(api, "render_jobs", "render_jobs")
+    timed(api, "colorize_format_async", "colorize_format_async")
+    timed(api, "colorize_device", "colorize_device")
+    timed(api, "wait_image", "wait_image")
+    timed(api, "batch_frames", "batch_frames")
+    timed(api.ParallelRenderer, "__init__", "ParallelRenderer()")
+
+    units, jpt = a.jobs // 4, 4
+    scfg = S.Config.solar_sail(iterations=100_000_000, width=1800, height=2000, scale=1.0, transparent=0)
+    todo = [f for f in sequence_frames(0.0, float(a.frames), 1.0) if f[0] % a.world == 0]
+    done = [0]
+
+    def sink(k, name, img):
+        done[0] += 1
+
+    torch.cuda.init()
+    torch.cuda.synchronize()
+    reps = []
+    kept = []
+    for rep in range(a.reps):
+        acc.clear()
+        del timeline[:]
+        done[0] = 0
+        hbm = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t_origin[0] = t0
+        kw = dict(units=units, jobs_per_thread=jpt, seed=4, device=0, lanes=a.lanes, batch=a.batch, max_batch=a.max_batch, delivery=a.delivery)
+        if a.mode == "hbm":
+            slots = ((a.lanes or 2) + 1) * max(a.batch, a.max_batch) + 1
+            hbm = [torch.empty(1800 * 2000 * 4, dtype=torch.int16, device="cuda") for _ in range(slots)]
+            seq = SequenceRenderer(scfg, device_ring=[t.data_ptr() for t in hbm], ring=slots, **kw)
+        else:
+            seq = SequenceRenderer(scfg, image_format=S.SAR_FMT_RGB16, **kw)
+        t1 = time.perf_counter()
+        seq.run(todo, sink, zero_copy=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        sizes = list(seq.frames_per_launch)
+        launch = seq.groups[0][0].describe_last_launch() if seq.groups and seq.groups[0] else ""
+        n_rt = sum(len(g) for g in seq.groups)
+        if a.keep:
+            kept.append((seq, hbm))   # freed memory that is handed out again has to be scrubbed by the driver first (0.2 s for 10 GB
+        else:                         # on one box): with --keep every repetition gets memory nobody has used in this process
+            seq.close()
+        t3 = time.perf_counter()
+        assert done[0] == len(todo)
+        reps.append({"rep": rep, "frames": len(todo), "construct_ms": (t1 - t0) * 1e3, "sweep_ms": (t2 - t1) * 1e3,
+                     "cold_ms": (t2 - t0) * 1e3, "cold_ms_per_frame": (t2 - t0) * 1e3 / len(todo), "close_ms": (t3 - t2) * 1e3,
+                     "frames_per_launch": sizes, "runtimes": n_rt, "launch": launch,
+                     "host_ms": {k: [round(v[0] * 1e3, 3), v[1]] for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])}})
+        if a.timeline:
+            reps[-1]["timeline"] = list(timeline)
+        print(json.dumps({k: v for k, v in reps[-1].items() if k != "timeline"}), flush=True)
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump({"args": vars(a), "reps": reps}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

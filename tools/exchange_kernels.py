@@ -39,10 +39,19 @@ for world in a.worlds:
     rgba = torch.empty(sp * 8, dtype=torch.uint8, device="cuda")
     sc = torch.empty(4, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
+    ex = S.Exchange(rt, world, 0)
+    flags = torch.empty(ex.granules, dtype=torch.uint8, device="cuda")
+    flags_all = torch.zeros(world * ex.granules, dtype=torch.uint8, device="cuda")
+    ex.flags(flags.data_ptr())
+    rt.synchronize()
+    flags_all.view(world, ex.granules)[:] = flags        # every rank touched what this one did
+    torch.cuda.synchronize()
     out = {"size": a.size, "world": world, "slice_pixels": sp,
-           "pack_ms": timed(lambda: rt.exchange_pack(world, pack.data_ptr())),
-           "merge_slices_ms": timed(lambda: rt.exchange_merge_slices(world, 0, recv.data_ptr())),
-           "scalars_ms": timed(lambda: (rt.exchange_scalars_export(sc.data_ptr()), rt.exchange_scalars_import(sc.data_ptr()))),
+           "pack_dense_ms": timed(lambda: ex.pack(None, 0.5, pack.data_ptr())),
+           "merge_dense_ms": timed(lambda: ex.merge(recv.data_ptr(), sc.data_ptr())),
+           "flags_ms": timed(lambda: ex.flags(flags.data_ptr())),
+           "plan_and_pack_sparse_ms (one host wait)": timed(lambda: ex.pack(flags_all.data_ptr(), 2.0, pack.data_ptr())),
+           "scalars_ms": timed(lambda: ex.finish(sc.data_ptr())),
            "colorize_slice_ms": timed(lambda: S.colorize_range_device(cfg, rt, 0, min(sp, npix), rgba.data_ptr())),
            "all_to_all_bytes_out_per_gpu": (world - 1) * sp * 16, "gather_bytes_to_root": (world - 1) * sp * 8}
     print(json.dumps(out), flush=True)
