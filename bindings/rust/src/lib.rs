@@ -169,6 +169,8 @@ extern "C" {
     pub fn sar_colorize_format(cfg: *const SarConfig, rt: *mut SarRuntime, format: c_int, out_host: *mut c_void) -> c_int;
     pub fn sar_colorize_format_async(cfg: *const SarConfig, rt: *mut SarRuntime, format: c_int, out_host: *mut c_void, ticket_out: *mut u64) -> c_int;
     pub fn sar_runtime_wait_image(rt: *mut SarRuntime, ticket: u64) -> c_int;
+    pub fn sar_runtime_read_image_async(rt: *mut SarRuntime, out_host: *mut c_void, ticket_out: *mut u64) -> c_int;
+    pub fn sar_runtime_image_done(rt: *mut SarRuntime, ticket: u64, done_out: *mut c_int) -> c_int;
     pub fn sar_host_alloc(bytes: usize, out: *mut *mut c_void) -> c_int;
     pub fn sar_host_free(p: *mut c_void) -> c_int;
     pub fn sar_write_png(path: *const c_char, format: c_int, width: u32, height: u32, pixels: *const c_void) -> c_int;

@@ -153,11 +153,9 @@ int sar_start_points(uint64_t seed, uint64_t first_job, uint32_t n_jobs, double*
  * resets them, seeds the start-point stream with cfg->seed. */
 int sar_runtime_new(const sar_config* cfg, int device, sar_runtime** out);
 int sar_runtime_free(sar_runtime* rt);
-/* n runtimes like sar_runtime_new's for the frames of ONE batch (sar_render_jobs_batch; the `sequence` loop, src/bin/main.rs:493-517,
- * keeps one renderer for all its frames): they share one stream and one read-back stream, and their buffers — sized for frames
- * like cfg (its image, jobs_total and iterations) in batches of n — are carved from ONE device and ONE page-locked allocation
- * instead of some twenty each (a 45-frame sweep renders in 32 ms; sixteen runtimes built one by one cost 15 ms). Every out[i] is
- * an ordinary runtime (1 <= n <= 32), freed with sar_runtime_free in any order; the shared parts go with the last one. */
+/* n runtimes (1..32) for the frames of ONE batch (sar_render_jobs_batch; the `sequence` loop, src/bin/main.rs:493-517, keeps one
+ * renderer for all its frames): one stream, one read-back stream, every runtime's buffers — sized for frames like cfg in batches
+ * of n — carved from ONE device allocation instead of some twenty. Each out[i] is an ordinary runtime, freed in any order. */
 int sar_runtime_new_group(const sar_config* cfg, int device, uint32_t n, sar_runtime** out /* [n] */);
 /* Runtime::reset (:682-699): count<-0, steps<-0.0, zbuf<--1.0, max<-0. The RNG stream is NOT reseeded. */
 int sar_runtime_reset(sar_runtime* rt);
@@ -201,27 +199,21 @@ int sar_render_job_range(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs
 int sar_render_job_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t n_jobs,
                                 uint64_t iters_per_job, const double* starts_xyz_dev);
 
-/*
- * F frames of a sweep in ONE set of launches — F iterations of the CLI's frame loop (src/bin/main.rs:493-517: every frame is a
- * reset, src/lib.rs:950-951, and a render_parallel of fresh jobs) at a time. Frame i is sar_render_jobs(cfgs[i], rts[i],
- * starts_xyz_host[i]) and the result is exactly that, bit for bit; what changes is how the chip is filled: a frame of 65 536
- * jobs occupies a third of an MI355X (a quarter once solar-sail has lost 38 % of its start points in the warm-up), so the frames'
- * workgroups share ONE launch of each kernel (workgroup -> frame -> that frame's argument block and buffers). The batched
- * launch applies to runtimes on one device with one image size, configs with the same jobs_total, iterations per job and scale
- * whose jobs are resident at once (the wave-pair form of the iterate kernel, one launch chunk, at most 4 Mpx); anything else —
- * and n_frames == 1 — runs the frames one after the other, same result. The runtimes must be distinct; the work is enqueued
- * on rts[0]'s stream, and a runtime with another stream is ordered with it through events (give the runtimes of a batch one
- * stream, sar_runtime_set_stream, and nothing needs ordering). starts_xyz_host[i] == NULL (or starts_xyz_host == NULL)
- * draws frame i's points from rts[i]'s own stream. The launch options (sar_runtime_set_option) are rts[0]'s.
- */
+/* F frames of a sweep in ONE set of launches — F iterations of the CLI's frame loop (src/bin/main.rs:493-517: every frame a reset,
+ * src/lib.rs:950-951, and a render_parallel of fresh jobs) at a time. Frame i is sar_render_jobs(cfgs[i], rts[i],
+ * starts_xyz_host[i]), bit for bit; what changes is how the chip is filled: a frame of 65 536 jobs occupies a third of an MI355X,
+ * so the frames' workgroups share ONE launch of each kernel (workgroup -> frame -> its argument block and buffers), the frames
+ * dealt to the XCDs. It applies to distinct runtimes on one device with one image size (make them with sar_runtime_new_group) and
+ * configs with the same jobs_total, iterations per job and scale whose jobs are resident at once (one launch chunk, at most
+ * 4 Mpx); anything else — and n_frames == 1 — runs frame after frame, same result. The work is enqueued on rts[0]'s stream (a
+ * runtime on another stream is ordered with it through events); the launch options (sar_runtime_set_option) are rts[0]'s.
+ * starts_xyz_host[i] == NULL (or starts_xyz_host == NULL) draws frame i's points from rts[i]'s own stream. */
 int sar_render_jobs_batch(uint32_t n_frames, const sar_config* const* cfgs, sar_runtime* const* rts,
                           const double* const* starts_xyz_host);
 /* How many frames like cfg to render per batch: 1 when frames of this shape cannot share launches (the test sar_render_jobs_batch
- * makes: beyond 4 Mpx, jobs of several launch chunks — a caller then builds ONE runtime per lane, not a batch of them); otherwise
- * a multiple of eight, 8..32 (every XCD runs its own frames, one after the other; any other number is dealt as well — three frames
- * or more in eight equal runs of wave pairs): the smallest whose last round of equally long wave pairs fills the XCD — eight pairs
- * per CU, a frame takes one per 64 jobs that survive the warm-up (the survivor share of this runtime's last launch; before any
- * launch has reported: 16). rt may be NULL: the answer for a runtime yet to be made. */
+ * makes — a caller then builds ONE runtime per lane, not a batch of them); otherwise a multiple of eight, 8..32, the smallest
+ * whose last round of equally long wave pairs fills an XCD (eight pairs per CU; a frame takes one per 64 jobs that survive the
+ * warm-up, by this runtime's last launch — before any has reported: 16). rt may be NULL: the answer for a runtime yet to be made. */
 int sar_runtime_batch_frames(const sar_config* cfg, sar_runtime* rt, uint32_t* out_frames);
 
 /* Announces the NEXT sar_render_job_range_device call on this runtime — these start points, job count and iterations per
@@ -271,12 +263,15 @@ int sar_image_convert_device(sar_runtime* rt, const void* rgba16_dev, int format
 /* colorize + conversion on the device, then ONE device-to-host copy of the converted image
  * (sar_image_bytes(format) bytes: 12 MiB instead of 32 MiB for RGB8 at 2048x2048). Samples are host-endian. */
 int sar_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host);
-/* The same, returning as soon as the work is ENQUEUED on rt's stream: the image is in out_host once
- * sar_runtime_wait_image(rt, ticket) has returned. A `sequence` sweep (src/bin/main.rs:493-517 hands frame k to its
- * writer threads and goes on with frame k+1) reads frame k back while frame k+1 renders. out_host should be page-locked
- * (sar_host_alloc); with pageable memory the copy is staged by the HIP runtime and the call may block. The runtime may be
- * reset and rendered into again before the ticket is waited for; out_host must stay untouched until then. */
+/* The same, returning as soon as the work is ENQUEUED: the image is in out_host once sar_runtime_wait_image(rt, ticket) has returned
+ * (sar_runtime_image_done asks without waiting). A `sequence` sweep (src/bin/main.rs:493-517 hands frame k to its writer threads
+ * and goes on with frame k+1) reads frame k back while frame k+1 renders. out_host should be page-locked (sar_host_alloc; pageable
+ * memory is staged by the HIP runtime and the call may block) and stay untouched until the ticket is done; the runtime may be reset
+ * and rendered into again before that. out_host == NULL: colorize + conversion only — the image stays in device memory until
+ * sar_runtime_read_image_async fetches it (page-locking a host image takes 1-3 ms, a frame renders in 0.7). */
 int sar_colorize_format_async(const sar_config* cfg, sar_runtime* rt, int format, void* out_host, uint64_t* ticket_out);
+int sar_runtime_read_image_async(sar_runtime* rt, void* out_host, uint64_t* ticket_out);
+int sar_runtime_image_done(sar_runtime* rt, uint64_t ticket, int* done_out);
 int sar_runtime_wait_image(sar_runtime* rt, uint64_t ticket);
 /* Page-locked host memory for those read-backs. */
 int sar_host_alloc(size_t bytes, void** out);
@@ -329,7 +324,7 @@ typedef struct sar_exchange_layout {
 } sar_exchange_layout;
 #define SAR_EXCHANGE_GRANULE 64
 int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice_pixels);   /* host arithmetic only */
-/* rt is borrowed and must outlive the exchange; layout_out may be NULL. */
+/* rt is borrowed: every call on the exchange but sar_exchange_free needs it alive; layout_out may be NULL. */
 int sar_exchange_new(sar_runtime* rt, uint32_t world, uint32_t rank, sar_exchange** out, sar_exchange_layout* layout_out);
 int sar_exchange_free(sar_exchange* ex);
 int sar_exchange_flags(sar_exchange* ex, uint8_t* flags_out_dev /* [granules] */);
@@ -353,17 +348,14 @@ int sar_colorize_range_device(const sar_config* cfg, sar_runtime* rt, uint32_t f
  * CLI's default of 12 jobs per thread (src/bin/main.rs:305) becomes 196 608 trajectories = three waves per SIMD.
  * The renderer owns one runtime on `device`, seeded with `seed`. */
 int sar_renderer_new(int device, uint32_t units, uint64_t seed, sar_renderer** out);
-/* The same over SEVERAL GPUs of one node, behind this ABI alone (no Python, no RCCL): ParallelRenderer::new owns every
- * execution unit of the machine (:919-1004). devices[n_devices] are HIP device ordinals in FOLD ORDER (device 0 is the
- * accumulator of :1070; a device may be listed more than once — each entry is its own shard). units == 0: 64 per CU
- * summed over the devices. render_parallel then cuts the units*jobs_per_unit jobs into contiguous slices, one per
- * device, renders them concurrently (one host thread + one stream per device), lets every device own one slice of
- * the image, moves the partial buffers point-to-point (hipMemcpyPeerAsync: every pair of GPUs over its own xGMI link,
- * 16 B/px; an owner's G-1 pulls run on G-1 copy streams, so they use their links at the same time), folds them with
- * Runtime::merge in device order, colorizes each slice where it lives and copies it into rgba_out_host (straight into it
- * when that memory is pinned, through a pinned staging buffer per device otherwise). The result is bit-identical to the
- * single-device renderer's for the same units. (Validated with one physical GPU listed several times; a node with several
- * GPUs has not been available to this build.) */
+/* The same over SEVERAL GPUs of one node, behind this ABI alone (no Python, no RCCL): ParallelRenderer::new owns every execution
+ * unit of the machine (:919-1004). devices[n_devices] are HIP device ordinals in FOLD ORDER (device 0 is the accumulator of :1070;
+ * a device may be listed more than once — each entry is its own shard). units == 0: 64 per CU summed over the devices.
+ * render_parallel then cuts the units*jobs_per_unit jobs into contiguous slices, one per device (one host thread + one stream
+ * each), lets every device own one slice of the image, exchanges the partial buffers point-to-point (sar_renderer_set_exchange),
+ * folds them with Runtime::merge in device order, colorizes each slice where it lives and copies it into rgba_out_host. The
+ * result is bit-identical to the single-device renderer's for the same units. (Validated with one physical GPU listed several
+ * times; a node with several GPUs has not been available to this build.) */
 int sar_renderer_new_multi(const int* devices, uint32_t n_devices, uint32_t units, uint64_t seed, sar_renderer** out);
 int sar_renderer_num_devices(const sar_renderer* r, uint32_t* out_devices);
 int sar_renderer_num_units(const sar_renderer* r, uint32_t* out_units);
@@ -398,8 +390,9 @@ int sar_renderer_last_timing(const sar_renderer* r, sar_parallel_timing* out);
 /* How a multi-device renderer exchanges its partial buffers before colorize. 2 = sparse: every device writes the records of the
  * 64-pixel granules it has touched (1 KiB each: count, zbuf, steps) straight into their owners' buffers — kernels storing to
  * peer memory over xGMI — and the owners fold what arrived (a fifth of a frame at the BASELINE shapes); 1 = dense: whole slices,
- * 16 B/px, by hipMemcpyPeerAsync; 0 (default) = sparse when every pair of devices has direct peer access, dense otherwise. The
- * merged frame is the same bit for bit. */
+ * 16 B/px, by hipMemcpyPeerAsync; 0 (default) = sparse when every pair of devices has direct peer access AND every device could
+ * give its receive buffers fine-grained (device-coherent) memory, dense otherwise — where either is missing, a render call under
+ * mode 2 fails with SAR_ERR_INVALID instead of folding what may be stale. The merged frame is the same bit for bit. */
 int sar_renderer_set_exchange(sar_renderer* r, uint32_t mode);
 
 /* ---- measurement ----------------------------------------------------------------------------------- */

@@ -146,6 +146,8 @@ PROTOTYPES = {
     "sar_colorize_format": (C.c_int, [_cfg_p, _vp, C.c_int, _vp]),
     "sar_colorize_format_async": (C.c_int, [_cfg_p, _vp, C.c_int, _vp, _P(C.c_uint64)]),
     "sar_runtime_wait_image": (C.c_int, [_vp, C.c_uint64]),
+    "sar_runtime_read_image_async": (C.c_int, [_vp, _vp, _P(C.c_uint64)]),
+    "sar_runtime_image_done": (C.c_int, [_vp, C.c_uint64, _P(C.c_int)]),
     "sar_host_alloc": (C.c_int, [C.c_size_t, _P(C.c_void_p)]),
     "sar_host_free": (C.c_int, [_vp]),
     "sar_write_png": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, _vp]),

@@ -16,6 +16,7 @@ There is no CPU fallback: without the library or without a HIP device these call
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import os
 from dataclasses import dataclass
 
@@ -172,6 +173,11 @@ class Runtime:
         return out
 
     def close(self):
+        for ref in getattr(self, "_exchanges", []):       # contexts that borrow this runtime go first
+            ex = ref()
+            if ex is not None:
+                ex.close()
+        self._exchanges = []
         if getattr(self, "_h", None) and self._own:
             _lib().sar_runtime_free(self._h)
         self._h = None
@@ -325,7 +331,9 @@ class Exchange:
     def __init__(self, runtime: Runtime, world: int, rank: int):
         h, lay = C.c_void_p(), _abi.SarExchangeLayout()
         _check(_lib().sar_exchange_new(runtime.handle, world, rank, C.byref(h), C.byref(lay)), "sar_exchange_new")
-        self._h, self.runtime = h, runtime      # (keeps the runtime alive: the context borrows it)
+        self._h, self.runtime = h, runtime      # (the context borrows the runtime: Runtime.close closes its exchanges first)
+        runtime._exchanges = getattr(runtime, "_exchanges", [])
+        runtime._exchanges.append(weakref.ref(self))
         self.world, self.rank = world, rank
         self.slice_pixels, self.first, self.count = lay.slice_pixels, lay.first_px, lay.n_px
         self.granules, self.block_bytes = lay.granules, lay.block_bytes
@@ -539,6 +547,26 @@ def colorize_format_async(config: Config, runtime: Runtime, image: HostImage) ->
     _check(_lib().sar_colorize_format_async(C.byref(config.c), runtime.handle, image.fmt, C.c_void_p(image.ptr), C.byref(t)),
            "sar_colorize_format_async")
     return int(t.value)
+
+
+def colorize_format_device(config: Config, runtime: Runtime, fmt: int):
+    """colorize + the CLI's conversion, the image left in the runtime's device memory (sar_colorize_format_async with no host
+    image): `read_image_async` fetches it later. Enqueues only."""
+    _check(_lib().sar_colorize_format_async(C.byref(config.c), runtime.handle, fmt, None, None), "sar_colorize_format_async")
+
+
+def read_image_async(runtime: Runtime, image: "HostImage") -> int:
+    """The read-back of the image `colorize_format_device` left, into a page-locked host image; returns the ticket."""
+    t = C.c_uint64()
+    _check(_lib().sar_runtime_read_image_async(runtime.handle, C.c_void_p(image.ptr), C.byref(t)), "sar_runtime_read_image_async")
+    return int(t.value)
+
+
+def image_done(runtime: Runtime, ticket: int) -> bool:
+    """Whether the read-back behind `ticket` has completed (no wait)."""
+    d = C.c_int(0)
+    _check(_lib().sar_runtime_image_done(runtime.handle, ticket, C.byref(d)), "sar_runtime_image_done")
+    return bool(d.value)
 
 
 def wait_image(runtime: Runtime, ticket: int):

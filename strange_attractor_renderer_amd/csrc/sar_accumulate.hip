@@ -17,12 +17,18 @@ namespace sar {
 //   PACKED: two 16-bit counters per LDS word, 128 KiB for the whole bin, ONE workgroup reads the lists
 //     once. A counter is 15 bits plus a guard bit: the lane whose (returning) add sets the guard bit takes 32768 out again
 //     and notes the pixel in a short event list; every event is worth 32768 hits when the histogram is written out.
-//     No carry can reach the neighbouring counter, by a BOUND, not by timing: an add that FINDS the guard bit set (the
-//     setter's subtraction is still on its way) takes itself out again and counts its hit in memory instead (out[pixel] + 1,
-//     the write-out then adds to what is there). While the guard bit is set the counter therefore holds only adds that have
-//     not yet undone themselves — at most what the hardware lets the workgroup have in flight: 15 LDS operations per wave
-//     (lgkmcnt is four bits) x 64 lanes x 16 waves = 15360 < 32768. The tests drive one pixel through 9000 guard events and
-//     past 2^32 hits; a build with -DSAR_ACC_GUARD_CHECK asserts the bound (traps on a guarded counter above 0x4000).
+//     No carry reaches the neighbouring counter WHILE A GUARD BIT IS SET, by a bound, not by timing: an add that FINDS the guard
+//     bit set (the setter's subtraction is still on its way) takes itself out again and counts its hit in memory instead
+//     (out[pixel] + 1, the write-out then adds to what is there). While the guard bit is set the counter therefore holds only adds
+//     that have not yet undone themselves — one per lane (a lane waits for every add before its next): 1024, and never more than
+//     the hardware lets a workgroup have in flight, 15 LDS operations per wave (lgkmcnt is four bits) x 64 lanes x 16 waves =
+//     15360 < 32768. What the bound does NOT cover are undo-subtractions that land AFTER the setter cleared the guard: they are
+//     still inside the counter, and a second guard event before they land leaves the counter below zero — a borrow from the
+//     neighbouring counter (the word stays right modulo 2^32, the two 16-bit halves do not). Between an add and its undo lie two
+//     trips through the LDS unit's queue — with every lane of the workgroup on ONE counter some 2 000 operations — against the
+//     32768 adds a second event needs: a margin of 15x, and a TIMING argument, said to be one (round 6 measured where it ends:
+//     eight adds in flight per lane stretch the window tenfold and the hot-pixel test fails). The tests drive one pixel through
+//     9000 guard events and past 2^32 hits; a build with -DSAR_ACC_GUARD_CHECK asserts the bound (traps on a guarded counter above 0x4000).
 //     (Round 2 counted such a bin in two halves, two workgroups reading every list: 4.35 ms per launch of configs[3] on one
 //     GPU against 2.82 ms, which is the rate of isolated 64-byte reads, 2.7 of the 3.4 TB/s MI355X serves; that form left the
 //     tree in round 4. Rounds 2-4 let the adds under a pending subtraction stand — correct unless 32768 of them fell into
@@ -91,40 +97,48 @@ __device__ __forceinline__ void bin_accumulate_body(const BinAccArgs& a, uint32_
                 const uint32_t r0 = q == 0u ? v[k].z : v[k].x, r1 = q == 0u ? v[k].w : v[k].y;
                 // PACKED: one returning add per record; the counter's 15 bits were all set before it <=> this add set the
                 // guard bit (inc = 1 or 1 << 16, so inc * 0x7FFF masks the counter)
-                auto packed_add = [&](uint32_t rec) {
-                    const uint32_t inc = __umul24(rec & 1u, 0xFFFFu) + 1u;
+                // what an add does that saw its counter's guard bit after itself (old: the word before the add): either the bit was set
+                // already — its setter's subtraction is pending: this add steps back out, so that the counter never holds more than the
+                // adds in flight (< 32768: no carry), and the hit is counted in memory — or this add set it: 32768 hits leave the
+                // counter as one event
+                auto packed_guard = [&](uint32_t rec, uint32_t inc, uint32_t old) {
                     const uint32_t guard = inc << 15;
-                    const uint32_t old = atomicAdd(&hist[rec >> 1], inc);
-                    // ONE test on the common path: the counter's half of the word shows its guard bit after this add — either this
-                    // add set it (the 15 bits were all set) or it was set already
-#ifdef SAR_EXPERIMENT_ACC_NO_UNDO  // A/B timing only: rounds 2-4's form (adds under a pending subtraction stand)
-                    if (__builtin_expect((old & __umul24(inc, 0x7FFFu)) == __umul24(inc, 0x7FFFu), 0)) {
-                        if (false) {
-#else
-                    if (__builtin_expect(((old + inc) & guard) != 0u, 0)) {
-                        if (old & guard) {
-#endif
-                            // the guard bit was set: its setter's subtraction is pending. This add steps back out — so that the
-                            // counter never holds more than the adds in flight (< 32768: no carry) — and the hit is counted in memory.
+                    if (old & guard) {
 #ifdef SAR_ACC_GUARD_CHECK  // the bound itself: a guarded counter holds at most the adds in flight
-                            if ((old & __umul24(inc, 0x7FFFu)) >= __umul24(inc, 0x4000u)) __builtin_trap();
+                        if ((old & __umul24(inc, 0x7FFFu)) >= __umul24(inc, 0x4000u)) __builtin_trap();
 #endif
-                            atomicSub(&hist[rec >> 1], inc);
-                            atomicAdd(&out[pixel_of(rec)], 1u);
+                        atomicSub(&hist[rec >> 1], inc);
+                        atomicAdd(&out[pixel_of(rec)], 1u);
+                        ev_ctl[1] = 1u;
+                    } else {
+                        atomicSub(&hist[rec >> 1], guard);
+                        const uint32_t e = atomicAdd(&ev_ctl[0], 1u);
+                        if (e < kAccEvents) {
+                            ev[e] = (unsigned short)rec;
+                        } else {  // more than 2040 x 32768 hits on a handful of pixels in one block: straight to memory
+                            atomicAdd(&out[pixel_of(rec)], 32768u);
                             ev_ctl[1] = 1u;
-                        } else {  // this add set it: 32768 hits leave the counter as one event
-                            atomicSub(&hist[rec >> 1], guard);
-                            const uint32_t e = atomicAdd(&ev_ctl[0], 1u);
-                            if (e < kAccEvents) {
-                                ev[e] = (unsigned short)rec;
-                            } else {  // more than 2040 x 32768 hits on a handful of pixels in one block: straight to memory
-                                atomicAdd(&out[pixel_of(rec)], 32768u);
-                                ev_ctl[1] = 1u;
-                            }
                         }
                     }
                 };
-                if (PACKED && nrec == R) {  // a full chunk (all but the last of a list): every record of this lane's quad counts
+                // PACKED: one returning add per record; ONE test on the common path: the counter's half of the word shows its guard
+                // bit after this add — either this add set it (the 15 bits were all set) or it was set already (inc = 1 or 1 << 16)
+                auto packed_add = [&](uint32_t rec) {
+                    const uint32_t inc = __umul24(rec & 1u, 0xFFFFu) + 1u;
+                    const uint32_t old = atomicAdd(&hist[rec >> 1], inc);
+#ifdef SAR_EXPERIMENT_ACC_NO_UNDO  // A/B timing only: rounds 2-4's form (adds under a pending subtraction stand)
+                    if (__builtin_expect((old & __umul24(inc, 0x7FFFu)) == __umul24(inc, 0x7FFFu), 0)) packed_guard(rec, inc, old & ~(inc << 15));
+#else
+                    if (__builtin_expect(((old + inc) & (inc << 15)) != 0u, 0)) packed_guard(rec, inc, old);
+#endif
+                };
+                // (Round 6 issued the quad's eight returning adds back to back and looked at them together — one wait, one branch. Dropped:
+                // 3.55 against 3.21 ms per launch of configs[3]'s frame — the LDS atomic unit is what is busy, a deeper queue in front
+                // of it buys nothing — and WRONG on the hot-pixel test: with eight operations per lane queued in front of one counter,
+                // the window between an add that found the guard set and its undo grows from ~2 000 to ~20 000 other operations, a
+                // second guard event meets undos still pending and the counter ends below zero — a borrow from the neighbour that
+                // stays. profiles/dead_ends.md, "Round 6".)
+                if (PACKED && nrec == R) {
                     if (q < Q) {
                         packed_add(r0 & 0xFFFFu);
                         packed_add(r0 >> 16);

@@ -12,7 +12,8 @@
 using namespace sar;
 
 struct sar_exchange {
-    sar_runtime* rt = nullptr;  // borrowed: the runtime outlives its exchange
+    sar_runtime* rt = nullptr;  // borrowed: every call but sar_exchange_free needs it alive
+    int device = 0;
     uint32_t world = 1, rank = 0;
     uint32_t S = 0;             // pixels per slice
     uint32_t sps = 0;           // granules per slice
@@ -48,10 +49,11 @@ int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice
 int sar_exchange_new(sar_runtime* rt, uint32_t world, uint32_t rank, sar_exchange** out, sar_exchange_layout* layout_out) try {
     if (!out) return SAR_ERR_INVALID;
     *out = nullptr;
-    if (!rt || world == 0 || rank >= world) { set_error("sar_exchange_new: rank %u of %u", rank, world); return SAR_ERR_INVALID; }
+    if (!rt || world == 0 || rank >= world || world > kMaxExchRanks) { set_error("sar_exchange_new: rank %u of %u (at most %u ranks)", rank, world, kMaxExchRanks); return SAR_ERR_INVALID; }
     sar_exchange* ex = new (std::nothrow) sar_exchange();
     if (!ex) return SAR_ERR_OOM;
     ex->rt = rt;
+    ex->device = rt->device;
     ex->world = world;
     ex->rank = rank;
     int st = slice_pixels(rt->npix, world, ex->S);
@@ -84,10 +86,9 @@ int sar_exchange_new(sar_runtime* rt, uint32_t world, uint32_t rank, sar_exchang
 
 int sar_exchange_free(sar_exchange* ex) try {
     if (!ex) return SAR_OK;
-    if (ex->rt) {
-        hipSetDevice(ex->rt->device);
-        if (ex->rt->stream) hipStreamSynchronize(ex->rt->stream);  // (the slot tables may still be read)
-    }
+    // (the slot tables may still be read by a kernel in flight; the runtime itself may be gone already — it is not touched here)
+    hipSetDevice(ex->device);
+    hipDeviceSynchronize();
     if (ex->d_send_slot) hipFree(ex->d_send_slot);
     if (ex->d_recv_slot) hipFree(ex->d_recv_slot);
     if (ex->d_counts) hipFree(ex->d_counts);

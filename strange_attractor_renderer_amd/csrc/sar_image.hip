@@ -76,16 +76,30 @@ __global__ void __launch_bounds__(256) k_colorize_gas(const uint32_t* count, con
                                                       const uint32_t* scalars, const double* lut,
                                                       uint32_t lut_len, const PaletteParams pal,
                                                       double b_offset, double b_factor, int transparent,
-                                                      uint32_t npix, ushort4* out) {
+                                                      uint32_t npix, ushort4* out, int plain_palette) {
     __shared__ double s_pal[(SAR_PALETTE_MAX + 1) * 3];
     for (uint32_t k = threadIdx.x; k < (pal.len + 1) * 3; k += blockDim.x) s_pal[k] = pal.rgb[k / 3][k % 3];
     __syncthreads();
     const uint32_t rmax = scalars[SC_WRAP] ? 0xFFFFFFFFu : scalars[SC_MAX];
     const double ln_base = ln_u32(rmax + 1u, lut, lut_len);  // ln(max + 1), :860
     const double count_f64 = (double)pal.len;
+    // A pixel nobody visited — four fifths of a frame, and whole waves of them — has factor = ln(1) / ln(max + 1) = +0, -0 (the
+    // wrapped max: ln(0) = -inf) or NaN (an empty frame: 0 / 0), and a colour r >= 0 that is finite whenever the palette is
+    // (plain_palette: every entry finite, >= 0 and far from overflow — checked on the host) and steps is not NaN: r * factor is
+    // then the factor itself, whatever r — the pixel needs no palette, no square root, no division. The same expressions on the
+    // same values: the same bits.
+    const double factor0 = ln_u32(1u, lut, lut_len) / ln_base;
+    ushort4 o0;
+    o0.x = o0.y = o0.z = as_u16((factor0 + b_offset) * b_factor * 65535.);
+    o0.w = transparent ? as_u16(factor0 * 65535.) : (uint16_t)65535;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
         // Palette::interpolate (:442-472)
         double v = steps[p];
+        const uint32_t cnt = count[p];
+        if (plain_palette && cnt == 0u && v == v) {
+            out[p] = o0;
+            continue;
+        }
         if (v < 0.) v = 0.;
         else if (v >= 1.) v = 0.999999;
         v = v * count_f64;
@@ -100,7 +114,7 @@ __global__ void __launch_bounds__(256) k_colorize_gas(const uint32_t* count, con
         const double g = sqrt(c2[1] * t + c1[1] * t1);
         const double b = sqrt(c2[2] * t + c1[2] * t1);
         // factor = ln(count+1) / ln(max+1)  (f64::log(self, base), :860)
-        const double factor = ln_u32(count[p] + 1u, lut, lut_len) / ln_base;
+        const double factor = ln_u32(cnt + 1u, lut, lut_len) / ln_base;
         ushort4 o;
         o.x = as_u16((r * factor + b_offset) * b_factor * 65535.);
         o.y = as_u16((g * factor + b_offset) * b_factor * 65535.);
@@ -293,8 +307,7 @@ __global__ void __launch_bounds__(256) k_exch_flags(const uint32_t* __restrict__
 //   recv_slot[r][s]   where rank r's record of granule s of MY slice arrives, source by source; -1 = none
 //   counts[0..world) records I send to each owner, [world..2 world) records I receive from each source (the split sizes of the
 //   all-to-all: the only numbers that go to the host), [2 world] granules touched on all ranks together (dense or sparse)
-// Block 0 scans my row, block 1 the column of my slice, the other blocks count: every rank runs the same arithmetic on the same
-// flags. A scan is two passes over a thread's consecutive elements around ONE block-wide exclusive sum.
+// 32 workgroups scan my row, 32 the column of my slice, the others count: every rank runs the same arithmetic on the same flags.
 __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* s_wave /* [17] */) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t inc = v;
@@ -317,46 +330,75 @@ __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* s_
     return s_wave[wave] + inc - v;
 }
 
+// A scan is cut over `parts` workgroups: part p owns a run of consecutive 64-element groups. It first COUNTS the flags before its
+// run (all its waves stride over them: at most n bytes out of the L2 — cheaper than a second launch or a look-back chain), then
+// every wave takes a sub-run, one element per lane (coalesced): the flags of a group are one ballot, an element's slot the count
+// before its group plus the flagged lanes below it. Slices are whole 2048-pixel blocks, so an owner's / a source's range of
+// granules starts on a multiple of 32: each HALF of a group belongs to one of them.
 template <typename FlagAt>
 __device__ __forceinline__ void exch_plan_scan(uint32_t n, uint32_t sps, FlagAt flag, int32_t* __restrict__ slot, uint32_t* __restrict__ group_counts,
-                                               uint32_t* s_wave) {
-    const uint32_t per = (n + blockDim.x - 1u) / blockDim.x;
-    const uint32_t b = threadIdx.x * per < n ? threadIdx.x * per : n, e = b + per < n ? b + per : n;
-    uint32_t c = 0;
-    for (uint32_t i = b; i < e; ++i) c += flag(i) ? 1u : 0u;
-    uint32_t at = block_exclusive_sum(c, s_wave);
-    uint32_t g_cur = b / sps, g_cnt = 0;
-    for (uint32_t i = b; i < e; ++i) {
-        const bool f = flag(i);
-        const uint32_t g = i / sps;
-        if (g != g_cur) {
-            if (g_cnt) atomicAdd(&group_counts[g_cur], g_cnt);
-            g_cur = g;
-            g_cnt = 0;
-        }
-        slot[i] = f ? (int32_t)at : -1;
-        at += f ? 1u : 0u;
-        g_cnt += f ? 1u : 0u;
+                                               uint32_t n_groups_out, uint32_t part, uint32_t parts, uint32_t* s_wave, uint32_t* s_cnt) {
+    const uint32_t waves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t groups = (n + 63u) / 64u, per_part = (groups + parts - 1u) / parts;
+    const uint32_t p0 = part * per_part < groups ? part * per_part : groups, p1 = p0 + per_part < groups ? p0 + per_part : groups;
+    const uint32_t per = (p1 - p0 + waves - 1u) / waves;
+    const uint32_t g0 = p0 + wave * per < p1 ? p0 + wave * per : p1, g1 = g0 + per < p1 ? g0 + per : p1;
+    for (uint32_t k = threadIdx.x; k < n_groups_out; k += blockDim.x) s_cnt[k] = 0u;
+    uint32_t before = 0, c = 0;
+    for (uint32_t g = wave; g < p0; g += waves) before += (uint32_t)__popcll(wave_ballot(g * 64u + lane < n && flag(g * 64u + lane)));
+    for (uint32_t g = g0; g < g1; ++g) {
+        const uint32_t i = g * 64u + lane;
+        c += (uint32_t)__popcll(wave_ballot(i < n && flag(i)));
     }
-    if (g_cnt) atomicAdd(&group_counts[g_cur], g_cnt);
+    if (lane == 0u) { s_wave[wave] = c; s_wave[17u + wave] = before; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < waves; ++w) run += s_wave[17u + w];   // everything before this part
+        for (uint32_t w = 0; w < waves; ++w) {
+            const uint32_t t = s_wave[w];
+            s_wave[w] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+    uint32_t at = s_wave[wave];
+    for (uint32_t g = g0; g < g1; ++g) {
+        const uint32_t i = g * 64u + lane;
+        const bool f = i < n && flag(i);
+        const unsigned long long mask = wave_ballot(f);
+        if (i < n) slot[i] = f ? (int32_t)(at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))) : -1;
+        at += (uint32_t)__popcll(mask);
+        if (lane == 0u) {
+            const uint32_t lo = (uint32_t)__popcll(mask & 0xFFFFFFFFull), hi = (uint32_t)__popcll(mask >> 32);
+            if (lo) atomicAdd(&s_cnt[(g * 64u) / sps], lo);
+            if (hi) atomicAdd(&s_cnt[(g * 64u + 32u) / sps], hi);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_groups_out; k += blockDim.x)
+        if (s_cnt[k]) atomicAdd(&group_counts[k], s_cnt[k]);
 }
 
+constexpr uint32_t kExchPlanParts = 32;  // workgroups per scan
 __global__ void __launch_bounds__(1024) k_exch_plan(const unsigned char* __restrict__ flags_all, uint32_t world, uint32_t rank, uint32_t nseg, uint32_t sps,
                                                     int32_t* __restrict__ send_slot, int32_t* __restrict__ recv_slot, uint32_t* __restrict__ counts) {
-    __shared__ uint32_t s_wave[17];
-    if (blockIdx.x == 0u) {
+    __shared__ uint32_t s_wave[34];
+    __shared__ uint32_t s_cnt[kMaxExchRanks];
+    if (blockIdx.x < kExchPlanParts) {
         const unsigned char* mine = flags_all + (size_t)rank * nseg;
-        exch_plan_scan(nseg, sps, [&](uint32_t g) { return mine[g] != 0; }, send_slot, counts, s_wave);
-    } else if (blockIdx.x == 1u) {
+        exch_plan_scan(nseg, sps, [&](uint32_t g) { return mine[g] != 0; }, send_slot, counts, world, blockIdx.x, kExchPlanParts, s_wave, s_cnt);
+    } else if (blockIdx.x < 2u * kExchPlanParts) {
         const uint32_t g0 = rank * sps;
         exch_plan_scan(world * sps, sps, [&](uint32_t e) {
             const uint32_t r = e / sps, g = g0 + (e - r * sps);
             return g < nseg && flags_all[(size_t)r * nseg + g] != 0;
-        }, recv_slot, counts + world, s_wave);
+        }, recv_slot, counts + world, world, blockIdx.x - kExchPlanParts, kExchPlanParts, s_wave, s_cnt);
     } else {
         const size_t total = (size_t)world * nseg;
+        const uint32_t part = blockIdx.x - 2u * kExchPlanParts, parts = gridDim.x - 2u * kExchPlanParts;
         uint32_t c = 0;
-        for (size_t i = (size_t)(blockIdx.x - 2u) * blockDim.x + threadIdx.x; i < total; i += (size_t)(gridDim.x - 2u) * blockDim.x) c += flags_all[i] ? 1u : 0u;
+        for (size_t i = (size_t)part * blockDim.x + threadIdx.x; i < total; i += (size_t)parts * blockDim.x) c += flags_all[i] ? 1u : 0u;
         c = block_exclusive_sum(c, s_wave) + c;   // (the last thread holds the block's sum)
         if (threadIdx.x == blockDim.x - 1u && c) atomicAdd(&counts[2u * world], c);
     }
@@ -558,8 +600,16 @@ void launch_merge(uint32_t* count, unsigned long long* key, double* steps, const
 void launch_colorize_gas(const uint32_t* count, const double* steps, const uint32_t* scalars, const double* lut,
                          uint32_t lut_len, const PaletteParams& pal, double b_offset, double b_factor,
                          int transparent, uint32_t npix, void* out, hipStream_t s) {
+    // (k_colorize_gas's short way for unvisited pixels needs colours that are finite whatever the blend: every entry a finite,
+    // non-negative number — no -0.0, whose square root keeps its sign — far from overflow)
+    int plain = 1;
+    for (uint32_t k = 0; k <= pal.len && k <= SAR_PALETTE_MAX; ++k)
+        for (int ch = 0; ch < 3; ++ch) {
+            const double v = pal.rgb[k][ch];
+            if (!(v >= 0.) || v > 1e300 || __builtin_signbit(v)) plain = 0;
+        }
     hipLaunchKernelGGL(k_colorize_gas, dim3(grid_for(npix, 256, 8192)), dim3(256), 0, s, count, steps, scalars, lut,
-                       lut_len, pal, b_offset, b_factor, transparent, npix, (ushort4*)out);
+                       lut_len, pal, b_offset, b_factor, transparent, npix, (ushort4*)out, plain);
 }
 
 void launch_colorize_depth(const unsigned long long* key, uint32_t* scalars, uint32_t npix, void* out,
@@ -595,7 +645,7 @@ void launch_exch_flags(const uint32_t* count, const unsigned long long* key, uin
 }
 void launch_exch_plan(const void* flags_all, uint32_t world, uint32_t rank, uint32_t nseg, uint32_t sps, int32_t* send_slot, int32_t* recv_slot,
                       uint32_t* counts /* [2 * world + 1], zeroed */, hipStream_t s) {
-    hipLaunchKernelGGL(k_exch_plan, dim3(2u + 30u), dim3(1024), 0, s, (const unsigned char*)flags_all, world, rank, nseg, sps, send_slot, recv_slot, counts);
+    hipLaunchKernelGGL(k_exch_plan, dim3(2u * kExchPlanParts + 32u), dim3(1024), 0, s, (const unsigned char*)flags_all, world, rank, nseg, sps, send_slot, recv_slot, counts);
 }
 void launch_exch_pack_sparse(const uint32_t* count, const unsigned long long* key, const double* steps, uint32_t npix, const int32_t* send_slot,
                              void* out, hipStream_t s) {

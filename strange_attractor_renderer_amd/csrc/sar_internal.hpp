@@ -199,6 +199,7 @@ constexpr uint32_t kMaxBatchFrames = 32;
 // touches a fifth of its pixels, and 21 % of its 64-pixel granules: measured on BASELINE configs[1]; whole 2048-pixel rows: 51 %).
 constexpr uint32_t kExchSeg = 64;
 constexpr size_t kExchRecordBytes = (size_t)kExchSeg * 16u;
+constexpr uint32_t kMaxExchRanks = 256;      // ranks one sar_exchange serves (the per-owner counters of k_exch_plan live in LDS)
 constexpr uint32_t kExchSliceAlign = 2048;   // slices are whole 2048-pixel blocks (k_fold_resolve's), hence whole granules
 constexpr uint32_t kMaxExchDevices = 64;
 // k_exch_push (the multi-device renderer): device `src` writes the records of its touched granules straight into every owner's

@@ -46,6 +46,7 @@ struct Shard {
     // sparse form: the other devices WRITE the records of their touched segments into d_recv ([G * sps] records) and their places
     // into d_slot ([G][sps], -1 = nothing sent); d_bytes counts what this device wrote to others (statistic)
     int32_t* d_slot = nullptr;
+    bool coherent = false;    // d_recv and d_slot are fine-grained device memory: other devices' kernel stores are seen by this owner's fold
     unsigned long long* d_bytes = nullptr;
     uint16_t* h_rgba = nullptr;  // pinned [S*4]: the colorized slice on its way into a pageable host image
     std::vector<hipStream_t> pull_streams;  // one per source device: this owner's pulls run side by side
@@ -149,10 +150,13 @@ int ensure_shard(sar_renderer* r, Shard& sh, const sar_config* cfg, uint32_t S) 
         HIP_TRY(hipMalloc(&sh.d_pack, static_cast<size_t>(G) * S * 16u));
         // What the OTHER devices' kernels store into (sparse exchange): fine-grained device memory — coherent between devices, no
         // stale line of the previous frame in this device's L2 when the owner folds (plain device memory is only guaranteed
-        // coherent at kernel boundaries for its own device). A device that cannot provide it gets plain memory.
+        // coherent at kernel boundaries for its own device). A device that cannot provide it gets plain memory — and the renderer
+        // then exchanges the dense way (hipMemcpyPeerAsync, no peer stores): see `coherent`.
+        sh.coherent = true;
         if (hipExtMallocWithFlags(&sh.d_recv, static_cast<size_t>(G) * S * 16u, hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
             sh.d_recv = nullptr;
+            sh.coherent = false;
             HIP_TRY(hipMalloc(&sh.d_recv, static_cast<size_t>(G) * S * 16u));
         }
         HIP_TRY(hipMalloc(&sh.d_rgba, static_cast<size_t>(S) * 8u));
@@ -161,6 +165,7 @@ int ensure_shard(sar_renderer* r, Shard& sh, const sar_config* cfg, uint32_t S) 
                                   hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
             sh.d_slot = nullptr;
+            sh.coherent = false;
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sh.d_slot), static_cast<size_t>(G) * (S / kExchSeg) * sizeof(int32_t)));
         }
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sh.d_bytes), sizeof(unsigned long long)));
@@ -579,7 +584,17 @@ int sar_render_parallel(sar_renderer* r, const sar_config* cfg, uint32_t jobs_pe
         return status;
     };
 
-    const bool sparse = G > 1 && G <= kMaxExchDevices && (r->exchange_mode == 2u || (r->exchange_mode == 0u && r->peer_access_failures == 0));
+    // Sparse = every device's kernels STORE into the owners' buffers: that needs direct peer access between every pair and
+    // fine-grained (device-coherent) buffers on every owner — with plain memory a stale line of the previous frame in the owner's L2
+    // could reach its fold. Where either is missing the automatic mode goes dense, and a sparse exchange asked for is an error.
+    bool peer_stores_ok = r->peer_access_failures == 0;
+    for (const Shard& sh : r->shards) peer_stores_ok = peer_stores_ok && sh.coherent;
+    if (G > 1 && r->exchange_mode == 2u && !peer_stores_ok) {
+        set_error("sparse exchange asked for (sar_renderer_set_exchange 2), but %s", r->peer_access_failures
+                  ? "some pair of devices has no direct peer access" : "a device could not provide fine-grained memory for its receive buffers");
+        return failed(SAR_ERR_INVALID);
+    }
+    const bool sparse = G > 1 && G <= kMaxExchDevices && peer_stores_ok && r->exchange_mode != 1u;
     if (G == 1) {
         Shard& sh = r->shards[0];
         render_shard(r, &sh, cfg, per_job, S, from_ahead, false);

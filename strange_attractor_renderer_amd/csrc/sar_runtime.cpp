@@ -118,6 +118,7 @@ int free_device_buffers(sar_runtime* rt) {
     if (rt->d_rgba) dev_free(rt, rt->d_rgba);
     if (rt->d_export) dev_free(rt, rt->d_export);
     rt->d_export = nullptr;
+    rt->export_src = nullptr;
     if (rt->d_ztmp) dev_free(rt, rt->d_ztmp);
     if (rt->d_zhint) dev_free(rt, rt->d_zhint);
     rt->d_zhint = nullptr;
@@ -655,10 +656,12 @@ int sar_image_convert_device(sar_runtime* rt, const void* rgba16_dev, int format
     return SAR_OK;
 } catch (...) { return sar::abi_caught(); }
 
-static int enqueue_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host, bool own_copy_stream) {
+// colorize + the CLI's conversion into the runtime's own buffers (d_rgba, d_export), on the launch stream; remembers where the
+// image lies and how long it is
+static int enqueue_colorize_convert(const sar_config* cfg, sar_runtime* rt, int format) {
     SAR_TRY(check_cfg_matches(cfg, rt));
     const size_t bytes = sar_image_bytes(format, rt->W, rt->H);
-    if (!out_host || bytes == 0) { set_error("sar_colorize_format: bad format or NULL output"); return SAR_ERR_INVALID; }
+    if (bytes == 0) { set_error("sar_colorize_format: bad format"); return SAR_ERR_INVALID; }
     HIP_TRY(hipSetDevice(rt->device));
     SAR_TRY(ensure_rgba(rt));
     if (rt->copy_in_flight) {  // the last async frame's read-back still reads d_rgba / d_export
@@ -666,18 +669,25 @@ static int enqueue_colorize_format(const sar_config* cfg, sar_runtime* rt, int f
         rt->copy_in_flight = false;
     }
     SAR_TRY(do_colorize(cfg, rt, rt->d_rgba));
-    const void* src = rt->d_rgba;
+    rt->export_src = rt->d_rgba;
     if (format != SAR_FMT_RGBA16) {
         if (!rt->d_export) HIP_TRY(dev_alloc(rt, &rt->d_export, static_cast<size_t>(rt->npix) * 6));  // largest converted format
         SAR_TRY(sar_image_convert_device(rt, rt->d_rgba, format, rt->d_export));
-        src = rt->d_export;
+        rt->export_src = rt->d_export;
     }
+    rt->export_bytes = bytes;
+    return SAR_OK;
+}
+
+// the read-back of that image: on the launch stream, or — the async form — on the copy stream behind an event, so that the next
+// frame's kernels do not queue behind 20-30 MB over PCIe (d_rgba / d_export are written again only behind this copy's event)
+static int enqueue_read_image(sar_runtime* rt, void* out_host, bool own_copy_stream) {
+    if (!out_host || !rt->export_src) { set_error("read-back: NULL output, or no colorized image to read"); return SAR_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(rt->device));
     if (!own_copy_stream || rt->readback_inline) {
-        HIP_TRY(hipMemcpyAsync(out_host, src, bytes, hipMemcpyDeviceToHost, rt->stream));
+        HIP_TRY(hipMemcpyAsync(out_host, rt->export_src, rt->export_bytes, hipMemcpyDeviceToHost, rt->stream));
         return SAR_OK;
     }
-    // the copy leaves the launch stream: the next frame's kernels do not queue behind 20-30 MB over PCIe; d_rgba / d_export
-    // are written again only behind this copy's event (above)
     if (!rt->copy_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&rt->copy_stream, hipStreamNonBlocking));
         rt->own_copy_stream = true;
@@ -685,24 +695,47 @@ static int enqueue_colorize_format(const sar_config* cfg, sar_runtime* rt, int f
     if (!rt->img_ready) HIP_TRY(hipEventCreateWithFlags(&rt->img_ready, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(rt->img_ready, rt->stream));
     HIP_TRY(hipStreamWaitEvent(rt->copy_stream, rt->img_ready, 0));
-    HIP_TRY(hipMemcpyAsync(out_host, src, bytes, hipMemcpyDeviceToHost, rt->copy_stream));
+    HIP_TRY(hipMemcpyAsync(out_host, rt->export_src, rt->export_bytes, hipMemcpyDeviceToHost, rt->copy_stream));
     return SAR_OK;
 }
 
-int sar_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host) try {
-    SAR_TRY(enqueue_colorize_format(cfg, rt, format, out_host, false));
-    HIP_TRY(hipStreamSynchronize(rt->stream));
-    return SAR_OK;
-} catch (...) { return sar::abi_caught(); }
-
-int sar_colorize_format_async(const sar_config* cfg, sar_runtime* rt, int format, void* out_host, uint64_t* ticket_out) try {
-    if (!ticket_out) { set_error("sar_colorize_format_async: NULL ticket"); return SAR_ERR_INVALID; }
-    SAR_TRY(enqueue_colorize_format(cfg, rt, format, out_host, true));
+static int ticket_for_read(sar_runtime* rt, uint64_t* ticket_out) {
     hipEvent_t& ev = rt->img_events[rt->img_next % 8];
     if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(ev, rt->readback_inline ? rt->stream : rt->copy_stream));
     rt->copy_in_flight = !rt->readback_inline;
     *ticket_out = rt->img_next++;
+    return SAR_OK;
+}
+
+int sar_colorize_format(const sar_config* cfg, sar_runtime* rt, int format, void* out_host) try {
+    if (!out_host) { set_error("sar_colorize_format: NULL output"); return SAR_ERR_INVALID; }
+    SAR_TRY(enqueue_colorize_convert(cfg, rt, format));
+    SAR_TRY(enqueue_read_image(rt, out_host, false));
+    HIP_TRY(hipStreamSynchronize(rt->stream));
+    return SAR_OK;
+} catch (...) { return sar::abi_caught(); }
+
+int sar_colorize_format_async(const sar_config* cfg, sar_runtime* rt, int format, void* out_host, uint64_t* ticket_out) try {
+    if (out_host && !ticket_out) { set_error("sar_colorize_format_async: NULL ticket"); return SAR_ERR_INVALID; }
+    SAR_TRY(enqueue_colorize_convert(cfg, rt, format));
+    if (!out_host) return SAR_OK;  // the image stays in device memory: sar_runtime_read_image_async fetches it
+    SAR_TRY(enqueue_read_image(rt, out_host, true));
+    return ticket_for_read(rt, ticket_out);
+} catch (...) { return sar::abi_caught(); }
+
+int sar_runtime_read_image_async(sar_runtime* rt, void* out_host, uint64_t* ticket_out) try {
+    if (!rt || !ticket_out) { set_error("sar_runtime_read_image_async: NULL argument"); return SAR_ERR_INVALID; }
+    SAR_TRY(enqueue_read_image(rt, out_host, true));
+    return ticket_for_read(rt, ticket_out);
+} catch (...) { return sar::abi_caught(); }
+
+int sar_runtime_image_done(sar_runtime* rt, uint64_t ticket, int* done_out) try {
+    if (!rt || !done_out || ticket >= rt->img_next) { set_error("sar_runtime_image_done: no such ticket"); return SAR_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(rt->device));
+    const hipError_t e = hipEventQuery(rt->img_events[ticket % 8]);
+    if (e != hipSuccess && e != hipErrorNotReady) HIP_TRY(e);
+    *done_out = e == hipSuccess ? 1 : 0;
     return SAR_OK;
 } catch (...) { return sar::abi_caught(); }
 

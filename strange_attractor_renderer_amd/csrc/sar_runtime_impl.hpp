@@ -148,6 +148,8 @@ struct sar_runtime {
     double* d_lnlut = nullptr;
     void* d_rgba = nullptr;
     void* d_export = nullptr;  // converted image of sar_colorize_format (<= 6 bytes per pixel)
+    const void* export_src = nullptr;  // where the last sar_colorize_format* left its image (d_rgba or d_export) and how long it is:
+    size_t export_bytes = 0;           // what a read-back copies
     float* d_ztmp = nullptr;
 
     // batched launches (sar_batch.cpp). As the LEADER of a batch: the table of per-frame argument blocks in device memory and

@@ -114,11 +114,12 @@ class SequenceRenderer:
         self.settle: dict = {}                                     # stream synchronisations done per group (see run)
         self.images: list = []
         self.busy: list = []                                       # per host image: what its last consumer returned
-        self.next_slot = 0
+        self.free_slots = __import__("collections").deque()        # ring slots no frame occupies
+        self.slots_made = 0                                        # device-ring slots handed out so far
         self.frames_per_launch: list = []                          # statistic: the batch sizes of the last run
         self.first_enqueued_at = None                              # statistic: time.perf_counter() when the last run's first batch was enqueued
 
-    def _setup(self, cfg: "api.Config"):
+    def _setup(self, cfg: "api.Config", n_frames: int = 0):
         """Lanes, ring and batch size, once the shape of a frame is known. Frames that cannot share launches (beyond 4 Mpx, jobs of
         several launch chunks: the library answers 1) go frame by frame on two lanes with a ring of lanes + 2 images — ONE runtime
         per lane, not a batch of them. Otherwise: ONE lane of batches when the frames are read back (the read-back runs on the lane's
@@ -134,6 +135,12 @@ class SequenceRenderer:
         else:
             self.lanes = self.want_lanes or (2 if self.device_ring else 1)
             self.max_batch = self.want_max_batch
+            # A short sweep (BASELINE configs[4] on eight GPUs: 45 frames each) is set-up and pipeline fill as much as rendering:
+            # batches of a quarter of it — fewer runtimes to build and images to page-lock before the GPU has work, a shorter wait
+            # for the first frame — beat full ones (45 frames, cold: 62 ms in batches of 12 against 80 in batches of 16; a 360-frame
+            # sweep renders the same either way, so it keeps the size that fills the chip's rounds best)
+            if not self.batch and 0 < n_frames < 4 * self.max_batch:
+                self.max_batch = max(min(8, self.max_batch), -(-n_frames // 4))
             # a frame keeps its host image from the enqueue of its read-back until it is delivered, `lanes` batches later — frame by
             # frame, each delivery right before the read-back that takes its place in the ring (page-locking an image costs 1-3 ms:
             # a ring of two batches per lane was 100 ms of a cold sweep, and half of it never held two frames at once)
@@ -231,14 +238,29 @@ class SequenceRenderer:
             waiting = deque()                                     # frames enqueued and not yet delivered: (batch, lane, runtime, slot, ticket, k, name, first)
             pos, turn = 0, 0
             cfg0 = self.frame_config(todo[0][1])
-            self._setup(cfg0)
+            self._setup(cfg0, len(todo))
             images, busy, ring, lanes = self.images, self.busy, self.ring, self.lanes
+            free = self.free_slots                                # host images (device-ring slots) no frame occupies, oldest release first
             size = self._batch_size(0, cfg0, len(todo))
             pending = draw([k for k, _, _ in todo[:size]])
 
             def deliver_one():
                 fr = waiting.popleft()
                 deliver(*fr[1:7], first_of_batch=fr[7])
+                free.append(fr[3])
+
+            def take_slot(cfg):
+                """A slot for the next read-back: one that is free; else a NEW image while the ring may grow (page-locking one costs
+                1-3 ms: only when nothing is free); else the oldest frame is waited for and delivered."""
+                if not free and self.device_ring is None and len(images) < ring:
+                    self._image(len(images), cfg)
+                    return len(images) - 1
+                if not free and self.device_ring is not None and self.slots_made < ring:
+                    self.slots_made += 1
+                    return self.slots_made - 1
+                while not free:
+                    deliver_one()
+                return free.popleft()
 
             while pos < len(todo):
                 g = turn % lanes
@@ -259,25 +281,29 @@ class SequenceRenderer:
                 if not self.frames_per_launch:
                     self.first_enqueued_at = time.perf_counter()  # statistic: everything before this was set-up
                 self.frames_per_launch.append(len(part))
+                if self.device_ring is None:
+                    # the whole batch's colorize + conversion first (device memory only): the launch stream then never waits for a
+                    # host image — only the copies do, on their own stream
+                    for cfg, rt in zip(cfgs, rts):
+                        api.colorize_format_device(cfg, rt, self.fmt)  # :1080
                 for i, ((k, _, name), cfg, rt) in enumerate(zip(part, cfgs, rts)):
-                    # the frame `lanes` batches back, while the GPU is busy with the later ones: one delivery per read-back enqueued
+                    # frames whose read-back has completed are delivered as we go (no wait): their images take this batch's frames,
+                    # and the ring only grows while the copies cannot keep up
+                    while waiting and waiting[0][0] < turn and self.device_ring is None and api.image_done(waiting[0][2], waiting[0][4]):
+                        deliver_one()
                     if self.delivery == "frame" and waiting and waiting[0][0] <= turn - lanes:
                         deliver_one()
-                    slot = self.next_slot % ring
-                    self.next_slot += 1
-                    while any(fr[3] == slot for fr in waiting):   # (a ring smaller than the frames in flight: deliver until the slot is free)
-                        deliver_one()
+                    slot = take_slot(cfg)
                     if self.device_ring is not None:
                         api.colorize_device(cfg, rt, self.device_ring[slot % len(self.device_ring)])
                         waiting.append((turn, g, rt, slot, 0, k, name, i == 0))
                         continue
-                    self._image(slot, cfg)
                     if hasattr(busy[slot], "result"):             # the consumer of the frame that last used this image
                         busy[slot].result()
                     busy[slot] = None
-                    ticket = api.colorize_format_async(cfg, rt, images[slot])  # :1080
+                    ticket = api.read_image_async(rt, images[slot])
                     waiting.append((turn, g, rt, slot, ticket, k, name, i == 0))
-                while waiting and waiting[0][0] <= turn - lanes:  # (a longer batch than this one `lanes` back: the rest of it)
+                while waiting and waiting[0][0] <= turn - lanes:  # the batch `lanes` back, while the GPU is busy with the later ones
                     deliver_one()
                 turn += 1
             while waiting:
@@ -303,7 +329,8 @@ class SequenceRenderer:
             for rt in reversed(grp):
                 rt.close()
         self.groups, self.images, self.busy, self.settle = [], [], [], {}
-        self.next_slot = 0
+        self.free_slots.clear()
+        self.slots_made = 0
 
     def __enter__(self):
         return self
@@ -329,13 +356,12 @@ def render_sequence(config: "api.Config", start: float, end: float, step: float,
     (each has its own Runtime state, :950-951 resets it), so with two lanes the GPU fills one frame's latency-bound parts
     (the 1000-iteration warm-up of a few waves per SIMD, the kernel tails, the read-back on the copy engine) with the other
     frame's arithmetic. A sink receives its own copy of the frame (as every frame was a fresh array before the images were
-    recycled). With `zero_copy` it receives a VIEW of one of the `ring` page-locked images instead; the image is written again
-    when the frame `ring` later is read back, which is enqueued once the frames up to `lanes` batches before THAT one are delivered —
-    with the default ring the view stays valid until the next delivery but one, or, when the sink returns an object with
-    `.result()` (a Future of its consumer), until that has returned, which the loop waits for before it reuses the image. `batch`
-    consecutive frames go through ONE set of launches (sar_render_jobs_batch; 0 = as many as fill the chip, at most `max_batch`;
-    1 = a frame per launch) — a frame of 65 536 jobs fills a third of an MI355X — and a lane's turn is then a batch. ring 0 = lanes *
-    max_batch + 1 (a frame per launch: lanes + 2); a smaller ring caps the batch at (ring - 1) // lanes."""
+    recycled). With `zero_copy` it receives a VIEW of one of the page-locked images instead, valid until the sink returns — or, when
+    the sink returns an object with `.result()` (a Future of its consumer), until that has returned: the loop waits for it before
+    it reuses the image. `batch` consecutive frames go through ONE set of launches (sar_render_jobs_batch; 0 = as many as fill the
+    chip, at most `max_batch`; 1 = a frame per launch) — a frame of 65 536 jobs fills a third of an MI355X — and a lane's turn is
+    then a batch. `ring` bounds the page-locked images (0 = (lanes + 1) * max_batch + 1; a frame per launch: lanes + 2): an image is
+    page-locked only when no delivered frame's image is free, so a sweep whose read-backs keep up holds about one batch of them."""
     todo = [(k, a, f) for (k, a, f) in frames(start, end, step, file_name) if k % world == rank]
     if not todo:
         return []

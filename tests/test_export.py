@@ -173,3 +173,40 @@ def test_reencoding_the_reference_png_gives_the_same_samples_and_file_size(sar, 
     np.testing.assert_array_equal(D.decode_png(out), im)
     ref_size, size = os.path.getsize(REF_PNG), os.path.getsize(out)
     assert abs(size / ref_size - 1.0) < 0.005, (size, ref_size)
+
+
+@pytest.mark.gpu
+def test_conversion_and_read_back_as_two_steps(sar, oracle, gpu):
+    """sar_colorize_format_async with no host image leaves the converted frame in device memory; sar_runtime_read_image_async
+    fetches it (a sweep enqueues a batch's conversions at once and hands out host images as they come free), sar_runtime_image_done
+    asks without waiting: the same bytes as the one-step call, for every format, also with the runtime rendered into again in between."""
+    cfg = sar.Config.solar_sail(iterations=256 * 700, width=200, height=120, jobs_total=256, scale=1.0, transparent=1)
+    st = sar.start_points(3, 0, 256)
+    rt = sar.Runtime(cfg)
+    sar.render_jobs(cfg, rt, st)
+    for fmt in (sar.SAR_FMT_RGBA16, sar.SAR_FMT_RGB16, sar.SAR_FMT_RGBA8, sar.SAR_FMT_RGB8):
+        want = sar.colorize_format(cfg, rt, fmt)
+        img = sar.HostImage(200, 120, fmt)
+        sar.colorize_format_device(cfg, rt, fmt)
+        ticket = sar.read_image_async(rt, img)
+        sar.wait_image(rt, ticket)
+        assert sar.image_done(rt, ticket)
+        np.testing.assert_array_equal(img.array, want)
+        img.close()
+    # the converted image survives a reset + render of the runtime's other buffers until it is read
+    want = sar.colorize_format(cfg, rt, sar.SAR_FMT_RGB16)
+    sar.colorize_format_device(cfg, rt, sar.SAR_FMT_RGB16)
+    rt.reset()
+    sar.render_jobs(cfg, rt, sar.start_points(4, 0, 256))
+    img = sar.HostImage(200, 120, sar.SAR_FMT_RGB16)
+    ticket = sar.read_image_async(rt, img)
+    sar.wait_image(rt, ticket)
+    np.testing.assert_array_equal(img.array, want)
+    img.close()
+    with pytest.raises(sar.SarError):
+        fresh = sar.Runtime(cfg)
+        try:
+            sar.read_image_async(fresh, sar.HostImage(200, 120, sar.SAR_FMT_RGB16))   # nothing colorized yet
+        finally:
+            fresh.close()
+    rt.close()

@@ -266,6 +266,50 @@ def test_custom_palette_and_brightness(sar, oracle, gpu):
     np.testing.assert_array_equal(sar.colorize(cfg, rt), oracle.colorize(cfg.c, ort))
 
 
+@pytest.mark.parametrize("transparent", [0, 1])
+@pytest.mark.parametrize("case", ["plain", "empty_frame", "wrapped_max", "negative_zero_palette", "inf_palette", "nan_palette",
+                                  "negative_palette", "zero_offset", "negative_zero_offset"])
+def test_colorize_of_unvisited_pixels_takes_no_shortcut_it_cannot_prove(sar, oracle, gpu, case, transparent):
+    """k_colorize_gas skips the palette, the square roots and the division for a pixel nobody visited (factor = ln 1 / ln(max + 1) =
+    +0, -0 or NaN; r * factor is then the factor whatever r) — where r is provably finite. Unvisited pixels with every kind of
+    `steps` (the reset 0.0, NaN, infinities, out of range), under palettes with -0.0 / inf / NaN / negative entries, an empty
+    frame (max 0: 0 / 0), a wrapped max (ln 0 = -inf: factor -0.0) and zero brightness offsets: bit for bit the oracle's image."""
+    w, h = 64, 32
+    pal = np.array([[0.1, 0.9, 0.3], [0.8, 0.0, 0.6], [0.4, 0.4, 1.0]])
+    kw = dict(brightness_offset=-0.15, brightness_factor=5.0 / 3.0)
+    if case == "negative_zero_palette":
+        pal[0] = [-0.0, -0.0, 0.5]; pal[1] = [-0.0, 0.2, -0.0]
+    elif case == "inf_palette":
+        pal[0, 1] = np.inf
+    elif case == "nan_palette":
+        pal[1, 2] = np.nan
+    elif case == "negative_palette":
+        pal[0, 0] = -0.3
+    elif case == "zero_offset":
+        kw["brightness_offset"] = 0.0
+    elif case == "negative_zero_offset":
+        kw["brightness_offset"] = -0.0
+    cfg = _cfg(sar, "poisson_saturne", width=w, height=h, transparent=transparent, palette_rgb=pal, **kw)
+    rng = np.random.default_rng(17)
+    cnt = np.zeros((h, w), np.uint32)
+    steps = np.zeros((h, w))
+    visited = rng.random((h, w)) < 0.25
+    if case != "empty_frame":
+        cnt[visited] = rng.integers(1, 5000, size=int(visited.sum()))
+        steps[visited] = rng.uniform(0, 1, size=int(visited.sum()))
+    odd = [np.nan, np.inf, -np.inf, -0.0, 1.0, 0.999999, 1.5, -2.0, 5e-324, 0.3333]
+    free = np.argwhere(cnt == 0)
+    for i, v in enumerate(odd * 6):                           # unvisited pixels whose steps are not the reset state
+        steps[tuple(free[i * 7 % len(free)])] = v
+    mx = 0xFFFFFFFF if case == "wrapped_max" else int(cnt.max())
+    z = np.full((h, w), -1.0, np.float32)
+    rt, ort = sar.Runtime(cfg), oracle.Runtime(w, h)
+    rt.load(cnt, steps, z, mx)
+    ort.count[:] = cnt; ort.steps[:] = steps; ort.zbuf[:] = z; ort.set_max(mx)
+    np.testing.assert_array_equal(sar.colorize(cfg, rt), oracle.colorize(cfg.c, ort))
+    rt.close()
+
+
 def test_colorize_beyond_ln_table_within_one_lsb(sar, oracle, gpu):
     """count+1 > 2^20 uses the device log (<= 1 ulp): RGBA16 may differ by at most 1 LSB there."""
     w = h = 16

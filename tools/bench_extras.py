@@ -171,6 +171,43 @@ def native_measure(S, torch, devices, config, steps, warmup, K):
 
 
 
+def n1_same_node(S, torch, np, device, width, total_jobs, iters_total, steps, warmup=1, seed=1):
+    """The N = 1 denominator of a strong-scaling entry, measured by THIS job on THIS node: rank 0 alone renders the whole frame
+    (every job, no exchange) on its GPU — reset, render, colorize to RGBA16 in HBM, every frame announcing its successor as the
+    timed loop of the line does — while the other ranks wait. (The pool's boxes differ by ~6 %: a figure from another box's
+    profile is not a denominator.)"""
+    n = int(iters_total) // total_jobs
+    cfg = S.Config.poisson_saturne(iterations=n * total_jobs, width=width, height=width, jobs_total=total_jobs, transparent=0, seed=seed)
+    starts = S.start_points(seed, 0, total_jobs)
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
+        rt = S.Runtime(cfg, device=device)
+        rt.set_stream(stream.cuda_stream)
+        rgba = torch.empty(width * width * 4, dtype=torch.int16, device=f"cuda:{device}")
+        starts_dev = torch.from_numpy(np.ascontiguousarray(starts)).to(f"cuda:{device}")
+
+        def step(more):
+            rt.reset()
+            S.render_job_range_device(cfg, rt, total_jobs, n, starts_dev.data_ptr())
+            if more:
+                S.prefetch_device(cfg, rt, total_jobs, n, starts_dev.data_ptr())
+            S.colorize_device(cfg, rt, rgba.data_ptr())
+
+        for k in range(warmup):
+            step(k + 1 < warmup)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k + 1 < steps)
+        torch.cuda.synchronize(device)
+        el = time.perf_counter() - t0
+        launch = rt.describe_last_launch()
+        rt.close()
+    return {"value": n * total_jobs * steps / el, "unit": "iterations/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warmup,
+            "jobs_total": total_jobs, "launch": launch, "device": device,
+            "note": "rank 0 alone, the whole frame on one GPU of this node, RGBA16 in HBM, the other ranks idle"}
+
+
 # ---- frame checksums against the committed goldens --------------------------------------------------------------------
 
 def fnv1a64(S, a) -> str:

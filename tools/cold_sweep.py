@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--max-batch", type=int, default=16)
     ap.add_argument("--jobs", type=int, default=65536)
+    ap.add_argument("--ring", type=int, default=0)
     ap.add_argument("--keep", action="store_true", help="keep every repetition's renderer alive until the end (no reuse of just-freed memory)")
     ap.add_argument("--delivery", default="batch", choices=["frame", "batch"])
     ap.add_argument("--json", default="")
@@ -80,6 +81,9 @@ def main():
     timed(api, "render_jobs_batch", "render_jobs_batch")
     timed(api, "render_jobs", "render_jobs")
     timed(api, "colorize_format_async", "colorize_format_async")
+    for name in ("colorize_format_device", "read_image_async", "image_done"):
+        if hasattr(api, name):
+            timed(api, name, name)
     timed(api, "colorize_device", "colorize_device")
     timed(api, "wait_image", "wait_image")
     timed(api, "batch_frames", "batch_frames")
@@ -111,7 +115,7 @@ def main():
             hbm = [torch.empty(1800 * 2000 * 4, dtype=torch.int16, device="cuda") for _ in range(slots)]
             seq = SequenceRenderer(scfg, device_ring=[t.data_ptr() for t in hbm], ring=slots, **kw)
         else:
-            seq = SequenceRenderer(scfg, image_format=S.SAR_FMT_RGB16, **kw)
+            seq = SequenceRenderer(scfg, image_format=S.SAR_FMT_RGB16, ring=a.ring, **kw)
         t1 = time.perf_counter()
         seq.run(todo, sink, zero_copy=True)
         torch.cuda.synchronize()
