@@ -8,14 +8,18 @@ namespace sar {
 // ---------------------------------------------------------------------------------------------------
 // state management
 // ---------------------------------------------------------------------------------------------------
+// (+ the depth hints a launch has written since they were last cleared: one launch instead of a kernel and a fill per frame of a sweep)
 __global__ void k_reset(uint32_t* count, unsigned long long* key, double* steps, uint32_t npix,
-                        uint32_t* scalars) {
+                        uint32_t* scalars, uint32_t* hints, uint32_t hint_words, uint32_t hint_fill) {
     const unsigned long long init = ((unsigned long long)f32_sortable(-1.0f) << 32) | 0xFFFFFFFFull;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
         count[p] = 0u;   // :687
         steps[p] = 0.;   // :690
         key[p] = init;   // zbuf = -1.0, :693
     }
+    const uint4 fill = make_uint4(hint_fill, hint_fill, hint_fill, hint_fill);
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < hint_words / 4u; q += gridDim.x * blockDim.x) ((uint4*)hints)[q] = fill;
+    if (blockIdx.x == 0 && threadIdx.x < (hint_words & 3u)) hints[(hint_words & ~3u) + threadIdx.x] = hint_fill;
     if (blockIdx.x == 0 && threadIdx.x < SC_COUNT) scalars[threadIdx.x] = 0u;  // max = 0, :694
 }
 
@@ -577,9 +581,10 @@ __global__ void __launch_bounds__(256) k_convert(const ushort4* __restrict__ in,
     }
 }
 
-void launch_reset(uint32_t* count, unsigned long long* key, double* steps, uint32_t npix, uint32_t* scalars,
-                  hipStream_t s) {
-    hipLaunchKernelGGL(k_reset, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, count, key, steps, npix, scalars);
+void launch_reset(uint32_t* count, unsigned long long* key, double* steps, uint32_t npix, uint32_t* scalars, void* hints,
+                  uint32_t hint_words, uint32_t hint_fill, hipStream_t s) {
+    hipLaunchKernelGGL(k_reset, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, count, key, steps, npix, scalars, (uint32_t*)hints,
+                       hints ? hint_words : 0u, hint_fill);
 }
 
 void launch_zbuf_out(const unsigned long long* key, float* out, uint32_t npix, hipStream_t s) {

@@ -181,8 +181,12 @@ int sar::clear_hints(sar_runtime* rt) {
 namespace {
 
 int do_reset(sar_runtime* rt) {
-    SAR_TRY(clear_hints(rt));
-    launch_reset(rt->d_count, rt->d_key, rt->d_steps, rt->npix, rt->d_scalars, rt->stream);
+    // the hints go with the buffers, in the same launch (clear_hints: what they are cleared to, and which of them)
+    const size_t entries = rt->d_zhint ? kHintStride(rt->npix) * rt->hint_copies_used : 0;
+    const uint32_t words = static_cast<uint32_t>(rt->zhint_bytes == 4 ? entries : entries / 2u);  // (kHintStride is even)
+    launch_reset(rt->d_count, rt->d_key, rt->d_steps, rt->npix, rt->d_scalars, rt->d_zhint, words, rt->zhint_bytes == 4 ? 0xBF7FFFFFu : 0u, rt->stream);
+    rt->hint_copies_used = 0;
+    rt->hint_range_set = false;
     HIP_TRY(hipGetLastError());
     return SAR_OK;
 }

@@ -475,3 +475,80 @@ def test_host_is_off_the_critical_path_of_a_multi_device_frame(sar, oracle, gpu)
     oracle.render_jobs_mt(frames[2].replace(jobs_total=units * jpu).c, ort, oracle.start_points(5, 2 * units * jpu, units * jpu), 120)
     np.testing.assert_array_equal(want[2], oracle.colorize(frames[2].c, ort))
     multi.shutdown()
+
+
+@pytest.mark.parametrize("world,W,H,dense_above", [(2, 512, 384, 2.0), (3, 333, 257, 2.0), (5, 640, 480, 2.0), (8, 1024, 1024, 2.0), (8, 200, 120, 2.0),
+                                                   (4, 512, 384, 0.0), (3, 512, 384, 0.5)])
+def test_exchange_context_plans_packs_and_folds_like_merge_in_rank_order(sar, oracle, gpu, world, W, H, dense_above):
+    """The library's exchange context (sar_exchange_*: flags -> plan -> pack -> merge -> finish) for `world` ranks living in ONE
+    process: every rank renders its job slice, the collectives between the steps are done by hand with numpy (all-gather of the
+    flags, all-to-all with the split sizes the plan returns, MAX of the scalars) — image sizes whose granule counts are no multiple
+    of 64 or of the slice, 2..8 ranks, the sparse form forced (dense_above 2), refused (0) and chosen (0.5). The split sizes must
+    agree between every sender and receiver, and every owner's slice must be Runtime::merge folded in rank order (:708-738,
+    :1068-1076) by the oracle, bit for bit."""
+    import torch
+    from strange_attractor_renderer_amd.distributed import shard_jobs
+    jobs, n, seed = 97, 900, 12
+    cfg = sar.Config.poisson_saturne(iterations=jobs * n, width=W, height=H, jobs_total=jobs, transparent=0)
+    rts, orts, exs = [], [], []
+    for r in range(world):
+        first, cnt = shard_jobs(jobs, world, r)
+        st = sar.start_points(seed, first, cnt)
+        rt, ort = sar.Runtime(cfg), oracle.Runtime(W, H)
+        sar.render_job_range(cfg, rt, n, st)
+        oracle.render_jobs(cfg.c, ort, st, n)
+        rts.append(rt); orts.append(ort); exs.append(sar.Exchange(rt, world, r))
+    ex0 = exs[0]
+    nseg, blk = ex0.granules, ex0.block_bytes
+    assert nseg == (W * H + 63) // 64 and blk == world * ex0.slice_pixels * 16
+    dev = lambda nbytes: torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    flags = [dev(nseg) for _ in range(world)]
+    for r in range(world):
+        exs[r].flags(flags[r].data_ptr())
+        rts[r].synchronize()
+    flags_all = torch.cat(flags).contiguous()                                     # the all-gather
+    torch.cuda.synchronize()
+    send, sb, rb, forms = [], [], [], []
+    for r in range(world):
+        buf = dev(blk)
+        sparse, s_bytes, r_bytes = exs[r].pack(flags_all.data_ptr() if dense_above > 0 else None, dense_above, buf.data_ptr())
+        rts[r].synchronize()
+        send.append(buf.cpu().numpy()); sb.append(s_bytes); rb.append(r_bytes); forms.append(sparse)
+    assert len(set(forms)) == 1                                                   # every rank decides alike
+    fa = flags_all.cpu().numpy().reshape(world, nseg)
+    touched_share = fa.sum() / (world * nseg)
+    assert forms[0] == (dense_above > 0 and touched_share <= dense_above)
+    for r in range(world):
+        for d in range(world):
+            assert sb[r][d] == rb[d][r], (r, d, sb[r][d], rb[d][r])               # what r sends to d is what d expects from r
+        if forms[0]:
+            sps = ex0.slice_pixels // 64
+            own = [int(fa[r, d * sps:(d + 1) * sps].sum()) * 1024 for d in range(world)]
+            assert sb[r] == own                                                   # the plan's counts are the flags' (numpy)
+    sc = []
+    for d in range(world):                                                        # the all-to-all: owner d receives, source by source
+        parts = [send[r][sum(sb[r][:d]):sum(sb[r][:d]) + sb[r][d]] for r in range(world)]
+        recv = np.zeros(blk, np.uint8)
+        cat = np.concatenate(parts) if sum(len(p) for p in parts) else np.zeros(0, np.uint8)
+        recv[:len(cat)] = cat
+        rbuf = torch.from_numpy(recv).cuda()
+        s4 = torch.zeros(4, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        exs[d].merge(rbuf.data_ptr(), s4.data_ptr())
+        rts[d].synchronize()
+        sc.append(s4.cpu().numpy())
+    red = torch.from_numpy(np.max(np.stack(sc), axis=0)).cuda()                   # the all-reduce MAX
+    torch.cuda.synchronize()
+    acc = orts[0]
+    for other in orts[1:]:
+        assert oracle.merge(acc, other) == 0
+    for d in range(world):
+        exs[d].finish(red.data_ptr())
+        f, c = exs[d].first, exs[d].count
+        assert rts[d].max() == acc.max
+        np.testing.assert_array_equal(rts[d].count().ravel()[f:f + c], acc.count.ravel()[f:f + c])
+        np.testing.assert_array_equal(_bits(rts[d].zbuf().ravel()[f:f + c]), _bits(acc.zbuf.ravel()[f:f + c]))
+        np.testing.assert_array_equal(_bits(rts[d].steps().ravel()[f:f + c]), _bits(acc.steps.ravel()[f:f + c]))
+    assert sum(e.count for e in exs) == W * H
+    for rt in rts:
+        rt.close()                                                                # (closes its exchange context first)

@@ -28,6 +28,8 @@ for cmd in share full; do
   run_pmc $cmd l2 TCC_HIT_sum TCC_MISS_sum
   run_pmc $cmd l2req TCC_REQ_sum TCC_ATOMIC_sum
   run_pmc $cmd ea TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
+  run_pmc $cmd rdsize TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
+  run_pmc $cmd wrsize TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WR_UNCACHED_32B_sum TCC_EA0_WRREQ_WRITE_DRAM_32B_sum
   run_pmc $cmd insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES
   run_pmc $cmd act SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY
   run_pmc $cmd lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS

@@ -23,6 +23,9 @@ run_pmc l2 TCC_HIT_sum TCC_MISS_sum
 run_pmc l2req TCC_REQ_sum TCC_ATOMIC_sum
 run_pmc ea TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 run_pmc eaatom TCC_EA0_ATOMIC_sum
+# what a fabric request weighs: reads by size (FETCH_SIZE tallies 64 B per request whatever its size), writes in 32-byte units
+run_pmc rdsize TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
+run_pmc wrsize TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WR_UNCACHED_32B_sum TCC_EA0_WRREQ_WRITE_DRAM_32B_sum
 run_pmc sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD
 run_pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES
 run_pmc grbm GRBM_GUI_ACTIVE GRBM_COUNT

@@ -26,6 +26,11 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
               f" — the first three dispatches are bench.py's untimed warm-up steps (cold caches, first touch of the arena), the 24th "
               f"is the untimed frame whose checksums the line's `parity` reports; mean of the 20 timed ones "
               f"{sum(timed) / max(len(timed), 1):.3f} ms, which is what bench.py's HIP events average.\n")
+        med = sorted(timed)[len(timed) // 2] if timed else 0.0
+        slow = [k + 4 for k, x in enumerate(timed) if x > 1.08 * med]
+        print(f"timed dispatches slower than 1.08 x their median ({med:.3f} ms): {slow or 'none'} (round 5's trace held six, in pairs eight "
+              f"dispatches apart; profiles/r06_questions.md: the tracer and HIP events agree to 6 us on the same dispatches, the pairs did not "
+              f"come back on three other boxes).\n")
 try:
     line = [l for l in open(os.path.join(root, "trace_bench.json")) if l.startswith("{")][-1]
     b = json.loads(line)
