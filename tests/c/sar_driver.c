@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
     CHECK(sar_runtime_free(rt));
 
     /* a `sequence` sweep's frames (main.rs:493-517 renders them one after the other) through ONE set of launches:
-     * sar_render_jobs_batch — three frames, each with its own Runtime, view angle and start-point stream */
+     * sar_render_jobs_batch — three frames, each with its own Runtime (of ONE frame group), view angle and start-point stream */
     enum { FRAMES = 3 };
     sar_config fc[FRAMES];
     const sar_config* fcp[FRAMES];
@@ -77,12 +77,35 @@ int main(int argc, char** argv) {
         fc[i].angle = 0.3 * i;
         fc[i].seed = seed + 1u + (uint64_t)i;
         fcp[i] = &fc[i];
-        CHECK(sar_runtime_new(&fc[i], 0, &fr[i]));
     }
     uint32_t advice = 0;
-    CHECK(sar_runtime_batch_frames(&fc[0], fr[0], &advice));
+    CHECK(sar_runtime_batch_frames(&fc[0], NULL, &advice));       /* before any runtime exists: 1 = frame by frame */
     if (advice < 1u) { fprintf(stderr, "sar_runtime_batch_frames said %u\n", advice); return 1; }
+    CHECK(sar_runtime_new_group(&fc[0], 0, FRAMES, fr));           /* one stream, one allocation per runtime */
+    for (int i = 0; i < FRAMES; ++i) CHECK(sar_runtime_seed(fr[i], fc[i].seed));
     CHECK(sar_render_jobs_batch(FRAMES, fcp, (sar_runtime* const*)fr, NULL));
+    /* the sweep's read-back in two steps: the batch's conversions at once (device memory only), then every frame into a
+     * page-locked image, polled without waiting (sar_runtime_image_done) and waited for at the end */
+    const int fmt = sar_image_format(0, 1);                        /* --8bit, not transparent: RGB8 (main.rs:52-57) */
+    const size_t img_bytes = sar_image_bytes(fmt, W, H);
+    void* img[FRAMES];
+    uint64_t ticket[FRAMES];
+    for (int i = 0; i < FRAMES; ++i) CHECK(sar_colorize_format_async(&fc[i], fr[i], fmt, NULL, NULL));
+    for (int i = 0; i < FRAMES; ++i) {
+        CHECK(sar_host_alloc(img_bytes, &img[i]));
+        CHECK(sar_runtime_read_image_async(fr[i], img[i], &ticket[i]));
+    }
+    for (int i = 0; i < FRAMES; ++i) {
+        char name[64];
+        int done = 0;
+        CHECK(sar_runtime_image_done(fr[i], ticket[i], &done));    /* 0 or 1: never blocks */
+        CHECK(sar_runtime_wait_image(fr[i], ticket[i]));
+        CHECK(sar_runtime_image_done(fr[i], ticket[i], &done));
+        if (!done) { fprintf(stderr, "a waited-for image is not done\n"); return 1; }
+        snprintf(name, sizeof name, "rgb8_batch_%d.bin", i);
+        if (dump(dir, name, img[i], img_bytes)) return 1;
+        CHECK(sar_host_free(img[i]));
+    }
     uint64_t sums[FRAMES];
     for (int i = 0; i < FRAMES; ++i) {
         char name[64];

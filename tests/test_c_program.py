@@ -61,6 +61,8 @@ def test_c_driver_results_equal_the_oracle(sar, oracle, gpu, tmp_path, shards):
         assert np.array_equal(rd(f"count_batch_{i}.bin", np.uint32).reshape(H, W), o.count), f"batched frame {i}"
         assert np.array_equal(rd(f"rgba_batch_{i}.bin", np.uint16).reshape(H, W, 4), oracle.colorize(c, o)), f"batched frame {i}"
         assert int(sums[i]) == oracle.fnv1a64(o.count)                      # sar_checksum_fnv1a64
+        # ... and read back in two steps (conversion in device memory, then sar_runtime_read_image_async) as RGB8
+        assert np.array_equal(rd(f"rgb8_batch_{i}.bin", np.uint8).reshape(H, W, 3), oracle.convert(3, oracle.colorize(c, o))), f"RGB8 frame {i}"
     if shards > 1:   # the second frame of the renderer went through the dense exchange: the stream ran on, other jobs
         o2 = oracle.Runtime(W, H)
         oracle.render_jobs(cfg, o2, oracle.start_points(seed, jobs, jobs), n)
