@@ -65,7 +65,11 @@ def frame_seed(seed: int, k: int) -> int:
     return (seed + 0x9E3779B97F4A7C15 * (k + 1)) & 0xFFFFFFFFFFFFFFFF
 
 
-SETTLE = 1  # stream synchronisations a new runtime's first frames are waited for with (SequenceRenderer.run)
+# Stream synchronisations a lane's first frames are waited for with (SequenceRenderer.run). Rounds 3-5 needed ONE: the kernels of two
+# freshly created streams did not overlap until one of them had been synchronised while the other was busy. With a lane's streams
+# made together (a frame group, round 6) the sweep runs the same without it — 1440 frames 1070 / 830 ms (read-back / in HBM) either
+# way — and a cold 360-frame sweep is 10-20 ms shorter (307-331 against 327-358 ms): 0.
+SETTLE = 0
 
 
 class SequenceRenderer:
@@ -213,7 +217,7 @@ class SequenceRenderer:
         draw = _Drawn
 
         def deliver(g: int, rt, slot: int, ticket: int, k: int, name: str, first_of_batch: bool = False):
-            if self.settle.get(g, 0) < SETTLE:
+            if self.settle.get(g, 0) < (SETTLE if self.max_batch > 1 else 1):   # (lanes of single runtimes: streams made one by one)
                 # Measured on ROCm 7.2, in a process that uses nothing but this library: the kernels of two freshly created
                 # streams do not overlap — as if they shared a hardware queue — until one of them has been synchronised
                 # ONCE while the other was busy (1.7 ms per frame for the first ~70 frames per runtime, 1.2 after; an event

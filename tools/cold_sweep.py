@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--max-batch", type=int, default=16)
     ap.add_argument("--jobs", type=int, default=65536)
     ap.add_argument("--ring", type=int, default=0)
+    ap.add_argument("--settle", type=int, default=-1, help="override sequence.SETTLE (stream synchronisations a lane's first frames are waited for with)")
     ap.add_argument("--keep", action="store_true", help="keep every repetition's renderer alive until the end (no reuse of just-freed memory)")
     ap.add_argument("--delivery", default="batch", choices=["frame", "batch"])
     ap.add_argument("--json", default="")
@@ -37,6 +38,8 @@ def main():
     from strange_attractor_renderer_amd import api, sequence
     from strange_attractor_renderer_amd.sequence import SequenceRenderer, frames as sequence_frames
 
+    if a.settle >= 0:
+        sequence.SETTLE = a.settle
     acc: dict = {}
     timeline: list = []
     t_origin = [0.0]
