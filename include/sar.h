@@ -273,7 +273,7 @@ int sar_colorize_format_async(const sar_config* cfg, sar_runtime* rt, int format
 int sar_runtime_read_image_async(sar_runtime* rt, void* out_host, uint64_t* ticket_out);
 int sar_runtime_image_done(sar_runtime* rt, uint64_t ticket, int* done_out);
 int sar_runtime_wait_image(sar_runtime* rt, uint64_t ticket);
-/* Page-locked host memory for those read-backs. */
+/* Page-locked host memory for those read-backs (4 MiB and more: mapped with huge pages, touched, hipHostRegister'ed). */
 int sar_host_alloc(size_t bytes, void** out);
 int sar_host_free(void* p);
 /* Encoders (host only; no device needed). `pixels` is a host image in `format`, host-endian samples.

@@ -5,6 +5,8 @@
 // Host logic only (allocation, argument blocks, stream ordering); all arithmetic on image data happens in the kernel files
 // (sar_iterate.hip, sar_accumulate.hip, sar_image.hip). There is no CPU fallback: without a HIP device every entry point
 // that touches a runtime returns SAR_ERR_NO_DEVICE.
+#include <sys/mman.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -750,14 +752,63 @@ int sar_runtime_wait_image(sar_runtime* rt, uint64_t ticket) try {
     return SAR_OK;
 } catch (...) { return sar::abi_caught(); }
 
+// Page-locked host memory for the read-backs. hipHostMalloc page-locks 4 KiB page by 4 KiB page (1.0-1.4 ms per 21.6 MB image on
+// most boxes of the pool, 3-4 on some: 33-100 ms of a sweep's set-up); an anonymous mapping that asks for transparent huge pages,
+// touched once and then registered with the HIP runtime, is the same memory to a copy and takes 0.4 of the time (tools/ubench/
+// alloc_cost.py: 352 MiB in 20 ms against 48-55). Large blocks go that way; what fails on the way falls back to hipHostMalloc.
+namespace {
+struct MappedBlock { void* p; size_t bytes; };
+std::mutex g_mapped_mu;
+std::vector<MappedBlock> g_mapped;
+constexpr size_t kHugePage = 2u << 20;
+
+void* map_and_register(size_t bytes) {
+    const size_t len = (bytes + kHugePage - 1) & ~(kHugePage - 1);
+    // (over-map by one huge page so that the block can start on a 2 MiB boundary: only aligned ranges get huge pages)
+    char* raw = static_cast<char*>(mmap(nullptr, len + kHugePage, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+    if (raw == MAP_FAILED) return nullptr;
+    char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(raw) + kHugePage - 1) & ~static_cast<uintptr_t>(kHugePage - 1));
+    if (p > raw) munmap(raw, static_cast<size_t>(p - raw));
+    if (p + len < raw + len + kHugePage) munmap(p + len, static_cast<size_t>(raw + len + kHugePage - (p + len)));
+    madvise(p, len, MADV_HUGEPAGE);                       // (advice: refused or unavailable, the pages are small ones)
+    for (size_t off = 0; off < len; off += 4096) p[off] = 0;  // first touch: the pages exist before they are locked
+    if (hipHostRegister(p, len, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        munmap(p, len);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_mapped_mu);
+    g_mapped.push_back({p, len});
+    return p;
+}
+}  // namespace
+
 int sar_host_alloc(size_t bytes, void** out) try {
     if (!out || bytes == 0) { set_error("sar_host_alloc: NULL output or zero size"); return SAR_ERR_INVALID; }
+#ifndef SAR_EXPERIMENT_HOST_ALLOC_PLAIN  // (A/B timing only)
+    if (bytes >= (4u << 20)) {
+        *out = map_and_register(bytes);
+        if (*out) return SAR_OK;
+    }
+#endif
     HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
     return SAR_OK;
 } catch (...) { return sar::abi_caught(); }
 
 int sar_host_free(void* p) try {
-    if (p) HIP_TRY(hipHostFree(p));
+    if (!p) return SAR_OK;
+    size_t mapped = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_mapped_mu);
+        for (size_t k = 0; k < g_mapped.size(); ++k)
+            if (g_mapped[k].p == p) { mapped = g_mapped[k].bytes; g_mapped.erase(g_mapped.begin() + static_cast<long>(k)); break; }
+    }
+    if (mapped) {
+        HIP_TRY(hipHostUnregister(p));
+        munmap(p, mapped);
+        return SAR_OK;
+    }
+    HIP_TRY(hipHostFree(p));
     return SAR_OK;
 } catch (...) { return sar::abi_caught(); }
 
