@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--max-batch", type=int, default=16)
     ap.add_argument("--jobs", type=int, default=65536)
     ap.add_argument("--ring", type=int, default=0)
+    ap.add_argument("--copy-cus", type=int, default=0, help="experiment: the lanes' read-back streams on this many CUs of their own (a multiple "
+                    "of 8: bit i of a CU mask is CU i / 8 of XCD i %% 8), the launch streams on the others")
     ap.add_argument("--settle", type=int, default=-1, help="override sequence.SETTLE (stream synchronisations a lane's first frames are waited for with)")
     ap.add_argument("--keep", action="store_true", help="keep every repetition's renderer alive until the end (no reuse of just-freed memory)")
     ap.add_argument("--delivery", default="batch", choices=["frame", "batch"])
@@ -76,6 +78,31 @@ def main():
                 if len(timeline) < a.timeline:
                     timeline.append([round((t - t_origin[0]) * 1e3, 3), round((e - t) * 1e3, 3), "Runtime.group()"])
         api.Runtime.group = classmethod(timed_group)
+    if a.copy_cus:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+        masked_streams = []
+
+        def masked(bits_on):
+            words = (C.c_uint32 * 8)(*([0] * 8))
+            for b in bits_on:
+                words[b // 32] |= 1 << (b % 32)
+            st = C.c_void_p()
+            assert hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, words) == 0
+            masked_streams.append(st)
+            return st.value
+
+        plain_group = api.Runtime.group.__func__
+
+        def group_on_masked_streams(cls, *args, **kw):
+            rts = plain_group(cls, *args, **kw)
+            launch, copy = masked(range(a.copy_cus, 256)), masked(range(a.copy_cus))
+            for rt in rts:
+                rt.set_stream(launch)
+                rt.set_copy_stream(copy)
+            return rts
+        api.Runtime.group = classmethod(group_on_masked_streams)
     timed(api.Runtime, "reset", "reset")
     timed(api.Runtime, "synchronize", "synchronize")
     timed(api.Runtime, "close", "Runtime.close")
