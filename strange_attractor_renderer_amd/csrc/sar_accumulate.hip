@@ -107,7 +107,11 @@ __device__ __forceinline__ void bin_accumulate_body(const BinAccArgs& a, uint32_
 #ifdef SAR_ACC_GUARD_CHECK  // the bound itself: a guarded counter holds at most the adds in flight
                         if ((old & __umul24(inc, 0x7FFFu)) >= __umul24(inc, 0x4000u)) __builtin_trap();
 #endif
+#ifdef SAR_ACC_GUARD_CHECK  // ... and what the bound does not cover: an undo must never find its counter's 15 bits at zero (a borrow)
+                        if ((atomicSub(&hist[rec >> 1], inc) & __umul24(inc, 0x7FFFu)) == 0u) __builtin_trap();
+#else
                         atomicSub(&hist[rec >> 1], inc);
+#endif
                         atomicAdd(&out[pixel_of(rec)], 1u);
                         ev_ctl[1] = 1u;
                     } else {
