@@ -355,3 +355,52 @@ def test_runtimes_of_a_frame_group_are_ordinary_runtimes(sar, oracle, gpu):
     sar.render_jobs(cfgs[2], one, starts[2])
     _assert_same(_state(sar, cfgs[2], one), _oracle_state(oracle, cfgs[2], starts[2], n)[1], "after the group")
     one.close()
+
+
+def test_frames_that_cannot_share_launches_keep_one_runtime_per_lane(sar, oracle, gpu):
+    """beyond 4 Mpx (bins of 65 536 pixels) frames do not share launches — sar_runtime_batch_frames answers 1, and the sweep
+    keeps ONE runtime per lane, two lanes and a ring of four images (not sixteen full-size runtimes per lane rendered one after the
+    other on one stream); the frames are the oracle's."""
+    from strange_attractor_renderer_amd.sequence import SequenceRenderer, frames
+    cfg = sar.Config.poisson_saturne(iterations=64 * 300, width=4096, height=1536, transparent=0)      # 6.3 Mpx
+    kw = dict(units=16, jobs_per_thread=4, seed=9)
+    assert sar.batch_frames(cfg.replace(jobs_total=64)) == 1
+    with SequenceRenderer(cfg, image_format=sar.SAR_FMT_RGB8, **kw) as seq:
+        got = seq.run(frames(0.0, 5.0, 1.0))
+        assert (seq.lanes, seq.ring, seq.max_batch) == (2, 4, 1)
+        assert [len(g) for g in seq.groups] == [1, 1] and seq.frames_per_launch == [1] * 5 and len(seq.images) <= 4
+        assert "batch" not in seq.groups[0][0].describe_last_launch()
+    n = 64 * 300 // 16 // 4
+    for k in (0, 4):
+        c = cfg.replace(angle=k * math.pi / 180.0, jobs_total=64, iterations=n * 64)
+        _, o = _oracle_state(oracle, c, oracle.start_points(frame_seed(9, k), 0, 64), n)
+        np.testing.assert_array_equal(got[k][2], oracle.convert(3, o[4]))
+
+
+def test_a_member_with_another_hint_layout_renders_on_its_own(sar, oracle, gpu):
+    """a batched frame's depth hints are laid out by the LEADER's options. A member whose own hints may have been written
+    in another layout (its hint_tile option differs) is not batched — the frames run one after the other, same results."""
+    F, W, H, jobs, n = 3, 512, 256, 2048, 300
+    cfg_kw = dict(seed=23)
+    cfgs, starts = _frames(sar, "poisson_saturne", 0, F, W, H, jobs, n, **cfg_kw)
+    rts = [sar.Runtime(c) for c in cfgs]
+    for rt in rts:
+        rt.set_option("hint_bits", 16)
+    rts[1].set_option("hint_tile", 1)                              # row-major hints on ONE member
+    sar.render_jobs(cfgs[1], rts[1], starts[1])                    # ... which it has written in that layout
+    sar.render_jobs_batch(cfgs, rts, starts)                       # (un-reset: frame 1 accumulates on top)
+    assert "batch" not in rts[0].describe_last_launch() and "batch" not in rts[1].describe_last_launch()
+    for i in range(F):
+        ort, want = _oracle_state(oracle, cfgs[i], starts[i], n)
+        if i == 1:
+            _, want = _oracle_state(oracle, cfgs[i], starts[i], n, ort)
+        _assert_same(_state(sar, cfgs[i], rts[i]), want, f"frame {i}, mixed hint layouts")
+    rts[1].set_option("hint_tile", 0)                              # the same layout again: batched
+    for rt in rts:
+        rt.reset()
+    sar.render_jobs_batch(cfgs, rts, starts)
+    assert "batch of 3 frames" in rts[1].describe_last_launch()
+    for i in range(F):
+        _assert_same(_state(sar, cfgs[i], rts[i]), _oracle_state(oracle, cfgs[i], starts[i], n)[1], f"frame {i}, one layout")
+    for rt in reversed(rts):
+        rt.close()
