@@ -398,6 +398,6 @@ def render_sequence_to_files(config: "api.Config", start: float, end: float, ste
             return f                                  # the page-locked image is reused only after its file is written
 
         lanes_ = kw.get("lanes", 0) or 1
-        kw.setdefault("ring", max(1, encoders) + lanes_ * (kw.get("batch", 0) or kw.get("max_batch", 16)) + 1)
+        kw.setdefault("ring", max(1, encoders) + (lanes_ + 1) * (kw.get("batch", 0) or kw.get("max_batch", 16)) + 1)
         render_sequence(config, start, end, step, file_name=file_name, image_format=fmt, sink=sink, zero_copy=True, **kw)  # the encoder's Future guards the view
         return [f.result() for f in pending]
