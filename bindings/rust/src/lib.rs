@@ -153,6 +153,8 @@ extern "C" {
                                  starts_xyz_host: *const *const f64) -> c_int;
     /// n runtimes for the frames of one batch: one stream, one device and one page-locked allocation for all of them.
     pub fn sar_runtime_new_group(cfg: *const SarConfig, device: c_int, n: u32, out: *mut *mut SarRuntime) -> c_int;
+    pub fn sar_runtime_reset_batch(n: u32, rts: *const *mut SarRuntime) -> c_int;
+    pub fn sar_colorize_device_batch(n: u32, cfgs: *const *const SarConfig, rts: *const *mut SarRuntime, rgba_out_dev: *const *mut c_void) -> c_int;
     pub fn sar_runtime_batch_frames(cfg: *const SarConfig, rt: *mut SarRuntime, out_frames: *mut u32) -> c_int;
     pub fn sar_renderer_set_exchange(r: *mut SarRenderer, mode: u32) -> c_int;
     pub fn sar_runtime_get_copy_stream(rt: *mut SarRuntime, hip_stream_out: *mut *mut c_void) -> c_int;

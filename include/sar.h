@@ -159,6 +159,8 @@ int sar_runtime_free(sar_runtime* rt);
 int sar_runtime_new_group(const sar_config* cfg, int device, uint32_t n, sar_runtime** out /* [n] */);
 /* Runtime::reset (:682-699): count<-0, steps<-0.0, zbuf<--1.0, max<-0. The RNG stream is NOT reseeded. */
 int sar_runtime_reset(sar_runtime* rt);
+/* n resets at once — the frames of a batch of a sweep (:950-951 per frame): ONE launch for the runtimes that share a stream. */
+int sar_runtime_reset_batch(uint32_t n, sar_runtime* const* rts);
 /* Runtime::set_width_height (:667-675): reallocates + resets only when the size changes. */
 int sar_runtime_set_width_height(sar_runtime* rt, uint32_t width, uint32_t height);
 /* Reseed the start-point stream (the reference has no equivalent; needed for reproducibility). */
@@ -232,6 +234,8 @@ int sar_runtime_prefetch_device(const sar_config* cfg, sar_runtime* rt, uint32_t
 int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host);
 /* Same, leaving the image in device memory (width*height*8 bytes); stream-ordered, no host sync. */
 int sar_colorize_device(const sar_config* cfg, sar_runtime* rt, void* rgba_out_dev);
+/* n of them at once (frame i: cfgs[i], rts[i] -> rgba_out_dev[i]): ONE launch for Gas frames of one palette on one stream. */
+int sar_colorize_device_batch(uint32_t n, const sar_config* const* cfgs, sar_runtime* const* rts, void* const* rgba_out_dev);
 
 /* ---- attractor extent: the "first pass" the reference leaves as a TODO (src/lib.rs:326-333) ----------------- *
  * n_jobs trajectories (start points from starts_xyz_host[n_jobs*3], or from the runtime's stream when NULL), each

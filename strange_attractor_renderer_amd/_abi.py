@@ -118,6 +118,8 @@ PROTOTYPES = {
     "sar_start_points": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, _P(C.c_double)]),
     "sar_runtime_new": (C.c_int, [_cfg_p, C.c_int, _P(_vp)]),
     "sar_runtime_new_group": (C.c_int, [_cfg_p, C.c_int, C.c_uint32, _P(_vp)]),
+    "sar_runtime_reset_batch": (C.c_int, [C.c_uint32, _P(_vp)]),
+    "sar_colorize_device_batch": (C.c_int, [C.c_uint32, _P(_cfg_p), _P(_vp), _P(_vp)]),
     "sar_runtime_free": (C.c_int, [_vp]),
     "sar_runtime_reset": (C.c_int, [_vp]),
     "sar_runtime_set_width_height": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),

@@ -470,6 +470,23 @@ def colorize(config: Config, runtime: Runtime) -> np.ndarray:
     return out
 
 
+def reset_batch(runtimes):
+    """Runtime::reset for every runtime of the list, in ONE launch where they share a stream (sar_runtime_reset_batch)."""
+    n = len(runtimes)
+    handles = (C.c_void_p * n)(*[rt.handle for rt in runtimes])
+    _check(_lib().sar_runtime_reset_batch(n, handles), "sar_runtime_reset_batch")
+
+
+def colorize_device_batch(configs, runtimes, rgba_dev_ptrs):
+    """colorize of frame i = (configs[i], runtimes[i]) into rgba_dev_ptrs[i] (device memory), ONE launch for Gas frames of one
+    palette on one stream (sar_colorize_device_batch)."""
+    n = len(runtimes)
+    cfgs = (C.POINTER(_abi.SarConfig) * n)(*[C.pointer(c.c) for c in configs])
+    handles = (C.c_void_p * n)(*[rt.handle for rt in runtimes])
+    outs = (C.c_void_p * n)(*[C.c_void_p(p) for p in rgba_dev_ptrs])
+    _check(_lib().sar_colorize_device_batch(n, cfgs, handles, outs), "sar_colorize_device_batch")
+
+
 def colorize_device(config: Config, runtime: Runtime, rgba_dev_ptr: int):
     """colorize into a caller-provided device buffer (H*W*8 bytes); stream-ordered, no host sync."""
     _check(_lib().sar_colorize_device(C.byref(config.c), runtime.handle, C.c_void_p(rgba_dev_ptr)),

@@ -23,6 +23,22 @@ __global__ void k_reset(uint32_t* count, unsigned long long* key, double* steps,
     if (blockIdx.x == 0 && threadIdx.x < SC_COUNT) scalars[threadIdx.x] = 0u;  // max = 0, :694
 }
 
+// F resets in one launch (the frames of a batch of a sweep: sixteen launches of k_reset one behind the other under another lane's
+// iterate kernel cost a tenth of the sweep): blockIdx.y is the frame, the table comes by value
+__global__ void k_reset_batch(const ResetBatch t, uint32_t npix) {
+    const ResetBatch::Frame f = t.f[blockIdx.y];
+    const unsigned long long init = ((unsigned long long)f32_sortable(-1.0f) << 32) | 0xFFFFFFFFull;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        f.count[p] = 0u;
+        f.steps[p] = 0.;
+        f.key[p] = init;
+    }
+    const uint4 fill = make_uint4(f.hint_fill, f.hint_fill, f.hint_fill, f.hint_fill);
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < f.hint_words / 4u; q += gridDim.x * blockDim.x) ((uint4*)f.hints)[q] = fill;
+    if (blockIdx.x == 0 && threadIdx.x < (f.hint_words & 3u)) f.hints[(f.hint_words & ~3u) + threadIdx.x] = f.hint_fill;
+    if (blockIdx.x == 0 && threadIdx.x < SC_COUNT) f.scalars[threadIdx.x] = 0u;
+}
+
 __global__ void k_zbuf_out(const unsigned long long* key, float* out, uint32_t npix) {
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x)
         out[p] = sortable_f32((uint32_t)(key[p] >> 32));
@@ -76,12 +92,9 @@ __device__ __forceinline__ double ln_u32(uint32_t c, const double* lut, uint32_t
     return (k < lut_len) ? lut[k] : log((double)c);
 }
 
-__global__ void __launch_bounds__(256) k_colorize_gas(const uint32_t* count, const double* steps,
-                                                      const uint32_t* scalars, const double* lut,
-                                                      uint32_t lut_len, const PaletteParams pal,
-                                                      double b_offset, double b_factor, int transparent,
-                                                      uint32_t npix, ushort4* out, int plain_palette) {
-    __shared__ double s_pal[(SAR_PALETTE_MAX + 1) * 3];
+__device__ __forceinline__ void colorize_gas_body(const uint32_t* count, const double* steps, const uint32_t* scalars, const double* lut,
+                                                  uint32_t lut_len, const PaletteParams& pal, double b_offset, double b_factor, int transparent,
+                                                  uint32_t npix, ushort4* out, int plain_palette, double* s_pal) {
     for (uint32_t k = threadIdx.x; k < (pal.len + 1) * 3; k += blockDim.x) s_pal[k] = pal.rgb[k / 3][k % 3];
     __syncthreads();
     const uint32_t rmax = scalars[SC_WRAP] ? 0xFFFFFFFFu : scalars[SC_MAX];
@@ -126,6 +139,22 @@ __global__ void __launch_bounds__(256) k_colorize_gas(const uint32_t* count, con
         o.w = transparent ? as_u16(factor * 65535.) : (uint16_t)65535;
         out[p] = o;
     }
+}
+
+__global__ void __launch_bounds__(256) k_colorize_gas(const uint32_t* count, const double* steps,
+                                                      const uint32_t* scalars, const double* lut,
+                                                      uint32_t lut_len, const PaletteParams pal,
+                                                      double b_offset, double b_factor, int transparent,
+                                                      uint32_t npix, ushort4* out, int plain_palette) {
+    __shared__ double s_pal[(SAR_PALETTE_MAX + 1) * 3];
+    colorize_gas_body(count, steps, scalars, lut, lut_len, pal, b_offset, b_factor, transparent, npix, out, plain_palette, s_pal);
+}
+// F frames of one palette in one launch (blockIdx.y: the frame)
+__global__ void __launch_bounds__(256) k_colorize_gas_batch(const ColorizeBatch t, const double* lut, uint32_t lut_len, const PaletteParams pal,
+                                                            double b_offset, double b_factor, int transparent, uint32_t npix, int plain_palette) {
+    __shared__ double s_pal[(SAR_PALETTE_MAX + 1) * 3];
+    const ColorizeBatch::Frame f = t.f[blockIdx.y];
+    colorize_gas_body(f.count, f.steps, f.scalars, lut, lut_len, pal, b_offset, b_factor, transparent, npix, (ushort4*)f.out, plain_palette, s_pal);
 }
 
 // fold (max, min) over zbuf != -1.0 with seeds (0.0, f32::MAX) (:877-882); the sortable image turns
@@ -602,19 +631,32 @@ void launch_merge(uint32_t* count, unsigned long long* key, double* steps, const
                        osteps, npix, scalars);
 }
 
-void launch_colorize_gas(const uint32_t* count, const double* steps, const uint32_t* scalars, const double* lut,
-                         uint32_t lut_len, const PaletteParams& pal, double b_offset, double b_factor,
-                         int transparent, uint32_t npix, void* out, hipStream_t s) {
-    // (k_colorize_gas's short way for unvisited pixels needs colours that are finite whatever the blend: every entry a finite,
-    // non-negative number — no -0.0, whose square root keeps its sign — far from overflow)
+static int plain_palette(const PaletteParams& pal) {
     int plain = 1;
     for (uint32_t k = 0; k <= pal.len && k <= SAR_PALETTE_MAX; ++k)
         for (int ch = 0; ch < 3; ++ch) {
             const double v = pal.rgb[k][ch];
             if (!(v >= 0.) || v > 1e300 || __builtin_signbit(v)) plain = 0;
         }
+    return plain;
+}
+void launch_colorize_gas(const uint32_t* count, const double* steps, const uint32_t* scalars, const double* lut,
+                         uint32_t lut_len, const PaletteParams& pal, double b_offset, double b_factor,
+                         int transparent, uint32_t npix, void* out, hipStream_t s) {
+    // (k_colorize_gas's short way for unvisited pixels needs colours that are finite whatever the blend: every entry a finite,
+    // non-negative number — no -0.0, whose square root keeps its sign — far from overflow)
+    const int plain = plain_palette(pal);
     hipLaunchKernelGGL(k_colorize_gas, dim3(grid_for(npix, 256, 8192)), dim3(256), 0, s, count, steps, scalars, lut,
                        lut_len, pal, b_offset, b_factor, transparent, npix, (ushort4*)out, plain);
+}
+
+void launch_colorize_gas_batch(const ColorizeBatch& t, uint32_t n_frames, const double* lut, uint32_t lut_len, const PaletteParams& pal, double b_offset,
+                               double b_factor, int transparent, uint32_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_colorize_gas_batch, dim3(grid_for(npix, 256, 2048), n_frames), dim3(256), 0, s, t, lut, lut_len, pal, b_offset, b_factor,
+                       transparent, npix, plain_palette(pal));
+}
+void launch_reset_batch(const ResetBatch& t, uint32_t n_frames, uint32_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_reset_batch, dim3(grid_for(npix, 256, 1024), n_frames), dim3(256), 0, s, t, npix);
 }
 
 void launch_colorize_depth(const unsigned long long* key, uint32_t* scalars, uint32_t npix, void* out,

@@ -220,6 +220,26 @@ struct PaletteParams {
     double rgb[SAR_PALETTE_MAX + 1][3];
 };
 
+// the tables of the batched reset / colorize launches (kernel arguments by value: 32 frames fit the 4 KB of a launch)
+struct ResetBatch {
+    struct Frame {
+        uint32_t* count;
+        unsigned long long* key;
+        double* steps;
+        uint32_t* scalars;
+        uint32_t* hints;
+        uint32_t hint_words, hint_fill;
+    } f[kMaxBatchFrames];
+};
+struct ColorizeBatch {
+    struct Frame {
+        const uint32_t* count;
+        const double* steps;
+        const uint32_t* scalars;
+        void* out;
+    } f[kMaxBatchFrames];
+};
+
 enum ScalarSlot : uint32_t {
     SC_MAX = 0,        // Runtime::max
     SC_WRAP = 1,       // a count wrapped u32 (running max would have hit u32::MAX)

@@ -20,6 +20,9 @@ int iterate_kernel_attributes();     // sar_iterate.hip
 int accumulate_kernel_attributes();  // sar_accumulate.hip
 int binned_kernel_attributes();      // both
 void launch_fold_resolve(const FoldArgs& a, hipStream_t s);
+void launch_reset_batch(const ResetBatch& t, uint32_t n_frames, uint32_t npix, hipStream_t s);
+void launch_colorize_gas_batch(const ColorizeBatch& t, uint32_t n_frames, const double* lut, uint32_t lut_len, const PaletteParams& pal, double b_offset,
+                               double b_factor, int transparent, uint32_t npix, hipStream_t s);
 void launch_reset(uint32_t* count, unsigned long long* key, double* steps, uint32_t npix, uint32_t* scalars, void* hints,
                   uint32_t hint_words, uint32_t hint_fill, hipStream_t s);
 void launch_zbuf_out(const unsigned long long* key, float* out, uint32_t npix, hipStream_t s);

@@ -492,6 +492,43 @@ int sar_runtime_reset(sar_runtime* rt) try {
     return do_reset(rt);
 } catch (...) { return sar::abi_caught(); }
 
+int sar_runtime_reset_batch(uint32_t n, sar_runtime* const* rts) try {
+    if (n && !rts) return SAR_ERR_INVALID;
+    for (uint32_t i = 0; i < n; ++i)
+        if (!rts[i]) return SAR_ERR_INVALID;
+    for (uint32_t first = 0; first < n;) {
+        // runs of runtimes that share a device, a stream and an image size go through ONE launch
+        sar_runtime* lead = rts[first];
+        uint32_t m = 1;
+        while (first + m < n && m < kMaxBatchFrames && rts[first + m]->device == lead->device && rts[first + m]->stream == lead->stream &&
+               rts[first + m]->npix == lead->npix) ++m;
+        HIP_TRY(hipSetDevice(lead->device));
+        if (m == 1) {
+            SAR_TRY(do_reset(lead));
+        } else {
+            ResetBatch t;
+            std::memset(&t, 0, sizeof(t));
+            for (uint32_t i = 0; i < m; ++i) {
+                sar_runtime* rt = rts[first + i];
+                const size_t entries = rt->d_zhint ? kHintStride(rt->npix) * rt->hint_copies_used : 0;
+                t.f[i].count = rt->d_count;
+                t.f[i].key = rt->d_key;
+                t.f[i].steps = rt->d_steps;
+                t.f[i].scalars = rt->d_scalars;
+                t.f[i].hints = static_cast<uint32_t*>(rt->d_zhint);
+                t.f[i].hint_words = static_cast<uint32_t>(rt->zhint_bytes == 4 ? entries : entries / 2u);
+                t.f[i].hint_fill = rt->zhint_bytes == 4 ? 0xBF7FFFFFu : 0u;
+                rt->hint_copies_used = 0;
+                rt->hint_range_set = false;
+            }
+            launch_reset_batch(t, m, lead->npix, lead->stream);
+            HIP_TRY(hipGetLastError());
+        }
+        first += m;
+    }
+    return SAR_OK;
+} catch (...) { return sar::abi_caught(); }
+
 int sar_runtime_set_width_height(sar_runtime* rt, uint32_t width, uint32_t height) try {
     if (!rt) return SAR_ERR_INVALID;
     if (rt->W == width && rt->H == height) return SAR_OK;  // :668
@@ -583,6 +620,53 @@ int sar_colorize_device(const sar_config* cfg, sar_runtime* rt, void* rgba_out_d
     SAR_TRY(check_cfg_matches(cfg, rt));
     if (!rgba_out_dev) return SAR_ERR_INVALID;
     return do_colorize(cfg, rt, rgba_out_dev);
+} catch (...) { return sar::abi_caught(); }
+
+int sar_colorize_device_batch(uint32_t n, const sar_config* const* cfgs, sar_runtime* const* rts, void* const* rgba_out_dev) try {
+    if (n && (!cfgs || !rts || !rgba_out_dev)) return SAR_ERR_INVALID;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!cfgs[i] || !rts[i] || !rgba_out_dev[i]) return SAR_ERR_INVALID;
+        SAR_TRY(check_cfg_matches(cfgs[i], rts[i]));
+    }
+    for (uint32_t first = 0; first < n;) {
+        // runs of Gas frames of one palette, brightness and alpha rule on one device, stream and image size: ONE launch
+        const sar_config* c0 = cfgs[first];
+        sar_runtime* lead = rts[first];
+        auto same_colours = [&](const sar_config* c) {
+            return c->render_kind == SAR_RENDER_GAS && c->palette_len == c0->palette_len && c->transparent == c0->transparent &&
+                   std::memcmp(&c->brightness_offset, &c0->brightness_offset, sizeof(double)) == 0 &&
+                   std::memcmp(&c->brightness_factor, &c0->brightness_factor, sizeof(double)) == 0 &&
+                   std::memcmp(c->palette_rgb, c0->palette_rgb, sizeof(double) * 3 * c0->palette_len) == 0;
+        };
+        uint32_t m = 1;
+        if (c0->render_kind == SAR_RENDER_GAS && !lead->timing)
+            while (first + m < n && m < kMaxBatchFrames && rts[first + m]->device == lead->device && rts[first + m]->stream == lead->stream &&
+                   rts[first + m]->npix == lead->npix && same_colours(cfgs[first + m])) ++m;
+        if (m == 1) {
+            SAR_TRY(do_colorize(c0, lead, rgba_out_dev[first]));
+        } else {
+            HIP_TRY(hipSetDevice(lead->device));
+            PaletteParams pal;
+            std::memset(&pal, 0, sizeof(pal));
+            pal.len = c0->palette_len;
+            for (uint32_t k = 0; k < c0->palette_len; ++k)
+                for (int ch = 0; ch < 3; ++ch) pal.rgb[k][ch] = c0->palette_rgb[k][ch];
+            for (int ch = 0; ch < 3; ++ch) pal.rgb[c0->palette_len][ch] = c0->palette_rgb[c0->palette_len - 1][ch];  // :416-418
+            ColorizeBatch t;
+            std::memset(&t, 0, sizeof(t));
+            for (uint32_t i = 0; i < m; ++i) {
+                t.f[i].count = rts[first + i]->d_count;
+                t.f[i].steps = rts[first + i]->d_steps;
+                t.f[i].scalars = rts[first + i]->d_scalars;
+                t.f[i].out = rgba_out_dev[first + i];
+            }
+            launch_colorize_gas_batch(t, m, lead->d_lnlut, kLnLutEntries, pal, c0->brightness_offset, c0->brightness_factor, c0->transparent ? 1 : 0,
+                                      lead->npix, lead->stream);
+            HIP_TRY(hipGetLastError());
+        }
+        first += m;
+    }
+    return SAR_OK;
 } catch (...) { return sar::abi_caught(); }
 
 int sar_colorize(const sar_config* cfg, sar_runtime* rt, uint16_t* rgba_out_host) try {

@@ -276,8 +276,7 @@ class SequenceRenderer:
                 if pos < len(todo):                               # the next batch: its size is the next lane's to say
                     size = self._batch_size((turn + 1) % lanes, cfg0, len(todo) - pos)
                     pending = draw([k for k, _, _ in todo[pos:pos + size]])
-                for rt in rts:
-                    rt.reset()                                    # :950-951
+                api.reset_batch(rts)                              # :950-951, the batch's frames in one launch
                 if len(part) > 1:
                     api.render_jobs_batch(cfgs, rts, starts)
                 else:
@@ -290,18 +289,20 @@ class SequenceRenderer:
                     # host image — only the copies do, on their own stream
                     for cfg, rt in zip(cfgs, rts):
                         api.colorize_format_device(cfg, rt, self.fmt)  # :1080
-                for i, ((k, _, name), cfg, rt) in enumerate(zip(part, cfgs, rts)):
+                else:
+                    # RGBA16 left in device memory: the batch's slots first, then ONE colorize launch for all of its frames
+                    slots = [take_slot(cfg) for cfg in cfgs]
+                    api.colorize_device_batch(cfgs, rts, [self.device_ring[slot % len(self.device_ring)] for slot in slots])  # :1080
+                    for i, ((k, _, name), rt, slot) in enumerate(zip(part, rts, slots)):
+                        waiting.append((turn, g, rt, slot, 0, k, name, i == 0))
+                for i, ((k, _, name), cfg, rt) in enumerate(zip(part, cfgs, rts) if self.device_ring is None else ()):
                     # frames whose read-back has completed are delivered as we go (no wait): their images take this batch's frames,
                     # and the ring only grows while the copies cannot keep up
-                    while waiting and waiting[0][0] < turn and self.device_ring is None and api.image_done(waiting[0][2], waiting[0][4]):
+                    while waiting and waiting[0][0] < turn and api.image_done(waiting[0][2], waiting[0][4]):
                         deliver_one()
                     if self.delivery == "frame" and waiting and waiting[0][0] <= turn - lanes:
                         deliver_one()
                     slot = take_slot(cfg)
-                    if self.device_ring is not None:
-                        api.colorize_device(cfg, rt, self.device_ring[slot % len(self.device_ring)])
-                        waiting.append((turn, g, rt, slot, 0, k, name, i == 0))
-                        continue
                     if hasattr(busy[slot], "result"):             # the consumer of the frame that last used this image
                         busy[slot].result()
                     busy[slot] = None

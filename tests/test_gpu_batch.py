@@ -404,3 +404,47 @@ def test_a_member_with_another_hint_layout_renders_on_its_own(sar, oracle, gpu):
         _assert_same(_state(sar, cfgs[i], rts[i]), _oracle_state(oracle, cfgs[i], starts[i], n)[1], f"frame {i}, one layout")
     for rt in reversed(rts):
         rt.close()
+
+
+@pytest.mark.parametrize("kind,options", [(0, {}), (0, {"hint_bits": 16}), (1, {})])
+def test_reset_and_colorize_of_a_batch_in_one_launch_each(sar, oracle, gpu, kind, options):
+    """sar_runtime_reset_batch / sar_colorize_device_batch: frame i is Runtime::reset (:684-695) / colorize (:1080) of runtime i —
+    one launch for the members of a frame group, frame after frame for whoever does not fit (another stream, Depth, another palette)."""
+    import torch
+    W, H, jobs, n = 320, 240, 900, 301
+    cfgs, starts = _frames(sar, "solar_sail", kind, 7, W, H, jobs, n, seed=11)
+    cfgs[5] = cfgs[5].replace(brightness_factor=cfgs[5].c.brightness_factor * 1.5)   # a frame of other colours: a launch of its own
+    rts = sar.Runtime.group(cfgs[0], 6) + [sar.Runtime(cfgs[6])]                  # six of a group and one on a stream of its own
+    for rt in rts:
+        for k, v in options.items():
+            rt.set_option(k, v)
+    outs = [torch.zeros(W * H * 4, dtype=torch.int16, device="cuda") for _ in range(7)]
+
+    def images():
+        sar.colorize_device_batch(cfgs, rts, [o.data_ptr() for o in outs])
+        for rt in rts[5:]:
+            rt.synchronize()
+        return [o.cpu().numpy().view(np.uint16).reshape(H, W, 4) for o in outs]
+
+    for round_ in range(2):                                                       # the second round renders on what reset_batch left
+        sar.render_jobs_batch(cfgs[:6], rts[:6], starts[:6])
+        sar.render_jobs(cfgs[6], rts[6], starts[6])
+        got = images()
+        for i in range(7):
+            want = _oracle_state(oracle, cfgs[i], starts[i], n)[1]
+            assert np.array_equal(got[i], want[4].reshape(H, W, 4)), f"round {round_}: image {i} of the batched colorize"
+            _assert_same(_state(sar, cfgs[i], rts[i]), want, f"round {round_}: frame {i}")
+        sar.reset_batch(rts)
+        for i, rt in enumerate(rts):
+            assert not rt.count().any() and rt.max() == 0 and not rt.steps().any(), f"round {round_}: runtime {i} after reset_batch"
+            assert np.array_equal(_bits(rt.zbuf()), np.full(W * H, np.float32(-1.0)).view(np.uint32).reshape(rt.zbuf().shape))
+    blank = images()                                                              # unvisited pixels only: the short path of every frame
+    ort = oracle.Runtime(W, H)
+    for i in range(7):
+        assert np.array_equal(blank[i], oracle.colorize(cfgs[i].c, ort).reshape(H, W, 4)), f"blank image {i}"
+    sar.reset_batch([])
+    sar.colorize_device_batch([], [], [])
+    with pytest.raises(sar.SarError):
+        sar.colorize_device_batch(cfgs[:2], rts[:2], [outs[0].data_ptr(), 0])
+    for rt in rts:
+        rt.close()

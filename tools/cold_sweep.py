@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--max-batch", type=int, default=16)
     ap.add_argument("--jobs", type=int, default=65536)
     ap.add_argument("--ring", type=int, default=0)
+    ap.add_argument("--skip", default="", help="TIMING EXPERIMENT ONLY (wrong images): comma list of per-frame calls to leave out: reset, colorize")
+    ap.add_argument("--per-frame", action="store_true", help="A/B: reset and colorize as one call per frame instead of one per batch")
     ap.add_argument("--copy-cus", type=int, default=0, help="experiment: the lanes' read-back streams on this many CUs of their own (a multiple "
                     "of 8: bit i of a CU mask is CU i / 8 of XCD i %% 8), the launch streams on the others")
     ap.add_argument("--settle", type=int, default=-1, help="override sequence.SETTLE (stream synchronisations a lane's first frames are waited for with)")
@@ -103,6 +105,19 @@ def main():
                 rt.set_copy_stream(copy)
             return rts
         api.Runtime.group = classmethod(group_on_masked_streams)
+    if "reset" in a.skip:
+        api.reset_batch = lambda rts: None
+    if "colorize" in a.skip:
+        api.colorize_device_batch = lambda *args, **kw: None
+    if a.per_frame:                   # the A/B of the batched reset / colorize launches: one call per frame as before
+        def reset_each(rts):
+            for rt in rts:
+                rt.reset()
+
+        def colorize_each(cfgs, rts, outs):
+            for c, rt, o in zip(cfgs, rts, outs):
+                api.colorize_device(c, rt, o)
+        api.reset_batch, api.colorize_device_batch = reset_each, colorize_each
     timed(api.Runtime, "reset", "reset")
     timed(api.Runtime, "synchronize", "synchronize")
     timed(api.Runtime, "close", "Runtime.close")
@@ -115,6 +130,8 @@ def main():
         if hasattr(api, name):
             timed(api, name, name)
     timed(api, "colorize_device", "colorize_device")
+    timed(api, "colorize_device_batch", "colorize_device_batch")
+    timed(api, "reset_batch", "reset_batch")
     timed(api, "wait_image", "wait_image")
     timed(api, "batch_frames", "batch_frames")
     timed(api.ParallelRenderer, "__init__", "ParallelRenderer()")
