@@ -328,7 +328,8 @@ typedef struct sar_exchange_layout {
 } sar_exchange_layout;
 #define SAR_EXCHANGE_GRANULE 64
 int sar_exchange_slice_pixels(uint32_t npix, uint32_t world, uint32_t* out_slice_pixels);   /* host arithmetic only */
-/* rt is borrowed: every call on the exchange but sar_exchange_free needs it alive; layout_out may be NULL. */
+/* rt is borrowed: every call on the exchange but sar_exchange_free needs it alive, at the image size it had here (a resized
+ * runtime: SAR_ERR_DIM_MISMATCH, make a new context); layout_out may be NULL. */
 int sar_exchange_new(sar_runtime* rt, uint32_t world, uint32_t rank, sar_exchange** out, sar_exchange_layout* layout_out);
 int sar_exchange_free(sar_exchange* ex);
 int sar_exchange_flags(sar_exchange* ex, uint8_t* flags_out_dev /* [granules] */);

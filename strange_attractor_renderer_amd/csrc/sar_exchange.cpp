@@ -15,6 +15,7 @@ struct sar_exchange {
     sar_runtime* rt = nullptr;  // borrowed: every call but sar_exchange_free needs it alive
     int device = 0;
     uint32_t world = 1, rank = 0;
+    uint32_t npix = 0;          // the runtime's image size when the context was made (a resized runtime needs a new context)
     uint32_t S = 0;             // pixels per slice
     uint32_t sps = 0;           // granules per slice
     uint32_t nseg = 0;          // granules of the image
@@ -37,6 +38,12 @@ int slice_pixels(uint32_t npix, uint32_t world, uint32_t& out) {
     return SAR_OK;
 }
 
+int same_image(const sar_exchange* ex) {
+    if (ex->rt->npix == ex->npix) return SAR_OK;
+    set_error("exchange context made for %u pixels, the runtime now holds %u: make a new one", ex->npix, ex->rt->npix);
+    return SAR_ERR_DIM_MISMATCH;
+}
+
 }  // namespace
 
 extern "C" {
@@ -56,6 +63,7 @@ int sar_exchange_new(sar_runtime* rt, uint32_t world, uint32_t rank, sar_exchang
     ex->device = rt->device;
     ex->world = world;
     ex->rank = rank;
+    ex->npix = rt->npix;
     int st = slice_pixels(rt->npix, world, ex->S);
     if (st != SAR_OK) { delete ex; return st; }
     ex->sps = ex->S / kExchSeg;
@@ -101,6 +109,7 @@ int sar_exchange_free(sar_exchange* ex) try {
 int sar_exchange_flags(sar_exchange* ex, uint8_t* flags_out_dev) try {
     if (!ex || !flags_out_dev) return SAR_ERR_INVALID;
     sar_runtime* rt = ex->rt;
+    SAR_TRY(same_image(ex));
     HIP_TRY(hipSetDevice(rt->device));
     launch_exch_flags(rt->d_count, rt->d_key, rt->npix, flags_out_dev, rt->stream);
     HIP_TRY(hipGetLastError());
@@ -112,6 +121,7 @@ int sar_exchange_pack(sar_exchange* ex, const uint8_t* flags_all_dev, double den
     if (!ex || !send_dev || !send_bytes || !recv_bytes) return SAR_ERR_INVALID;
     sar_runtime* rt = ex->rt;
     const uint32_t G = ex->world;
+    SAR_TRY(same_image(ex));
     HIP_TRY(hipSetDevice(rt->device));
     bool sparse = false;
     if (flags_all_dev) {
@@ -145,6 +155,7 @@ int sar_exchange_pack(sar_exchange* ex, const uint8_t* flags_all_dev, double den
 int sar_exchange_merge(sar_exchange* ex, const void* recv_dev, int64_t* scalars_out_dev) try {
     if (!ex || !recv_dev || !scalars_out_dev) return SAR_ERR_INVALID;
     sar_runtime* rt = ex->rt;
+    SAR_TRY(same_image(ex));
     HIP_TRY(hipSetDevice(rt->device));
     if (ex->sparse)
         launch_exch_merge_sparse(rt->d_count, rt->d_key, rt->d_steps, ex->first, ex->n, ex->sps, ex->world, recv_dev, ex->d_recv_slot, rt->d_scalars,
@@ -160,6 +171,7 @@ int sar_exchange_merge(sar_exchange* ex, const void* recv_dev, int64_t* scalars_
 int sar_exchange_finish(sar_exchange* ex, const int64_t* scalars_dev) try {
     if (!ex || !scalars_dev) return SAR_ERR_INVALID;
     sar_runtime* rt = ex->rt;
+    SAR_TRY(same_image(ex));
     HIP_TRY(hipSetDevice(rt->device));
     launch_exch_scalars_import(rt->d_scalars, scalars_dev, rt->stream);
     HIP_TRY(hipGetLastError());
@@ -169,6 +181,7 @@ int sar_exchange_finish(sar_exchange* ex, const int64_t* scalars_dev) try {
 int sar_exchange_rooted(sar_exchange* ex, uint32_t step, void* key_i64_dev, void* sum_i32_dev) try {
     if (!ex || !key_i64_dev || step > 2u || (step && !sum_i32_dev)) return SAR_ERR_INVALID;
     sar_runtime* rt = ex->rt;
+    SAR_TRY(same_image(ex));
     HIP_TRY(hipSetDevice(rt->device));
     if (step == 0u) launch_exch_export(rt->d_key, ex->rank, key_i64_dev, rt->npix, rt->stream);
     else if (step == 1u) launch_exch_select(rt->d_count, rt->d_key, rt->d_steps, ex->rank, key_i64_dev, sum_i32_dev, rt->npix, rt->stream);

@@ -552,3 +552,26 @@ def test_exchange_context_plans_packs_and_folds_like_merge_in_rank_order(sar, or
     assert sum(e.count for e in exs) == W * H
     for rt in rts:
         rt.close()                                                                # (closes its exchange context first)
+
+
+def test_exchange_context_refuses_a_runtime_that_was_resized(sar, gpu):
+    """The context's slice geometry and slot tables are those of the image it was made for: after Runtime::set_width_height
+    (:667-675) every call answers SAR_ERR_DIM_MISMATCH instead of reading past the buffers; a new context works."""
+    import torch
+    cfg = sar.Config.poisson_saturne(iterations=1000, width=320, height=200, jobs_total=4, transparent=0)
+    rt = sar.Runtime(cfg)
+    ex = sar.Exchange(rt, 2, 1)
+    flags = torch.zeros(ex.granules, dtype=torch.uint8, device="cuda")
+    ex.flags(flags.data_ptr())
+    rt.set_width_height(640, 400)
+    with pytest.raises(sar.SarError) as err:
+        ex.flags(flags.data_ptr())
+    assert err.value.status == 2 and "make a new one" in str(err.value)
+    ex.close()
+    ex = sar.Exchange(rt, 2, 1)
+    assert ex.granules == 640 * 400 // 64
+    flags = torch.zeros(ex.granules, dtype=torch.uint8, device="cuda")
+    ex.flags(flags.data_ptr())
+    rt.synchronize()
+    ex.close()
+    rt.close()
