@@ -840,6 +840,10 @@ int sar_runtime_wait_image(sar_runtime* rt, uint64_t ticket) try {
 // most boxes of the pool, 3-4 on some: 33-100 ms of a sweep's set-up); an anonymous mapping that asks for transparent huge pages,
 // touched once and then registered with the HIP runtime, is the same memory to a copy and takes 0.4 of the time (tools/ubench/
 // alloc_cost.py: 352 MiB in 20 ms against 48-55). Large blocks go that way; what fails on the way falls back to hipHostMalloc.
+}  // extern "C" (an unnamed namespace inside it gives its variables C names with EXTERNAL linkage: two copies of this library in
+   // one process — the product and the test-suite's hooks build, loaded RTLD_GLOBAL — would share them, and construct and destroy
+   // them twice)
+
 namespace {
 struct MappedBlock { void* p; size_t bytes; };
 std::mutex g_mapped_mu;
@@ -866,6 +870,8 @@ void* map_and_register(size_t bytes) {
     return p;
 }
 }  // namespace
+
+extern "C" {
 
 int sar_host_alloc(size_t bytes, void** out) try {
     if (!out || bytes == 0) { set_error("sar_host_alloc: NULL output or zero size"); return SAR_ERR_INVALID; }

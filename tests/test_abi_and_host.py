@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 import tempfile
 
 import numpy as np
@@ -372,3 +373,27 @@ def test_batch_frames_answers_one_where_frames_cannot_share_launches():
     assert S.batch_frames(c2.replace(width=9000, height=9000)) == 1     # 81 Mpx: one global atomic per visit
     assert S.batch_frames(c2.replace(jobs_total=16, iterations=16 * (1 << 33))) == 1   # jobs of several segments
     assert S.batch_frames(c2.replace(iterations=400_000_000_000, jobs_total=1 << 22)) == 1   # several launch chunks (the 24 GiB scratch cap)
+
+
+def test_the_library_exports_no_c_named_variable(sar):
+    """Two copies of the library live in one process in this test-suite (the product and the hooks build, loaded RTLD_GLOBAL): a
+    variable with a C name and external linkage — what an unnamed namespace inside `extern "C"` produces — is shared between them,
+    constructed and destroyed twice (a double free at exit once it owns memory; found that way in round 6). Every unmangled name
+    the product defines is a `sar_` function or the HIP compiler's per-file id."""
+    from strange_attractor_renderer_amd import _abi
+    for path in (_abi.LIB_PATH, _abi.HOOKS_PATH):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+        odd = []
+        for line in out.splitlines():
+            kind, name = line.split()[-2:]
+            if name.startswith("_Z") or name.startswith("__hip_cuid_"):
+                continue
+            if not (name.startswith("sar_") and kind == "T"):
+                odd.append(line)
+        assert not odd, (path, odd)
+    both = subprocess.run([sys.executable, "-c",
+                           "import ctypes as C; from strange_attractor_renderer_amd import _abi; "
+                           "a = C.CDLL(_abi.HOOKS_PATH, mode=C.RTLD_GLOBAL); b = C.CDLL(_abi.LIB_PATH, mode=C.RTLD_GLOBAL); "
+                           "assert a.sar_abi_version() == b.sar_abi_version()"],
+                          cwd=ROOT, capture_output=True, text=True)
+    assert both.returncode == 0, both.stderr
