@@ -92,6 +92,26 @@ int main() {
             printf("alone   hsa_amd_memory_async_copy (%d in flight)   : %7.2f ms  %5.1f GB/s\n", fl, t, reps * bytes / t / 1e6);
         }
     }
+    hipStream_t sc2; CK(hipStreamCreateWithFlags(&sc2, hipStreamNonBlocking));
+    hipStream_t sc3; CK(hipStreamCreateWithFlags(&sc3, hipStreamNonBlocking));
+    // the same images over two / three streams at once (copies pending at the same time take different engines)
+    auto hip_copies_split = [&](int n, int ways) {
+        hipStream_t ss[3] = {sc, sc2, sc3};
+        const double t = now_ms();
+        for (int i = 0; i < n; ++i) CK(hipMemcpyAsync(dst[i], src, bytes, hipMemcpyDeviceToHost, ss[i % ways]));
+        for (int w = 0; w < ways; ++w) CK(hipStreamSynchronize(ss[w]));
+        return now_ms() - t;
+    };
+    // every image in two halves on two streams
+    auto hip_copies_halves = [&](int n) {
+        const double t = now_ms();
+        for (int i = 0; i < n; ++i) {
+            CK(hipMemcpyAsync(dst[i], src, bytes / 2, hipMemcpyDeviceToHost, sc));
+            CK(hipMemcpyAsync(dst[i] + bytes / 2, src + bytes / 2, bytes - bytes / 2, hipMemcpyDeviceToHost, sc2));
+        }
+        CK(hipStreamSynchronize(sc)); CK(hipStreamSynchronize(sc2));
+        return now_ms() - t;
+    };
     const int n = 60000;
     kernel(n); double alone = kernel_ms();
     kernel(n); alone = kernel_ms();
@@ -99,6 +119,12 @@ int main() {
     for (int round = 0; round < 2; ++round) {
         kernel(n); double t = hip_copies(reps); double k = kernel_ms(); check("hip busy");
         printf("busy    hipMemcpyAsync            : copies %7.2f ms %5.1f GB/s, kernel %.2f ms (+%.1f %%)\n", t, reps * bytes / t / 1e6, k, (k / alone - 1) * 100);
+        for (int ways : {2, 3}) {
+            kernel(n); t = hip_copies_split(reps, ways); k = kernel_ms(); check("hip split busy");
+            printf("busy    hipMemcpyAsync over %d streams: copies %7.2f ms %5.1f GB/s, kernel %.2f ms (+%.1f %%)\n", ways, t, reps * bytes / t / 1e6, k, (k / alone - 1) * 100);
+        }
+        kernel(n); t = hip_copies_halves(reps); k = kernel_ms(); check("hip halves busy");
+        printf("busy    hipMemcpyAsync, halves on 2 streams: copies %7.2f ms %5.1f GB/s, kernel %.2f ms (+%.1f %%)\n", t, reps * bytes / t / 1e6, k, (k / alone - 1) * 100);
         for (int fl : {1, 2}) {
             kernel(n); t = hsa_copies(reps, fl); k = kernel_ms(); check("hsa busy");
             printf("busy    hsa_amd_memory_async_copy (%d): copies %7.2f ms %5.1f GB/s, kernel %.2f ms (+%.1f %%)\n", fl, t, reps * bytes / t / 1e6, k, (k / alone - 1) * 100);
