@@ -1,4 +1,4 @@
-// CU masks (hipExtStreamCreateWithCUMask): which CUs does bit i of the mask name, and what does a device-to-host copy (a blit
+// CU masks (hipExtStreamCreateWithCUMask): which CUs does bit i of the mask name, and what does a device-to-host copy (under a profiler a blit
 // kernel in ROCm 7.2 on these boxes) reach on a stream of its own FEW CUs while another stream — masked to the other CUs — keeps
 // the chip busy? (The read-back of a `sequence` frame runs at 55 GB/s alone and at 30 GB/s next to the render: DESIGN.md 3.5.)
 //   hipcc --offload-arch=gfx950 -O2 -o cumask_probe cumask_probe.hip ; gpurun -- tools/ubench/cumask_probe
