@@ -641,7 +641,7 @@ int sar_colorize_device_batch(uint32_t n, const sar_config* const* cfgs, sar_run
         uint32_t m = 1;
         if (c0->render_kind == SAR_RENDER_GAS && !lead->timing)
             while (first + m < n && m < kMaxBatchFrames && rts[first + m]->device == lead->device && rts[first + m]->stream == lead->stream &&
-                   rts[first + m]->npix == lead->npix && same_colours(cfgs[first + m])) ++m;
+                   rts[first + m]->npix == lead->npix && !rts[first + m]->timing && same_colours(cfgs[first + m])) ++m;  // (a timed runtime records its own span)
         if (m == 1) {
             SAR_TRY(do_colorize(c0, lead, rgba_out_dev[first]));
         } else {
