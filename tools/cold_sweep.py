@@ -27,6 +27,11 @@ def main():
     ap.add_argument("--jobs", type=int, default=65536)
     ap.add_argument("--ring", type=int, default=0)
     ap.add_argument("--skip", default="", help="TIMING EXPERIMENT ONLY (wrong images): comma list of per-frame calls to leave out: reset, colorize")
+    ap.add_argument("--reuse-images", action="store_true", help="experiment: the host images of the first repetition serve the later ones "
+                    "(runtimes are still built anew): is a cold sweep slower because its page-locked memory is new?")
+    ap.add_argument("--reuse-runtimes", action="store_true", help="experiment: the frame groups of the first repetition serve the later ones")
+    ap.add_argument("--pause", type=float, default=0.0, help="seconds between a repetition's close() and the next one's clock (the driver wipes freed "
+                    "device memory in the background, on the copy engines the next sweep's read-backs use)")
     ap.add_argument("--per-frame", action="store_true", help="A/B: reset and colorize as one call per frame instead of one per batch")
     ap.add_argument("--copy-cus", type=int, default=0, help="experiment: the lanes' read-back streams on this many CUs of their own (a multiple "
                     "of 8: bit i of a CU mask is CU i / 8 of XCD i %% 8), the launch streams on the others")
@@ -148,6 +153,7 @@ def main():
     torch.cuda.synchronize()
     reps = []
     kept = []
+    stolen: dict = {}
     for rep in range(a.reps):
         acc.clear()
         del timeline[:]
@@ -163,6 +169,11 @@ def main():
             seq = SequenceRenderer(scfg, device_ring=[t.data_ptr() for t in hbm], ring=slots, **kw)
         else:
             seq = SequenceRenderer(scfg, image_format=S.SAR_FMT_RGB16, ring=a.ring, **kw)
+        if a.reuse_images and stolen.get("images"):
+            seq.images, seq.busy = stolen["images"], [None] * len(stolen["images"])
+            seq.free_slots.extend(range(len(seq.images)))
+        if a.reuse_runtimes and stolen.get("groups"):
+            seq.groups = stolen["groups"]
         t1 = time.perf_counter()
         seq.run(todo, sink, zero_copy=True)
         torch.cuda.synchronize()
@@ -170,11 +181,18 @@ def main():
         sizes = list(seq.frames_per_launch)
         launch = seq.groups[0][0].describe_last_launch() if seq.groups and seq.groups[0] else ""
         n_rt = sum(len(g) for g in seq.groups)
+        if a.reuse_images and a.mode != "hbm":
+            stolen["images"], seq.images, seq.busy = seq.images, [], []
+            seq.free_slots.clear()
+        if a.reuse_runtimes:
+            stolen["groups"], seq.groups = seq.groups, []
         if a.keep:
             kept.append((seq, hbm))   # freed memory that is handed out again has to be scrubbed by the driver first (0.2 s for 10 GB
         else:                         # on one box): with --keep every repetition gets memory nobody has used in this process
             seq.close()
         t3 = time.perf_counter()
+        if a.pause:
+            time.sleep(a.pause)
         assert done[0] == len(todo)
         reps.append({"rep": rep, "frames": len(todo), "construct_ms": (t1 - t0) * 1e3, "sweep_ms": (t2 - t1) * 1e3,
                      "cold_ms": (t2 - t0) * 1e3, "cold_ms_per_frame": (t2 - t0) * 1e3 / len(todo), "close_ms": (t3 - t2) * 1e3,

@@ -14,7 +14,7 @@ python bench.py --config c5 --steps 1440 --warmup 32 > $out/bench_c5_n1.json 2> 
 timeout 900 python bench.py --gpus 2 --steps 6 --warmup 2 --extras-seconds 400 > $out/bench_n2_gloo_one_gpu.json 2> $out/bench_n2_gloo_one_gpu.err
 timeout 900 python bench.py --gpus 8 --steps 4 --warmup 1 --extras-seconds 600 > $out/bench_n8_gloo_one_gpu.json 2> $out/bench_n8_gloo_one_gpu.err
 # the cold sweeps by the stand-alone tool as well (a fresh process each: its first repetition is a PROCESS-cold sweep)
-for f in 360 45; do for m in readback hbm; do python tools/cold_sweep.py --frames $f --mode $m --reps 3 --json $out/cold_${f}_$m.json > /dev/null 2>> $out/cold.err; done; done
+for f in 360 45; do for m in readback hbm; do python tools/cold_sweep.py --frames $f --mode $m --reps 3 --pause 1.0 --json $out/cold_${f}_$m.json > /dev/null 2>> $out/cold.err; done; done
 for c in c2 c4; do python bench.py --native --gpus 8 --config $c --steps 4 --warmup 2 > $out/bench_native_8shards_$c.json 2> /dev/null; done
 python bench.py --native --gpus 1 --steps 20 --warmup 3 > $out/bench_native_1dev_c2.json 2> /dev/null
 python - <<PY
