@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--reuse-runtimes", action="store_true", help="experiment: the frame groups of the first repetition serve the later ones")
     ap.add_argument("--pause", type=float, default=0.0, help="seconds between a repetition's close() and the next one's clock (the driver wipes freed "
                     "device memory in the background, on the copy engines the next sweep's read-backs use)")
+    ap.add_argument("--share-copy-stream", action="store_true", help="experiment: every lane's read-backs on the FIRST lane's copy stream")
+    ap.add_argument("--gpu-marks", action="store_true", help="HIP events per batch: start of its kernels, end of its conversions (launch stream), "
+                    "start of its read-backs (copy stream) - printed for the middle of the last repetition")
     ap.add_argument("--per-frame", action="store_true", help="A/B: reset and colorize as one call per frame instead of one per batch")
     ap.add_argument("--copy-cus", type=int, default=0, help="experiment: the lanes' read-back streams on this many CUs of their own (a multiple "
                     "of 8: bit i of a CU mask is CU i / 8 of XCD i %% 8), the launch streams on the others")
@@ -110,6 +113,19 @@ def main():
                 rt.set_copy_stream(copy)
             return rts
         api.Runtime.group = classmethod(group_on_masked_streams)
+    if a.share_copy_stream:
+        inner = api.Runtime.group.__func__
+        first_copy = []
+
+        def group_sharing(cls, *args, **kw):
+            rts = inner(cls, *args, **kw)
+            if not first_copy:
+                first_copy.append(rts[0].copy_stream())
+            else:
+                for rt in rts:
+                    rt.set_copy_stream(first_copy[0])
+            return rts
+        api.Runtime.group = classmethod(group_sharing)
     if "reset" in a.skip:
         api.reset_batch = lambda rts: None
     if "colorize" in a.skip:
@@ -123,6 +139,33 @@ def main():
             for c, rt, o in zip(cfgs, rts, outs):
                 api.colorize_device(c, rt, o)
         api.reset_batch, api.colorize_device_batch = reset_each, colorize_each
+    marks: list = []
+    if a.gpu_marks:
+        ext = {}
+
+        def ev_on(stream_ptr):
+            st = ext.setdefault(stream_ptr, torch.cuda.ExternalStream(stream_ptr))
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(st)
+            return e
+        inner_reset, inner_read = api.reset_batch, api.read_image_async
+
+        def reset_marked(rts):
+            marks.append({"lane_stream": rts[0].stream(), "start": ev_on(rts[0].stream()), "frames": len(rts)})
+            inner_reset(rts)
+
+        def read_marked(rt, image):
+            m = marks[-1]
+            if "kernels_done" not in m:
+                m["kernels_done"] = ev_on(rt.stream())
+                m["copies_start"] = ev_on(rt.copy_stream())
+                m["copy_stream"] = rt.copy_stream()
+            t = inner_read(rt, image)
+            m["n_read"] = m.get("n_read", 0) + 1
+            if m["n_read"] == m["frames"]:
+                m["copies_enqueued_end"] = ev_on(rt.copy_stream())
+            return t
+        api.reset_batch, api.read_image_async = reset_marked, read_marked
     timed(api.Runtime, "reset", "reset")
     timed(api.Runtime, "synchronize", "synchronize")
     timed(api.Runtime, "close", "Runtime.close")
@@ -157,6 +200,8 @@ def main():
     for rep in range(a.reps):
         acc.clear()
         del timeline[:]
+        if a.share_copy_stream:
+            del first_copy[:]
         done[0] = 0
         hbm = None
         torch.cuda.synchronize()
@@ -178,6 +223,17 @@ def main():
         seq.run(todo, sink, zero_copy=True)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
+        if a.gpu_marks and rep == a.reps - 1:
+            base = marks[0]["start"]
+            ms = lambda e: round(base.elapsed_time(e), 2)
+            print("batch lane  kernels: start   end  (dur)   copies: start   end  (dur)   | next batch's kernels start")
+            lanes_seen = sorted({m["lane_stream"] for m in marks})
+            for i, m in enumerate(marks):
+                if "copies_enqueued_end" not in m or not (len(marks) // 2 - 8 <= i < len(marks) // 2 + 8):
+                    continue
+                ks, ke, cs, ce = ms(m["start"]), ms(m["kernels_done"]), ms(m["copies_start"]), ms(m["copies_enqueued_end"])
+                print(f"{i:5d} {lanes_seen.index(m['lane_stream']):4d}   {ks:9.2f} {ke:9.2f} ({ke - ks:6.2f})   {max(cs, ke):9.2f} {ce:9.2f} ({ce - max(cs, ke):6.2f})")
+        del marks[:]
         sizes = list(seq.frames_per_launch)
         launch = seq.groups[0][0].describe_last_launch() if seq.groups and seq.groups[0] else ""
         n_rt = sum(len(g) for g in seq.groups)
