@@ -10,7 +10,7 @@ out=gpurun_out/$tag; mkdir -p $out
 bash tools/gpu_round.sh $tag
 B="--no-cpu-baseline --no-pipeline --sustained-seconds 0 --no-traffic"
 python bench.py --config c4 --steps 6 --warmup 2 $B > $out/bench_c4_n1.json 2> $out/bench_c4_n1.err
-python bench.py --config c5 --steps 1440 --warmup 32 > $out/bench_c5_n1.json 2> $out/bench_c5_n1.err
+python bench.py --config c5 --steps 1440 --warmup 720 > $out/bench_c5_n1.json 2> $out/bench_c5_n1.err
 timeout 900 python bench.py --gpus 2 --steps 6 --warmup 2 --extras-seconds 400 > $out/bench_n2_gloo_one_gpu.json 2> $out/bench_n2_gloo_one_gpu.err
 timeout 900 python bench.py --gpus 8 --steps 4 --warmup 1 --extras-seconds 600 > $out/bench_n8_gloo_one_gpu.json 2> $out/bench_n8_gloo_one_gpu.err
 # the cold sweeps by the stand-alone tool as well (a fresh process each: its first repetition is a PROCESS-cold sweep)
