@@ -175,6 +175,7 @@ extern "C" {
     pub fn sar_runtime_image_done(rt: *mut SarRuntime, ticket: u64, done_out: *mut c_int) -> c_int;
     pub fn sar_host_alloc(bytes: usize, out: *mut *mut c_void) -> c_int;
     pub fn sar_host_free(p: *mut c_void) -> c_int;
+    pub fn sar_host_reserve(bytes: usize, count: u32) -> c_int;
     pub fn sar_write_png(path: *const c_char, format: c_int, width: u32, height: u32, pixels: *const c_void) -> c_int;
     pub fn sar_write_bmp(path: *const c_char, format: c_int, width: u32, height: u32, pixels: *const c_void) -> c_int;
     pub fn sar_write_pam(path: *const c_char, format: c_int, width: u32, height: u32, pixels: *const c_void) -> c_int;

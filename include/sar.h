@@ -280,6 +280,10 @@ int sar_runtime_wait_image(sar_runtime* rt, uint64_t ticket);
 /* Page-locked host memory for those read-backs (4 MiB and more: mapped with huge pages, touched, hipHostRegister'ed). */
 int sar_host_alloc(size_t bytes, void** out);
 int sar_host_free(void* p);
+/* Announces `count` sar_host_alloc(bytes) calls to come (a sweep's ring of images): helper threads map and zero the blocks ahead —
+ * most of what page-locking costs, and no HIP call — and sar_host_alloc only locks them. One announcement per process at a time; a
+ * new one, or count 0, releases what the last one left. */
+int sar_host_reserve(size_t bytes, uint32_t count);
 /* Encoders (host only; no device needed). `pixels` is a host image in `format`, host-endian samples.
  * PNG: 8/16-bit RGB(A), zlib default compression, per-row adaptive filter (minimum sum of absolute differences).
  * BMP / PAM: SAR_FMT_RGBA8 or SAR_FMT_RGB8 only (the CLI requires --8bit for them); BMP 24 bpp BI_RGB or

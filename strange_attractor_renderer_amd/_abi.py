@@ -152,6 +152,7 @@ PROTOTYPES = {
     "sar_runtime_image_done": (C.c_int, [_vp, C.c_uint64, _P(C.c_int)]),
     "sar_host_alloc": (C.c_int, [C.c_size_t, _P(C.c_void_p)]),
     "sar_host_free": (C.c_int, [_vp]),
+    "sar_host_reserve": (C.c_int, [C.c_size_t, C.c_uint32]),
     "sar_write_png": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, _vp]),
     "sar_write_bmp": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, _vp]),
     "sar_write_pam": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, _vp]),

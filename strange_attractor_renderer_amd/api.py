@@ -529,6 +529,16 @@ def colorize_format(config: Config, runtime: Runtime, fmt: int) -> np.ndarray:
     return out
 
 
+def host_reserve(nbytes: int, count: int):
+    """Announces `count` page-locked blocks of `nbytes` to come (sar_host_reserve): helper threads map and zero them ahead of the
+    HostImage()s that take them. (0, 0) releases what is left."""
+    _check(_lib().sar_host_reserve(int(nbytes), int(count)), "sar_host_reserve")
+
+
+def image_bytes(fmt: int, width: int, height: int) -> int:
+    return int(_lib().sar_image_bytes(fmt, width, height))
+
+
 class HostImage:
     """A page-locked host image of (height, width, channels-of-fmt) for ``colorize_format_async``; `array` is a numpy
     view of it, valid until ``close``."""

@@ -11,8 +11,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "sar_plan.hpp"
@@ -850,8 +853,10 @@ std::mutex g_mapped_mu;
 std::vector<MappedBlock> g_mapped;
 constexpr size_t kHugePage = 2u << 20;
 
-void* map_and_register(size_t bytes) {
-    const size_t len = (bytes + kHugePage - 1) & ~(kHugePage - 1);
+size_t mapped_len(size_t bytes) { return (bytes + kHugePage - 1) & ~(kHugePage - 1); }
+
+// An anonymous mapping of len bytes on a 2 MiB boundary, asked to be huge pages, every page touched — no HIP call in here.
+char* map_and_touch(size_t len) {
     // (over-map by one huge page so that the block can start on a 2 MiB boundary: only aligned ranges get huge pages)
     char* raw = static_cast<char*>(mmap(nullptr, len + kHugePage, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
     if (raw == MAP_FAILED) return nullptr;
@@ -860,6 +865,64 @@ void* map_and_register(size_t bytes) {
     if (p + len < raw + len + kHugePage) munmap(p + len, static_cast<size_t>(raw + len + kHugePage - (p + len)));
     madvise(p, len, MADV_HUGEPAGE);                       // (advice: refused or unavailable, the pages are small ones)
     for (size_t off = 0; off < len; off += 4096) p[off] = 0;  // first touch: the pages exist before they are locked
+    return p;
+}
+
+// Blocks announced by sar_host_reserve: helper threads map and touch them ahead of their sar_host_alloc (zeroing fresh pages is
+// nine tenths of what page-locking an image costs, and needs no HIP call: the helpers never contend for the HIP runtime's locks,
+// which is what made page-locking itself on a helper thread slower — profiles/dead_ends.md, Round 6).
+struct HostReserve {
+    static constexpr int kHelpers = 3;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<char*> ready;   // mapped + touched, not registered
+    size_t len = 0;            // their size (a multiple of 2 MiB)
+    uint32_t pending = 0;      // blocks nobody has started on yet
+    int working = 0;           // helper threads alive
+    std::vector<std::thread> helpers;
+    ~HostReserve() { drop(); }
+    void drop() {
+        std::unique_lock<std::mutex> lock(mu);
+        pending = 0;
+        cv.wait(lock, [&] { return working == 0; });
+        for (char* p : ready) munmap(p, len);
+        ready.clear();
+        lock.unlock();
+        for (std::thread& t : helpers)
+            if (t.joinable()) t.join();
+        helpers.clear();
+    }
+    void work(uint64_t generation_len) {
+        std::unique_lock<std::mutex> lock(mu);
+        while (pending) {
+            --pending;
+            lock.unlock();
+            char* p = map_and_touch(generation_len);
+            lock.lock();
+            if (!p) { pending = 0; break; }
+            ready.push_back(p);
+            cv.notify_all();
+        }
+        --working;
+        cv.notify_all();
+    }
+    // a touched block of `want` bytes, or nullptr (none announced: the caller maps its own)
+    char* take(size_t want) {
+        std::unique_lock<std::mutex> lock(mu);
+        if (want != len) return nullptr;
+        cv.wait(lock, [&] { return !ready.empty() || working == 0; });
+        if (ready.empty()) return nullptr;
+        char* p = ready.front();
+        ready.pop_front();
+        return p;
+    }
+} g_reserve;
+
+void* map_and_register(size_t bytes) {
+    const size_t len = mapped_len(bytes);
+    char* p = g_reserve.take(len);
+    if (!p) p = map_and_touch(len);
+    if (!p) return nullptr;
     if (hipHostRegister(p, len, hipHostRegisterDefault) != hipSuccess) {
         (void)hipGetLastError();
         munmap(p, len);
@@ -872,6 +935,20 @@ void* map_and_register(size_t bytes) {
 }  // namespace
 
 extern "C" {
+
+int sar_host_reserve(size_t bytes, uint32_t count) try {
+    g_reserve.drop();                                   // what an earlier announcement left goes first (its helpers have ended)
+    if (bytes < (4u << 20) || count == 0) return SAR_OK;  // (smaller blocks are hipHostMalloc'ed: nothing to prepare)
+    if (count > 4096u) { set_error("sar_host_reserve: at most 4096 blocks"); return SAR_ERR_RANGE; }
+    std::lock_guard<std::mutex> lock(g_reserve.mu);
+    g_reserve.len = mapped_len(bytes);
+    g_reserve.pending = count;
+    const size_t len = g_reserve.len;
+    const int n = count < static_cast<uint32_t>(HostReserve::kHelpers) ? static_cast<int>(count) : HostReserve::kHelpers;
+    g_reserve.working = n;
+    for (int i = 0; i < n; ++i) g_reserve.helpers.emplace_back([len] { g_reserve.work(len); });
+    return SAR_OK;
+} catch (...) { return sar::abi_caught(); }
 
 int sar_host_alloc(size_t bytes, void** out) try {
     if (!out || bytes == 0) { set_error("sar_host_alloc: NULL output or zero size"); return SAR_ERR_INVALID; }

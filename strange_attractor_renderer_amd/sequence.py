@@ -69,6 +69,7 @@ def frame_seed(seed: int, k: int) -> int:
 # freshly created streams did not overlap until one of them had been synchronised while the other was busy. With a lane's streams
 # made together (a frame group, round 6) the sweep runs the same without it — 1440 frames 1070 / 830 ms (read-back / in HBM) either
 # way — and a cold 360-frame sweep is 10-20 ms shorter (307-331 against 327-358 ms): 0.
+PRETOUCH = True   # the ring's host images are mapped and zeroed ahead by the library's helper threads (sar_host_reserve)
 SETTLE = 0
 
 
@@ -121,6 +122,7 @@ class SequenceRenderer:
         self.free_slots = __import__("collections").deque()        # ring slots no frame occupies
         self.slots_made = 0                                        # device-ring slots handed out so far
         self.frames_per_launch: list = []                          # statistic: the batch sizes of the last run
+        self.reserved = False                                      # host blocks announced to the library (sar_host_reserve)
         self.first_enqueued_at = None                              # statistic: time.perf_counter() when the last run's first batch was enqueued
 
     def _setup(self, cfg: "api.Config", n_frames: int = 0):
@@ -153,6 +155,13 @@ class SequenceRenderer:
             self.max_batch = max(1, min(self.max_batch, (self.ring - 1) // per_lane))
         if self.ring < self.lanes + 1:
             raise ValueError("ring must be at least lanes + 1")
+        if self.device_ring is None and PRETOUCH:
+            # the ring's images are page-locked one by one as the read-backs need them (`_image`); helper threads of the library
+            # map and zero their pages meanwhile — no HIP call on them — so that locking one is 0.1 instead of 1-3 ms
+            want = min(self.ring, n_frames or self.ring) - len(self.images)
+            if want > 0:
+                api.host_reserve(api.image_bytes(self.fmt, cfg.c.width, cfg.c.height), want)
+                self.reserved = True
 
     def frame_config(self, angle: float) -> "api.Config":
         return self.config.replace(angle=angle, jobs_total=self.total_jobs, iterations=self.per_job * self.total_jobs,
@@ -330,6 +339,9 @@ class SequenceRenderer:
                 rt.synchronize()
         for im in self.images:
             im.close()
+        if self.reserved:
+            api.host_reserve(0, 0)                                # what the sweep did not take
+            self.reserved = False
         for grp in self.groups:
             for rt in reversed(grp):
                 rt.close()

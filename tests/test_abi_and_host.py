@@ -397,3 +397,16 @@ def test_the_library_exports_no_c_named_variable(sar):
                            "assert a.sar_abi_version() == b.sar_abi_version()"],
                           cwd=ROOT, capture_output=True, text=True)
     assert both.returncode == 0, both.stderr
+
+
+def test_host_reserve_prepares_and_releases_blocks_without_a_device():
+    """sar_host_reserve only maps and zeroes memory on a helper thread (no HIP call): it works, can be replaced and dropped —
+    also while the helper is still at it — on a machine without a GPU."""
+    import strange_attractor_renderer_amd as S
+    S.host_reserve(8 << 20, 6)
+    S.host_reserve(24 << 20, 3)          # replaces the first announcement (its blocks are unmapped)
+    S.host_reserve(0, 0)
+    S.host_reserve(1 << 20, 5)           # below 4 MiB: sar_host_alloc does not map such blocks, nothing to prepare
+    S.host_reserve(0, 0)
+    with pytest.raises(S.SarError):
+        S.host_reserve(8 << 20, 5000)

@@ -210,3 +210,33 @@ def test_conversion_and_read_back_as_two_steps(sar, oracle, gpu):
         finally:
             fresh.close()
     rt.close()
+
+
+@pytest.mark.gpu
+def test_page_locked_images_from_announced_blocks(sar, oracle, gpu):
+    """sar_host_reserve + sar_host_alloc: images that take a block the helper thread prepared, images beyond the announcement and
+    images of another size are all ordinary page-locked images (read-backs land in them), in any order of alloc and free; what an
+    announcement leaves is released by the next one."""
+    cfg = sar.Config.solar_sail(iterations=256 * 700, width=1200, height=900, jobs_total=256, scale=1.0, transparent=0)
+    rt = sar.Runtime(cfg)
+    sar.render_jobs(cfg, rt, sar.start_points(3, 0, 256))
+    want = sar.colorize_format(cfg, rt, sar.SAR_FMT_RGB16)
+    nbytes = sar.image_bytes(sar.SAR_FMT_RGB16, 1200, 900)
+    assert nbytes == 1200 * 900 * 6 and nbytes >= 4 << 20
+    sar.host_reserve(nbytes, 3)
+    imgs = [sar.HostImage(1200, 900, sar.SAR_FMT_RGB16) for _ in range(5)]       # three announced, two beyond
+    other = sar.HostImage(1200, 900, sar.SAR_FMT_RGBA16)                          # another size: mapped on the spot
+    sar.colorize_format_device(cfg, rt, sar.SAR_FMT_RGB16)
+    for img in imgs:
+        sar.wait_image(rt, sar.read_image_async(rt, img))
+        np.testing.assert_array_equal(img.array, want)
+    imgs[1].close()
+    imgs[3].close()
+    sar.host_reserve(nbytes, 2)
+    again = sar.HostImage(1200, 900, sar.SAR_FMT_RGB16)                           # one of two taken, one left for the drop
+    sar.wait_image(rt, sar.read_image_async(rt, again))
+    np.testing.assert_array_equal(again.array, want)
+    sar.host_reserve(0, 0)
+    for img in (imgs[0], imgs[2], imgs[4], other, again):
+        img.close()
+    rt.close()

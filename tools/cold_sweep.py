@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--share-copy-stream", action="store_true", help="experiment: every lane's read-backs on the FIRST lane's copy stream")
     ap.add_argument("--gpu-marks", action="store_true", help="HIP events per batch: start of its kernels, end of its conversions (launch stream), "
                     "start of its read-backs (copy stream) - printed for the middle of the last repetition")
+    ap.add_argument("--no-pretouch", action="store_true", help="A/B: no sar_host_reserve (every image mapped, zeroed and locked at its first use)")
     ap.add_argument("--per-frame", action="store_true", help="A/B: reset and colorize as one call per frame instead of one per batch")
     ap.add_argument("--copy-cus", type=int, default=0, help="experiment: the lanes' read-back streams on this many CUs of their own (a multiple "
                     "of 8: bit i of a CU mask is CU i / 8 of XCD i %% 8), the launch streams on the others")
@@ -50,6 +51,8 @@ def main():
     from strange_attractor_renderer_amd import api, sequence
     from strange_attractor_renderer_amd.sequence import SequenceRenderer, frames as sequence_frames
 
+    if a.no_pretouch:
+        sequence.PRETOUCH = False
     if a.settle >= 0:
         sequence.SETTLE = a.settle
     acc: dict = {}
