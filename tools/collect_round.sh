@@ -18,7 +18,7 @@ for m in readback hbm; do cp $(ls gpurun_out/profiles_c5_$tag/trace_$m/*/k_kerne
 for f in 360 45; do for m in readback hbm; do python - $o/cold_${f}_$m.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
-print(sys.argv[1].split("/")[-1], "cold ms per repetition (the first is process-cold):", [round(r["cold_ms"], 1) for r in d["reps"]], "batches", d["reps"][-1]["frames_per_launch"][:4])
+print(sys.argv[1].split("/")[-1], "cold ms per repetition (the first is process-cold; 1 s pause before each of the others):", [round(r["cold_ms"], 1) for r in d["reps"]], "batches", d["reps"][-1]["frames_per_launch"][:4])
 PY
 done; done > profiles/${tag}_cold_sweep_tool.txt
 cat profiles/${tag}_cold_sweep_tool.txt
