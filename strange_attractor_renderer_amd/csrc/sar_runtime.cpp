@@ -937,6 +937,8 @@ void* map_and_register(size_t bytes) {
 extern "C" {
 
 int sar_host_reserve(size_t bytes, uint32_t count) try {
+    static std::mutex one_at_a_time;                    // (announcements from several threads follow each other)
+    std::lock_guard<std::mutex> serial(one_at_a_time);
     g_reserve.drop();                                   // what an earlier announcement left goes first (its helpers have ended)
     if (bytes < (4u << 20) || count == 0) return SAR_OK;  // (smaller blocks are hipHostMalloc'ed: nothing to prepare)
     if (count > 4096u) { set_error("sar_host_reserve: at most 4096 blocks"); return SAR_ERR_RANGE; }

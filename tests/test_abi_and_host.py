@@ -410,3 +410,14 @@ def test_host_reserve_prepares_and_releases_blocks_without_a_device():
     S.host_reserve(0, 0)
     with pytest.raises(S.SarError):
         S.host_reserve(8 << 20, 5000)
+    import threading                     # announcements from several threads follow each other (helpers counted right: no hang)
+
+    def announce(k):
+        for _ in range(10):
+            S.host_reserve((8 + 2 * k) << 20, 3)
+    threads = [threading.Thread(target=announce, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    S.host_reserve(0, 0)
