@@ -76,54 +76,22 @@ __device__ __forceinline__ void bin_accumulate_body(const BinAccArgs& a, uint32_
             chunk[k] = w < a.n_waves ? a.heads[(size_t)b * a.n_waves + w] : kNoChunk;
             base[k] = arena + (size_t)(w < a.n_waves ? w : 0u) * a.chunks_per_wave * kChunkStride(R) + (q < Q ? q : 0u);
         }
-#ifdef SAR_ACC_PREFETCH
-        uint4 v[K];
-#pragma unroll
-        for (uint32_t k = 0; k < K; ++k) {
-            v[k] = make_uint4(kNoChunk, 0u, 0u, 0u);  // an ended list: no predecessor, no record
-            if (chunk[k] != kNoChunk) v[k] = base[k][(size_t)chunk[k] * kChunkStride(R)];
-        }
-#endif
         for (;;) {
             bool live = false;
 #pragma unroll
             for (uint32_t k = 0; k < K; ++k) live |= chunk[k] != kNoChunk;
             if (!live) break;
-#ifdef SAR_ACC_PREFETCH
-            // the links first, and the NEXT chunks' loads on their way before this step's adds: a wave's loads and its LDS adds overlap
-            uint32_t link[K];
-            uint4 vn[K];
-#pragma unroll
-            for (uint32_t k = 0; k < K; ++k) link[k] = __shfl(v[k].x, 0, G);
-            uint32_t cnt[K];  // (all the steps' LDS reads before its first add: a read waits for every add issued before it)
-#pragma unroll
-            for (uint32_t k = 0; k < K; ++k) cnt[k] = __shfl(v[k].y, 0, G);
-#pragma unroll
-            for (uint32_t k = 0; k < K; ++k) {
-                vn[k] = make_uint4(kNoChunk, 0u, 0u, 0u);
-                if (link[k] != kNoChunk) vn[k] = base[k][(size_t)link[k] * kChunkStride(R)];
-            }
-#else
             uint4 v[K];
 #pragma unroll
             for (uint32_t k = 0; k < K; ++k) {
                 v[k] = make_uint4(kNoChunk, 0u, 0u, 0u);  // an ended list: no predecessor, no record
                 if (chunk[k] != kNoChunk) v[k] = base[k][(size_t)chunk[k] * kChunkStride(R)];
             }
-#endif
 #pragma unroll
             for (uint32_t k = 0; k < K; ++k) {
                 // the chunk header {previous chunk of the list, record count} sits in lane 0's quad
-#ifdef SAR_ACC_PREFETCH
-                const uint32_t prev = link[k];
-#else
                 const uint32_t prev = __shfl(v[k].x, 0, G);
-#endif
-#ifdef SAR_ACC_PREFETCH
-                const uint32_t nrec = q < Q ? cnt[k] : 0u;
-#else
                 const uint32_t nrec = q < Q ? __shfl(v[k].y, 0, G) : 0u;
-#endif
                 // records held by this lane: lane 0 -> records 0..3 (its .z/.w), lane q -> 8q-4 .. 8q+3
                 const uint32_t first = q == 0u ? 0u : 8u * q - 4u;
                 const uint32_t r0 = q == 0u ? v[k].z : v[k].x, r1 = q == 0u ? v[k].w : v[k].y;
@@ -190,22 +158,6 @@ __device__ __forceinline__ void bin_accumulate_body(const BinAccArgs& a, uint32_
                     chunk[k] = prev;
                     continue;
                 }
-#ifdef SAR_ACC_FULLFAST
-                if (!PACKED && nrec == R) {  // a full chunk (every chunk of a list but its newest): no test per record
-                    atomicAdd(&hist[r0 & 0xFFFFu], 1u);
-                    atomicAdd(&hist[r0 >> 16], 1u);
-                    atomicAdd(&hist[r1 & 0xFFFFu], 1u);
-                    atomicAdd(&hist[r1 >> 16], 1u);
-                    if (q != 0u) {
-                        atomicAdd(&hist[v[k].z & 0xFFFFu], 1u);
-                        atomicAdd(&hist[v[k].z >> 16], 1u);
-                        atomicAdd(&hist[v[k].w & 0xFFFFu], 1u);
-                        atomicAdd(&hist[v[k].w >> 16], 1u);
-                    }
-                    chunk[k] = prev;
-                    continue;
-                }
-#endif
                 auto count = [&](bool valid, uint32_t rec) {  // rec: 16 bits
                     if (PACKED) {
                         if (valid) packed_add(rec);
@@ -225,10 +177,6 @@ __device__ __forceinline__ void bin_accumulate_body(const BinAccArgs& a, uint32_
                 }
                 chunk[k] = prev;
             }
-#ifdef SAR_ACC_PREFETCH
-#pragma unroll
-            for (uint32_t k = 0; k < K; ++k) v[k] = vn[k];
-#endif
         }
     }
     __syncthreads();
