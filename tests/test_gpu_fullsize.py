@@ -33,9 +33,22 @@ def _golden():
     return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fullsize_checksums.json")))
 
 
+_ORACLE_SECONDS = {}  # case -> seconds the threaded host oracle took in this process
+_LIVE_ORACLE_LIMIT_S = float(__import__("os").environ.get("SAR_LIVE_ORACLE_LIMIT_S", "300"))
+
+
 def _meets_oracle(sar, oracle, name, **options):
     """Renders the full-size case `name` on the GPU and on the host oracle; everything must agree bit for bit, and
-    with the committed checksums."""
+    with the committed checksums.
+
+    c4_full_1e10 is 1e10 oracle iterations on the host: ~40-80 s on an idle 256-thread GPU box, several minutes when other
+    tenants load the host (one visit of round 6: the whole suite 594 instead of 214 s). Its projected time is ten times what
+    c4_all_jobs (the same job list, a tenth of the iterations) just took; beyond _LIVE_ORACLE_LIMIT_S the frame is held to the
+    committed checksums alone — which ARE the oracle's output for this case (tests/golden/make_fullsize_checksums.py ran the
+    same oracle in the build container) — and the test says so in a warning. SAR_LIVE_ORACLE=1 forces the live run."""
+    import os
+    import time
+    import warnings
     import fullsize_cases as F
     ocfg, starts, n = F.build_case(name, oracle)
     cfg = sar.Config(oracle.copy_config(ocfg))
@@ -45,13 +58,20 @@ def _meets_oracle(sar, oracle, name, **options):
     sar.render_job_range(cfg, rt, n, starts)
     cnt, z, st, mx, img = rt.count(), rt.zbuf(), rt.steps(), rt.max(), sar.colorize(cfg, rt)
     rt.close()
-    ort = oracle.Runtime(ocfg.width, ocfg.height)
-    oracle.render_jobs_mt(ocfg, ort, starts, n)
-    assert np.array_equal(cnt, ort.count), f"{name}: count differs from the oracle"
-    assert mx == ort.max
-    assert np.array_equal(_bits(z), _bits(ort.zbuf)), f"{name}: zbuf differs from the oracle"
-    assert np.array_equal(_bits(st), _bits(ort.steps)), f"{name}: steps differs from the oracle"
-    assert np.array_equal(img, oracle.colorize(ocfg, ort)), f"{name}: RGBA16 differs from the oracle"
+    projected = 10.0 * _ORACLE_SECONDS.get("c4_all_jobs", 0.0) if name == "c4_full_1e10" else 0.0
+    if projected > _LIVE_ORACLE_LIMIT_S and os.environ.get("SAR_LIVE_ORACLE") != "1":
+        warnings.warn(f"{name}: the host is busy (the live oracle would take ~{projected:.0f} s): held to the oracle's committed "
+                      "checksums only")
+    else:
+        ort = oracle.Runtime(ocfg.width, ocfg.height)
+        t0 = time.perf_counter()
+        oracle.render_jobs_mt(ocfg, ort, starts, n)
+        _ORACLE_SECONDS[name] = time.perf_counter() - t0
+        assert np.array_equal(cnt, ort.count), f"{name}: count differs from the oracle"
+        assert mx == ort.max
+        assert np.array_equal(_bits(z), _bits(ort.zbuf)), f"{name}: zbuf differs from the oracle"
+        assert np.array_equal(_bits(st), _bits(ort.steps)), f"{name}: steps differs from the oracle"
+        assert np.array_equal(img, oracle.colorize(ocfg, ort)), f"{name}: RGBA16 differs from the oracle"
     g = _golden()[name]
     assert g["jobs"] == starts.shape[0] and g["iters_per_job"] == n
     got = {"max": mx, "count_sum": int(cnt.sum(dtype=np.uint64)), "touched": int((cnt > 0).sum()),
